@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the SampleNeRFRO hot path on MI355X (contract: see the task brief / DESIGN.md §Measurement).
+
+One "step" = one pass of the hot path (march -> bkgd MLP -> PE+NerfMLP -> composite [-> resample -> PE+NerfMLP ->
+composite]) over one synthetic batch of rays that is already resident in HBM.  Default workload = BASELINE.json
+configs[1] ("ship_straight": 4096 rays x 128 samples, G=512 grid == 1, flat N_f=0).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--fine F] [--precision P] [--rays B]
+
+N > 1 is launched by the driver through torch.distributed.run (one process per GPU, RCCL).  Rays shard
+embarrassingly (weak scaling, no data-path collective); the only collectives are the timing barrier / max.
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MLP_FLOP_PER_ROW = 2 * 593408          # NerfMLP MACs*2 per sample row
+BKGD_FLOP_PER_RAY = 2 * 56448
+PEAK_MFMA_16BIT = 2.5e15               # dense bf16/f16 MFMA peak (MI355X_MICROARCH.md)
+PEAK_HBM = 8.0e12
+
+
+def build_scene(cfg, device, precision, fine):
+    import torch
+    from samplenerfro_amd import models, ops, synthetic as syn
+    G, ext = cfg["G"], cfg["extent"]
+    ndim, nmin, nmax = [G] * 3, [-ext] * 3, [ext] * 3
+    if cfg["radius"] > 0:
+        a = torch.linspace(-ext, ext, G, dtype=torch.float64, device=device)
+        r = torch.sqrt(a[:, None, None] ** 2 + a[None, :, None] ** 2 + a[None, None, :] ** 2)
+        h = 2.0 * ext / (G - 1)
+        raw = 1.0 + 0.33 * torch.clamp((cfg["radius"] - r) / h + 0.5, 0.0, 1.0)
+        grid = ((raw - 1.0) * cfg["ri"] / 0.33 + 1.0).float()
+        del raw, r
+        if cfg["ksize"] > 0:
+            grid = ops.grid_prefilter(grid, cfg["ksize"], cfg["ksigma"])
+    else:
+        grid = torch.ones((G, G, G), dtype=torch.float32, device=device)
+    model = models.NerfModel(ndim=ndim, nmin=nmin, nmax=nmax, grid=grid, near=cfg["near"], far=cfg["far"],
+                             num_coarse_samples=cfg["S"], num_fine_samples=fine, num_path_samples=cfg["P"],
+                             precision=precision, device=device)
+    del grid
+    pf = syn.init_params_flat(0, fine=fine > 0)
+    variables = models.make_variables({k: torch.from_numpy(v).to(device) for k, v in pf.items()})
+    return model, variables, pf
+
+
+def cpu_baseline(cfg, pf, fine, sample_rays, seed):
+    """The oracle (numpy fp32 restatement, multi-threaded BLAS for the matmuls) on a bounded sample of the workload."""
+    from oracle import ref_np as R
+    from samplenerfro_amd import synthetic as syn
+    G, ext = cfg["G"], cfg["extent"]
+    ndim, nmin, nmax = [G] * 3, [-ext] * 3, [ext] * 3
+    if cfg["radius"] > 0:
+        grid = syn.scale_ior(syn.sphere_grid(G, ext, cfg["radius"]), cfg["ri"]).astype(np.float32)
+        # the prefilter is a one-off, not part of a step: the separable fp32 filter is enough for a timing input
+        from scipy.ndimage import gaussian_filter1d  # noqa: F401  (only to smooth the timing input)
+        for ax in range(3):
+            grid = gaussian_filter1d(grid, cfg["ksigma"], axis=ax, mode="nearest", truncate=(cfg["ksize"] // 2) / cfg["ksigma"])
+    else:
+        grid = np.ones((G, G, G), np.float32)
+    table = R.build_table(grid, ndim, nmin, nmax)
+    del grid
+    o, d = syn.sphere_rays(sample_rays, seed=seed)
+    mc = R.ModelConfig(ndim, nmin, nmax, near=cfg["near"], far=cfg["far"], num_coarse_samples=cfg["S"],
+                       num_fine_samples=fine, num_path_samples=cfg["P"])
+    jitter = np.arange(0, mc.num_samples, cfg["P"]) + (cfg["P"] // 2)
+    params = syn.params_tree(pf)
+    t0 = time.perf_counter()
+    R.nerf_forward(mc, params, table, o, d, jitter)
+    dt = time.perf_counter() - t0
+    return sample_rays / dt, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="ship_straight")
+    ap.add_argument("--fine", type=int, default=None, help="num_fine_samples (default: the workload's flat variant, 0)")
+    ap.add_argument("--precision", default="f16x3")
+    ap.add_argument("--rays", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rays", type=int, default=256)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from samplenerfro_amd import synthetic as syn
+    from samplenerfro_amd.utils import Rays
+    from samplenerfro_amd import prng
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (the hot path has no CPU implementation)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    cfg = dict(syn.CONFIGS[args.workload])
+    fine = cfg["F"] if args.fine is None else args.fine
+    B = args.rays or min(cfg["B"], 4096 if args.workload != "glass_frame" else 8192)
+    model, variables, pf = build_scene(cfg, device, args.precision, fine)
+    # weak scaling: every rank marches its own B rays (different seed per rank), grid + weights replicated
+    o, d = syn.sphere_rays(B, seed=syn.SEED + rank)
+    rays = Rays(torch.from_numpy(o).to(device), None, torch.from_numpy(d).to(device), None)
+    key = prng.PRNGKey(syn.SEED)
+
+    def step():
+        return model.apply(variables, key, key, rays, False)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ret, _ = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    assert torch.isfinite(ret[-1][0]).all()
+
+    # ---- per-kernel roofline of the dominant kernel (PE + NerfMLP), HIP events on the launch stream --------------------
+    from samplenerfro_amd import ops, _lib
+    S = cfg["S"]
+    N = S * cfg["P"]
+    path_pd, path_dr, _, _ = ops.march(model.table, model.spec, rays.origins, rays.viewdirs, cfg["near"], cfg["far"], N)
+    jit = model._jitter_dev(model.make_jitter(key))
+    packed = model._packed_weights(variables, "coarse_mlp")
+    reps = max(5, min(args.steps, 20))
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+    out = None
+    ops.nerfmlp_forward(packed, model.precision, path_pd, path_dr, jit, S, B)
+    torch.cuda.synchronize()
+    ev[0].record()
+    for i in range(reps):
+        out = ops.nerfmlp_forward(packed, model.precision, path_pd, path_dr, jit, S, B, out=out)
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    mlp_ms = float(np.mean([ev[i].elapsed_time(ev[i + 1]) for i in range(reps)]))
+    mlp_flops = MLP_FLOP_PER_ROW * S * B
+    mlp_achieved = mlp_flops / (mlp_ms * 1e-3)
+    # march kernel (HBM-bound by its algorithmic gather bytes: 8 corners x 16 B per step)
+    ev2 = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+    ev2[0].record()
+    for i in range(reps):
+        ops.march(model.table, model.spec, rays.origins, rays.viewdirs, cfg["near"], cfg["far"], N, out=(path_pd, path_dr))
+        ev2[i + 1].record()
+    torch.cuda.synchronize()
+    march_ms = float(np.mean([ev2[i].elapsed_time(ev2[i + 1]) for i in range(reps)]))
+    march_bytes = B * (N * 128 + 24)
+    march_achieved = march_bytes / (march_ms * 1e-3)
+
+    if rank == 0:
+        total_rays = B * args.steps * world
+        rows_per_ray = S + (S + fine if fine > 0 else 0)
+        line = {
+            "metric": "rays_per_sec", "value": total_rays / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32 (MLP on %s MFMA, fp32 accumulate)" % args.precision, "data": "synthetic",
+            "config": {"workload": f"{args.workload}: forward render pass, {B} rays/GPU x {S} coarse + {fine} fine samples, "
+                                   f"P={cfg['P']} (N={N} eikonal steps), grid {cfg['G']}^3", "rays_per_gpu": B,
+                       "mlp_rows_per_ray": rows_per_ray, "precision": args.precision, "pass": "forward"},
+            "roofline": {"kernel": "nerfmlp_fwd_kernel", "bound": "mfma", "achieved": mlp_achieved / 1e12, "peak": PEAK_MFMA_16BIT / 1e12,
+                         "unit": "TFLOP/s", "frac": mlp_achieved / PEAK_MFMA_16BIT, "traffic": None,
+                         "avg_launch_ms": mlp_ms, "algorithmic_flop_per_launch": mlp_flops,
+                         "mfma_issue_frac": (3 if "x3" in args.precision else 1) * mlp_achieved / PEAK_MFMA_16BIT},
+            "roofline_march": {"kernel": "march_kernel", "bound": "hbm", "achieved": march_achieved / 1e9, "peak": PEAK_HBM / 1e9,
+                               "unit": "GB/s", "frac": march_achieved / PEAK_HBM, "traffic": None, "avg_launch_ms": march_ms,
+                               "algorithmic_bytes_per_launch": march_bytes},
+        }
+        if not args.no_cpu_baseline:
+            cpu_rps, cpu_dt = cpu_baseline(cfg, pf, fine, args.cpu_rays, syn.SEED)
+            line["cpu_baseline"] = {"value": cpu_rps, "unit": "rays/s", "cores": os.cpu_count(), "kind": "port",
+                                    "sample": f"{args.cpu_rays} rays of the same workload, one pass of the numpy fp32 oracle "
+                                              f"(threaded BLAS), {cpu_dt:.1f} s"}
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,134 @@
+/*
+ * rnerf.h — C ABI of librnerf.so, the MI355X (gfx950) implementation of the SampleNeRFRO
+ * volumetric-rendering hot path.
+ *
+ * The reference (alexkeroro86/SampleNeRFRO) has no FFI/plugin layer: the path sits behind
+ * Python callables.  Each entry point below names the reference function
+ * (file:line under the reference checkout) whose arithmetic it replaces; the Python host
+ * (samplenerfro_amd/) re-creates the reference call surface (NerfModel.__call__, render_image,
+ * train_step) on top of these.  INTEGRATION.md shows the binding a maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller unless named h_*;
+ *   - nothing is allocated per call; scratch comes from the caller (`*_workspace_bytes`);
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*);
+ *   - return value: 0 = ok, <0 = error (message via rnerf_last_error(), thread local);
+ *   - "sample-major" layout: an array indexed [s][b] stores sample/node s of ray b at s*B + b,
+ *     so that one-lane-per-ray kernels read and write coalesced.
+ *   - a "row record" is two float4 arrays: pd = (pos.x, pos.y, pos.z, dist) and
+ *     dr = (dir.x, dir.y, dir.z, 0) with dir already safe-l2-normalised.
+ */
+#ifndef RNERF_H_
+#define RNERF_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RNERF_VERSION 1
+
+enum rnerf_status {
+  RNERF_OK = 0,
+  RNERF_ERR_ARG = -1,   /* bad argument (null pointer, size, alignment) */
+  RNERF_ERR_HIP = -2,   /* a HIP runtime call failed */
+  RNERF_ERR_UNSUPPORTED = -3
+};
+
+/* MLP arithmetic. F32 = v_mfma_f32_32x32x2_f32 (exact fp32 fma chain); F16X3 / BF16X3 = hi/lo split of
+ * both operands, 3 MFMAs per tile (error ~2^-21 / ~2^-16 per product); F16 / BF16 = single MFMA. */
+enum rnerf_precision {
+  RNERF_PREC_F32 = 0,
+  RNERF_PREC_F16X3 = 1,
+  RNERF_PREC_BF16X3 = 2,
+  RNERF_PREC_F16 = 3,
+  RNERF_PREC_BF16 = 4
+};
+
+/* Voxel grid geometry: reference VoxMLP.ndim/nmin/nmax (rnerf/ior_utils.py:124-144).  Doubles, because the
+ * reference derives ndelta = (nmax-nmin)/(ndim-1) in Python doubles before it meets float32 data. */
+typedef struct rnerf_grid {
+  int32_t dims[3];
+  double nmin[3];
+  double nmax[3];
+} rnerf_grid;
+
+/* Sizes of the flat fp32 parameter buffers (flax creation order Dense_0.. ; per layer kernel[in][out]
+ * row-major followed by bias[out]).  NerfMLP: rnerf/model_utils.py:30-90, MLP: :93-140. */
+#define RNERF_NERFMLP_PARAMS 595844
+#define RNERF_BKGDMLP_PARAMS 56963
+
+const char* rnerf_last_error(void);
+int rnerf_version(void);
+/* Number of compute units of the current device (for host-side sizing); <0 on error. */
+int rnerf_device_cus(void);
+
+/* ---- G1: Gaussian prefilter of the IoR grid.  Replaces ior_utils.conv3d_normal (rnerf/ior_utils.py:327-363).
+ * src/dst/tmp: float[dims0*dims1*dims2], x slowest.  Separable evaluation of the same normalised kernel. */
+int rnerf_grid_prefilter(const float* src, float* dst, float* tmp, const int32_t dims[3], int ksize, double ksigma,
+                         void* stream);
+
+/* ---- G2: n + central-difference gradient table.  Replaces VoxMLP.setup/_compute_grad
+ * (rnerf/ior_utils.py:139-172).  table: float4[G^3] = (n, dn/dx, dn/dy, dn/dz). */
+int rnerf_grid_build_table(const float* grid, float* table, const rnerf_grid* g, void* stream);
+
+/* ---- G3: trilinear lookup with clamp-to-edge.  Replaces VoxMLP._linear3 (rnerf/ior_utils.py:188-223).
+ * pts: float[n][3]; out: float[n][4]; idx (nullable): int32[n][6] = clamped x0,x1,y0,y1,z0,z1 (debug tap). */
+int rnerf_grid_query(const float* table, const rnerf_grid* g, const float* pts, int64_t n, float* out, int32_t* idx,
+                     void* stream);
+
+/* ---- E1/E2/E3: eikonal march.  Replaces PathSampler.__call__ + OneEikonalStep.__call__
+ * (rnerf/eikonal_utils.py:29-49,100-124) with stage="radiance*" and math_utils.safe_l2_normalize
+ * (rnerf/math_utils.py:6-12).  num_nodes = N_c*P, step = (far-near)/(num_nodes-1) (rnerf/models.py:121-122).
+ * origins, viewdirs: float[B][3].  path_pd, path_dr: float4[num_nodes][B] node records (node k = state before
+ * step k).  path_ior (nullable): float4[num_nodes][B] = (n, grad n) at node k.  vox (nullable): int32
+ * [num_nodes][B][6] clamped voxel indices (debug tap for the bit-exact test). */
+int rnerf_march(const float* table, const rnerf_grid* g, const float* origins, const float* viewdirs, int32_t B,
+                double near, double far, int32_t num_nodes, float* path_pd, float* path_dr, float* path_ior,
+                int32_t* vox, void* stream);
+
+/* ---- N1 weights: pack a flat fp32 NerfMLP parameter buffer into the MFMA operand stream of `precision`. */
+size_t rnerf_nerfmlp_packed_bytes(int precision);
+int rnerf_nerfmlp_pack(const float* params, int precision, void* packed, void* stream);
+
+/* ---- P1 + N1: positional encoding + NerfMLP over sample rows.  Replaces model_utils.pos_enc
+ * (rnerf/model_utils.py:187-214) and NerfMLP.__call__ (:30-90) as called at rnerf/models.py:257,289,305,394,426,441.
+ * Rows are sample-major: row = s*B + b.  If node_of_sample != NULL (int32[S], device) the record of row (s,b) is
+ * read at node_of_sample[s]*B + b (coarse pass reading the path record through the jitter); otherwise at s*B + b.
+ * packed: the buffer written by rnerf_nerfmlp_pack (weight stream + fp32 biases and sigma/rgb heads).
+ * out_raw: float4[S*B] = (raw_r, raw_g, raw_b, raw_sigma) before activation. */
+int rnerf_nerfmlp_forward(const void* packed, int precision, const float* rows_pd, const float* rows_dr,
+                          const int32_t* node_of_sample, int32_t S, int32_t B, float* out_raw, void* stream);
+
+/* ---- P1 + N2: background MLP on one direction per ray.  Replaces bkgd_mlp(viewdirs_enc[:, -1:]) +
+ * rgb activation (rnerf/models.py:303,336-337) and NerfModel.forward_envmap (:181-191).
+ * dirs: float[n][dir_stride] (dir_stride 3 or 4), out_rgb: float[n][3] after sigmoid*(1+2p)-p. */
+int rnerf_bkgd_forward(const float* params, const float* dirs, int32_t dir_stride, int64_t n, double rgb_padding,
+                       float* out_rgb, void* stream);
+
+/* ---- V1: activations + alpha compositing.  Replaces rgb/sigma activation (rnerf/models.py:334-338) and
+ * model_utils.volumetric_rendering (rnerf/model_utils.py:247-309).  Row addressing as rnerf_nerfmlp_forward.
+ * bkgd: float[B][3].  Outputs: rgb float[B][3], dist float[B], acc float[B], trans float[B],
+ * trans_bkgd float[B][3]; weights (nullable) float[S][B]; alpha (nullable) float[S][B]. */
+int rnerf_composite(const float* raw, const float* rows_pd, const float* rows_dr, const int32_t* node_of_sample,
+                    int32_t S, int32_t B, const float* bkgd, int white_bkgd, double rgb_padding, double sigma_bias,
+                    float* rgb, float* dist, float* acc, float* trans, float* trans_bkgd, float* weights,
+                    float* alpha, void* stream);
+
+/* ---- S1 + S2: PDF resampling along the bent path.  Replaces sorted_piecewise_constant_pdf and sample_pdf
+ * (rnerf/model_utils.py:312-435) as called at rnerf/models.py:371-384.
+ * jitter: int32[S] coarse node indices; weights: float[S][B] coarse weights; u: the uniform draws,
+ * float[num_fine][B] if u_per_ray else float[num_fine] shared by all rays (randomized=False: linspace(0, 1-eps32, F),
+ * rnerf/model_utils.py:355-356).  u must be non-decreasing along the sample axis (true for both reference branches).
+ * Outputs (S+num_fine rows per ray, sample-major): rows_pd/rows_dr records, node_idx (nullable) int32[S+F][B]
+ * the searchsorted node index (bit-exact contract). */
+int rnerf_resample(const float* path_pd, const float* path_dr, int32_t num_nodes, int32_t B, const int32_t* jitter,
+                   int32_t S, const float* weights, const float* u, int32_t u_per_ray, int32_t num_fine, float* rows_pd,
+                   float* rows_dr, int32_t* node_idx, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RNERF_H_ */

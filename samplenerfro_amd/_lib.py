@@ -1,0 +1,94 @@
+"""ctypes binding of librnerf.so (the C ABI declared in include/rnerf.h).
+
+There is no CPU fallback: if the library is missing or a call fails, this raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "librnerf.so")
+
+PREC_F32, PREC_F16X3, PREC_BF16X3, PREC_F16, PREC_BF16 = 0, 1, 2, 3, 4
+PRECISIONS = {"f16x3": PREC_F16X3, "bf16x3": PREC_BF16X3, "f16": PREC_F16, "bf16": PREC_BF16}
+NERFMLP_PARAMS = 595844
+BKGDMLP_PARAMS = 56963
+
+
+class RnerfError(RuntimeError):
+    pass
+
+
+class Grid(C.Structure):
+    """rnerf_grid (include/rnerf.h): reference VoxMLP.ndim/nmin/nmax (rnerf/ior_utils.py:124-144)."""
+    _fields_ = [("dims", C.c_int32 * 3), ("nmin", C.c_double * 3), ("nmax", C.c_double * 3)]
+
+    @classmethod
+    def make(cls, ndim, nmin, nmax) -> "Grid":
+        g = cls()
+        for i in range(3):
+            g.dims[i] = int(ndim[i]); g.nmin[i] = float(nmin[i]); g.nmax[i] = float(nmax[i])
+        return g
+
+
+_vp, _i32, _i64, _dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+_GP = C.POINTER(Grid)
+
+# name -> (restype, argtypes); must list every symbol declared in include/rnerf.h
+SIGNATURES = {
+    "rnerf_last_error": (C.c_char_p, []),
+    "rnerf_version": (C.c_int, []),
+    "rnerf_device_cus": (C.c_int, []),
+    "rnerf_grid_prefilter": (C.c_int, [_vp, _vp, _vp, C.POINTER(_i32 * 3), C.c_int, _dbl, _vp]),
+    "rnerf_grid_build_table": (C.c_int, [_vp, _vp, _GP, _vp]),
+    "rnerf_grid_query": (C.c_int, [_vp, _GP, _vp, _i64, _vp, _vp, _vp]),
+    "rnerf_march": (C.c_int, [_vp, _GP, _vp, _vp, _i32, _dbl, _dbl, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "rnerf_nerfmlp_packed_bytes": (C.c_size_t, [C.c_int]),
+    "rnerf_nerfmlp_pack": (C.c_int, [_vp, C.c_int, _vp, _vp]),
+    "rnerf_nerfmlp_forward": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _i32, _i32, _vp, _vp]),
+    "rnerf_bkgd_forward": (C.c_int, [_vp, _vp, _i32, _i64, _dbl, _vp, _vp]),
+    "rnerf_composite": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, C.c_int, _dbl, _dbl,
+                                  _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "rnerf_resample": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load(path: Optional[str] = None) -> C.CDLL:
+    """Load librnerf.so and bind every entry point; raises RnerfError if the HIP library is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RnerfError(f"{p} not found: build it with `python -m samplenerfro_amd.build` "
+                         "(there is no CPU fallback for the hot path)")
+    lib = C.CDLL(p)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if a declared symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def check(status: int, what: str = "") -> None:
+    if status != 0:
+        msg = load().rnerf_last_error()
+        raise RnerfError(f"{what} failed ({status}): {msg.decode() if msg else '?'}")
+
+
+def ptr(t) -> Optional[int]:
+    """Device pointer of a torch tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def current_stream() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,60 @@
+"""Build librnerf.so (hand-written HIP for gfx950) in-tree with hipcc.
+
+`python -m samplenerfro_amd.build` or `samplenerfro_amd.build.build()`.  hipcc cross-compiles without a GPU.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "librnerf.so")
+SOURCES = ["grid.hip", "march.hip", "render.hip", "mlp.hip"]
+# -ffp-contract=off + correctly rounded div/sqrt: the march/lookup/resample kernels reproduce the reference's
+# individually rounded fp32 op order so that integer indices are bit-exact against the oracle.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+         "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wno-unused-value"]
+
+
+def _hipcc() -> str:
+    for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found (need ROCm >= 7.0 for gfx950)")
+
+
+def _stale(out: str, deps) -> bool:
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(LIBDIR, exist_ok=True)
+    hipcc = _hipcc()
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "rnerf.h")]
+    objs = []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(LIBDIR, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or _stale(o, [s] + headers):
+            cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.check_call(cmd)
+    if force or _stale(LIB, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,106 @@
+// Shared helpers for librnerf.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/rnerf.h"
+
+namespace rnerf {
+
+void set_error(const char* fmt, ...);
+
+#define RNERF_CHECK_ARG(cond, ...)                 \
+  do {                                             \
+    if (!(cond)) {                                 \
+      ::rnerf::set_error(__VA_ARGS__);             \
+      return RNERF_ERR_ARG;                        \
+    }                                              \
+  } while (0)
+
+#define RNERF_CHECK_HIP(expr)                                                          \
+  do {                                                                                 \
+    hipError_t e_ = (expr);                                                            \
+    if (e_ != hipSuccess) {                                                            \
+      ::rnerf::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return RNERF_ERR_HIP;                                                            \
+    }                                                                                  \
+  } while (0)
+
+#define RNERF_CHECK_LAUNCH() RNERF_CHECK_HIP(hipGetLastError())
+
+// float32 view of the grid geometry; every value is rounded from the double the reference computes
+// (rnerf/ior_utils.py:140-144: ndelta = (nmax-nmin)/(ndim-1) in Python doubles, then weak-typed to f32).
+struct GridParams {
+  int dx, dy, dz;
+  float nminx, nminy, nminz;
+  float ndx, ndy, ndz;        // f32(ndelta)
+  float tdx, tdy, tdz;        // f32(2*ndelta)
+};
+
+inline bool make_grid_params(const rnerf_grid* g, GridParams* p) {
+  if (!g) return false;
+  for (int i = 0; i < 3; ++i)
+    if (g->dims[i] < 2) return false;
+  double nd[3];
+  for (int i = 0; i < 3; ++i) nd[i] = (g->nmax[i] - g->nmin[i]) / (g->dims[i] - 1.0);
+  p->dx = g->dims[0]; p->dy = g->dims[1]; p->dz = g->dims[2];
+  p->nminx = (float)g->nmin[0]; p->nminy = (float)g->nmin[1]; p->nminz = (float)g->nmin[2];
+  p->ndx = (float)nd[0]; p->ndy = (float)nd[1]; p->ndz = (float)nd[2];
+  p->tdx = (float)(2 * nd[0]); p->tdy = (float)(2 * nd[1]); p->tdz = (float)(2 * nd[2]);
+  return true;
+}
+
+// Individually rounded fp32 ops: the march / lookup / resample kernels must not contract a*b+c
+// (bit-exact integer indices against the oracle).  The library is also built with -ffp-contract=off.
+__device__ __forceinline__ float fmul(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ float fadd(float a, float b) { return __fadd_rn(a, b); }
+__device__ __forceinline__ float fsub(float a, float b) { return __fsub_rn(a, b); }
+__device__ __forceinline__ float fdiv(float a, float b) { return __fdiv_rn(a, b); }
+__device__ __forceinline__ float fsqrt(float a) { return __fsqrt_rn(a); }
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// a*(1-t) + b*t with the reference's op order (rnerf/ior_utils.py:214-222)
+__device__ __forceinline__ float4 lerp4(const float4 a, const float4 b, float omt, float t) {
+  float4 r;
+  r.x = fadd(fmul(a.x, omt), fmul(b.x, t));
+  r.y = fadd(fmul(a.y, omt), fmul(b.y, t));
+  r.z = fadd(fmul(a.z, omt), fmul(b.z, t));
+  r.w = fadd(fmul(a.w, omt), fmul(b.w, t));
+  return r;
+}
+
+// VoxMLP._linear3 (rnerf/ior_utils.py:188-223).  idx6 (nullable) receives the clamped x0,x1,y0,y1,z0,z1.
+__device__ __forceinline__ float4 trilinear(const float4* __restrict__ tab, const GridParams& g, float px, float py,
+                                            float pz, int* idx6) {
+  const float x = fdiv(fsub(px, g.nminx), g.ndx);
+  const float y = fdiv(fsub(py, g.nminy), g.ndy);
+  const float z = fdiv(fsub(pz, g.nminz), g.ndz);
+  const float fx = floorf(x), fy = floorf(y), fz = floorf(z);
+  int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+  int x1 = x0 + 1, y1 = y0 + 1, z1 = z0 + 1;
+  // (x - x0) / (x1 - x0): the divisor is exactly 1.0f, so the quotient is the (rounded) difference.
+  const float xd = fsub(x, (float)x0), yd = fsub(y, (float)y0), zd = fsub(z, (float)z0);
+  x0 = clampi(x0, 0, g.dx - 1); x1 = clampi(x1, 0, g.dx - 1);
+  y0 = clampi(y0, 0, g.dy - 1); y1 = clampi(y1, 0, g.dy - 1);
+  z0 = clampi(z0, 0, g.dz - 1); z1 = clampi(z1, 0, g.dz - 1);
+  if (idx6) { idx6[0] = x0; idx6[1] = x1; idx6[2] = y0; idx6[3] = y1; idx6[4] = z0; idx6[5] = z1; }
+  const size_t s1 = (size_t)g.dy * g.dz, s2 = (size_t)g.dz;
+  const size_t bx0 = s1 * x0, bx1 = s1 * x1, by0 = s2 * y0, by1 = s2 * y1;
+  const float4 d000 = tab[bx0 + by0 + z0], d100 = tab[bx1 + by0 + z0];
+  const float4 d001 = tab[bx0 + by0 + z1], d101 = tab[bx1 + by0 + z1];
+  const float4 d010 = tab[bx0 + by1 + z0], d110 = tab[bx1 + by1 + z0];
+  const float4 d011 = tab[bx0 + by1 + z1], d111 = tab[bx1 + by1 + z1];
+  const float oxd = fsub(1.0f, xd), oyd = fsub(1.0f, yd), ozd = fsub(1.0f, zd);
+  const float4 c00 = lerp4(d000, d100, oxd, xd);
+  const float4 c01 = lerp4(d001, d101, oxd, xd);
+  const float4 c10 = lerp4(d010, d110, oxd, xd);
+  const float4 c11 = lerp4(d011, d111, oxd, xd);
+  const float4 c0 = lerp4(c00, c10, oyd, yd);
+  const float4 c1 = lerp4(c01, c11, oyd, yd);
+  return lerp4(c0, c1, ozd, zd);
+}
+
+}  // namespace rnerf

@@ -1,0 +1,153 @@
+// IoR grid kernels: Gaussian prefilter (G1), gradient table (G2), trilinear query (G3).
+// Reference: rnerf/ior_utils.py:327-363 (conv3d_normal), :139-172 (VoxMLP.setup/_compute_grad), :188-223 (_linear3).
+#include "common.h"
+
+#include <math.h>
+#include <string.h>
+
+namespace rnerf {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+#define MAX_TAPS 33
+struct Taps {
+  int n;
+  float w[MAX_TAPS];
+};
+
+// One 1-D pass of the separable Gaussian along AXIS with clamp-to-edge reads (== 'edge' padding of
+// rnerf/ior_utils.py:341).  Lanes run along z (contiguous) for every axis, so all reads are coalesced.
+template <int AXIS>
+__global__ void conv1d_kernel(const float* __restrict__ src, float* __restrict__ dst, int dx, int dy, int dz, Taps taps) {
+  const size_t total = (size_t)dx * dy * dz;
+  const int h = taps.n / 2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int z = (int)(i % dz);
+    const int y = (int)((i / dz) % dy);
+    const int x = (int)(i / ((size_t)dz * dy));
+    float acc = 0.f;
+    for (int t = 0; t < taps.n; ++t) {
+      int xx = x, yy = y, zz = z;
+      if (AXIS == 0) xx = clampi(x + t - h, 0, dx - 1);
+      if (AXIS == 1) yy = clampi(y + t - h, 0, dy - 1);
+      if (AXIS == 2) zz = clampi(z + t - h, 0, dz - 1);
+      acc = fmaf(taps.w[t], src[((size_t)xx * dy + yy) * dz + zz], acc);
+    }
+    dst[i] = acc;
+  }
+}
+
+// rnerf/ior_utils.py:165-172: edge-pad by one voxel, central differences / (2*ndelta).
+__global__ void build_table_kernel(const float* __restrict__ grid, float4* __restrict__ table, GridParams g) {
+  const size_t total = (size_t)g.dx * g.dy * g.dz;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int z = (int)(i % g.dz);
+    const int y = (int)((i / g.dz) % g.dy);
+    const int x = (int)(i / ((size_t)g.dz * g.dy));
+    const size_t s1 = (size_t)g.dy * g.dz, s2 = (size_t)g.dz;
+    const int xm = x > 0 ? x - 1 : 0, xp = x < g.dx - 1 ? x + 1 : g.dx - 1;
+    const int ym = y > 0 ? y - 1 : 0, yp = y < g.dy - 1 ? y + 1 : g.dy - 1;
+    const int zm = z > 0 ? z - 1 : 0, zp = z < g.dz - 1 ? z + 1 : g.dz - 1;
+    float4 o;
+    o.x = grid[i];
+    o.y = fdiv(fsub(grid[s1 * xp + s2 * y + z], grid[s1 * xm + s2 * y + z]), g.tdx);
+    o.z = fdiv(fsub(grid[s1 * x + s2 * yp + z], grid[s1 * x + s2 * ym + z]), g.tdy);
+    o.w = fdiv(fsub(grid[s1 * x + s2 * y + zp], grid[s1 * x + s2 * y + zm]), g.tdz);
+    table[i] = o;
+  }
+}
+
+__global__ void query_kernel(const float4* __restrict__ table, GridParams g, const float* __restrict__ pts, int64_t n,
+                             float4* __restrict__ out, int* __restrict__ idx) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int id[6];
+  const float4 c = trilinear(table, g, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], idx ? id : nullptr);
+  out[i] = c;
+  if (idx)
+    for (int k = 0; k < 6; ++k) idx[6 * i + k] = id[k];
+}
+
+static int grid_for(size_t total, int block) {
+  size_t b = (total + block - 1) / block;
+  return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
+}
+
+}  // namespace rnerf
+
+using namespace rnerf;
+
+extern "C" const char* rnerf_last_error(void) { return g_err; }
+extern "C" int rnerf_version(void) { return RNERF_VERSION; }
+
+extern "C" int rnerf_device_cus(void) {
+  int dev = 0;
+  RNERF_CHECK_HIP(hipGetDevice(&dev));
+  int cus = 0;
+  RNERF_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  return cus;
+}
+
+extern "C" int rnerf_grid_prefilter(const float* src, float* dst, float* tmp, const int32_t dims[3], int ksize,
+                                    double ksigma, void* stream) {
+  RNERF_CHECK_ARG(src && dst && tmp && dims, "rnerf_grid_prefilter: null pointer");
+  RNERF_CHECK_ARG(dims[0] > 0 && dims[1] > 0 && dims[2] > 0, "rnerf_grid_prefilter: bad dims");
+  RNERF_CHECK_ARG(ksize >= 1 && ksize <= MAX_TAPS && (ksize & 1), "rnerf_grid_prefilter: ksize must be odd, 1..%d", MAX_TAPS);
+  RNERF_CHECK_ARG(ksigma > 0, "rnerf_grid_prefilter: ksigma must be > 0");
+  RNERF_CHECK_ARG(dst != src && tmp != src && tmp != dst, "rnerf_grid_prefilter: src/dst/tmp must be distinct");
+  // 1-D factor of the reference's normalised 3-D kernel (rnerf/ior_utils.py:345-348):
+  // exp(-(x^2+y^2+z^2)/2s^2)/sum == prod_axis exp(-a^2/2s^2)/sum_a.
+  Taps taps;
+  taps.n = ksize;
+  const int h = ksize / 2;
+  double e[MAX_TAPS], sum = 0;
+  for (int t = 0; t < ksize; ++t) {
+    const double a = (double)(t - h);
+    e[t] = exp(-(a * a) / (2.0 * ksigma * ksigma));
+    sum += e[t];
+  }
+  for (int t = 0; t < ksize; ++t) taps.w[t] = (float)(e[t] / sum);
+  const size_t total = (size_t)dims[0] * dims[1] * dims[2];
+  const int block = 256, grid = grid_for(total, block);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(conv1d_kernel<0>, dim3(grid), dim3(block), 0, st, src, dst, dims[0], dims[1], dims[2], taps);
+  hipLaunchKernelGGL(conv1d_kernel<1>, dim3(grid), dim3(block), 0, st, dst, tmp, dims[0], dims[1], dims[2], taps);
+  hipLaunchKernelGGL(conv1d_kernel<2>, dim3(grid), dim3(block), 0, st, tmp, dst, dims[0], dims[1], dims[2], taps);
+  RNERF_CHECK_LAUNCH();
+  return RNERF_OK;
+}
+
+extern "C" int rnerf_grid_build_table(const float* grid, float* table, const rnerf_grid* g, void* stream) {
+  RNERF_CHECK_ARG(grid && table && g, "rnerf_grid_build_table: null pointer");
+  GridParams p;
+  RNERF_CHECK_ARG(make_grid_params(g, &p), "rnerf_grid_build_table: bad grid (dims must be >= 2)");
+  RNERF_CHECK_ARG(((uintptr_t)table & 15) == 0, "rnerf_grid_build_table: table must be 16-byte aligned");
+  const size_t total = (size_t)p.dx * p.dy * p.dz;
+  const int block = 256;
+  hipLaunchKernelGGL(build_table_kernel, dim3(grid_for(total, block)), dim3(block), 0, (hipStream_t)stream, grid,
+                     (float4*)table, p);
+  RNERF_CHECK_LAUNCH();
+  return RNERF_OK;
+}
+
+extern "C" int rnerf_grid_query(const float* table, const rnerf_grid* g, const float* pts, int64_t n, float* out,
+                                int32_t* idx, void* stream) {
+  RNERF_CHECK_ARG(table && g && out && (pts || n == 0), "rnerf_grid_query: null pointer");
+  RNERF_CHECK_ARG(n >= 0, "rnerf_grid_query: n < 0");
+  GridParams p;
+  RNERF_CHECK_ARG(make_grid_params(g, &p), "rnerf_grid_query: bad grid");
+  RNERF_CHECK_ARG(((uintptr_t)table & 15) == 0 && ((uintptr_t)out & 15) == 0, "rnerf_grid_query: table/out must be 16-byte aligned");
+  if (n == 0) return RNERF_OK;
+  const int block = 256;
+  hipLaunchKernelGGL(query_kernel, dim3((unsigned)((n + block - 1) / block)), dim3(block), 0, (hipStream_t)stream,
+                     (const float4*)table, p, pts, n, (float4*)out, idx);
+  RNERF_CHECK_LAUNCH();
+  return RNERF_OK;
+}

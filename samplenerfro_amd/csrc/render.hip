@@ -1,0 +1,182 @@
+// Compositing (V1) and hierarchical resampling along the bent path (S1/S2).
+// Reference: rnerf/models.py:334-349 (activations + call), rnerf/model_utils.py:247-309 (volumetric_rendering),
+// :312-374 (sorted_piecewise_constant_pdf), :377-435 (sample_pdf).
+//
+// Both kernels are one-lane-per-ray sequential walks over sample-major arrays: every per-step load/store of a wave is
+// one contiguous segment, no scan or sort network is needed (the coarse depths, the inverse-CDF samples and the path
+// node depths are all already sorted, so sort + searchsorted collapse into one three-way merge walk).
+#include "common.h"
+
+#include <float.h>
+
+namespace rnerf {
+
+__device__ __forceinline__ float sigmoidf_ref(float x) { return fdiv(1.0f, fadd(1.0f, expf(-x))); }
+// jax.nn.softplus = logaddexp(x, 0) = max(x,0) + log1p(exp(-|x|))
+__device__ __forceinline__ float softplusf_ref(float x) { return fadd(fmaxf(x, 0.f), log1pf(expf(-fabsf(x)))); }
+
+__global__ void __launch_bounds__(64) composite_kernel(const float4* __restrict__ raw, const float4* __restrict__ rows_pd,
+                                                       const float4* __restrict__ rows_dr,
+                                                       const int* __restrict__ node_of_sample, int S, int B,
+                                                       const float* __restrict__ bkgd, int white_bkgd, float pad_scale,
+                                                       float pad, float sigma_bias, float* __restrict__ rgb_out,
+                                                       float* __restrict__ dist_out, float* __restrict__ acc_out,
+                                                       float* __restrict__ trans_out, float* __restrict__ trans_bkgd_out,
+                                                       float* __restrict__ weights, float* __restrict__ alpha_out) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= B) return;
+  auto rec = [&](int s) -> size_t { return (size_t)(node_of_sample ? node_of_sample[s] : s) * B + r; };
+  float cum = 0.f, sr = 0.f, sg = 0.f, sb = 0.f, acc = 0.f, wt = 0.f;
+  size_t o = rec(0);
+  float t_cur = rows_pd[o].w;
+  const float t0 = t_cur;
+  float t_last = t_cur;
+  for (int s = 0; s < S; ++s) {
+    const float4 d = rows_dr[o];
+    const float4 rw = raw[(size_t)s * B + r];
+    float t_next = 0.f, tdist = 1e-3f;                      // model_utils.py:265-268
+    size_t o_next = o;
+    if (s + 1 < S) { o_next = rec(s + 1); t_next = rows_pd[o_next].w; tdist = fsub(t_next, t_cur); }
+    const float nrm = fsqrt(fadd(fadd(fmul(d.x, d.x), fmul(d.y, d.y)), fmul(d.z, d.z)));
+    const float delta = fmul(tdist, nrm);                    // :270
+    const float sigma = softplusf_ref(fadd(rw.w, sigma_bias));   // models.py:338
+    const float cr = fsub(fmul(sigmoidf_ref(rw.x), pad_scale), pad);   // models.py:334-335
+    const float cg = fsub(fmul(sigmoidf_ref(rw.y), pad_scale), pad);
+    const float cb = fsub(fmul(sigmoidf_ref(rw.z), pad_scale), pad);
+    const float dd = fmul(sigma, delta);                     // :272
+    const float a = fsub(1.0f, expf(-dd));                   // :285
+    const float T = expf(-cum);                              // :286-289
+    const float w = fmul(a, T);                              // :296
+    sr = fadd(sr, fmul(w, cr)); sg = fadd(sg, fmul(w, cg)); sb = fadd(sb, fmul(w, cb));
+    acc = fadd(acc, w);
+    wt = fadd(wt, fmul(w, t_cur));
+    cum = fadd(cum, dd);
+    if (weights) weights[(size_t)s * B + r] = w;
+    if (alpha_out) alpha_out[(size_t)s * B + r] = a;
+    t_last = t_cur;
+    t_cur = t_next; o = o_next;
+  }
+  const float Tl = expf(-cum);
+  float br = 1.f, bg = 1.f, bb = 1.f;                       // rgb_bkgd=None -> ones (:301)
+  if (bkgd) {
+    br = bkgd[3 * r]; bg = bkgd[3 * r + 1]; bb = bkgd[3 * r + 2];
+    sr = fadd(sr, fmul(Tl, br)); sg = fadd(sg, fmul(Tl, bg)); sb = fadd(sb, fmul(Tl, bb));   // :298-299
+  }
+  float dist = fdiv(wt, acc);                                // :303
+  // jnp.nan_to_num(distance, jnp.inf): 2nd positional is `copy` -> NaN->0, +-inf -> +-FLT_MAX (:304)
+  if (dist != dist) dist = 0.f;
+  else if (dist > FLT_MAX) dist = FLT_MAX;
+  else if (dist < -FLT_MAX) dist = -FLT_MAX;
+  dist = fminf(fmaxf(dist, t0), t_last);
+  if (white_bkgd) { const float q = fsub(1.0f, acc); sr = fadd(sr, q); sg = fadd(sg, q); sb = fadd(sb, q); }   // :307-308
+  rgb_out[3 * r] = sr; rgb_out[3 * r + 1] = sg; rgb_out[3 * r + 2] = sb;
+  dist_out[r] = dist;
+  acc_out[r] = acc;
+  trans_out[r] = Tl;
+  trans_bkgd_out[3 * r] = fmul(Tl, br); trans_bkgd_out[3 * r + 1] = fmul(Tl, bg); trans_bkgd_out[3 * r + 2] = fmul(Tl, bb);
+}
+
+// sorted_piecewise_constant_pdf + sort + searchsorted + gather as one forward walk per ray.
+//   bins  = mids of the S coarse depths (S-1 values), weights = w[1..S-2] (S-2 values)         models.py:371-374
+//   cdf   = [0, min(1, cumsum(pdf[:-1])), 1]  (S-1 values)                                      model_utils.py:335-340
+//   i*(u) = #(cdf <= u) - 1 ; sample = bins[i*] + clip((u-cdf[i*])/(cdf[i*+1]-cdf[i*]),0,1)*(bins[i*+1]-bins[i*])
+// u must be non-decreasing along the sample axis of each ray (true for both branches at :345-356), which makes the
+// samples non-decreasing, so jnp.sort(concat(coarse, fine)) (:405) is a two-way merge and searchsorted(left) into the
+// node depths (:415-421) is a third forward pointer.
+__global__ void __launch_bounds__(64) resample_kernel(const float4* __restrict__ path_pd, const float4* __restrict__ path_dr,
+                                                      int num_nodes, int B, const int* __restrict__ jitter, int S,
+                                                      const float* __restrict__ weights, const float* __restrict__ u,
+                                                      int u_per_ray, int F, float4* __restrict__ rows_pd,
+                                                      float4* __restrict__ rows_dr, int* __restrict__ node_idx) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= B) return;
+  const int nb = S - 1;        // number of bin edges / cdf entries
+  const int nw = S - 2;        // number of weights
+  // weight_sum, padding (model_utils.py:327-331)
+  float wsum = 0.f;
+  for (int i = 0; i < nw; ++i) wsum = fadd(wsum, weights[(size_t)(i + 1) * B + r]);
+  const float padding = fmaxf(0.f, fsub(1e-5f, wsum));
+  const float padw = fdiv(padding, (float)nw);
+  wsum = fadd(wsum, padding);
+  auto tc = [&](int i) -> float { return path_pd[(size_t)jitter[i] * B + r].w; };
+  auto cdf_at = [&](int k, float cumsum) -> float { return k == 0 ? 0.f : (k == nb - 1 ? 1.f : fminf(1.f, cumsum)); };
+  // walk state of the inverse CDF: interval i, cum = cumsum(pdf[0..i-1]) (valid for entry i), cdf entries c0=cdf[i], c1=cdf[i+1]
+  int i = 0;
+  float cum_i = 0.f;                                  // cumsum up to entry i
+  float cum_n = fdiv(fadd(weights[(size_t)1 * B + r], padw), wsum);   // cumsum up to entry i+1 = pdf[0]
+  float c0 = 0.f, c1 = cdf_at(1, cum_n);
+  float tca = tc(0), tcb = tc(1), tcc = (nb > 1) ? tc(2) : tcb;
+  float b0 = fmul(0.5f, fadd(tcb, tca));              // mids (models.py:371): .5*(t[1:] + t[:-1])
+  float b1 = (nb > 1) ? fmul(0.5f, fadd(tcc, tcb)) : b0;
+  auto fine_at = [&](int j) -> float {
+    const float uj = u_per_ray ? u[(size_t)j * B + r] : u[j];
+    while (c1 <= uj && i < nb - 2) {                  // advance to the last entry with cdf <= u
+      ++i;
+      c0 = c1; cum_i = cum_n;
+      if (i + 1 < nb - 1) cum_n = fadd(cum_n, fdiv(fadd(weights[(size_t)(i + 1) * B + r], padw), wsum));
+      c1 = cdf_at(i + 1, cum_n);
+      tca = tcb; tcb = tcc; tcc = (i + 2 < S) ? tc(i + 2) : tcc;
+      b0 = b1; b1 = fmul(0.5f, fadd(tcc, tcb));
+    }
+    float t = fdiv(fsub(uj, c0), fsub(c1, c0));
+    if (t != t) t = 0.f;                              // nan_to_num(., 0): NaN -> 0, inf -> +-FLT_MAX then clip
+    t = fminf(fmaxf(t, 0.f), 1.f);
+    return fadd(b0, fmul(t, fsub(b1, b0)));
+  };
+  (void)cum_i;
+  int ic = 0, jf = 0, p = 0;
+  float zc = tc(0);
+  float zf = (F > 0) ? fine_at(0) : 0.f;
+  float pdist = path_pd[r].w;                         // depth of node p (p = 0)
+  const int total = S + F;
+  for (int q = 0; q < total; ++q) {
+    float z;
+    const bool take_c = (jf >= F) || (ic < S && zc <= zf);
+    if (take_c) { z = zc; ++ic; if (ic < S) zc = tc(ic); }
+    else { z = zf; ++jf; if (jf < F) zf = fine_at(jf); }
+    // searchsorted(z_vals, z, 'left') = #(node depth < z); idx = max(that - 1, 0)  (model_utils.py:415-421)
+    while (p < num_nodes && pdist < z) { ++p; if (p < num_nodes) pdist = path_pd[(size_t)p * B + r].w; }
+    const int idx = p > 0 ? p - 1 : 0;
+    const float4 pd = path_pd[(size_t)idx * B + r];
+    const float4 dr = path_dr[(size_t)idx * B + r];
+    const float dz = fsub(z, pd.w);
+    const size_t o = (size_t)q * B + r;
+    rows_pd[o] = make_float4(fadd(pd.x, fmul(dr.x, dz)), fadd(pd.y, fmul(dr.y, dz)), fadd(pd.z, fmul(dr.z, dz)), z);
+    rows_dr[o] = dr;
+    if (node_idx) node_idx[o] = idx;
+  }
+}
+
+}  // namespace rnerf
+
+using namespace rnerf;
+
+extern "C" int rnerf_composite(const float* raw, const float* rows_pd, const float* rows_dr,
+                               const int32_t* node_of_sample, int32_t S, int32_t B, const float* bkgd, int white_bkgd,
+                               double rgb_padding, double sigma_bias, float* rgb, float* dist, float* acc, float* trans,
+                               float* trans_bkgd, float* weights, float* alpha, void* stream) {
+  RNERF_CHECK_ARG(raw && rows_pd && rows_dr && rgb && dist && acc && trans && trans_bkgd, "rnerf_composite: null pointer");
+  RNERF_CHECK_ARG(S >= 1 && B >= 1, "rnerf_composite: need S >= 1 and B >= 1");
+  RNERF_CHECK_ARG((((uintptr_t)raw | (uintptr_t)rows_pd | (uintptr_t)rows_dr) & 15) == 0, "rnerf_composite: float4 buffers must be 16-byte aligned");
+  hipLaunchKernelGGL(composite_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const float4*)raw,
+                     (const float4*)rows_pd, (const float4*)rows_dr, node_of_sample, S, B, bkgd, white_bkgd,
+                     (float)(1 + 2 * rgb_padding), (float)rgb_padding, (float)sigma_bias, rgb, dist, acc, trans, trans_bkgd,
+                     weights, alpha);
+  RNERF_CHECK_LAUNCH();
+  return RNERF_OK;
+}
+
+extern "C" int rnerf_resample(const float* path_pd, const float* path_dr, int32_t num_nodes, int32_t B,
+                              const int32_t* jitter, int32_t S, const float* weights, const float* u, int32_t u_per_ray,
+                              int32_t num_fine, float* rows_pd, float* rows_dr, int32_t* node_idx, void* stream) {
+  RNERF_CHECK_ARG(path_pd && path_dr && jitter && weights && rows_pd && rows_dr, "rnerf_resample: null pointer");
+  RNERF_CHECK_ARG(u || num_fine == 0, "rnerf_resample: u must be given (use linspace(0,1-eps,F) for randomized=False)");
+  RNERF_CHECK_ARG(S >= 3 && B >= 1 && num_nodes >= 1 && num_fine >= 0, "rnerf_resample: need S >= 3, B >= 1");
+  RNERF_CHECK_ARG((((uintptr_t)path_pd | (uintptr_t)path_dr | (uintptr_t)rows_pd | (uintptr_t)rows_dr) & 15) == 0,
+                  "rnerf_resample: float4 buffers must be 16-byte aligned");
+  hipLaunchKernelGGL(resample_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const float4*)path_pd,
+                     (const float4*)path_dr, num_nodes, B, jitter, S, weights, u, u_per_ray, num_fine, (float4*)rows_pd,
+                     (float4*)rows_dr, node_idx);
+  RNERF_CHECK_LAUNCH();
+  return RNERF_OK;
+}

@@ -1,0 +1,161 @@
+"""Thin torch-tensor wrappers over the C ABI (one function per entry point of include/rnerf.h).
+
+PyTorch is plumbing here: it owns the device memory and the stream; all arithmetic is in librnerf.so.
+Layouts: "sample-major" arrays are [S, B, ...] tensors (sample/node index first, ray index second).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import Grid, check, current_stream, ptr
+
+
+def _chk(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
+    if not t.is_cuda:
+        raise _lib.RnerfError(f"{name}: expected a CUDA (ROCm) tensor; the hot path has no CPU implementation")
+    if t.dtype != dtype:
+        raise _lib.RnerfError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def grid_prefilter(grid: torch.Tensor, ksize: int, ksigma: float) -> torch.Tensor:
+    """G1: ior_utils.conv3d_normal (rnerf/ior_utils.py:327-363). grid [Gx,Gy,Gz] f32 -> same shape."""
+    lib = _lib.load()
+    g = _chk(grid, "grid")
+    dst = torch.empty_like(g); tmp = torch.empty_like(g)
+    dims = (C.c_int32 * 3)(*g.shape)
+    check(lib.rnerf_grid_prefilter(ptr(g), ptr(dst), ptr(tmp), C.byref(dims), int(ksize), float(ksigma), current_stream()),
+          "rnerf_grid_prefilter")
+    return dst
+
+
+def grid_build_table(grid: torch.Tensor, spec: Grid) -> torch.Tensor:
+    """G2: VoxMLP.setup/_compute_grad (rnerf/ior_utils.py:139-172). -> table [G^3, 4] = (n, grad n)."""
+    lib = _lib.load()
+    g = _chk(grid, "grid")
+    n = spec.dims[0] * spec.dims[1] * spec.dims[2]
+    if g.numel() != n:
+        raise _lib.RnerfError(f"grid has {g.numel()} voxels, spec says {n}")
+    table = torch.empty((n, 4), dtype=torch.float32, device=g.device)
+    check(lib.rnerf_grid_build_table(ptr(g), ptr(table), C.byref(spec), current_stream()), "rnerf_grid_build_table")
+    return table
+
+
+def grid_query(table: torch.Tensor, spec: Grid, pts: torch.Tensor, want_idx: bool = False):
+    """G3: VoxMLP._linear3 (rnerf/ior_utils.py:188-223). pts [n,3] -> [n,4] (+ int32 [n,6])."""
+    lib = _lib.load()
+    table = _chk(table, "table"); pts = _chk(pts, "pts")
+    n = pts.shape[0]
+    out = torch.empty((n, 4), dtype=torch.float32, device=pts.device)
+    idx = torch.empty((n, 6), dtype=torch.int32, device=pts.device) if want_idx else None
+    check(lib.rnerf_grid_query(ptr(table), C.byref(spec), ptr(pts), n, ptr(out), ptr(idx), current_stream()), "rnerf_grid_query")
+    return (out, idx) if want_idx else out
+
+
+def march(table: torch.Tensor, spec: Grid, origins: torch.Tensor, viewdirs: torch.Tensor, near: float, far: float,
+          num_nodes: int, want_ior: bool = False, want_vox: bool = False, out=None):
+    """E1/E2: PathSampler.__call__ (rnerf/eikonal_utils.py:100-124). -> path_pd [N,B,4], path_dr [N,B,4], ior?, vox?"""
+    lib = _lib.load()
+    table = _chk(table, "table"); o = _chk(origins, "origins"); d = _chk(viewdirs, "viewdirs")
+    B = o.shape[0]
+    if out is not None:
+        path_pd, path_dr = out
+    else:
+        path_pd = torch.empty((num_nodes, B, 4), dtype=torch.float32, device=o.device)
+        path_dr = torch.empty((num_nodes, B, 4), dtype=torch.float32, device=o.device)
+    ior = torch.empty((num_nodes, B, 4), dtype=torch.float32, device=o.device) if want_ior else None
+    vox = torch.empty((num_nodes, B, 6), dtype=torch.int32, device=o.device) if want_vox else None
+    check(lib.rnerf_march(ptr(table), C.byref(spec), ptr(o), ptr(d), B, float(near), float(far), int(num_nodes),
+                          ptr(path_pd), ptr(path_dr), ptr(ior), ptr(vox), current_stream()), "rnerf_march")
+    return path_pd, path_dr, ior, vox
+
+
+def nerfmlp_pack(params_flat: torch.Tensor, precision: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Pack a flat fp32 NerfMLP parameter buffer (595844 floats, flax order) into the MFMA operand stream."""
+    lib = _lib.load()
+    p = _chk(params_flat, "params_flat")
+    if p.numel() != _lib.NERFMLP_PARAMS:
+        raise _lib.RnerfError(f"NerfMLP flat params must have {_lib.NERFMLP_PARAMS} floats, got {p.numel()}")
+    nbytes = lib.rnerf_nerfmlp_packed_bytes(int(precision))
+    if nbytes == 0:
+        check(-1, "rnerf_nerfmlp_packed_bytes")
+    if out is None:
+        out = torch.empty(nbytes, dtype=torch.uint8, device=p.device)
+    check(lib.rnerf_nerfmlp_pack(ptr(p), int(precision), ptr(out), current_stream()), "rnerf_nerfmlp_pack")
+    return out
+
+
+def nerfmlp_forward(packed: torch.Tensor, precision: int, rows_pd: torch.Tensor, rows_dr: torch.Tensor,
+                    node_of_sample: Optional[torch.Tensor], S: int, B: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """P1+N1: pos_enc + NerfMLP (rnerf/model_utils.py:187-214, :30-90). -> raw [S,B,4] = (rgb raw, sigma raw)."""
+    lib = _lib.load()
+    rows_pd = _chk(rows_pd, "rows_pd"); rows_dr = _chk(rows_dr, "rows_dr")
+    if node_of_sample is not None:
+        node_of_sample = _chk(node_of_sample, "node_of_sample", torch.int32)
+    if out is None:
+        out = torch.empty((S, B, 4), dtype=torch.float32, device=rows_pd.device)
+    check(lib.rnerf_nerfmlp_forward(ptr(packed), int(precision), ptr(rows_pd), ptr(rows_dr), ptr(node_of_sample), int(S), int(B),
+                                    ptr(out), current_stream()), "rnerf_nerfmlp_forward")
+    return out
+
+
+def bkgd_forward(params_flat: torch.Tensor, dirs: torch.Tensor, rgb_padding: float = 0.001) -> torch.Tensor:
+    """P1+N2: bkgd_mlp(pos_enc(dir,0,4)) + rgb activation (rnerf/models.py:181-191,303,336-337). dirs [n,3|4] -> [n,3]."""
+    lib = _lib.load()
+    p = _chk(params_flat, "params_flat"); d = _chk(dirs, "dirs")
+    if p.numel() != _lib.BKGDMLP_PARAMS:
+        raise _lib.RnerfError(f"bkgd MLP flat params must have {_lib.BKGDMLP_PARAMS} floats, got {p.numel()}")
+    n = d.shape[0]
+    out = torch.empty((n, 3), dtype=torch.float32, device=d.device)
+    check(lib.rnerf_bkgd_forward(ptr(p), ptr(d), int(d.shape[-1]), n, float(rgb_padding), ptr(out), current_stream()),
+          "rnerf_bkgd_forward")
+    return out
+
+
+def composite(raw: torch.Tensor, rows_pd: torch.Tensor, rows_dr: torch.Tensor, node_of_sample: Optional[torch.Tensor],
+              S: int, B: int, bkgd: Optional[torch.Tensor], white_bkgd: bool = False, rgb_padding: float = 0.001,
+              sigma_bias: float = -1.0, want_weights: bool = True, want_alpha: bool = False):
+    """V1: activations + volumetric_rendering (rnerf/models.py:334-349, rnerf/model_utils.py:247-309)."""
+    lib = _lib.load()
+    raw = _chk(raw, "raw"); dev = raw.device
+    rgb = torch.empty((B, 3), dtype=torch.float32, device=dev)
+    dist = torch.empty((B,), dtype=torch.float32, device=dev)
+    acc = torch.empty((B,), dtype=torch.float32, device=dev)
+    trans = torch.empty((B, 1), dtype=torch.float32, device=dev)
+    trans_bkgd = torch.empty((B, 3), dtype=torch.float32, device=dev)
+    weights = torch.empty((S, B), dtype=torch.float32, device=dev) if want_weights else None
+    alpha = torch.empty((S, B), dtype=torch.float32, device=dev) if want_alpha else None
+    if bkgd is not None:
+        bkgd = _chk(bkgd, "bkgd")
+    check(lib.rnerf_composite(ptr(raw), ptr(rows_pd), ptr(rows_dr), ptr(node_of_sample), int(S), int(B), ptr(bkgd),
+                              int(bool(white_bkgd)), float(rgb_padding), float(sigma_bias), ptr(rgb), ptr(dist), ptr(acc),
+                              ptr(trans), ptr(trans_bkgd), ptr(weights), ptr(alpha), current_stream()), "rnerf_composite")
+    return rgb, dist, acc, trans, trans_bkgd, weights, alpha
+
+
+def resample(path_pd: torch.Tensor, path_dr: torch.Tensor, jitter: torch.Tensor, weights: torch.Tensor, u: torch.Tensor,
+             num_fine: int, want_idx: bool = False):
+    """S1+S2: sample_pdf along the bent path (rnerf/model_utils.py:312-435).
+
+    u: [num_fine] (shared by all rays) or [num_fine, B]; non-decreasing along axis 0.
+    -> rows_pd [S+F,B,4], rows_dr [S+F,B,4], node_idx int32 [S+F,B] (if want_idx).
+    """
+    lib = _lib.load()
+    N, B = path_pd.shape[0], path_pd.shape[1]
+    S = jitter.shape[0]
+    jitter = _chk(jitter, "jitter", torch.int32); weights = _chk(weights, "weights"); u = _chk(u, "u")
+    per_ray = 1 if u.dim() == 2 else 0
+    if u.shape[0] != num_fine or (per_ray and u.shape[1] != B):
+        raise _lib.RnerfError(f"u must be [F] or [F,B] with F={num_fine}, B={B}; got {tuple(u.shape)}")
+    dev = path_pd.device
+    T = S + num_fine
+    rows_pd = torch.empty((T, B, 4), dtype=torch.float32, device=dev)
+    rows_dr = torch.empty((T, B, 4), dtype=torch.float32, device=dev)
+    idx = torch.empty((T, B), dtype=torch.int32, device=dev) if want_idx else None
+    check(lib.rnerf_resample(ptr(path_pd), ptr(path_dr), int(N), int(B), ptr(jitter), int(S), ptr(weights), ptr(u), per_ray,
+                             int(num_fine), ptr(rows_pd), ptr(rows_dr), ptr(idx), current_stream()), "rnerf_resample")
+    return rows_pd, rows_dr, idx

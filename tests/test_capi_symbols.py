@@ -1,0 +1,46 @@
+"""The C-ABI library builds for gfx950 (no GPU needed) and exports every symbol include/rnerf.h declares."""
+import ctypes
+import os
+import re
+
+from samplenerfro_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "rnerf.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rnerf_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported(lib_path):
+    syms = declared_symbols()
+    assert len(syms) >= 13
+    lib = ctypes.CDLL(lib_path)
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/rnerf.h but not exported"
+
+
+def test_binding_covers_header(lib_path):
+    assert sorted(_lib.SIGNATURES) == declared_symbols()
+    lib = _lib.load()
+    assert lib.rnerf_version() == 1
+    assert lib.rnerf_nerfmlp_packed_bytes(_lib.PREC_F16X3) == 1160 * 2 * 1024 + 3208 * 4
+    assert lib.rnerf_nerfmlp_packed_bytes(_lib.PREC_BF16) == 1160 * 1024 + 3208 * 4
+    assert lib.rnerf_nerfmlp_packed_bytes(99) == 0
+    assert b"precision" in lib.rnerf_last_error()
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    import pytest
+    with pytest.raises(_lib.RnerfError):
+        _lib.load(str(tmp_path / "nope.so"))
+
+
+def test_argument_errors_do_not_need_a_gpu(lib_path):
+    lib = _lib.load()
+    g = _lib.Grid.make([1, 8, 8], [-1, -1, -1], [1, 1, 1])
+    rc = lib.rnerf_grid_build_table(ctypes.c_void_p(16), ctypes.c_void_p(32), ctypes.byref(g), None)
+    assert rc == -1 and b"dims" in lib.rnerf_last_error()
+    assert lib.rnerf_march(None, ctypes.byref(g), None, None, 4, 2.0, 6.0, 8, None, None, None, None, None) == -1
