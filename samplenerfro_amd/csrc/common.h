@@ -58,7 +58,8 @@ __device__ __forceinline__ float fmul(float a, float b) { return __fmul_rn(a, b)
 __device__ __forceinline__ float fadd(float a, float b) { return __fadd_rn(a, b); }
 __device__ __forceinline__ float fsub(float a, float b) { return __fsub_rn(a, b); }
 __device__ __forceinline__ float fdiv(float a, float b) { return __fdiv_rn(a, b); }
-__device__ __forceinline__ float fsqrt(float a) { return __fsqrt_rn(a); }
+// sqrtf (not __fsqrt_rn, which lowers to the bare 1-ulp v_sqrt_f32) gives the correctly rounded IEEE result
+__device__ __forceinline__ float fsqrt(float a) { return sqrtf(a); }
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
