@@ -92,7 +92,7 @@ def main():
     ap.add_argument("--precision", default="f16x3")
     ap.add_argument("--rays", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-rays", type=int, default=256)
+    ap.add_argument("--cpu-rays", type=int, default=2048)
     args = ap.parse_args()
 
     import torch

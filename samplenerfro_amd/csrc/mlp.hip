@@ -18,6 +18,8 @@
 //   * Persistent grid: each workgroup walks row tiles with stride gridDim.x and prefetches across layer and tile seams.
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace rnerf {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -274,7 +276,10 @@ __device__ __forceinline__ void encode(const float v0, const float v1, const flo
 template <int PREC>
 __global__ void __launch_bounds__(256, 1)
 nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ rows_pd, const float4* __restrict__ rows_dr,
-                   const int* __restrict__ node_of_sample, int B, long long total_rows, int n_tiles, float4* __restrict__ out_raw) {
+                   const int* __restrict__ node_of_sample, int B, long long total_rows, int n_tiles, float4* __restrict__ out_raw,
+                   int dbg) {
+  // dbg (profiling ablations only, RNERF_MLP_DEBUG env var; results are garbage when set):
+  //   bit0 = skip the weight-stream loads, bit1 = skip ds_read + MFMA, bit2 = skip the barrier
   using PP = Prec<PREC>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -308,9 +313,9 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
 
 #define RUN_SLAB(NT, B0H, B0L, B1H, B1L, NEXT_BYTES, DO_NEXT)                               \
   do {                                                                                      \
-    if (DO_NEXT) { issue_slab<NEXT_BYTES>(packed + off, smem + (buf ^ 1) * BUF, wave, lane); off += NEXT_BYTES; } \
-    slab_compute<PREC, NT>(acc, B0H, B0L, B1H, B1L, smem + buf * BUF, lane);                \
-    __syncthreads();                                                                        \
+    if (DO_NEXT) { if (!(dbg & 1)) issue_slab<NEXT_BYTES>(packed + off, smem + (buf ^ 1) * BUF, wave, lane); off += NEXT_BYTES; } \
+    if (!(dbg & 2)) slab_compute<PREC, NT>(acc, B0H, B0L, B1H, B1L, smem + buf * BUF, lane); \
+    if (!(dbg & 4)) __syncthreads();                                                        \
     buf ^= 1;                                                                               \
   } while (0)
 
@@ -530,6 +535,12 @@ extern "C" int rnerf_nerfmlp_pack(const float* params, int precision, void* pack
   return RNERF_OK;
 }
 
+static int mlp_debug_flags() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("RNERF_MLP_DEBUG"); v = e ? atoi(e) : 0; }
+  return v;
+}
+
 template <int PREC>
 static int launch_fwd(const void* packed, const float* rows_pd, const float* rows_dr, const int32_t* node_of_sample, int32_t B,
                       long long total_rows, float* out_raw, hipStream_t st) {
@@ -546,7 +557,7 @@ static int launch_fwd(const void* packed, const float* rows_pd, const float* row
     attr_set = true;
   }
   hipLaunchKernelGGL(nerfmlp_fwd_kernel<PREC>, dim3(grid), dim3(256), lds, st, (const char*)packed, (const float4*)rows_pd,
-                     (const float4*)rows_dr, node_of_sample, B, total_rows, n_tiles, (float4*)out_raw);
+                     (const float4*)rows_dr, node_of_sample, B, total_rows, n_tiles, (float4*)out_raw, mlp_debug_flags());
   RNERF_CHECK_LAUNCH();
   return RNERF_OK;
 }

@@ -1,0 +1,24 @@
+"""Profiling helper (not part of the product): time the PE+NerfMLP kernel alone, optionally under RNERF_MLP_DEBUG ablations."""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from samplenerfro_amd import ops, _lib, synthetic as syn
+prec = sys.argv[1] if len(sys.argv) > 1 else "f16x3"
+S, B = 128, 4096
+dev = torch.device("cuda:0")
+rng = np.random.default_rng(0)
+pd = torch.from_numpy(rng.uniform(-2, 2, (S, B, 4)).astype(np.float32)).to(dev)
+dr = torch.from_numpy(rng.uniform(-1, 1, (S, B, 4)).astype(np.float32)).to(dev)
+pf = syn.init_params_flat(0, fine=False)
+packed = ops.nerfmlp_pack(torch.from_numpy(pf["coarse_mlp"]).to(dev), _lib.PRECISIONS[prec])
+out = ops.nerfmlp_forward(packed, _lib.PRECISIONS[prec], pd, dr, None, S, B)
+torch.cuda.synchronize()
+ev = [torch.cuda.Event(enable_timing=True) for _ in range(11)]
+ev[0].record()
+for i in range(10):
+    ops.nerfmlp_forward(packed, _lib.PRECISIONS[prec], pd, dr, None, S, B, out=out)
+    ev[i + 1].record()
+torch.cuda.synchronize()
+ms = np.array([ev[i].elapsed_time(ev[i + 1]) for i in range(10)])
+fl = 2 * 593408 * S * B
+print(f"prec={prec} dbg={os.environ.get('RNERF_MLP_DEBUG','0')} ms(min/med)={ms.min():.3f}/{np.median(ms):.3f}  algTF/s={fl/np.median(ms)/1e9:.1f}")
