@@ -62,7 +62,7 @@ def load(path: Optional[str] = None) -> C.CDLL:
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("RNERF_LIB") or LIB_PATH   # RNERF_LIB: load an alternative build (profiling variants)
     if not os.path.exists(p):
         raise RnerfError(f"{p} not found: build it with `python -m samplenerfro_amd.build` "
                          "(there is no CPU fallback for the hot path)")

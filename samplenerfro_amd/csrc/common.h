@@ -73,9 +73,15 @@ __device__ __forceinline__ float4 lerp4(const float4 a, const float4 b, float om
   return r;
 }
 
-// VoxMLP._linear3 (rnerf/ior_utils.py:188-223).  idx6 (nullable) receives the clamped x0,x1,y0,y1,z0,z1.
-__device__ __forceinline__ float4 trilinear(const float4* __restrict__ tab, const GridParams& g, float px, float py,
-                                            float pz, int* idx6) {
+// VoxMLP._linear3 (rnerf/ior_utils.py:188-223), split in two so a caller can put independent work between issuing the
+// 8 corner loads and consuming them.  idx6 (nullable) receives the clamped x0,x1,y0,y1,z0,z1.
+struct TriCell {
+  float4 d000, d100, d001, d101, d010, d110, d011, d111;
+  float xd, yd, zd;
+};
+
+__device__ __forceinline__ void trilinear_load(const float4* __restrict__ tab, const GridParams& g, float px, float py,
+                                               float pz, int* idx6, TriCell& c) {
   const float x = fdiv(fsub(px, g.nminx), g.ndx);
   const float y = fdiv(fsub(py, g.nminy), g.ndy);
   const float z = fdiv(fsub(pz, g.nminz), g.ndz);
@@ -83,25 +89,35 @@ __device__ __forceinline__ float4 trilinear(const float4* __restrict__ tab, cons
   int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
   int x1 = x0 + 1, y1 = y0 + 1, z1 = z0 + 1;
   // (x - x0) / (x1 - x0): the divisor is exactly 1.0f, so the quotient is the (rounded) difference.
-  const float xd = fsub(x, (float)x0), yd = fsub(y, (float)y0), zd = fsub(z, (float)z0);
+  c.xd = fsub(x, (float)x0); c.yd = fsub(y, (float)y0); c.zd = fsub(z, (float)z0);
   x0 = clampi(x0, 0, g.dx - 1); x1 = clampi(x1, 0, g.dx - 1);
   y0 = clampi(y0, 0, g.dy - 1); y1 = clampi(y1, 0, g.dy - 1);
   z0 = clampi(z0, 0, g.dz - 1); z1 = clampi(z1, 0, g.dz - 1);
   if (idx6) { idx6[0] = x0; idx6[1] = x1; idx6[2] = y0; idx6[3] = y1; idx6[4] = z0; idx6[5] = z1; }
   const size_t s1 = (size_t)g.dy * g.dz, s2 = (size_t)g.dz;
   const size_t bx0 = s1 * x0, bx1 = s1 * x1, by0 = s2 * y0, by1 = s2 * y1;
-  const float4 d000 = tab[bx0 + by0 + z0], d100 = tab[bx1 + by0 + z0];
-  const float4 d001 = tab[bx0 + by0 + z1], d101 = tab[bx1 + by0 + z1];
-  const float4 d010 = tab[bx0 + by1 + z0], d110 = tab[bx1 + by1 + z0];
-  const float4 d011 = tab[bx0 + by1 + z1], d111 = tab[bx1 + by1 + z1];
-  const float oxd = fsub(1.0f, xd), oyd = fsub(1.0f, yd), ozd = fsub(1.0f, zd);
-  const float4 c00 = lerp4(d000, d100, oxd, xd);
-  const float4 c01 = lerp4(d001, d101, oxd, xd);
-  const float4 c10 = lerp4(d010, d110, oxd, xd);
-  const float4 c11 = lerp4(d011, d111, oxd, xd);
-  const float4 c0 = lerp4(c00, c10, oyd, yd);
-  const float4 c1 = lerp4(c01, c11, oyd, yd);
-  return lerp4(c0, c1, ozd, zd);
+  c.d000 = tab[bx0 + by0 + z0]; c.d100 = tab[bx1 + by0 + z0];
+  c.d001 = tab[bx0 + by0 + z1]; c.d101 = tab[bx1 + by0 + z1];
+  c.d010 = tab[bx0 + by1 + z0]; c.d110 = tab[bx1 + by1 + z0];
+  c.d011 = tab[bx0 + by1 + z1]; c.d111 = tab[bx1 + by1 + z1];
+}
+
+__device__ __forceinline__ float4 trilinear_finish(const TriCell& c) {
+  const float oxd = fsub(1.0f, c.xd), oyd = fsub(1.0f, c.yd), ozd = fsub(1.0f, c.zd);
+  const float4 c00 = lerp4(c.d000, c.d100, oxd, c.xd);
+  const float4 c01 = lerp4(c.d001, c.d101, oxd, c.xd);
+  const float4 c10 = lerp4(c.d010, c.d110, oxd, c.xd);
+  const float4 c11 = lerp4(c.d011, c.d111, oxd, c.xd);
+  const float4 c0 = lerp4(c00, c10, oyd, c.yd);
+  const float4 c1 = lerp4(c01, c11, oyd, c.yd);
+  return lerp4(c0, c1, ozd, c.zd);
+}
+
+__device__ __forceinline__ float4 trilinear(const float4* __restrict__ tab, const GridParams& g, float px, float py,
+                                            float pz, int* idx6) {
+  TriCell c;
+  trilinear_load(tab, g, px, py, pz, idx6, c);
+  return trilinear_finish(c);
 }
 
 }  // namespace rnerf

@@ -13,8 +13,9 @@
 //     and feeds k-step s, slot j with feature 16*s + 8*(j>>2) + 4*h + (j&3)  (= accumulator (t=s>>1, r=8*(s&1)+j)).
 //   * fp32 parity: the reference computes the MLP in fp32.  F16X3/BF16X3 split both operands into hi+lo 16-bit parts and
 //     issue 3 MFMAs per tile (hi*hi + hi*lo + lo*hi, fp32 accumulate).  F16/BF16 issue one.
-//   * A workgroup = 4 waves = 128 consecutive sample rows; the weight stream (2.3 MB for X3) is read from L2 through a
-//     double-buffered LDS ring with global_load_lds (16 B/lane), one slab = 2 k-steps of one layer, shared by the 4 waves.
+//   * A workgroup = 4 waves = 256 consecutive sample rows (64 per wave, two 32-row m-tiles); the weight stream (2.3 MB
+//     for X3) is read from L2 through a double-buffered LDS ring with global_load_lds (16 B/lane), one slab = one k-step
+//     of one layer, shared by the 4 waves: 1 KB of L2->LDS traffic per row and layer.
 //   * Persistent grid: each workgroup walks row tiles with stride gridDim.x and prefetches across layer and tile seams.
 #include "common.h"
 
@@ -65,7 +66,7 @@ __host__ __device__ constexpr int layer_blocks_before(int l) {   // in units of 
 }
 constexpr int kTotalBlocks = layer_blocks_before(10);   // 1160
 
-// aux section (floats) that follows the weight stream: biases in natural feature order (scaled by WSCALE), heads.
+// aux section (floats) that follows the weight stream: fp32 biases in natural feature order, sigma/rgb heads.
 constexpr int AUX_BIAS = 0;            // 10 layers x 256
 constexpr int AUX_WSIG = 2560;         // Dense_8 kernel [256]
 constexpr int AUX_BSIG = 2816;         // Dense_8 bias (+3 pad)
@@ -80,8 +81,7 @@ struct Prec {
   // power-of-two weight scale: keeps the lo part of an f16 split out of the f16 subnormal range
   static constexpr float WSCALE = F16 ? 256.f : 1.f;
   static constexpr size_t STREAM_BYTES = (size_t)kTotalBlocks * NP * 1024;
-  static constexpr int SLAB8 = 2 * 8 * NP * 1024;   // one slab = 2 k-steps of an N=256 layer
-  static constexpr int SLAB4 = 2 * 4 * NP * 1024;   // ... of the N=128 view layer
+  static constexpr int SLAB = 8 * NP * 1024;        // one slab = 1 k-step of an N=256 layer = 2 k-steps of the N=128 view layer
   static constexpr size_t PACKED_BYTES = STREAM_BYTES + (size_t)AUX_FLOATS * 4;
 };
 
@@ -165,7 +165,7 @@ __global__ void nerfmlp_pack_kernel(const float* __restrict__ params, char* __re
     float v = 0.f;
     if (gid < AUX_WSIG) {
       const int l = gid >> 8, n = gid & 255, d = mfma_layer(l).dense;
-      v = n < nerf_dense(d).out ? params[nerf_boff(d) + n] * PP::WSCALE : 0.f;
+      v = n < nerf_dense(d).out ? params[nerf_boff(d) + n] : 0.f;
     } else if (gid < AUX_BSIG) v = params[nerf_koff(8) + (gid - AUX_WSIG)];
     else if (gid == AUX_BSIG) v = params[nerf_boff(8)];
     else if (gid >= AUX_WRGB && gid < AUX_BRGB) { const int c = (gid - AUX_WRGB) / 128, n = (gid - AUX_WRGB) % 128; v = params[nerf_koff(11) + n * 3 + c]; }
@@ -175,10 +175,27 @@ __global__ void nerfmlp_pack_kernel(const float* __restrict__ params, char* __re
 }
 
 // ---- forward kernel -----------------------------------------------------------------------------------------------------
+// sin for the positional encoding: 3-constant Cody-Waite reduction by pi/2 (exact products through fma; |a| < ~2^15) and the
+// Cephes sinf/cosf minimax polynomials on [-pi/4, pi/4] (~1 ulp).  ~20 VALU ops instead of the ~100 of the generic ocml
+// sinf with its Payne-Hanek path.  The argument itself is formed exactly like the reference: fl(fl(x * 2^d) + fl(pi/2)).
+__device__ __forceinline__ float pe_sin(float a) {
+  const float k = rintf(a * 0.63661977236758134f);
+  float r = fmaf(-k, 1.5707963705062866f, a);
+  r = fmaf(-k, -4.3711388286737929e-08f, r);
+  r = fmaf(-k, -1.7151245100059311e-15f, r);
+  const int q = (int)k;
+  const float z = r * r;
+  const float sp = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, r, r);
+  const float cp = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f), z * z, fmaf(-0.5f, z, 1.0f));
+  const float v = (q & 1) ? cp : sp;
+  return (q & 2) ? -v : v;
+}
+
 template <int BYTES>
 __device__ __forceinline__ void issue_slab(const char* __restrict__ gsrc, char* lds_dst, int wave, int lane) {
   constexpr int PER_WAVE = BYTES / 4;
   constexpr int N = PER_WAVE / 1024;
+  static_assert(N >= 1 && N * 4096 == BYTES, "slab must be a multiple of 4 KiB");
 #pragma unroll
   for (int c = 0; c < N; ++c) {
     const char* g = gsrc + wave * PER_WAVE + c * 1024 + lane * 16;
@@ -187,208 +204,371 @@ __device__ __forceinline__ void issue_slab(const char* __restrict__ gsrc, char* 
   }
 }
 
-// 2 k-steps x NT n-tiles of MFMAs out of one LDS slab; (bh0,bl0) / (bh1,bl1) are this wave's B operands of the 2 k-steps.
-template <int PREC, int NT>
-__device__ __forceinline__ void slab_compute(f32x16 (&acc)[8], const uint4 bh0, const uint4 bl0, const uint4 bh1, const uint4 bl1,
-                                             const char* slab, int lane) {
-  using PP = Prec<PREC>;
-  const uint4* a = (const uint4*)slab + lane;
-#pragma unroll
-  for (int kk = 0; kk < 2; ++kk) {
-    const uint4 bh = kk ? bh1 : bh0, bl = kk ? bl1 : bl0;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const uint4 ah = a[((kk * NT + t) * PP::NP + 0) * 64];
-      acc[t] = mfma16<PP::F16>(ah, bh, acc[t]);
-      if constexpr (PP::NP == 2) {
-        const uint4 al = a[((kk * NT + t) * PP::NP + 1) * 64];
-        acc[t] = mfma16<PP::F16>(ah, bl, acc[t]);
-        acc[t] = mfma16<PP::F16>(al, bh, acc[t]);
-      }
-    }
-  }
-}
-
-template <int NT>
-__device__ __forceinline__ void init_bias(f32x16 (&acc)[8], const float* __restrict__ bias, int h) {
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const float4 b = *(const float4*)(bias + 32 * t + 8 * g + 4 * h);
-      acc[t][4 * g + 0] = b.x; acc[t][4 * g + 1] = b.y; acc[t][4 * g + 2] = b.z; acc[t][4 * g + 3] = b.w;
-    }
-}
-
-// accumulators (after scale, optional ReLU) -> next layer's B operands (hi / lo)
-template <int PREC, int NT>
-__device__ __forceinline__ void acc_to_operands(f32x16 (&acc)[8], float inv_scale, float floor_v, uint4 (&xh)[16], uint4 (&xl)[16]) {
-  using PP = Prec<PREC>;
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = fmaxf(acc[t][r] * inv_scale, floor_v);
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      uint32_t hi[4], lo[4];
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        const float a = acc[t][8 * half + 2 * p], b = acc[t][8 * half + 2 * p + 1];
-        if constexpr (PP::NP == 2) split2<PP::F16>(a, b, hi[p], lo[p]);
-        else { hi[p] = pack2<PP::F16>(a, b); lo[p] = 0; }
-      }
-      xh[2 * t + half] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-      xl[2 * t + half] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
-    }
-  }
-}
-
-// positional encoding of one 3-vector into NK k-steps of B operands (slot maps pe_feature / view_feature)
-template <int PREC, int NK, int NSIN>
-__device__ __forceinline__ void encode(const float v0, const float v1, const float v2, int h, uint4* eh, uint4* el) {
-  using PP = Prec<PREC>;
-  const float phase = h ? 1.5707963705062866f : 0.0f;   // f32(0.5*pi) (rnerf/model_utils.py:213)
-#pragma unroll
-  for (int s = 0; s < NK; ++s) {
-    float f[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int q = 8 * s + j;
-      if (q < NSIN) {
-        const int d = q / 3, c = q % 3;
-        const float x = c == 0 ? v0 : (c == 1 ? v1 : v2);
-        f[j] = sinf(fadd(fmul(x, (float)(1 << d)), phase));
-      } else if (q == NSIN) f[j] = h ? v2 : v0;
-      else if (q == NSIN + 1) f[j] = h ? 0.f : v1;
-      else f[j] = 0.f;
-    }
-    uint32_t hi[4], lo[4];
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      if constexpr (PP::NP == 2) split2<PP::F16>(f[2 * p], f[2 * p + 1], hi[p], lo[p]);
-      else { hi[p] = pack2<PP::F16>(f[2 * p], f[2 * p + 1]); lo[p] = 0; }
-    }
-    eh[s] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-    el[s] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
-  }
-}
+// B operands of one k-step for the wave's two 32-row m-tiles
+struct KOps { uint4 h0, l0, h1, l1; };
 
 template <int PREC>
+__device__ __forceinline__ void split8(const float (&x)[8], uint4& hi, uint4& lo) {
+  using PP = Prec<PREC>;
+  uint32_t h[4], l[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    if constexpr (PP::NP == 2) split2<PP::F16>(x[2 * p], x[2 * p + 1], h[p], l[p]);
+    else { h[p] = pack2<PP::F16>(x[2 * p], x[2 * p + 1]); l[p] = 0; }
+  }
+  hi = make_uint4(h[0], h[1], h[2], h[3]);
+  lo = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
+// Conversion of the previous layer's outputs into the B operands of the NEXT k-step, cut into small chunks that are issued
+// between the MFMAs of the CURRENT k-step (each MFMA occupies the matrix pipe for 32 cycles; an in-order wave can issue
+// ~5 independent VALU ops in that shadow).  hipcc does not build this interleave by itself (it emits the ~110 VALU ops as
+// one clump ahead of the 48 MFMAs and the matrix pipe idles), so the order is written out and pinned with sched_barrier.
+//   pair pi in [0,8): m-tile pi>>2, value pair pi&3 -> chunk 0: bias+scale+ReLU, chunk 1: hi + residual, chunk 2: lo
+template <int PREC, int S>
+struct PrevConv {
+  using PP = Prec<PREC>;
+  const f32x16& p0;   // m-tile 0: the accumulator registers holding features 32*(S>>1) .. +31 of the previous layer
+  float v1[8];        // m-tile 1: raw accumulator values of the 8 features of k-step S (from LDS)
+  float b[8];         // fp32 bias of the producing layer
+  __device__ __forceinline__ PrevConv(const f32x16& p) : p0(p) {}
+  float floor_v;   // 0 (ReLU) or -inf (bottleneck: no activation)
+  uint32_t hi[2][4], lo[2][4];
+  float x0, x1;
+
+  template <int C, int PI>
+  __device__ __forceinline__ void chunk() {
+    constexpr int mt = PI >> 2, p = PI & 3;
+    constexpr float INV_SCALE = 1.0f / PP::WSCALE;
+    if constexpr (C == 0) {
+      const float r0 = mt == 0 ? p0[8 * (S & 1) + 2 * p] : v1[2 * p];
+      const float r1 = mt == 0 ? p0[8 * (S & 1) + 2 * p + 1] : v1[2 * p + 1];
+      x0 = fmaxf(fmaf(r0, INV_SCALE, b[2 * p]), floor_v);
+      x1 = fmaxf(fmaf(r1, INV_SCALE, b[2 * p + 1]), floor_v);
+    } else if constexpr (C == 1) {
+      hi[mt][p] = pack2<PP::F16>(x0, x1);
+      if constexpr (PP::NP == 2) {
+        float ha, hb;
+        unpack2<PP::F16>(hi[mt][p], ha, hb);
+        x0 -= ha; x1 -= hb;
+      }
+    } else {
+      if constexpr (PP::NP == 2) lo[mt][p] = pack2<PP::F16>(x0, x1);
+      else lo[mt][p] = 0;
+    }
+  }
+  __device__ __forceinline__ KOps result() const {
+    KOps o;
+    o.h0 = make_uint4(hi[0][0], hi[0][1], hi[0][2], hi[0][3]); o.l0 = make_uint4(lo[0][0], lo[0][1], lo[0][2], lo[0][3]);
+    o.h1 = make_uint4(hi[1][0], hi[1][1], hi[1][2], hi[1][3]); o.l1 = make_uint4(lo[1][0], lo[1][1], lo[1][2], lo[1][3]);
+    return o;
+  }
+};
+
+struct NoWork {
+  template <int C, int PI>
+  __device__ __forceinline__ void chunk() {}
+};
+
+#define RNERF_PIN() __builtin_amdgcn_sched_barrier(0)
+
+// one n-tile of one k-step: 6 (X3) or 2 MFMAs with the conversion chunks of pair PI in their shadow
+template <int PREC, bool FIRST, int PI, typename W>
+__device__ __forceinline__ void tile_mfma(f32x16& a0, f32x16& a1, const uint4 ah, const uint4 al, const KOps& b, W& work) {
+  using PP = Prec<PREC>;
+  const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  a0 = mfma16<PP::F16>(ah, b.h0, FIRST ? zero : a0);
+  work.template chunk<0, PI>();
+  RNERF_PIN();
+  a1 = mfma16<PP::F16>(ah, b.h1, FIRST ? zero : a1);
+  if constexpr (PP::NP == 2) {
+    RNERF_PIN();
+    a0 = mfma16<PP::F16>(ah, b.l0, a0);
+    work.template chunk<1, PI>();
+    RNERF_PIN();
+    a1 = mfma16<PP::F16>(ah, b.l1, a1);
+    RNERF_PIN();
+    a0 = mfma16<PP::F16>(al, b.h0, a0);
+    work.template chunk<2, PI>();
+    RNERF_PIN();
+    a1 = mfma16<PP::F16>(al, b.h1, a1);
+  } else {
+    work.template chunk<1, PI>();
+    work.template chunk<2, PI>();
+  }
+  RNERF_PIN();
+}
+
+// one k-step (block KOFF of the slab) of MFMAs for NT n-tiles x 2 m-tiles; FIRST: accumulators start from 0.
+// The A fragments of tile t+1 are read from LDS before the MFMAs of tile t are issued.
+template <int PREC, int NT, int KOFF, bool FIRST, typename W>
+__device__ __forceinline__ void kstep_mfma(f32x16 (&acc0)[8], f32x16 (&acc1)[8], const KOps& b, const char* slab, int lane, W& work) {
+  using PP = Prec<PREC>;
+  const uint4* a = (const uint4*)slab + lane + (size_t)KOFF * NT * PP::NP * 64;
+  uint4 ah = a[0], al = a[(PP::NP - 1) * 64];
+#define RNERF_TILE(T)                                                                                     \
+  if constexpr (T < NT) {                                                                                 \
+    uint4 nh = ah, nl = al;                                                                               \
+    if constexpr (T + 1 < NT) { nh = a[((T + 1) * PP::NP) * 64]; nl = a[((T + 1) * PP::NP + PP::NP - 1) * 64]; } \
+    tile_mfma<PREC, FIRST, (T & 7), W>(acc0[T], acc1[T], ah, al, b, work);                                \
+    ah = nh; al = nl;                                                                                     \
+  }
+  RNERF_TILE(0) RNERF_TILE(1) RNERF_TILE(2) RNERF_TILE(3) RNERF_TILE(4) RNERF_TILE(5) RNERF_TILE(6) RNERF_TILE(7)
+#undef RNERF_TILE
+}
+
+// Workgroup = 4 waves = 256 consecutive sample rows; wave w owns rows [64w, 64w+64) as two 32-row m-tiles.
+//   registers : acc0/acc1 (fp32 accumulators of both m-tiles, 2 x 128), prev0 (fp32 outputs of the previous layer, m-tile 0)
+//   LDS       : 2 x SLAB weight ring (shared by the 4 waves) + 32 KiB per wave holding the previous layer's fp32 outputs
+//               of m-tile 1 ([n-tile][4-register group][lane] float4) = 160 KiB for the X3 modes.
+// The previous layer's outputs become this layer's B operands JUST IN TIME, one k-step ahead of use: bias + ReLU +
+// hi/lo split of 8 values per lane per m-tile, issued in the shadow of the 48 MFMAs of the current k-step.
+template <int PREC, int dbg>
 __global__ void __launch_bounds__(256, 1)
 nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ rows_pd, const float4* __restrict__ rows_dr,
-                   const int* __restrict__ node_of_sample, int B, long long total_rows, int n_tiles, float4* __restrict__ out_raw,
-                   int dbg) {
-  // dbg (profiling ablations only, RNERF_MLP_DEBUG env var; results are garbage when set):
-  //   bit0 = skip the weight-stream loads, bit1 = skip ds_read + MFMA, bit2 = skip the barrier
+                   const int* __restrict__ node_of_sample, int B, long long total_rows, int n_tiles, float4* __restrict__ out_raw) {
+  // dbg != 0: profiling ablations, only instantiated with -DRNERF_MLP_ABLATE (results are garbage):
+  //   bit0 = skip the weight-stream loads, bit1 = skip ds_read + MFMA, bit2 = skip the barrier.
+  // Compile-time on purpose: a runtime branch per k-step would split the scheduling region and stop the compiler from
+  // interleaving the operand conversion (VALU) with the MFMAs.
   using PP = Prec<PREC>;
+  constexpr int SLAB = PP::SLAB;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = lane & 31, h = lane >> 5;
   const float* __restrict__ aux = (const float*)(packed + PP::STREAM_BYTES);
+  float4* __restrict__ st1 = (float4*)(smem + 2 * SLAB + wave * 32768) + lane;   // + (t*4 + rq)*64
   constexpr float INV_SCALE = 1.0f / PP::WSCALE;
-  constexpr int BUF = PP::SLAB8;
+  const float NEG_INF = -__builtin_inff();
   int buf = 0;
   size_t off = 0;   // stream offset of the next slab to prefetch
 
-  if ((int)blockIdx.x < n_tiles) { issue_slab<PP::SLAB8>(packed, smem, wave, lane); off = PP::SLAB8; }
+  if ((int)blockIdx.x < n_tiles) { if (!(dbg & 1)) issue_slab<SLAB>(packed, smem, wave, lane); off = SLAB; }
   __syncthreads();
 
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const bool has_next_tile = tile + (int)gridDim.x < n_tiles;
-    long long row = (long long)tile * 128 + wave * 32 + m;
-    const bool row_ok = row < total_rows;
-    if (!row_ok) row = total_rows - 1;
-    size_t rec = (size_t)row;
-    if (node_of_sample) { const long long s = row / B; rec = (size_t)node_of_sample[s] * B + (size_t)(row - s * B); }
-    const float4 pd = rows_pd[rec];
-    const float4 dr = rows_dr[rec];
+    long long row[2]; bool row_ok[2];
+    float4 pd[2], dr[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      row[mt] = (long long)tile * 256 + wave * 64 + mt * 32 + m;
+      row_ok[mt] = row[mt] < total_rows;
+      if (!row_ok[mt]) row[mt] = total_rows - 1;
+      size_t rec = (size_t)row[mt];
+      if (node_of_sample) { const long long sidx = row[mt] / B; rec = (size_t)node_of_sample[sidx] * B + (size_t)(row[mt] - sidx * B); }
+      pd[mt] = rows_pd[rec];
+      dr[mt] = rows_dr[rec];
+    }
 
-    uint4 peh[4], pel[4], vwh[2], vwl[2];
-    encode<PREC, 4, 30>(pd.x, pd.y, pd.z, h, peh, pel);   // pos_enc(pos, 0, 10)  (rnerf/models.py:257)
-    encode<PREC, 2, 12>(dr.x, dr.y, dr.z, h, vwh, vwl);   // pos_enc(dir, 0, 4)   (rnerf/models.py:289-294)
+    f32x16 acc0[8], acc1[8], prev0[8];
 
-    f32x16 acc[8];
-    uint4 xh[16], xl[16];
+    // positional-encoding operands of k-step s (slot maps pe_feature / view_feature), for both m-tiles
+    auto enc_ops = [&](const float4 (&v)[2], int s, int nsin) -> KOps {
+      const float phase = h ? 1.5707963705062866f : 0.0f;   // f32(0.5*pi) (rnerf/model_utils.py:213)
+      float f[2][8];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int q = 8 * s + j;
+          if (q < nsin) {
+            const int d = q / 3, c = q % 3;
+            const float x = c == 0 ? v[mt].x : (c == 1 ? v[mt].y : v[mt].z);
+            f[mt][j] = pe_sin(fadd(fmul(x, (float)(1 << d)), phase));
+          } else if (q == nsin) f[mt][j] = h ? v[mt].z : v[mt].x;
+          else if (q == nsin + 1) f[mt][j] = h ? 0.f : v[mt].y;
+          else f[mt][j] = 0.f;
+        }
+      KOps o;
+      split8<PREC>(f[0], o.h0, o.l0);
+      split8<PREC>(f[1], o.h1, o.l1);
+      return o;
+    };
 
-#define RUN_SLAB(NT, B0H, B0L, B1H, B1L, NEXT_BYTES, DO_NEXT)                               \
-  do {                                                                                      \
-    if (DO_NEXT) { if (!(dbg & 1)) issue_slab<NEXT_BYTES>(packed + off, smem + (buf ^ 1) * BUF, wave, lane); off += NEXT_BYTES; } \
-    if (!(dbg & 2)) slab_compute<PREC, NT>(acc, B0H, B0L, B1H, B1L, smem + buf * BUF, lane); \
-    if (!(dbg & 4)) __syncthreads();                                                        \
-    buf ^= 1;                                                                               \
-  } while (0)
+    // operands of k-step s from the previous layer's outputs: x = max(acc * inv_scale + bias, floor), hi/lo split.
+    auto prev_ops = [&](int s, const float* __restrict__ bias, float floor_v) -> KOps {
+      const float4 b0 = *(const float4*)(bias + 16 * s + 4 * h), b1 = *(const float4*)(bias + 16 * s + 8 + 4 * h);
+      const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+      const float4 u0 = st1[((s >> 1) * 4 + 2 * (s & 1)) * 64], u1 = st1[((s >> 1) * 4 + 2 * (s & 1) + 1) * 64];
+      const float r1[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+      float x0[8], x1[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        x0[j] = fmaxf(fmaf(prev0[s >> 1][8 * (s & 1) + j], INV_SCALE, bb[j]), floor_v);
+        x1[j] = fmaxf(fmaf(r1[j], INV_SCALE, bb[j]), floor_v);
+      }
+      KOps o;
+      split8<PREC>(x0, o.h0, o.l0);
+      split8<PREC>(x1, o.h1, o.l1);
+      return o;
+    };
 
-    // ---- layer 0: 63 -> 256 (Dense_0), ReLU
-    init_bias<8>(acc, aux + AUX_BIAS, h);
-    RUN_SLAB(8, peh[0], pel[0], peh[1], pel[1], PP::SLAB8, true);
-    RUN_SLAB(8, peh[2], pel[2], peh[3], pel[3], PP::SLAB8, true);
-    acc_to_operands<PREC, 8>(acc, INV_SCALE, 0.f, xh, xl);
+    // bias of the 8 features of k-step s (global, L2/L1 resident).  Loaded one slab EARLIER than it is consumed: the
+    // vmcnt(0) of the barrier that ends the slab (needed for the weight DMA anyway) then also covers this load.
+    auto load_bias8 = [&](int s, const float* __restrict__ bias, float (&b)[8]) {
+      const float4 b0 = *(const float4*)(bias + 16 * s + 4 * h), b1 = *(const float4*)(bias + 16 * s + 8 + 4 * h);
+      b[0] = b0.x; b[1] = b0.y; b[2] = b0.z; b[3] = b0.w; b[4] = b1.x; b[5] = b1.y; b[6] = b1.z; b[7] = b1.w;
+    };
+    // raw accumulators of m-tile 1 for k-step s (this wave's LDS region)
+    auto load_state8 = [&](int s, float (&v)[8]) {
+      const float4 u0 = st1[((s >> 1) * 4 + 2 * (s & 1)) * 64], u1 = st1[((s >> 1) * 4 + 2 * (s & 1) + 1) * 64];
+      v[0] = u0.x; v[1] = u0.y; v[2] = u0.z; v[3] = u0.w; v[4] = u1.x; v[5] = u1.y; v[6] = u1.z; v[7] = u1.w;
+    };
+    NoWork nowork;
 
-    // ---- layers 1..8: Dense_1..Dense_7 (ReLU; Dense_5 takes the skip concat), Dense_9 = bottleneck (no activation)
-    float sigma_raw = 0.f;
+#define SLAB_PREFETCH(DO_NEXT)                                                                                       \
+  do { if (DO_NEXT) { if (!(dbg & 1)) issue_slab<SLAB>(packed + off, smem + (buf ^ 1) * SLAB, wave, lane); off += SLAB; } } while (0)
+#define SLAB_DONE()                                                                                                  \
+  do { if (!(dbg & 4)) __syncthreads(); buf ^= 1; } while (0)
+
+    // end of a 256-wide layer: m-tile 0 outputs stay in registers (prev0), m-tile 1 outputs go to this wave's LDS region
+    auto layer_end = [&]() {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        prev0[t] = acc0[t];
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq)
+          st1[(t * 4 + rq) * 64] = make_float4(acc1[t][4 * rq], acc1[t][4 * rq + 1], acc1[t][4 * rq + 2], acc1[t][4 * rq + 3]);
+      }
+    };
+
+    float sig0 = 0.f, sig1 = 0.f;
+
+    // ---- layer 0: pos_enc(pos, 0, 10) (63) -> 256 (Dense_0)  (rnerf/models.py:257)
+    {
+      KOps cur = enc_ops(pd, 0, 30);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        SLAB_PREFETCH(true);   // glds first: it is a scheduling boundary, conversion + MFMAs must share the region after it
+        KOps nxt = cur;
+        if (s + 1 < 4) nxt = enc_ops(pd, s + 1, 30);
+        if (!(dbg & 2)) { if (s == 0) kstep_mfma<PREC, 8, 0, true>(acc0, acc1, cur, smem + buf * SLAB, lane, nowork); else kstep_mfma<PREC, 8, 0, false>(acc0, acc1, cur, smem + buf * SLAB, lane, nowork); }
+        SLAB_DONE();
+        cur = nxt;
+      }
+      layer_end();
+    }
+
+    // ---- layers 1..8: Dense_1..Dense_7 (inputs ReLU'd; Dense_5 also takes the skip concat), Dense_9 = bottleneck
 #pragma unroll 1
     for (int l = 1; l <= 8; ++l) {
-      init_bias<8>(acc, aux + AUX_BIAS + 256 * l, h);
-      RUN_SLAB(8, xh[0], xl[0], xh[1], xl[1], PP::SLAB8, true);
-      RUN_SLAB(8, xh[2], xl[2], xh[3], xl[3], PP::SLAB8, true);
-      RUN_SLAB(8, xh[4], xl[4], xh[5], xl[5], PP::SLAB8, true);
-      RUN_SLAB(8, xh[6], xl[6], xh[7], xl[7], PP::SLAB8, true);
-      RUN_SLAB(8, xh[8], xl[8], xh[9], xl[9], PP::SLAB8, true);
-      RUN_SLAB(8, xh[10], xl[10], xh[11], xl[11], PP::SLAB8, true);
-      RUN_SLAB(8, xh[12], xl[12], xh[13], xl[13], PP::SLAB8, true);
-      if (l == 8) RUN_SLAB(8, xh[14], xl[14], xh[15], xl[15], PP::SLAB4, true);
-      else RUN_SLAB(8, xh[14], xl[14], xh[15], xl[15], PP::SLAB8, true);
-      if (l == 5) {   // skip concat: [x, inputs] (rnerf/model_utils.py:68-69)
-        RUN_SLAB(8, peh[0], pel[0], peh[1], pel[1], PP::SLAB8, true);
-        RUN_SLAB(8, peh[2], pel[2], peh[3], pel[3], PP::SLAB8, true);
+      const float* __restrict__ bias = aux + AUX_BIAS + 256 * (l - 1);
+      KOps cur = prev_ops(0, bias, 0.f);
+      float bnext[8];
+      load_bias8(1, bias, bnext);
+#define RNERF_KSTEP(S)                                                                                              \
+      {                                                                                                              \
+        float bnn[8];                                                                                                \
+        if constexpr (S + 2 < 16) load_bias8(S + 2, bias, bnn);   /* consumed in the NEXT slab */                     \
+        SLAB_PREFETCH(true);                                                                                         \
+        if constexpr (S + 1 < 16) {                                                                                  \
+          PrevConv<PREC, S + 1> cv(prev0[(S + 1) >> 1]);                                                             \
+          cv.floor_v = 0.f;                                                                                          \
+          _Pragma("unroll") for (int j = 0; j < 8; ++j) cv.b[j] = bnext[j];                                          \
+          load_state8(S + 1, cv.v1);                                                                                 \
+          if (!(dbg & 2)) kstep_mfma<PREC, 8, 0, S == 0>(acc0, acc1, cur, smem + buf * SLAB, lane, cv);              \
+          cur = cv.result();                                                                                         \
+        } else {                                                                                                     \
+          if (!(dbg & 2)) kstep_mfma<PREC, 8, 0, false>(acc0, acc1, cur, smem + buf * SLAB, lane, nowork);           \
+        }                                                                                                            \
+        if constexpr (S + 2 < 16) { _Pragma("unroll") for (int j = 0; j < 8; ++j) bnext[j] = bnn[j]; }               \
+        SLAB_DONE();                                                                                                 \
       }
-      acc_to_operands<PREC, 8>(acc, INV_SCALE, l == 8 ? -__builtin_inff() : 0.f, xh, xl);
-      if (l == 7) {   // sigma head on the fp32 trunk output (Dense_8, rnerf/model_utils.py:70)
-        float part = 0.f;
+      RNERF_KSTEP(0) RNERF_KSTEP(1) RNERF_KSTEP(2) RNERF_KSTEP(3) RNERF_KSTEP(4) RNERF_KSTEP(5) RNERF_KSTEP(6) RNERF_KSTEP(7)
+      RNERF_KSTEP(8) RNERF_KSTEP(9) RNERF_KSTEP(10) RNERF_KSTEP(11) RNERF_KSTEP(12) RNERF_KSTEP(13) RNERF_KSTEP(14) RNERF_KSTEP(15)
+#undef RNERF_KSTEP
+      if (l == 5) {   // skip concat: [x, inputs] (rnerf/model_utils.py:68-69)
+        cur = enc_ops(pd, 0, 30);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          SLAB_PREFETCH(true);
+          KOps nxt = cur;
+          if (s + 1 < 4) nxt = enc_ops(pd, s + 1, 30);
+          if (!(dbg & 2)) kstep_mfma<PREC, 8, 0, false>(acc0, acc1, cur, smem + buf * SLAB, lane, nowork);
+          SLAB_DONE();
+          cur = nxt;
+        }
+      }
+      if (l == 7) {   // sigma head (Dense_8, rnerf/model_utils.py:70) on the fp32 trunk output relu(acc + b7), once per tile
+        const float* __restrict__ b7 = aux + AUX_BIAS + 256 * 7;
 #pragma unroll
         for (int t = 0; t < 8; ++t)
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
-            const float4 w = *(const float4*)(aux + AUX_WSIG + 32 * t + 8 * g + 4 * h);
-            part = fmaf(acc[t][4 * g + 0], w.x, part); part = fmaf(acc[t][4 * g + 1], w.y, part);
-            part = fmaf(acc[t][4 * g + 2], w.z, part); part = fmaf(acc[t][4 * g + 3], w.w, part);
+            const float4 bb = *(const float4*)(b7 + 32 * t + 8 * g + 4 * h), ww = *(const float4*)(aux + AUX_WSIG + 32 * t + 8 * g + 4 * h);
+            const float bv[4] = {bb.x, bb.y, bb.z, bb.w}, wv[4] = {ww.x, ww.y, ww.z, ww.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              sig0 = fmaf(fmaxf(fmaf(acc0[t][4 * g + i], INV_SCALE, bv[i]), 0.f), wv[i], sig0);
+              sig1 = fmaf(fmaxf(fmaf(acc1[t][4 * g + i], INV_SCALE, bv[i]), 0.f), wv[i], sig1);
+            }
           }
-        sigma_raw = part + __shfl_xor(part, 32) + aux[AUX_BSIG];
       }
+      layer_end();
     }
 
-    // ---- view layer: [bottleneck(256), view_enc(27)] -> 128 (Dense_10), ReLU
-    init_bias<4>(acc, aux + AUX_BIAS + 256 * 9, h);
-    RUN_SLAB(4, xh[0], xl[0], xh[1], xl[1], PP::SLAB4, true);
-    RUN_SLAB(4, xh[2], xl[2], xh[3], xl[3], PP::SLAB4, true);
-    RUN_SLAB(4, xh[4], xl[4], xh[5], xl[5], PP::SLAB4, true);
-    RUN_SLAB(4, xh[6], xl[6], xh[7], xl[7], PP::SLAB4, true);
-    RUN_SLAB(4, xh[8], xl[8], xh[9], xl[9], PP::SLAB4, true);
-    RUN_SLAB(4, xh[10], xl[10], xh[11], xl[11], PP::SLAB4, true);
-    RUN_SLAB(4, xh[12], xl[12], xh[13], xl[13], PP::SLAB4, true);
-    RUN_SLAB(4, xh[14], xl[14], xh[15], xl[15], PP::SLAB4, true);
-    // last slab of the tile: prefetch the first slab of the next tile (stream restarts at 0)
-    if (has_next_tile) { off = 0; }
-    RUN_SLAB(4, vwh[0], vwl[0], vwh[1], vwl[1], PP::SLAB8, has_next_tile);
-
-    // ---- rgb head (Dense_11) on the fp32 view-layer output
-    float pr = 0.f, pg = 0.f, pb = 0.f;
+    // ---- view layer: [bottleneck(256) (no activation), pos_enc(dir, 0, 4) (27)] -> 128 (Dense_10)  (rnerf/models.py:289-294)
+    {
+      const float* __restrict__ bias = aux + AUX_BIAS + 256 * 8;
+      KOps c0 = prev_ops(0, bias, NEG_INF);
+      KOps c1 = prev_ops(1, bias, NEG_INF);
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float v = fmaxf(acc[t][r] * INV_SCALE, 0.f);
-        const int n = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
-        pr = fmaf(v, aux[AUX_WRGB + n], pr);
-        pg = fmaf(v, aux[AUX_WRGB + 128 + n], pg);
-        pb = fmaf(v, aux[AUX_WRGB + 256 + n], pb);
+      for (int sl = 0; sl < 8; ++sl) {
+        SLAB_PREFETCH(true);
+        KOps n0 = c0, n1 = c1;
+        if (sl + 1 < 8) { n0 = prev_ops(2 * sl + 2, bias, NEG_INF); n1 = prev_ops(2 * sl + 3, bias, NEG_INF); }
+        else { n0 = enc_ops(dr, 0, 12); n1 = enc_ops(dr, 1, 12); }
+        if (!(dbg & 2)) {
+          if (sl == 0) kstep_mfma<PREC, 4, 0, true>(acc0, acc1, c0, smem + buf * SLAB, lane, nowork); else kstep_mfma<PREC, 4, 0, false>(acc0, acc1, c0, smem + buf * SLAB, lane, nowork);
+          kstep_mfma<PREC, 4, 1, false>(acc0, acc1, c1, smem + buf * SLAB, lane, nowork);
+        }
+        SLAB_DONE();
+        c0 = n0; c1 = n1;
       }
-    pr = pr + __shfl_xor(pr, 32) + aux[AUX_BRGB];
-    pg = pg + __shfl_xor(pg, 32) + aux[AUX_BRGB + 1];
-    pb = pb + __shfl_xor(pb, 32) + aux[AUX_BRGB + 2];
-    if (row_ok && h == 0) out_raw[row] = make_float4(pr, pg, pb, sigma_raw);
-#undef RUN_SLAB
+      // last slab of the tile (the two view-encoding k-steps): prefetch the first slab of the next tile (stream restarts)
+      if (has_next_tile) off = 0;
+      SLAB_PREFETCH(has_next_tile);
+      if (!(dbg & 2)) { kstep_mfma<PREC, 4, 0, false>(acc0, acc1, c0, smem + buf * SLAB, lane, nowork); kstep_mfma<PREC, 4, 1, false>(acc0, acc1, c1, smem + buf * SLAB, lane, nowork); }
+      SLAB_DONE();
+    }
+
+    // ---- heads: sigma (Dense_8, accumulated above) and rgb (Dense_11) on the fp32 view-layer output
+    {
+      const float* __restrict__ b9 = aux + AUX_BIAS + 256 * 9;
+      float p0[3] = {0.f, 0.f, 0.f}, p1[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = 32 * t + 8 * g + 4 * h;
+          const float4 bb = *(const float4*)(b9 + n);
+          const float4 wr = *(const float4*)(aux + AUX_WRGB + n), wg = *(const float4*)(aux + AUX_WRGB + 128 + n), wb = *(const float4*)(aux + AUX_WRGB + 256 + n);
+          const float bv[4] = {bb.x, bb.y, bb.z, bb.w}, wrv[4] = {wr.x, wr.y, wr.z, wr.w}, wgv[4] = {wg.x, wg.y, wg.z, wg.w}, wbv[4] = {wb.x, wb.y, wb.z, wb.w};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float v0 = fmaxf(fmaf(acc0[t][4 * g + i], INV_SCALE, bv[i]), 0.f);
+            const float v1 = fmaxf(fmaf(acc1[t][4 * g + i], INV_SCALE, bv[i]), 0.f);
+            p0[0] = fmaf(v0, wrv[i], p0[0]); p0[1] = fmaf(v0, wgv[i], p0[1]); p0[2] = fmaf(v0, wbv[i], p0[2]);
+            p1[0] = fmaf(v1, wrv[i], p1[0]); p1[1] = fmaf(v1, wgv[i], p1[1]); p1[2] = fmaf(v1, wbv[i], p1[2]);
+          }
+        }
+      const float bsig = aux[AUX_BSIG];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        p0[c] = p0[c] + __shfl_xor(p0[c], 32) + aux[AUX_BRGB + c];
+        p1[c] = p1[c] + __shfl_xor(p1[c], 32) + aux[AUX_BRGB + c];
+      }
+      sig0 = sig0 + __shfl_xor(sig0, 32) + bsig;
+      sig1 = sig1 + __shfl_xor(sig1, 32) + bsig;
+      if (h == 0) {
+        if (row_ok[0]) out_raw[row[0]] = make_float4(p0[0], p0[1], p0[2], sig0);
+        if (row_ok[1]) out_raw[row[1]] = make_float4(p1[0], p1[1], p1[2], sig1);
+      }
+    }
+#undef SLAB_PREFETCH
+#undef SLAB_DONE
   }
 }
 
@@ -541,23 +721,43 @@ static int mlp_debug_flags() {
   return v;
 }
 
+template <int PREC, int DBG>
+static int launch_fwd_dbg(const void* packed, const float* rows_pd, const float* rows_dr, const int32_t* node_of_sample, int32_t B,
+                          long long total_rows, float* out_raw, hipStream_t st);
+
 template <int PREC>
 static int launch_fwd(const void* packed, const float* rows_pd, const float* rows_dr, const int32_t* node_of_sample, int32_t B,
                       long long total_rows, float* out_raw, hipStream_t st) {
+#ifdef RNERF_MLP_ABLATE
+  switch (mlp_debug_flags()) {
+    case 1: return launch_fwd_dbg<PREC, 1>(packed, rows_pd, rows_dr, node_of_sample, B, total_rows, out_raw, st);
+    case 2: return launch_fwd_dbg<PREC, 2>(packed, rows_pd, rows_dr, node_of_sample, B, total_rows, out_raw, st);
+    case 3: return launch_fwd_dbg<PREC, 3>(packed, rows_pd, rows_dr, node_of_sample, B, total_rows, out_raw, st);
+    case 4: return launch_fwd_dbg<PREC, 4>(packed, rows_pd, rows_dr, node_of_sample, B, total_rows, out_raw, st);
+    case 5: return launch_fwd_dbg<PREC, 5>(packed, rows_pd, rows_dr, node_of_sample, B, total_rows, out_raw, st);
+    default: break;
+  }
+#endif
+  return launch_fwd_dbg<PREC, 0>(packed, rows_pd, rows_dr, node_of_sample, B, total_rows, out_raw, st);
+}
+
+template <int PREC, int DBG>
+static int launch_fwd_dbg(const void* packed, const float* rows_pd, const float* rows_dr, const int32_t* node_of_sample, int32_t B,
+                      long long total_rows, float* out_raw, hipStream_t st) {
   using PP = Prec<PREC>;
-  const int n_tiles = (int)((total_rows + 127) / 128);
+  const int n_tiles = (int)((total_rows + 255) / 256);
   int dev = 0, cus = 0;
   RNERF_CHECK_HIP(hipGetDevice(&dev));
   RNERF_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
   const int grid = n_tiles < cus ? n_tiles : cus;
-  const size_t lds = 2 * (size_t)PP::SLAB8;
+  const size_t lds = 2 * (size_t)PP::SLAB + 4 * 32768;
   static bool attr_set = false;
   if (!attr_set) {
-    RNERF_CHECK_HIP(hipFuncSetAttribute((const void*)nerfmlp_fwd_kernel<PREC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    RNERF_CHECK_HIP(hipFuncSetAttribute((const void*)nerfmlp_fwd_kernel<PREC, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL(nerfmlp_fwd_kernel<PREC>, dim3(grid), dim3(256), lds, st, (const char*)packed, (const float4*)rows_pd,
-                     (const float4*)rows_dr, node_of_sample, B, total_rows, n_tiles, (float4*)out_raw, mlp_debug_flags());
+  hipLaunchKernelGGL((nerfmlp_fwd_kernel<PREC, DBG>), dim3(grid), dim3(256), lds, st, (const char*)packed, (const float4*)rows_pd,
+                     (const float4*)rows_dr, node_of_sample, B, total_rows, n_tiles, (float4*)out_raw);
   RNERF_CHECK_LAUNCH();
   return RNERF_OK;
 }
