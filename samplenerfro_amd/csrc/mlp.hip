@@ -191,17 +191,29 @@ __device__ __forceinline__ float pe_sin(float a) {
   return (q & 2) ? -v : v;
 }
 
+// Weight-stream DMA (global -> LDS, 16 B per lane, 1 KiB per wave-instruction).  Written as inline asm on purpose: for the
+// __builtin_amdgcn_global_load_lds form hipcc orders every later ds_read behind the DMA (it cannot prove the reads hit the
+// OTHER ring slot) and emits s_waitcnt vmcnt(0) right after the issue, which serialises the prefetch with the compute.
+// The asm form is invisible to the compiler's counters; slab_wait_dma() before the slab-end barrier is the only wait.
+// lds_off: wave-uniform LDS byte address (dynamic LDS starts at 0: the kernel has no static __shared__).
+__device__ __forceinline__ void glds16(const char* gsrc, unsigned lds_off) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_off) : "memory");
+}
+// vmcnt(0) as the BUILTIN (imm: vmcnt=0, expcnt=7, lgkmcnt=15): hipcc folds an explicit s_waitcnt into its own scoreboard,
+// so it also knows that every load it tracks itself (bias prefetch) has landed and emits no stricter wait later.
+__device__ __forceinline__ void slab_wait_dma() { __builtin_amdgcn_s_waitcnt(0x0F70); asm volatile("" ::: "memory"); }
+
 template <int BYTES>
-__device__ __forceinline__ void issue_slab(const char* __restrict__ gsrc, char* lds_dst, int wave, int lane) {
+__device__ __forceinline__ void issue_slab(const char* __restrict__ gsrc, unsigned lds_off, int wave, int lane) {
   constexpr int PER_WAVE = BYTES / 4;
   constexpr int N = PER_WAVE / 1024;
   static_assert(N >= 1 && N * 4096 == BYTES, "slab must be a multiple of 4 KiB");
 #pragma unroll
-  for (int c = 0; c < N; ++c) {
-    const char* g = gsrc + wave * PER_WAVE + c * 1024 + lane * 16;
-    char* l = lds_dst + wave * PER_WAVE + c * 1024;   // wave-uniform; hardware adds lane*16
-    __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)g, (LDS_AS void*)l, 16, 0, 0);
-  }
+  for (int c = 0; c < N; ++c)
+    glds16(gsrc + wave * PER_WAVE + c * 1024 + lane * 16,
+           __builtin_amdgcn_readfirstlane(lds_off + wave * PER_WAVE + c * 1024));   // hardware adds lane*16
 }
 
 // B operands of one k-step for the wave's two 32-row m-tiles
@@ -344,7 +356,8 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
   int buf = 0;
   size_t off = 0;   // stream offset of the next slab to prefetch
 
-  if ((int)blockIdx.x < n_tiles) { if (!(dbg & 1)) issue_slab<SLAB>(packed, smem, wave, lane); off = SLAB; }
+  if ((int)blockIdx.x < n_tiles) { if (!(dbg & 1)) issue_slab<SLAB>(packed, 0u, wave, lane); off = SLAB; }
+  slab_wait_dma();
   __syncthreads();
 
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -419,9 +432,9 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
     NoWork nowork;
 
 #define SLAB_PREFETCH(DO_NEXT)                                                                                       \
-  do { if (DO_NEXT) { if (!(dbg & 1)) issue_slab<SLAB>(packed + off, smem + (buf ^ 1) * SLAB, wave, lane); off += SLAB; } } while (0)
+  do { if (DO_NEXT) { if (!(dbg & 1)) issue_slab<SLAB>(packed + off, (unsigned)((buf ^ 1) * SLAB), wave, lane); off += SLAB; } } while (0)
 #define SLAB_DONE()                                                                                                  \
-  do { if (!(dbg & 4)) __syncthreads(); buf ^= 1; } while (0)
+  do { slab_wait_dma(); if (!(dbg & 4)) __syncthreads(); buf ^= 1; } while (0)
 
     // end of a 256-wide layer: m-tile 0 outputs stay in registers (prev0), m-tile 1 outputs go to this wave's LDS region
     auto layer_end = [&]() {
