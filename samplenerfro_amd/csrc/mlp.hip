@@ -248,6 +248,7 @@ struct PrevConv {
   uint32_t hi[2][4], lo[2][4];
   float x0, x1;
 
+  // five dependent stages of one value pair, one stage per MFMA slot (each stage = 1-2 independent VALU ops)
   template <int C, int PI>
   __device__ __forceinline__ void chunk() {
     constexpr int mt = PI >> 2, p = PI & 3;
@@ -255,14 +256,24 @@ struct PrevConv {
     if constexpr (C == 0) {
       const float r0 = mt == 0 ? p0[8 * (S & 1) + 2 * p] : v1[2 * p];
       const float r1 = mt == 0 ? p0[8 * (S & 1) + 2 * p + 1] : v1[2 * p + 1];
-      x0 = fmaxf(fmaf(r0, INV_SCALE, b[2 * p]), floor_v);
-      x1 = fmaxf(fmaf(r1, INV_SCALE, b[2 * p + 1]), floor_v);
+      x0 = fmaf(r0, INV_SCALE, b[2 * p]);
+      x1 = fmaf(r1, INV_SCALE, b[2 * p + 1]);
     } else if constexpr (C == 1) {
+      x0 = fmaxf(x0, floor_v);
+      x1 = fmaxf(x1, floor_v);
+    } else if constexpr (C == 2) {
       hi[mt][p] = pack2<PP::F16>(x0, x1);
+    } else if constexpr (C == 3) {
       if constexpr (PP::NP == 2) {
-        float ha, hb;
-        unpack2<PP::F16>(hi[mt][p], ha, hb);
-        x0 -= ha; x1 -= hb;
+        if constexpr (PP::F16) {   // x - (float)hi as one v_fma_mix_f32 per value (exact: the residual is representable)
+          const half2v hv = __builtin_bit_cast(half2v, hi[mt][p]);
+          x0 = __builtin_fmaf((float)hv[0], -1.0f, x0);
+          x1 = __builtin_fmaf((float)hv[1], -1.0f, x1);
+        } else {
+          float ha, hb;
+          unpack2<false>(hi[mt][p], ha, hb);
+          x0 -= ha; x1 -= hb;
+        }
       }
     } else {
       if constexpr (PP::NP == 2) lo[mt][p] = pack2<PP::F16>(x0, x1);
@@ -293,39 +304,52 @@ __device__ __forceinline__ void tile_mfma(f32x16& a0, f32x16& a1, const uint4 ah
   work.template chunk<0, PI>();
   RNERF_PIN();
   a1 = mfma16<PP::F16>(ah, b.h1, FIRST ? zero : a1);
+  work.template chunk<1, PI>();
+  RNERF_PIN();
   if constexpr (PP::NP == 2) {
-    RNERF_PIN();
     a0 = mfma16<PP::F16>(ah, b.l0, a0);
-    work.template chunk<1, PI>();
+    work.template chunk<2, PI>();
     RNERF_PIN();
     a1 = mfma16<PP::F16>(ah, b.l1, a1);
+    work.template chunk<3, PI>();
     RNERF_PIN();
     a0 = mfma16<PP::F16>(al, b.h0, a0);
-    work.template chunk<2, PI>();
+    work.template chunk<4, PI>();
     RNERF_PIN();
     a1 = mfma16<PP::F16>(al, b.h1, a1);
   } else {
-    work.template chunk<1, PI>();
     work.template chunk<2, PI>();
+    work.template chunk<3, PI>();
+    work.template chunk<4, PI>();
   }
   RNERF_PIN();
 }
 
 // one k-step (block KOFF of the slab) of MFMAs for NT n-tiles x 2 m-tiles; FIRST: accumulators start from 0.
 // The A fragments of tile t+1 are read from LDS before the MFMAs of tile t are issued.
-template <int PREC, int NT, int KOFF, bool FIRST, typename W>
-__device__ __forceinline__ void kstep_mfma(f32x16 (&acc0)[8], f32x16 (&acc1)[8], const KOps& b, const char* slab, int lane, W& work) {
+struct NoDma { __device__ __forceinline__ void operator()() const {} };
+
+// `dma` is invoked after tile 1: the weight DMA of the next slab is issued while MFMAs are already in the matrix pipe and
+// the A fragments of tiles 0..3 are already on their way (an LDS-DMA instruction costs ~100 issue cycles).
+template <int PREC, int NT, int KOFF, bool FIRST, typename W, bool NOREAD = false, bool SINK = false, typename D = NoDma>
+__device__ __forceinline__ void kstep_mfma(f32x16 (&acc0)[8], f32x16 (&acc1)[8], const KOps& b, const char* slab, int lane, W& work, D dma = D()) {
   using PP = Prec<PREC>;
   const uint4* a = (const uint4*)slab + lane + (size_t)KOFF * NT * PP::NP * 64;
+  // A fragments are read TWO tiles ahead of their MFMAs (LDS latency under 4-wave load is ~250-300 cycles > one tile)
   uint4 ah = a[0], al = a[(PP::NP - 1) * 64];
+  uint4 bh = ah, bl = al;
+  if constexpr (NT > 1) { bh = a[(1 * PP::NP) * 64]; bl = a[(1 * PP::NP + PP::NP - 1) * 64]; }
 #define RNERF_TILE(T)                                                                                     \
   if constexpr (T < NT) {                                                                                 \
     uint4 nh = ah, nl = al;                                                                               \
-    if constexpr (T + 1 < NT) { nh = a[((T + 1) * PP::NP) * 64]; nl = a[((T + 1) * PP::NP + PP::NP - 1) * 64]; } \
-    tile_mfma<PREC, FIRST, (T & 7), W>(acc0[T], acc1[T], ah, al, b, work);                                \
-    ah = nh; al = nl;                                                                                     \
+    if constexpr (T + 2 < NT && !NOREAD) { nh = a[((T + 2) * PP::NP) * 64]; nl = a[((T + 2) * PP::NP + PP::NP - 1) * 64]; } \
+    if constexpr (SINK) { tile_mfma<PREC, FIRST, (T & 7), W>(acc0[T], acc1[T], b.h0, b.l0, b, work); asm volatile("" :: "v"(ah.x), "v"(ah.y), "v"(ah.z), "v"(ah.w), "v"(al.x), "v"(al.y), "v"(al.z), "v"(al.w)); } \
+    else tile_mfma<PREC, FIRST, (T & 7), W>(acc0[T], acc1[T], ah, al, b, work);                           \
+    ah = bh; al = bl; bh = nh; bl = nl;                                                                   \
   }
-  RNERF_TILE(0) RNERF_TILE(1) RNERF_TILE(2) RNERF_TILE(3) RNERF_TILE(4) RNERF_TILE(5) RNERF_TILE(6) RNERF_TILE(7)
+  RNERF_TILE(0) RNERF_TILE(1)
+  dma();
+  RNERF_TILE(2) RNERF_TILE(3) RNERF_TILE(4) RNERF_TILE(5) RNERF_TILE(6) RNERF_TILE(7)
 #undef RNERF_TILE
 }
 
@@ -475,16 +499,17 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
       {                                                                                                              \
         float bnn[8];                                                                                                \
         if constexpr (S + 2 < 16) load_bias8(S + 2, bias, bnn);   /* consumed in the NEXT slab */                     \
-        SLAB_PREFETCH(true);                                                                                         \
+        auto dma = [&]() { SLAB_PREFETCH(true); };                                                                   \
         if constexpr (S + 1 < 16) {                                                                                  \
           PrevConv<PREC, S + 1> cv(prev0[(S + 1) >> 1]);                                                             \
           cv.floor_v = 0.f;                                                                                          \
           _Pragma("unroll") for (int j = 0; j < 8; ++j) cv.b[j] = bnext[j];                                          \
           load_state8(S + 1, cv.v1);                                                                                 \
-          if (!(dbg & 2)) kstep_mfma<PREC, 8, 0, S == 0>(acc0, acc1, cur, smem + buf * SLAB, lane, cv);              \
-          cur = cv.result();                                                                                         \
+          if (dbg & 8) { kstep_mfma<PREC, 8, 0, S == 0, NoWork, (dbg & 16) != 0>(acc0, acc1, cur, smem + buf * SLAB, lane, nowork, dma); } \
+          else { if (!(dbg & 2)) kstep_mfma<PREC, 8, 0, S == 0, PrevConv<PREC, S + 1>, (dbg & 16) != 0, (dbg & 32) != 0>(acc0, acc1, cur, smem + buf * SLAB, lane, cv, dma);              \
+          cur = cv.result(); }                                                                                       \
         } else {                                                                                                     \
-          if (!(dbg & 2)) kstep_mfma<PREC, 8, 0, false>(acc0, acc1, cur, smem + buf * SLAB, lane, nowork);           \
+          if (!(dbg & 2)) kstep_mfma<PREC, 8, 0, false>(acc0, acc1, cur, smem + buf * SLAB, lane, nowork, dma);      \
         }                                                                                                            \
         if constexpr (S + 2 < 16) { _Pragma("unroll") for (int j = 0; j < 8; ++j) bnext[j] = bnn[j]; }               \
         SLAB_DONE();                                                                                                 \
@@ -748,6 +773,11 @@ static int launch_fwd(const void* packed, const float* rows_pd, const float* row
     case 3: return launch_fwd_dbg<PREC, 3>(packed, rows_pd, rows_dr, node_of_sample, B, total_rows, out_raw, st);
     case 4: return launch_fwd_dbg<PREC, 4>(packed, rows_pd, rows_dr, node_of_sample, B, total_rows, out_raw, st);
     case 5: return launch_fwd_dbg<PREC, 5>(packed, rows_pd, rows_dr, node_of_sample, B, total_rows, out_raw, st);
+    case 8: return launch_fwd_dbg<PREC, 8>(packed, rows_pd, rows_dr, node_of_sample, B, total_rows, out_raw, st);
+    case 13: return launch_fwd_dbg<PREC, 13>(packed, rows_pd, rows_dr, node_of_sample, B, total_rows, out_raw, st);
+    case 16: return launch_fwd_dbg<PREC, 16>(packed, rows_pd, rows_dr, node_of_sample, B, total_rows, out_raw, st);
+    case 32: return launch_fwd_dbg<PREC, 32>(packed, rows_pd, rows_dr, node_of_sample, B, total_rows, out_raw, st);
+    case 29: return launch_fwd_dbg<PREC, 29>(packed, rows_pd, rows_dr, node_of_sample, B, total_rows, out_raw, st);
     default: break;
   }
 #endif
