@@ -123,10 +123,10 @@ int rnerf_composite(const float* raw, const float* rows_pd, const float* rows_dr
  * float[num_fine][B] if u_per_ray else float[num_fine] shared by all rays (randomized=False: linspace(0, 1-eps32, F),
  * rnerf/model_utils.py:355-356).  u must be non-decreasing along the sample axis (true for both reference branches).
  * Outputs (S+num_fine rows per ray, sample-major): rows_pd/rows_dr records, node_idx (nullable) int32[S+F][B]
- * the searchsorted node index (bit-exact contract). */
+ * the searchsorted node index (bit-exact contract).  scratch: float[S+num_fine][B] (the merged depths). */
 int rnerf_resample(const float* path_pd, const float* path_dr, int32_t num_nodes, int32_t B, const int32_t* jitter,
                    int32_t S, const float* weights, const float* u, int32_t u_per_ray, int32_t num_fine, float* rows_pd,
-                   float* rows_dr, int32_t* node_idx, void* stream);
+                   float* rows_dr, int32_t* node_idx, float* scratch, void* stream);
 
 #ifdef __cplusplus
 }

@@ -76,34 +76,46 @@ __global__ void __launch_bounds__(64) composite_kernel(const float4* __restrict_
   trans_bkgd_out[3 * r] = fmul(Tl, br); trans_bkgd_out[3 * r + 1] = fmul(Tl, bg); trans_bkgd_out[3 * r + 2] = fmul(Tl, bb);
 }
 
-// sorted_piecewise_constant_pdf + sort + searchsorted + gather as one forward walk per ray.
-//   bins  = mids of the S coarse depths (S-1 values), weights = w[1..S-2] (S-2 values)         models.py:371-374
-//   cdf   = [0, min(1, cumsum(pdf[:-1])), 1]  (S-1 values)                                      model_utils.py:335-340
-//   i*(u) = #(cdf <= u) - 1 ; sample = bins[i*] + clip((u-cdf[i*])/(cdf[i*+1]-cdf[i*]),0,1)*(bins[i*+1]-bins[i*])
-// u must be non-decreasing along the sample axis of each ray (true for both branches at :345-356), which makes the
-// samples non-decreasing, so jnp.sort(concat(coarse, fine)) (:405) is a two-way merge and searchsorted(left) into the
-// node depths (:415-421) is a third forward pointer.
-__global__ void __launch_bounds__(64) resample_kernel(const float4* __restrict__ path_pd, const float4* __restrict__ path_dr,
-                                                      int num_nodes, int B, const int* __restrict__ jitter, int S,
-                                                      const float* __restrict__ weights, const float* __restrict__ u,
-                                                      int u_per_ray, int F, float4* __restrict__ rows_pd,
-                                                      float4* __restrict__ rows_dr, int* __restrict__ node_idx) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= B) return;
+// Resampling = two kernels.
+//  (1) resample_depths_kernel, one lane per ray: sorted_piecewise_constant_pdf + jnp.sort(concat(coarse, fine)).
+//        bins  = mids of the S coarse depths (S-1 values), weights = w[1..S-2] (S-2 values)         models.py:371-374
+//        cdf   = [0, min(1, cumsum(pdf[:-1])), 1]  (S-1 values)                                      model_utils.py:335-340
+//        i*(u) = #(cdf <= u) - 1 ; sample = bins[i*] + clip((u-cdf[i*])/(cdf[i*+1]-cdf[i*]),0,1)*(bins[i*+1]-bins[i*])
+//      u must be non-decreasing along the sample axis of each ray (true for both branches at :345-356), which makes the
+//      samples non-decreasing, so the sort (:405) is a two-way merge of two sorted sequences.  The ray's coarse depths
+//      and weights are first staged into LDS with independent (pipelined) loads; the serial walk then runs out of LDS.
+//  (2) resample_gather_kernel, one lane per (sample, ray): searchsorted(z_vals, z, 'left') into the N node depths
+//      (:415-421) from an arithmetic guess + gallop + bisection (node depths are near + ~k*step), then the gather
+//      pos = path_pos[idx] + dir[idx]*(z - z_vals[idx]) (:423-427).  Neighbouring lanes = neighbouring rays at the same
+//      sample index, whose node indices nearly coincide, so the probes and gathers of a wave are near-contiguous.
+__global__ void __launch_bounds__(64) resample_depths_kernel(const float4* __restrict__ path_pd, int B,
+                                                             const int* __restrict__ jitter, int S,
+                                                             const float* __restrict__ weights, const float* __restrict__ u,
+                                                             int u_per_ray, int F, float* __restrict__ zbuf) {
+  extern __shared__ float lds[];                 // [2][S][64]: coarse depths, coarse weights
+  const int lane = threadIdx.x;
+  const int r0 = blockIdx.x * 64 + lane;
+  const int r = r0 < B ? r0 : B - 1;
+  float* s_tc = lds + lane;                      // + i*64
+  float* s_w = lds + (size_t)S * 64 + lane;
+  for (int i = 0; i < S; ++i) {
+    s_tc[i * 64] = path_pd[(size_t)jitter[i] * B + r].w;
+    s_w[i * 64] = weights[(size_t)i * B + r];
+  }
+  if (r0 >= B) return;
   const int nb = S - 1;        // number of bin edges / cdf entries
   const int nw = S - 2;        // number of weights
   // weight_sum, padding (model_utils.py:327-331)
   float wsum = 0.f;
-  for (int i = 0; i < nw; ++i) wsum = fadd(wsum, weights[(size_t)(i + 1) * B + r]);
+  for (int i = 0; i < nw; ++i) wsum = fadd(wsum, s_w[(i + 1) * 64]);
   const float padding = fmaxf(0.f, fsub(1e-5f, wsum));
   const float padw = fdiv(padding, (float)nw);
   wsum = fadd(wsum, padding);
-  auto tc = [&](int i) -> float { return path_pd[(size_t)jitter[i] * B + r].w; };
+  auto tc = [&](int i) -> float { return s_tc[i * 64]; };
   auto cdf_at = [&](int k, float cumsum) -> float { return k == 0 ? 0.f : (k == nb - 1 ? 1.f : fminf(1.f, cumsum)); };
-  // walk state of the inverse CDF: interval i, cum = cumsum(pdf[0..i-1]) (valid for entry i), cdf entries c0=cdf[i], c1=cdf[i+1]
+  // walk state of the inverse CDF: interval i, c0 = cdf[i], c1 = cdf[i+1], cum_n = cumsum(pdf[0..i])
   int i = 0;
-  float cum_i = 0.f;                                  // cumsum up to entry i
-  float cum_n = fdiv(fadd(weights[(size_t)1 * B + r], padw), wsum);   // cumsum up to entry i+1 = pdf[0]
+  float cum_n = fdiv(fadd(s_w[64], padw), wsum);
   float c0 = 0.f, c1 = cdf_at(1, cum_n);
   float tca = tc(0), tcb = tc(1), tcc = (nb > 1) ? tc(2) : tcb;
   float b0 = fmul(0.5f, fadd(tcb, tca));              // mids (models.py:371): .5*(t[1:] + t[:-1])
@@ -112,8 +124,8 @@ __global__ void __launch_bounds__(64) resample_kernel(const float4* __restrict__
     const float uj = u_per_ray ? u[(size_t)j * B + r] : u[j];
     while (c1 <= uj && i < nb - 2) {                  // advance to the last entry with cdf <= u
       ++i;
-      c0 = c1; cum_i = cum_n;
-      if (i + 1 < nb - 1) cum_n = fadd(cum_n, fdiv(fadd(weights[(size_t)(i + 1) * B + r], padw), wsum));
+      c0 = c1;
+      if (i + 1 < nb - 1) cum_n = fadd(cum_n, fdiv(fadd(s_w[(i + 1) * 64], padw), wsum));
       c1 = cdf_at(i + 1, cum_n);
       tca = tcb; tcb = tcc; tcc = (i + 2 < S) ? tc(i + 2) : tcc;
       b0 = b1; b1 = fmul(0.5f, fadd(tcc, tcb));
@@ -123,28 +135,62 @@ __global__ void __launch_bounds__(64) resample_kernel(const float4* __restrict__
     t = fminf(fmaxf(t, 0.f), 1.f);
     return fadd(b0, fmul(t, fsub(b1, b0)));
   };
-  (void)cum_i;
-  int ic = 0, jf = 0, p = 0;
+  int ic = 0, jf = 0;
   float zc = tc(0);
   float zf = (F > 0) ? fine_at(0) : 0.f;
-  float pdist = path_pd[r].w;                         // depth of node p (p = 0)
   const int total = S + F;
   for (int q = 0; q < total; ++q) {
     float z;
     const bool take_c = (jf >= F) || (ic < S && zc <= zf);
     if (take_c) { z = zc; ++ic; if (ic < S) zc = tc(ic); }
     else { z = zf; ++jf; if (jf < F) zf = fine_at(jf); }
-    // searchsorted(z_vals, z, 'left') = #(node depth < z); idx = max(that - 1, 0)  (model_utils.py:415-421)
-    while (p < num_nodes && pdist < z) { ++p; if (p < num_nodes) pdist = path_pd[(size_t)p * B + r].w; }
-    const int idx = p > 0 ? p - 1 : 0;
-    const float4 pd = path_pd[(size_t)idx * B + r];
-    const float4 dr = path_dr[(size_t)idx * B + r];
-    const float dz = fsub(z, pd.w);
-    const size_t o = (size_t)q * B + r;
-    rows_pd[o] = make_float4(fadd(pd.x, fmul(dr.x, dz)), fadd(pd.y, fmul(dr.y, dz)), fadd(pd.z, fmul(dr.z, dz)), z);
-    rows_dr[o] = dr;
-    if (node_idx) node_idx[o] = idx;
+    zbuf[(size_t)q * B + r] = z;
   }
+}
+
+__global__ void __launch_bounds__(256) resample_gather_kernel(const float4* __restrict__ path_pd, const float4* __restrict__ path_dr,
+                                                              int N, int B, const float* __restrict__ zbuf, long long total,
+                                                              float4* __restrict__ rows_pd, float4* __restrict__ rows_dr,
+                                                              int* __restrict__ node_idx) {
+  const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= total) return;
+  const int r = (int)(o % B);
+  const float z = zbuf[o];
+  auto D = [&](int k) -> float { return path_pd[(size_t)k * B + r].w; };
+  const float d0 = D(0), dl = D(N - 1);
+  const float inv_step = (float)(N - 1) / fmaxf(dl - d0, 1e-30f);
+  float gf = (z - d0) * inv_step + 1.0f;
+  gf = fminf(fmaxf(gf, 0.f), (float)N);
+  const int c = (int)gf;
+  // p = #(node depth < z) = smallest p in [0, N] with p == N or D(p) >= z
+  int lo = 0, hi = N;
+  if (c < N && D(c) < z) {
+    lo = c + 1;
+    int st = 1;
+    while (lo < N) {
+      const int t = lo + st - 1 < N - 1 ? lo + st - 1 : N - 1;
+      if (D(t) < z) { lo = t + 1; st <<= 1; } else { hi = t; break; }
+    }
+  } else {
+    hi = c;
+    int st = 1;
+    while (hi > 0) {
+      const int t = hi - st > 0 ? hi - st : 0;
+      if (D(t) >= z) { hi = t; st <<= 1; } else { lo = t + 1; break; }
+    }
+    if (hi == 0) lo = 0;
+  }
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (D(mid) < z) lo = mid + 1; else hi = mid;
+  }
+  const int idx = lo > 0 ? lo - 1 : 0;                  // y = hstack([y[0], y, y[-1]])[j] -> max(j-1, 0)
+  const float4 pd = path_pd[(size_t)idx * B + r];
+  const float4 dr = path_dr[(size_t)idx * B + r];
+  const float dz = fsub(z, pd.w);
+  rows_pd[o] = make_float4(fadd(pd.x, fmul(dr.x, dz)), fadd(pd.y, fmul(dr.y, dz)), fadd(pd.z, fmul(dr.z, dz)), z);
+  rows_dr[o] = dr;
+  if (node_idx) node_idx[o] = idx;
 }
 
 }  // namespace rnerf
@@ -168,15 +214,26 @@ extern "C" int rnerf_composite(const float* raw, const float* rows_pd, const flo
 
 extern "C" int rnerf_resample(const float* path_pd, const float* path_dr, int32_t num_nodes, int32_t B,
                               const int32_t* jitter, int32_t S, const float* weights, const float* u, int32_t u_per_ray,
-                              int32_t num_fine, float* rows_pd, float* rows_dr, int32_t* node_idx, void* stream) {
-  RNERF_CHECK_ARG(path_pd && path_dr && jitter && weights && rows_pd && rows_dr, "rnerf_resample: null pointer");
+                              int32_t num_fine, float* rows_pd, float* rows_dr, int32_t* node_idx, float* scratch,
+                              void* stream) {
+  RNERF_CHECK_ARG(path_pd && path_dr && jitter && weights && rows_pd && rows_dr && scratch, "rnerf_resample: null pointer");
   RNERF_CHECK_ARG(u || num_fine == 0, "rnerf_resample: u must be given (use linspace(0,1-eps,F) for randomized=False)");
-  RNERF_CHECK_ARG(S >= 3 && B >= 1 && num_nodes >= 1 && num_fine >= 0, "rnerf_resample: need S >= 3, B >= 1");
+  RNERF_CHECK_ARG(S >= 3 && B >= 1 && num_nodes >= 2 && num_fine >= 0, "rnerf_resample: need S >= 3, B >= 1, num_nodes >= 2");
+  RNERF_CHECK_ARG(S <= 320, "rnerf_resample: S > 320 coarse samples do not fit the 160 KiB LDS staging");
   RNERF_CHECK_ARG((((uintptr_t)path_pd | (uintptr_t)path_dr | (uintptr_t)rows_pd | (uintptr_t)rows_dr) & 15) == 0,
                   "rnerf_resample: float4 buffers must be 16-byte aligned");
-  hipLaunchKernelGGL(resample_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const float4*)path_pd,
-                     (const float4*)path_dr, num_nodes, B, jitter, S, weights, u, u_per_ray, num_fine, (float4*)rows_pd,
-                     (float4*)rows_dr, node_idx);
+  hipStream_t st = (hipStream_t)stream;
+  const size_t lds = (size_t)2 * S * 64 * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    RNERF_CHECK_HIP(hipFuncSetAttribute((const void*)resample_depths_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(resample_depths_kernel, dim3((B + 63) / 64), dim3(64), lds, st, (const float4*)path_pd, B, jitter, S, weights, u,
+                     u_per_ray, num_fine, scratch);
+  const long long total = (long long)(S + num_fine) * B;
+  hipLaunchKernelGGL(resample_gather_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float4*)path_pd,
+                     (const float4*)path_dr, num_nodes, B, scratch, total, (float4*)rows_pd, (float4*)rows_dr, node_idx);
   RNERF_CHECK_LAUNCH();
   return RNERF_OK;
 }

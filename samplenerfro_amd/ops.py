@@ -156,6 +156,7 @@ def resample(path_pd: torch.Tensor, path_dr: torch.Tensor, jitter: torch.Tensor,
     rows_pd = torch.empty((T, B, 4), dtype=torch.float32, device=dev)
     rows_dr = torch.empty((T, B, 4), dtype=torch.float32, device=dev)
     idx = torch.empty((T, B), dtype=torch.int32, device=dev) if want_idx else None
+    scratch = torch.empty((T, B), dtype=torch.float32, device=dev)
     check(lib.rnerf_resample(ptr(path_pd), ptr(path_dr), int(N), int(B), ptr(jitter), int(S), ptr(weights), ptr(u), per_ray,
-                             int(num_fine), ptr(rows_pd), ptr(rows_dr), ptr(idx), current_stream()), "rnerf_resample")
+                             int(num_fine), ptr(rows_pd), ptr(rows_dr), ptr(idx), ptr(scratch), current_stream()), "rnerf_resample")
     return rows_pd, rows_dr, idx
