@@ -108,9 +108,8 @@ def main():
         raise SystemExit("bench.py needs a ROCm GPU (the hot path has no CPU implementation)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+    from samplenerfro_amd import distributed as D
+    D.init("nccl")   # one process per GPU, RCCL; only used for the timing barrier and the max over ranks
 
     cfg = dict(syn.CONFIGS[args.workload])
     fine = cfg["F"] if args.fine is None else args.fine
@@ -137,10 +136,7 @@ def main():
         ret, _ = step()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    dt = D.max_over_ranks(dt, device)
     assert torch.isfinite(ret[-1][0]).all()
 
     # ---- per-kernel roofline of the dominant kernel (PE + NerfMLP), HIP events on the launch stream --------------------
@@ -174,6 +170,16 @@ def main():
     march_bytes = B * (N * 128 + 24)
     march_achieved = march_bytes / (march_ms * 1e-3)
 
+    # HBM bytes per launch from the committed rocprofv3 --pmc passes of this very command (profiles/);
+    # PMC counters cannot be collected from inside the process, so `traffic` is null when no matching profile exists.
+    traffic = {}
+    try:
+        if args.workload == "ship_straight" and fine == 0 and B == 4096:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01", "b_pmc_hbm_traffic.json")))["counters"]
+            for k, v in pm.items():
+                traffic[k.split("::")[-1].split("<")[0]] = 1024.0 * (v["FETCH_SIZE"]["mean"] + v["WRITE_SIZE"]["mean"])
+    except Exception:
+        traffic = {}
     if rank == 0:
         total_rays = B * args.steps * world
         rows_per_ray = S + (S + fine if fine > 0 else 0)
@@ -185,11 +191,11 @@ def main():
                                    f"P={cfg['P']} (N={N} eikonal steps), grid {cfg['G']}^3", "rays_per_gpu": B,
                        "mlp_rows_per_ray": rows_per_ray, "precision": args.precision, "pass": "forward"},
             "roofline": {"kernel": "nerfmlp_fwd_kernel", "bound": "mfma", "achieved": mlp_achieved / 1e12, "peak": PEAK_MFMA_16BIT / 1e12,
-                         "unit": "TFLOP/s", "frac": mlp_achieved / PEAK_MFMA_16BIT, "traffic": None,
+                         "unit": "TFLOP/s", "frac": mlp_achieved / PEAK_MFMA_16BIT, "traffic": traffic.get("nerfmlp_fwd_kernel"),
                          "avg_launch_ms": mlp_ms, "algorithmic_flop_per_launch": mlp_flops,
                          "mfma_issue_frac": (3 if "x3" in args.precision else 1) * mlp_achieved / PEAK_MFMA_16BIT},
             "roofline_march": {"kernel": "march_kernel", "bound": "hbm", "achieved": march_achieved / 1e9, "peak": PEAK_HBM / 1e9,
-                               "unit": "GB/s", "frac": march_achieved / PEAK_HBM, "traffic": None, "avg_launch_ms": march_ms,
+                               "unit": "GB/s", "frac": march_achieved / PEAK_HBM, "traffic": traffic.get("march_kernel"), "avg_launch_ms": march_ms,
                                "algorithmic_bytes_per_launch": march_bytes},
         }
         if not args.no_cpu_baseline:
