@@ -89,6 +89,11 @@ int rnerf_march(const float* table, const rnerf_grid* g, const float* origins, c
                 double near, double far, int32_t num_nodes, float* path_pd, float* path_dr, float* path_ior,
                 int32_t* vox, void* stream);
 
+/* Cap the persistent grid of rnerf_nerfmlp_forward at n workgroups (0 = one per CU).  The MLP kernel owns a whole CU
+ * (512 VGPRs, 160 KiB LDS); leaving a few CUs free lets the latency-bound march of the NEXT ray batch run concurrently
+ * on another stream.  Process-wide setting. */
+int rnerf_set_mlp_workgroup_limit(int n);
+
 /* ---- N1 weights: pack a flat fp32 NerfMLP parameter buffer into the MFMA operand stream of `precision`. */
 size_t rnerf_nerfmlp_packed_bytes(int precision);
 int rnerf_nerfmlp_pack(const float* params, int precision, void* packed, void* stream);

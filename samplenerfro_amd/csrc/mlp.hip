@@ -331,21 +331,29 @@ struct NoDma { __device__ __forceinline__ void operator()() const {} };
 
 // `dma` is invoked after tile 1: the weight DMA of the next slab is issued while MFMAs are already in the matrix pipe and
 // the A fragments of tiles 0..3 are already on their way (an LDS-DMA instruction costs ~100 issue cycles).
-template <int PREC, int NT, int KOFF, bool FIRST, typename W, bool NOREAD = false, bool SINK = false, typename D = NoDma>
+// A fragments are read FRAG_DEPTH tiles ahead of their MFMAs: with one wave per SIMD the LDS read rate is set by the
+// number of reads in flight (latency x concurrency), not by the 256 B/clk peak.
+constexpr int FRAG_DEPTH = 4;
+
+template <int PREC, int NT, int KOFF, bool FIRST, typename W, bool NOREAD = false, typename D = NoDma>
 __device__ __forceinline__ void kstep_mfma(f32x16 (&acc0)[8], f32x16 (&acc1)[8], const KOps& b, const char* slab, int lane, W& work, D dma = D()) {
   using PP = Prec<PREC>;
   const uint4* a = (const uint4*)slab + lane + (size_t)KOFF * NT * PP::NP * 64;
-  // A fragments are read TWO tiles ahead of their MFMAs (LDS latency under 4-wave load is ~250-300 cycles > one tile)
-  uint4 ah = a[0], al = a[(PP::NP - 1) * 64];
-  uint4 bh = ah, bl = al;
-  if constexpr (NT > 1) { bh = a[(1 * PP::NP) * 64]; bl = a[(1 * PP::NP + PP::NP - 1) * 64]; }
+  uint4 fh[FRAG_DEPTH], fl[FRAG_DEPTH];
+#pragma unroll
+  for (int t = 0; t < FRAG_DEPTH; ++t) {
+    const int tt = t < NT ? t : NT - 1;
+    fh[t] = a[(tt * PP::NP) * 64];
+    fl[t] = a[(tt * PP::NP + PP::NP - 1) * 64];
+  }
 #define RNERF_TILE(T)                                                                                     \
   if constexpr (T < NT) {                                                                                 \
-    uint4 nh = ah, nl = al;                                                                               \
-    if constexpr (T + 2 < NT && !NOREAD) { nh = a[((T + 2) * PP::NP) * 64]; nl = a[((T + 2) * PP::NP + PP::NP - 1) * 64]; } \
-    if constexpr (SINK) { tile_mfma<PREC, FIRST, (T & 7), W>(acc0[T], acc1[T], b.h0, b.l0, b, work); asm volatile("" :: "v"(ah.x), "v"(ah.y), "v"(ah.z), "v"(ah.w), "v"(al.x), "v"(al.y), "v"(al.z), "v"(al.w)); } \
-    else tile_mfma<PREC, FIRST, (T & 7), W>(acc0[T], acc1[T], ah, al, b, work);                           \
-    ah = bh; al = bl; bh = nh; bl = nl;                                                                   \
+    const uint4 ah = fh[T % FRAG_DEPTH], al = fl[T % FRAG_DEPTH];                                         \
+    tile_mfma<PREC, FIRST, (T & 7), W>(acc0[T], acc1[T], ah, al, b, work);                                \
+    if constexpr (T + FRAG_DEPTH < NT && !NOREAD) {                                                       \
+      fh[T % FRAG_DEPTH] = a[((T + FRAG_DEPTH) * PP::NP) * 64];                                           \
+      fl[T % FRAG_DEPTH] = a[((T + FRAG_DEPTH) * PP::NP + PP::NP - 1) * 64];                              \
+    }                                                                                                     \
   }
   RNERF_TILE(0) RNERF_TILE(1)
   dma();
@@ -379,6 +387,8 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
   const float NEG_INF = -__builtin_inff();
   int buf = 0;
   size_t off = 0;   // stream offset of the next slab to prefetch
+  float prof_dma = 0.f, prof_bar = 0.f, prof_tot = 0.f, prof_n = 0.f;
+  unsigned long long prof_last = __builtin_amdgcn_s_memtime();
 
   if ((int)blockIdx.x < n_tiles) { if (!(dbg & 1)) issue_slab<SLAB>(packed, 0u, wave, lane); off = SLAB; }
   slab_wait_dma();
@@ -458,7 +468,19 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
 #define SLAB_PREFETCH(DO_NEXT)                                                                                       \
   do { if (DO_NEXT) { if (!(dbg & 1)) issue_slab<SLAB>(packed + off, (unsigned)((buf ^ 1) * SLAB), wave, lane); off += SLAB; } } while (0)
 #define SLAB_DONE()                                                                                                  \
-  do { slab_wait_dma(); if (!(dbg & 4)) __syncthreads(); buf ^= 1; } while (0)
+  do {                                                                                                               \
+    if constexpr ((dbg & 64) != 0) {   /* profiling: where does a slab's time go (shader clocks, summed per wave) */   \
+      const unsigned long long ta = __builtin_amdgcn_s_memtime();                                                    \
+      slab_wait_dma();                                                                                               \
+      const unsigned long long tb = __builtin_amdgcn_s_memtime();                                                    \
+      __syncthreads();                                                                                               \
+      const unsigned long long tc2 = __builtin_amdgcn_s_memtime();                                                   \
+      prof_dma += (float)(tb - ta); prof_bar += (float)(tc2 - tb); prof_tot += (float)(tc2 - prof_last); prof_last = tc2; prof_n += 1.f; \
+    } else {                                                                                                         \
+      slab_wait_dma(); if (!(dbg & 4)) __syncthreads();                                                              \
+    }                                                                                                                \
+    buf ^= 1;                                                                                                        \
+  } while (0)
 
     // end of a 256-wide layer: m-tile 0 outputs stay in registers (prev0), m-tile 1 outputs go to this wave's LDS region
     auto layer_end = [&]() {
@@ -506,7 +528,7 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
           _Pragma("unroll") for (int j = 0; j < 8; ++j) cv.b[j] = bnext[j];                                          \
           load_state8(S + 1, cv.v1);                                                                                 \
           if (dbg & 8) { kstep_mfma<PREC, 8, 0, S == 0, NoWork, (dbg & 16) != 0>(acc0, acc1, cur, smem + buf * SLAB, lane, nowork, dma); } \
-          else { if (!(dbg & 2)) kstep_mfma<PREC, 8, 0, S == 0, PrevConv<PREC, S + 1>, (dbg & 16) != 0, (dbg & 32) != 0>(acc0, acc1, cur, smem + buf * SLAB, lane, cv, dma);              \
+          else { if (!(dbg & 2)) kstep_mfma<PREC, 8, 0, S == 0, PrevConv<PREC, S + 1>, (dbg & 16) != 0, decltype(dma)>(acc0, acc1, cur, smem + buf * SLAB, lane, cv, dma);              \
           cur = cv.result(); }                                                                                       \
         } else {                                                                                                     \
           if (!(dbg & 2)) kstep_mfma<PREC, 8, 0, false>(acc0, acc1, cur, smem + buf * SLAB, lane, nowork, dma);      \
@@ -607,6 +629,9 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
     }
 #undef SLAB_PREFETCH
 #undef SLAB_DONE
+  }
+  if constexpr ((dbg & 64) != 0) {
+    if (lane == 0) out_raw[blockIdx.x * 4 + wave] = make_float4(prof_tot, prof_dma, prof_bar, prof_n);
   }
 }
 
@@ -727,6 +752,14 @@ using namespace rnerf;
 
 static bool prec_ok(int p) { return p == RNERF_PREC_F16X3 || p == RNERF_PREC_BF16X3 || p == RNERF_PREC_F16 || p == RNERF_PREC_BF16; }
 
+static int g_mlp_wg_limit = 0;   // 0 = one workgroup per CU
+
+extern "C" int rnerf_set_mlp_workgroup_limit(int n) {
+  RNERF_CHECK_ARG(n >= 0, "rnerf_set_mlp_workgroup_limit: n must be >= 0");
+  g_mlp_wg_limit = n;
+  return RNERF_OK;
+}
+
 extern "C" size_t rnerf_nerfmlp_packed_bytes(int precision) {
   switch (precision) {
     case RNERF_PREC_F16X3: return Prec<RNERF_PREC_F16X3>::PACKED_BYTES;
@@ -776,6 +809,9 @@ static int launch_fwd(const void* packed, const float* rows_pd, const float* row
     case 8: return launch_fwd_dbg<PREC, 8>(packed, rows_pd, rows_dr, node_of_sample, B, total_rows, out_raw, st);
     case 13: return launch_fwd_dbg<PREC, 13>(packed, rows_pd, rows_dr, node_of_sample, B, total_rows, out_raw, st);
     case 16: return launch_fwd_dbg<PREC, 16>(packed, rows_pd, rows_dr, node_of_sample, B, total_rows, out_raw, st);
+    case 48: return launch_fwd_dbg<PREC, 48>(packed, rows_pd, rows_dr, node_of_sample, B, total_rows, out_raw, st);
+    case 128: return launch_fwd_dbg<PREC, 128>(packed, rows_pd, rows_dr, node_of_sample, B, total_rows, out_raw, st);
+    case 64: return launch_fwd_dbg<PREC, 64>(packed, rows_pd, rows_dr, node_of_sample, B, total_rows, out_raw, st);
     case 32: return launch_fwd_dbg<PREC, 32>(packed, rows_pd, rows_dr, node_of_sample, B, total_rows, out_raw, st);
     case 29: return launch_fwd_dbg<PREC, 29>(packed, rows_pd, rows_dr, node_of_sample, B, total_rows, out_raw, st);
     default: break;
@@ -792,7 +828,8 @@ static int launch_fwd_dbg(const void* packed, const float* rows_pd, const float*
   int dev = 0, cus = 0;
   RNERF_CHECK_HIP(hipGetDevice(&dev));
   RNERF_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-  const int grid = n_tiles < cus ? n_tiles : cus;
+  const int lim = (g_mlp_wg_limit > 0 && g_mlp_wg_limit < cus) ? g_mlp_wg_limit : cus;
+  const int grid = n_tiles < lim ? n_tiles : lim;
   const size_t lds = 2 * (size_t)PP::SLAB + 4 * 32768;
   static bool attr_set = false;
   if (!attr_set) {

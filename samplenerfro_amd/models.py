@@ -111,6 +111,7 @@ class NerfModel:
         self._packed: Dict[str, Tuple[int, int, torch.Tensor]] = {}
         self._jit_cache: Dict[bytes, torch.Tensor] = {}
         self._u_lin: Optional[torch.Tensor] = None
+        self._side: Optional[torch.cuda.Stream] = None
 
     # ---- parameters -------------------------------------------------------------------------------------------------------
     def init(self, key, **unused) -> Dict[str, Any]:
@@ -175,6 +176,29 @@ class NerfModel:
         u = np.minimum(u, np.float32(1.0 - eps)).astype(np.float32)
         return torch.from_numpy(np.ascontiguousarray(u.T)).to(self.device)
 
+    # ---- cross-batch pipelining ---------------------------------------------------------------------------------------------
+    def prefetch_path(self, rays: Rays, sync_inputs: bool = True, reserve_cus: int = 32) -> "PathHandle":
+        """March `rays` on a side stream so that it overlaps the MLP phase of the batch currently in flight.
+
+        The march is a latency-bound dependent gather chain (256 waves at B = 4096) and needs no matrix core; the MLP
+        kernel is MFMA-bound and owns whole CUs.  `reserve_cus` CUs are kept free of MLP workgroups so both can run at
+        once.  Pass the handle to `apply(..., path=handle)` (same rays).  sync_inputs=False skips the wait on the current
+        stream when the ray tensors are known to be complete already (e.g. slices of a resident image)."""
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+            lib = _lib.load()
+            cus = lib.rnerf_device_cus()
+            _lib.check(lib.rnerf_set_mlp_workgroup_limit(max(cus - int(reserve_cus), 1)), "rnerf_set_mlp_workgroup_limit")
+        cur = torch.cuda.current_stream()
+        if sync_inputs:
+            self._side.wait_stream(cur)
+        with torch.cuda.stream(self._side):
+            pd, dr, ior, _ = ops.march(self.table, self.spec, rays.origins, rays.viewdirs, self.near, self.far,
+                                       self.num_samples, want_ior=self.use_online_sparsity)
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+        return PathHandle(pd, dr, ior, ev, rays.origins.shape[0])
+
     # ---- forward ------------------------------------------------------------------------------------------------------------
     def apply(self, variables, *args, method=None, **kwargs):
         """flax-style entry: model.apply(variables, rng_0, rng_1, rays, randomized[, annealed_alpha]) or
@@ -184,7 +208,8 @@ class NerfModel:
         return self.forward(variables, *args, **kwargs)
 
     def forward(self, variables, rng_0, rng_1, rays: Rays, randomized: bool, annealed_alpha: float = 1.0, *,
-                jitter=None, u_fine: Optional[torch.Tensor] = None, taps: Optional[dict] = None):
+                jitter=None, u_fine: Optional[torch.Tensor] = None, taps: Optional[dict] = None,
+                path: Optional["PathHandle"] = None):
         """NerfModel.__call__ (rnerf/models.py:220-535)."""
         origins, viewdirs = rays.origins, rays.viewdirs                                   # rnerf/models.py:235-236
         if origins.dim() != 2 or origins.shape[-1] != 3:
@@ -193,8 +218,20 @@ class NerfModel:
         Nc, Nf, N = self.num_coarse_samples, self.num_fine_samples, self.num_samples
         key, rng_0 = prng.split(np.asarray(rng_0, np.uint32))
         want_ior = self.use_online_sparsity or (taps is not None)
-        path_pd, path_dr, path_ior, _ = ops.march(self.table, self.spec, origins, viewdirs, self.near, self.far, N,
-                                                  want_ior=want_ior)
+        if path is not None:
+            if path.batch != B:
+                raise ValueError("path handle was marched for a different batch size")
+            cur = torch.cuda.current_stream()
+            cur.wait_event(path.event)
+            path_pd, path_dr, path_ior = path.pd, path.dr, path.ior
+            for t in (path_pd, path_dr, path_ior):
+                if t is not None:
+                    t.record_stream(cur)
+            if want_ior and path_ior is None:
+                raise ValueError("path handle lacks the IoR record (prefetch it from a model with the same options)")
+        else:
+            path_pd, path_dr, path_ior, _ = ops.march(self.table, self.spec, origins, viewdirs, self.near, self.far, N,
+                                                      want_ior=want_ior)
         if jitter is None:
             jitter = self.make_jitter(key)
         jit = self._jitter_dev(jitter)
@@ -235,6 +272,13 @@ class NerfModel:
     def forward_envmap(self, variables, viewdirs: torch.Tensor) -> torch.Tensor:
         """rnerf/models.py:181-191: bkgd colour for arbitrary view directions [M,3] -> [M,3]."""
         return ops.bkgd_forward(self._flat(variables, "bkgd_mlp", BKGD_MLP_SHAPES).detach(), viewdirs, self.rgb_padding)
+
+
+class PathHandle:
+    """A marched path record produced on the side stream (NerfModel.prefetch_path)."""
+
+    def __init__(self, pd, dr, ior, event, batch):
+        self.pd, self.dr, self.ior, self.event, self.batch = pd, dr, ior, event, batch
 
 
 def make_variables(flat: Dict[str, torch.Tensor]) -> Dict[str, Any]:

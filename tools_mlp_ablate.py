@@ -22,3 +22,10 @@ torch.cuda.synchronize()
 ms = np.array([ev[i].elapsed_time(ev[i + 1]) for i in range(10)])
 fl = 2 * 593408 * S * B
 print(f"prec={prec} dbg={os.environ.get('RNERF_MLP_DEBUG','0')} ms(min/med)={ms.min():.3f}/{np.median(ms):.3f}  algTF/s={fl/np.median(ms)/1e9:.1f}")
+
+if os.environ.get('RNERF_MLP_DEBUG') == '64':
+    prof = out.reshape(-1, 4)[:1024].cpu().numpy()
+    n = prof[:, 3].mean()
+    print(f"slabs/wave={n:.0f}  cycles/slab total={prof[:,0].sum()/prof[:,3].sum():.0f}  dma-wait={prof[:,1].sum()/prof[:,3].sum():.0f}  barrier-wait={prof[:,2].sum()/prof[:,3].sum():.0f}")
+    w = prof.reshape(-1, 4, 4)
+    print("per-wave-slot barrier wait:", [round(float(w[:, k, 2].sum()/w[:, k, 3].sum())) for k in range(4)], " dma:", [round(float(w[:, k, 1].sum()/w[:, k, 3].sum())) for k in range(4)])
