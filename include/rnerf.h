@@ -133,6 +133,24 @@ int rnerf_resample(const float* path_pd, const float* path_dr, int32_t num_nodes
                    int32_t S, const float* weights, const float* u, int32_t u_per_ray, int32_t num_fine, float* rows_pd,
                    float* rows_dr, int32_t* node_idx, float* scratch, void* stream);
 
+/* ---- T1 (loss): the reductions of train_step.loss_fn (train.py:89-92,105) for stage "radiance*".
+ * rgb_c (nullable, N_f == 0), rgb_f: float[B][3]; trans_f: float[B]; trans_bkgd_f, pixels: float[B][3].
+ * sums: float[4] (device) = { sum (rgb_f-pix)^2, sum (rgb_c-pix)^2, sum mask*|trans_bkgd_f-pix|, sum mask },
+ * mask = trans_f > 0.5.  loss = sums0/(3B) + sums1/(3B) + bg_weight*1[alpha>0]*sums2/(sums3+1) + ... */
+int rnerf_loss_reduce(const float* rgb_c, const float* rgb_f, const float* trans_f, const float* trans_bkgd_f,
+                      const float* pixels, int32_t B, float* sums, void* stream);
+
+/* ---- T1 (backward of V1 + activations): d loss / d raw of one level, replacing jax.value_and_grad through
+ * volumetric_rendering and the rgb/sigma activations (rnerf/model_utils.py:247-309, rnerf/models.py:334-338; train.py:164).
+ * rgb: this level's comp_rgb float[B][3]; mse_scale = 2/(3B); bg_scale = bg_weight*1[annealed_alpha>0] for the level
+ * that carries loss_bg (the last one), 0 otherwise (then trans/trans_bkgd/sums may be NULL).
+ * d_raw: float4[S][B]; d_bkgd: float[B][3] gradient w.r.t. the activated background colour (accumulated if
+ * accumulate_bkgd != 0: both levels composite over the coarse pass's bkgd, rnerf/models.py:468-476). */
+int rnerf_composite_backward(const float* raw, const float* rows_pd, const float* rows_dr, const int32_t* node_of_sample,
+                             int32_t S, int32_t B, const float* bkgd, double rgb_padding, double sigma_bias, const float* rgb,
+                             const float* pixels, const float* trans, const float* trans_bkgd, const float* sums,
+                             double mse_scale, double bg_scale, float* d_raw, float* d_bkgd, int accumulate_bkgd, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

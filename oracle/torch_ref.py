@@ -1,0 +1,45 @@
+"""torch (CPU, float64) restatement of the DIFFERENTIABLE part of the path, for gradient checks (TEST INFRASTRUCTURE).
+
+Follows rnerf/models.py:334-349 (activations), rnerf/model_utils.py:247-309 (volumetric_rendering) and the radiance-stage
+terms of train.py:75-162 (loss_fn); jax.value_and_grad (train.py:164) is replaced by torch.autograd.  Parity unpinned
+(see oracle/__init__.py); validated against oracle/ref_np.py in tests/test_oracle_kat.py.
+"""
+from __future__ import annotations
+
+import torch
+
+
+def activations(raw, rgb_padding=0.001, sigma_bias=-1.0):
+    rgb = torch.sigmoid(raw[..., :3]) * (1 + 2 * rgb_padding) - rgb_padding
+    sigma = torch.nn.functional.softplus(raw[..., 3] + sigma_bias)
+    return rgb, sigma
+
+
+def volumetric_rendering(rgb, sigma, t_vals, dirs, bkgd):
+    """rgb [B,S,3], sigma [B,S], t_vals [B,S], dirs [B,S,3], bkgd [B,3] -> comp_rgb, acc, weights, trans [B,1], trans*sg(bkgd)."""
+    t_dists = torch.cat([t_vals[..., 1:] - t_vals[..., :-1], torch.full_like(t_vals[..., :1], 1e-3)], -1)
+    delta = t_dists * torch.linalg.norm(dirs, dim=-1)
+    dd = sigma * delta
+    alpha = 1 - torch.exp(-dd)
+    trans = torch.exp(-torch.cat([torch.zeros_like(dd[..., :1]), torch.cumsum(dd, -1)], -1))
+    weights = alpha * trans[..., :-1]
+    comp = (weights[..., None] * rgb).sum(-2) + trans[..., -1:] * bkgd
+    return comp, weights.sum(-1), weights, trans[..., -1:], trans[..., -1:] * bkgd.detach()
+
+
+def radiance_loss(levels, pixels, bg_weight=0.0, annealed_alpha=1.0):
+    """levels: list of (comp_rgb, trans, trans_rgb_bkgd), coarse first (train.py:87-110). Returns (loss, parts)."""
+    rgb, trans, tb = levels[-1]
+    loss = ((rgb - pixels) ** 2).mean()
+    parts = {"loss": loss}
+    total = loss
+    if bg_weight > 0:
+        mask = (trans > 0.5).to(rgb.dtype)
+        loss_bg = float(annealed_alpha > 0) * (mask * (tb - pixels).abs()).sum() / (mask.sum() + 1)
+        parts["loss_bg"] = loss_bg
+        total = total + bg_weight * loss_bg
+    if len(levels) > 1:
+        loss_c = ((levels[0][0] - pixels) ** 2).mean()
+        parts["loss_c"] = loss_c
+        total = total + loss_c
+    return total, parts

@@ -76,6 +76,103 @@ __global__ void __launch_bounds__(64) composite_kernel(const float4* __restrict_
   trans_bkgd_out[3 * r] = fmul(Tl, br); trans_bkgd_out[3 * r + 1] = fmul(Tl, bg); trans_bkgd_out[3 * r + 2] = fmul(Tl, bb);
 }
 
+// ---- T1 (first half): loss reductions and the backward of activations + volumetric_rendering ----------------------------------
+// train.py:89-92,105: loss = mean((rgb_f - pix)^2) + mean((rgb_c - pix)^2)
+//                            + bg_weight * 1[alpha>0] * sum(mask * |trans_rgb_bkgd_f - pix|) / (sum(mask) + 1),  mask = trans_f > 0.5
+// sums[0] = sum (rgb_f-pix)^2, sums[1] = sum (rgb_c-pix)^2, sums[2] = sum mask*|tb_f-pix|, sums[3] = sum mask (rays)
+__global__ void __launch_bounds__(256) loss_reduce_kernel(const float* __restrict__ rgb_c, const float* __restrict__ rgb_f,
+                                                          const float* __restrict__ trans_f, const float* __restrict__ tb_f,
+                                                          const float* __restrict__ pix, int B, float* __restrict__ sums) {
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < B; r += gridDim.x * blockDim.x) {
+    const float m = trans_f[r] > 0.5f ? 1.f : 0.f;
+    a3 += m;
+    for (int c = 0; c < 3; ++c) {
+      const float p = pix[3 * r + c];
+      const float df = rgb_f[3 * r + c] - p;
+      a0 += df * df;
+      if (rgb_c) { const float dc = rgb_c[3 * r + c] - p; a1 += dc * dc; }
+      a2 += m * fabsf(tb_f[3 * r + c] - p);
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) { a0 += __shfl_down(a0, o); a1 += __shfl_down(a1, o); a2 += __shfl_down(a2, o); a3 += __shfl_down(a3, o); }
+  if ((threadIdx.x & 63) == 0) { atomicAdd(sums + 0, a0); atomicAdd(sums + 1, a1); atomicAdd(sums + 2, a2); atomicAdd(sums + 3, a3); }
+}
+
+// Backward of one level: d loss / d raw (rgb, sigma) per sample and d loss / d bkgd per ray.
+//   C = sum_s w_s c_s + T_S bk,  w_s = (1 - exp(-dd_s)) T_s,  T_s = exp(-sum_{j<s} dd_j),  dd_s = softplus(raw_sigma + b) * delta_s
+//   d/d dd_s = (gC . c_s) T_{s+1} - sum_{j>s} (gC . c_j) w_j - G_T T_S,   G_T = gC . bk + gTB . bk     (model_utils.py:285-299,309)
+//   gC = 2 (C - pix) / (3B);  gTB = bg_scale * mask * sign(T_S bk - pix) / (sum(mask) + 1)  (fine level only; bk is stop_gradient there)
+// One lane per ray: a forward sweep for the total optical depth, then a reverse sweep that recomputes T on the way back.
+__global__ void __launch_bounds__(64) composite_bwd_kernel(const float4* __restrict__ raw, const float4* __restrict__ rows_pd,
+                                                           const float4* __restrict__ rows_dr, const int* __restrict__ node_of_sample,
+                                                           int S, int B, const float* __restrict__ bkgd, float pad_scale, float pad,
+                                                           float sigma_bias, const float* __restrict__ rgb, const float* __restrict__ pix,
+                                                           const float* __restrict__ trans, const float* __restrict__ tb,
+                                                           const float* __restrict__ sums, float mse_scale, float bg_scale,
+                                                           float4* __restrict__ d_raw, float* __restrict__ d_bkgd, int accumulate_bkgd) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= B) return;
+  auto rec = [&](int s) -> size_t { return (size_t)(node_of_sample ? node_of_sample[s] : s) * B + r; };
+  float gC[3], bk[3], gTB[3] = {0.f, 0.f, 0.f};
+  float GT = 0.f;
+  for (int c = 0; c < 3; ++c) {
+    bk[c] = bkgd[3 * r + c];
+    gC[c] = mse_scale * (rgb[3 * r + c] - pix[3 * r + c]);
+    GT += gC[c] * bk[c];
+  }
+  if (bg_scale != 0.f && trans[r] > 0.5f) {
+    const float inv = bg_scale / (sums[3] + 1.0f);
+    for (int c = 0; c < 3; ++c) {
+      const float d = tb[3 * r + c] - pix[3 * r + c];
+      gTB[c] = d > 0.f ? inv : (d < 0.f ? -inv : 0.f);
+      GT += gTB[c] * bk[c];
+    }
+  }
+  // forward sweep: total optical depth
+  auto dd_at = [&](int s, float& sg_out, float& delta_out) -> float {
+    const size_t o = rec(s);
+    const float4 d = rows_dr[o];
+    const float t_cur = rows_pd[o].w;
+    const float tdist = (s + 1 < S) ? fsub(rows_pd[rec(s + 1)].w, t_cur) : 1e-3f;
+    const float nrm = fsqrt(fadd(fadd(fmul(d.x, d.x), fmul(d.y, d.y)), fmul(d.z, d.z)));
+    delta_out = fmul(tdist, nrm);
+    const float x = fadd(raw[(size_t)s * B + r].w, sigma_bias);
+    sg_out = fdiv(1.0f, fadd(1.0f, expf(-x)));             // d softplus / dx
+    return fmul(softplusf_ref(x), delta_out);
+  };
+  float cum = 0.f;
+  for (int s = 0; s < S; ++s) { float a, b; cum = fadd(cum, dd_at(s, a, b)); }
+  const float TS = expf(-cum);
+  float suffix = 0.f;          // sum_{j>s} (gC . c_j) w_j
+  float cum_after = cum;
+  for (int s = S - 1; s >= 0; --s) {
+    float sgp, delta;
+    const float dd = dd_at(s, sgp, delta);
+    const float T_next = expf(-cum_after);
+    const float cum_before = fsub(cum_after, dd);
+    const float T_s = (s == 0) ? 1.0f : expf(-cum_before);
+    const float w = fmul(fsub(1.0f, expf(-dd)), T_s);
+    const float4 rw = raw[(size_t)s * B + r];
+    const float sr = sigmoidf_ref(rw.x), sgn = sigmoidf_ref(rw.y), sb = sigmoidf_ref(rw.z);
+    const float cr = sr * pad_scale - pad, cg = sgn * pad_scale - pad, cb = sb * pad_scale - pad;
+    const float gcc = gC[0] * cr + gC[1] * cg + gC[2] * cb;
+    const float g_dd = gcc * T_next - suffix - GT * TS;
+    float4 o;
+    o.x = gC[0] * w * pad_scale * sr * (1.0f - sr);
+    o.y = gC[1] * w * pad_scale * sgn * (1.0f - sgn);
+    o.z = gC[2] * w * pad_scale * sb * (1.0f - sb);
+    o.w = g_dd * delta * sgp;
+    d_raw[(size_t)s * B + r] = o;
+    suffix += gcc * w;
+    cum_after = cum_before;
+  }
+  for (int c = 0; c < 3; ++c) {
+    const float g = gC[c] * TS;
+    if (accumulate_bkgd) d_bkgd[3 * r + c] += g; else d_bkgd[3 * r + c] = g;
+  }
+}
+
 // Resampling = two kernels.
 //  (1) resample_depths_kernel, one lane per ray: sorted_piecewise_constant_pdf + jnp.sort(concat(coarse, fine)).
 //        bins  = mids of the S coarse depths (S-1 values), weights = w[1..S-2] (S-2 values)         models.py:371-374
@@ -234,6 +331,36 @@ extern "C" int rnerf_resample(const float* path_pd, const float* path_dr, int32_
   const long long total = (long long)(S + num_fine) * B;
   hipLaunchKernelGGL(resample_gather_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float4*)path_pd,
                      (const float4*)path_dr, num_nodes, B, scratch, total, (float4*)rows_pd, (float4*)rows_dr, node_idx);
+  RNERF_CHECK_LAUNCH();
+  return RNERF_OK;
+}
+
+extern "C" int rnerf_loss_reduce(const float* rgb_c, const float* rgb_f, const float* trans_f, const float* trans_bkgd_f,
+                                 const float* pixels, int32_t B, float* sums, void* stream) {
+  RNERF_CHECK_ARG(rgb_f && trans_f && trans_bkgd_f && pixels && sums, "rnerf_loss_reduce: null pointer");
+  RNERF_CHECK_ARG(B >= 1, "rnerf_loss_reduce: B must be >= 1");
+  hipStream_t st = (hipStream_t)stream;
+  RNERF_CHECK_HIP(hipMemsetAsync(sums, 0, 4 * sizeof(float), st));
+  const int blocks = (B + 255) / 256 < 256 ? (B + 255) / 256 : 256;
+  hipLaunchKernelGGL(loss_reduce_kernel, dim3(blocks), dim3(256), 0, st, rgb_c, rgb_f, trans_f, trans_bkgd_f, pixels, B, sums);
+  RNERF_CHECK_LAUNCH();
+  return RNERF_OK;
+}
+
+extern "C" int rnerf_composite_backward(const float* raw, const float* rows_pd, const float* rows_dr, const int32_t* node_of_sample,
+                                        int32_t S, int32_t B, const float* bkgd, double rgb_padding, double sigma_bias,
+                                        const float* rgb, const float* pixels, const float* trans, const float* trans_bkgd,
+                                        const float* sums, double mse_scale, double bg_scale, float* d_raw, float* d_bkgd,
+                                        int accumulate_bkgd, void* stream) {
+  RNERF_CHECK_ARG(raw && rows_pd && rows_dr && bkgd && rgb && pixels && d_raw && d_bkgd, "rnerf_composite_backward: null pointer");
+  RNERF_CHECK_ARG(bg_scale == 0.0 || (trans && trans_bkgd && sums), "rnerf_composite_backward: bg term needs trans, trans_bkgd and sums");
+  RNERF_CHECK_ARG(S >= 1 && B >= 1, "rnerf_composite_backward: need S >= 1 and B >= 1");
+  RNERF_CHECK_ARG((((uintptr_t)raw | (uintptr_t)rows_pd | (uintptr_t)rows_dr | (uintptr_t)d_raw) & 15) == 0,
+                  "rnerf_composite_backward: float4 buffers must be 16-byte aligned");
+  hipLaunchKernelGGL(composite_bwd_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const float4*)raw,
+                     (const float4*)rows_pd, (const float4*)rows_dr, node_of_sample, S, B, bkgd, (float)(1 + 2 * rgb_padding),
+                     (float)rgb_padding, (float)sigma_bias, rgb, pixels, trans, trans_bkgd, sums, (float)mse_scale, (float)bg_scale,
+                     (float4*)d_raw, d_bkgd, accumulate_bkgd);
   RNERF_CHECK_LAUNCH();
   return RNERF_OK;
 }

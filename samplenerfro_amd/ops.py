@@ -160,3 +160,32 @@ def resample(path_pd: torch.Tensor, path_dr: torch.Tensor, jitter: torch.Tensor,
     check(lib.rnerf_resample(ptr(path_pd), ptr(path_dr), int(N), int(B), ptr(jitter), int(S), ptr(weights), ptr(u), per_ray,
                              int(num_fine), ptr(rows_pd), ptr(rows_dr), ptr(idx), ptr(scratch), current_stream()), "rnerf_resample")
     return rows_pd, rows_dr, idx
+
+
+def loss_reduce(rgb_c: Optional[torch.Tensor], rgb_f: torch.Tensor, trans_f: torch.Tensor, trans_bkgd_f: torch.Tensor,
+                pixels: torch.Tensor) -> torch.Tensor:
+    """T1: the reductions of train_step.loss_fn (train.py:89-92,105). -> sums float[4] on the device."""
+    lib = _lib.load()
+    B = rgb_f.shape[0]
+    sums = torch.empty(4, dtype=torch.float32, device=rgb_f.device)
+    check(lib.rnerf_loss_reduce(ptr(rgb_c), ptr(_chk(rgb_f, "rgb_f")), ptr(_chk(trans_f, "trans_f")), ptr(_chk(trans_bkgd_f, "trans_bkgd_f")),
+                                ptr(_chk(pixels, "pixels")), int(B), ptr(sums), current_stream()), "rnerf_loss_reduce")
+    return sums
+
+
+def composite_backward(raw, rows_pd, rows_dr, node_of_sample, S: int, B: int, bkgd, rgb, pixels, trans=None, trans_bkgd=None,
+                       sums=None, mse_scale: float = 0.0, bg_scale: float = 0.0, d_bkgd: Optional[torch.Tensor] = None,
+                       rgb_padding: float = 0.001, sigma_bias: float = -1.0):
+    """T1: backward of activations + volumetric_rendering for one level. -> d_raw [S,B,4], d_bkgd [B,3] (accumulated if given)."""
+    lib = _lib.load()
+    dev = raw.device
+    d_raw = torch.empty((S, B, 4), dtype=torch.float32, device=dev)
+    acc = d_bkgd is not None
+    if d_bkgd is None:
+        d_bkgd = torch.empty((B, 3), dtype=torch.float32, device=dev)
+    check(lib.rnerf_composite_backward(ptr(_chk(raw, "raw")), ptr(rows_pd), ptr(rows_dr), ptr(node_of_sample), int(S), int(B),
+                                       ptr(_chk(bkgd, "bkgd")), float(rgb_padding), float(sigma_bias), ptr(_chk(rgb, "rgb")),
+                                       ptr(_chk(pixels, "pixels")), ptr(trans), ptr(trans_bkgd), ptr(sums), float(mse_scale),
+                                       float(bg_scale), ptr(d_raw), ptr(d_bkgd), int(acc), current_stream()),
+          "rnerf_composite_backward")
+    return d_raw, d_bkgd

@@ -1,0 +1,78 @@
+"""Backward kernels vs torch.autograd (float64) on the same inputs: loss reductions and d loss / d raw through compositing."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from oracle import ref_np as R, torch_ref as TR
+from samplenerfro_amd import _lib
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+
+
+def _level(rng, B, S):
+    t = np.sort(rng.uniform(2, 6, (B, S)).astype(F32), -1)
+    dirs = R.safe_l2_normalize(rng.standard_normal((B, S, 3)).astype(F32))
+    pos = rng.standard_normal((B, S, 3)).astype(F32)
+    raw = (2 * rng.standard_normal((B, S, 4))).astype(F32)
+    return t, dirs, pos, raw
+
+
+@pytest.mark.parametrize("bg_weight", [0.0, 0.025])
+def test_loss_and_composite_backward(bg_weight):
+    from samplenerfro_amd import ops
+    rng = np.random.default_rng(3)
+    B, Sc, Sf = 300, 12, 29
+    tc, dc, pc, rawc = _level(rng, B, Sc)
+    tf, df, pf_, rawf = _level(rng, B, Sf)
+    rawf[:40, :, 3] = -6.0                     # nearly transparent rays -> trans > 0.5 -> the bg mask fires
+    bk = rng.uniform(0, 1, (B, 3)).astype(F32)
+    pix = rng.uniform(0, 1, (B, 3)).astype(F32)
+
+    # ---- torch float64 reference with autograd
+    rc = torch.tensor(rawc, dtype=torch.float64, requires_grad=True)
+    rf = torch.tensor(rawf, dtype=torch.float64, requires_grad=True)
+    bkt = torch.tensor(bk, dtype=torch.float64, requires_grad=True)
+    px = torch.tensor(pix, dtype=torch.float64)
+    levels = []
+    for r_, t_, d_ in ((rc, tc, dc), (rf, tf, df)):
+        rgb, sig = TR.activations(r_)
+        comp, acc, w, tr, tb = TR.volumetric_rendering(rgb, sig, torch.tensor(t_, dtype=torch.float64), torch.tensor(d_, dtype=torch.float64), bkt)
+        levels.append((comp, tr, tb))
+    total, parts = TR.radiance_loss(levels, px, bg_weight=bg_weight)
+    total.backward()
+
+    # ---- HIP path: forward composite (to get the level outputs), reductions, backward
+    def rows(pos, dirs, t):
+        pd = np.concatenate([pos, t[..., None]], -1).transpose(1, 0, 2)
+        dr = np.concatenate([dirs, np.zeros(dirs.shape[:2] + (1,), F32)], -1).transpose(1, 0, 2)
+        return T(pd.astype(F32)), T(dr.astype(F32))
+    pdc, drc = rows(pc, dc, tc); pdf, drf = rows(pf_, df, tf)
+    rawc_d, rawf_d, bk_d, pix_d = T(rawc.transpose(1, 0, 2)), T(rawf.transpose(1, 0, 2)), T(bk), T(pix)
+    oc = ops.composite(rawc_d, pdc, drc, None, Sc, B, bk_d)
+    of = ops.composite(rawf_d, pdf, drf, None, Sf, B, bk_d)
+    sums = ops.loss_reduce(oc[0], of[0], of[3], of[4], pix_d)
+    s = sums.cpu().numpy().astype(np.float64)
+    loss_f, loss_c = s[0] / (3 * B), s[1] / (3 * B)
+    np.testing.assert_allclose(loss_f, parts["loss"].item(), rtol=2e-6)
+    np.testing.assert_allclose(loss_c, parts["loss_c"].item(), rtol=2e-6)
+    if bg_weight > 0:
+        assert s[3] >= 40
+        np.testing.assert_allclose(s[2] / (s[3] + 1), parts["loss_bg"].item(), rtol=5e-6)
+    mse_scale = 2.0 / (3 * B)
+    d_raw_c, d_bk = ops.composite_backward(rawc_d, pdc, drc, None, Sc, B, bk_d, oc[0], pix_d, mse_scale=mse_scale)
+    d_raw_f, d_bk = ops.composite_backward(rawf_d, pdf, drf, None, Sf, B, bk_d, of[0], pix_d, trans=of[3], trans_bkgd=of[4],
+                                           sums=sums, mse_scale=mse_scale, bg_scale=bg_weight, d_bkgd=d_bk)
+    gc = d_raw_c.cpu().numpy().transpose(1, 0, 2); gf = d_raw_f.cpu().numpy().transpose(1, 0, 2)
+    # fp32 kernels vs the float64 autograd: 2e-6 relative to the largest gradient entry
+    for g, ref in ((gc, rc.grad.numpy()), (gf, rf.grad.numpy()), (d_bk.cpu().numpy(), bkt.grad.numpy())):
+        scale = np.abs(ref).max()
+        assert scale > 0
+        err = np.abs(g - ref).max() / scale
+        print(f"max rel err {err:.2e} (scale {scale:.2e})")
+        assert err < 5e-6
