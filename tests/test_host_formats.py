@@ -1,0 +1,76 @@
+"""Host-side data formats either side of the path (no GPU): flax msgpack checkpoints, mesh.pkl, flags, LR schedule."""
+import math
+import pickle
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from samplenerfro_amd import checkpoint, models, utils
+from samplenerfro_amd import synthetic as syn
+
+
+def test_checkpoint_round_trip(tmp_path):
+    pf = syn.init_params_flat(5, fine=True, bias_scale=0.1)
+    variables = models.make_variables({k: torch.from_numpy(v) for k, v in pf.items()})
+    p = str(tmp_path / "checkpoint_1000")
+    checkpoint.save_state_dict(p, checkpoint.params_to_state_dict(variables, step=1000))
+    state = checkpoint.load_state_dict(p)
+    assert int(state["optimizer"]["state"]["step"]) == 1000
+    k = state["optimizer"]["target"]["params"]["coarse_mlp"]["Dense_5"]["kernel"]
+    assert k.shape == (319, 256) and k.dtype == np.float32
+    back = checkpoint.variables_from_checkpoint(p, "cpu")
+    for name in ("coarse_mlp", "fine_mlp", "bkgd_mlp"):
+        assert torch.equal(back["flat"][name], variables["flat"][name])
+    assert back["params"]["bkgd_mlp"]["Dense_3"]["kernel"].shape == (155, 128)
+    # views alias the flat buffers (what the kernels read and an optimiser updates)
+    back["flat"]["coarse_mlp"][0] = 42.0
+    assert back["params"]["coarse_mlp"]["Dense_0"]["kernel"][0, 0] == 42.0
+
+
+def test_flat_layout_matches_flax_order():
+    assert models.flat_size(models.NERF_MLP_SHAPES) == 595844 and models.flat_size(models.BKGD_MLP_SHAPES) == 56963
+    assert models.flat_size(models.SO3_MLP_SHAPES) == 65411
+    flat = torch.arange(595844, dtype=torch.float32)
+    tree = models.flat_to_tree(flat, models.NERF_MLP_SHAPES)
+    assert tree["Dense_0"]["kernel"][1, 0] == 256 and tree["Dense_0"]["bias"][0] == 63 * 256
+    assert tree["Dense_8"]["kernel"].shape == (256, 1) and tree["Dense_11"]["bias"].shape == (3,)
+    assert torch.equal(models.tree_to_flat(tree, models.NERF_MLP_SHAPES), flat)
+
+
+def test_mesh_pkl_rules(tmp_path):
+    from samplenerfro_amd import grid
+    G = 4
+    d = {"data": np.linspace(1, 1.33, G ** 3).reshape(-1, 1), "extent": 1.5, "min_point": [0, 0, 0], "max_point": [1, 2, 3], "num_voxels": G}
+    p = str(tmp_path / "mesh.pkl")
+    pickle.dump(d, open(p, "wb"))
+    data, ndim, nmin, nmax = grid.load_mesh_pkl(p)
+    assert ndim == [G] * 3 and nmin == [-1.5] * 3 and nmax == [1.5] * 3 and data.shape == (G ** 3, 1)
+    d["extent"] = -1
+    _, _, nmin, nmax = grid.mesh_dict_to_grid(d)
+    assert nmin == [0, 0, 0] and nmax == [1, 2, 3]
+    assert grid.refractive_index_for("configs/glass") == 0.33 and grid.refractive_index_for("dolphin") == 0.33
+    assert grid.refractive_index_for("ship_skydome-bkgd_no-partial-reflect_cycles") == 0.5 and grid.refractive_index_for("example") == 0.5
+
+
+def test_flags_and_lr_schedule():
+    f = utils.default_flags(num_coarse_samples=128, config="configs/example")
+    assert f.num_coarse_samples == 128 and f.near == 2.0 and f.far == 6.0 and f.deg_view == 4 and f.chunk == 8192
+    assert utils.learning_rate_decay(0, 5e-4, 5e-6, 200000, 2500, 0.01) == 0.0      # start_rate = clip(step - 0, 0, 1) (utils.py:524)
+    lr1 = utils.learning_rate_decay(1, 5e-4, 5e-6, 200000, 2500, 0.01)
+    t = 1 / 200000
+    exp1 = (0.01 + 0.99 * math.sin(0.5 * math.pi / 2500)) * math.exp(math.log(5e-4) * (1 - t) + math.log(5e-6) * t)
+    assert abs(lr1 - exp1) < 1e-15
+    lr_end = utils.learning_rate_decay(200000, 5e-4, 5e-6, 200000, 2500, 0.01)
+    assert abs(lr_end - 5e-6) < 1e-12
+    mid = utils.learning_rate_decay(100000, 5e-4, 5e-6, 200000, 2500, 0.01)
+    assert abs(mid - math.sqrt(5e-4 * 5e-6)) < 1e-9
+    assert abs(utils.compute_psnr(0.01) - 20.0) < 1e-9
+
+
+def test_model_rejects_unbuilt_options():
+    with pytest.raises(NotImplementedError):
+        models.NerfModel(ndim=[4] * 3, nmin=[-1] * 3, nmax=[1] * 3, grid=np.ones((4, 4, 4), np.float32), stage="all", device="cpu")
+    with pytest.raises(NotImplementedError):
+        models.NerfModel(ndim=[4] * 3, nmin=[-1] * 3, nmax=[1] * 3, grid=np.ones((4, 4, 4), np.float32), sh_deg=2, device="cpu")
