@@ -254,12 +254,17 @@ class NerfModel:
         if Nf > 0:
             key, rng_1 = prng.split(np.asarray(rng_1, np.uint32))
             u = u_fine if u_fine is not None else self.make_u(key, B, randomized)
-            rows_pd, rows_dr, idx = ops.resample(path_pd, path_dr, jit, weights, u, Nf, want_idx=taps is not None)
+            fine_sp = self.use_online_sparsity and self.use_fine_sparsity
+            rows_pd, rows_dr, idx = ops.resample(path_pd, path_dr, jit, weights, u, Nf, want_idx=(taps is not None) or fine_sp)
             S = Nc + Nf
             raw_f = ops.nerfmlp_forward(self._packed_weights(variables, "fine_mlp"), self.precision, rows_pd, rows_dr, None, S, B)
             rgb, dist, acc, trans, trans_bkgd, w_f, alpha_f = ops.composite(
                 raw_f, rows_pd, rows_dr, None, S, B, bkgd, self.white_bkgd, self.rgb_padding, self.sigma_bias,
                 want_weights=taps is not None, want_alpha=self.use_online_sparsity and self.use_fine_sparsity)
+            if fine_sp:                                                                   # rnerf/models.py:526-530
+                g = path_ior[idx.long(), torch.arange(B, device=self.device)[None, :]][..., 1:4]
+                mask = (torch.sqrt((g * g).sum(-1)) > 1e-6).float()
+                loss_sp = loss_sp + (mask * torch.log(torch.clamp(alpha_f, min=1e-6))).sum() / (mask.sum() + 1)
             if self.bd_cut_dist is not None:
                 raise NotImplementedError("bd_cut_dist (glass/pen/ball training masks, rnerf/models.py:479-524) is not built yet")
             ret.append((rgb, dist, acc, trans, trans_bkgd))

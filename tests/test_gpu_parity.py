@@ -278,3 +278,100 @@ def test_cpu_tensor_is_rejected():
     from samplenerfro_amd import ops
     with pytest.raises(_lib.RnerfError):
         ops.grid_prefilter(torch.ones(4, 4, 4), 3, 1.0)
+
+
+# ---- edge cases: ragged sizes, anisotropic grids, randomized draws, long marches ------------------------------------------
+def _aniso_scene(B=37, seed=21):
+    from samplenerfro_amd import ops
+    sc = Scene.__new__(Scene)
+    sc.ndim, sc.nmin, sc.nmax = [12, 20, 16], [-1.79, 0.71, -1.75], [1.71, 4.21, 1.75]     # OpenCV-style bbox (voxelize_opencv.sh:13)
+    rng = np.random.default_rng(seed)
+    g = (1.0 + 0.33 * rng.uniform(0, 1, sc.ndim) ** 3).astype(F32)
+    sc.grid = g
+    sc.table = R.build_table(g, sc.ndim, sc.nmin, sc.nmax)
+    sc.spec = _lib.Grid.make(sc.ndim, sc.nmin, sc.nmax)
+    sc.table_d = ops.grid_build_table(T(g), sc.spec)
+    o = rng.uniform(-3, 3, (B, 3)); o[:, 1] += 2.5
+    d = np.array([0.0, 2.4, 0.0]) + rng.uniform(-1, 1, (B, 3)) - o
+    sc.o = o.astype(F32); sc.d = (d / np.linalg.norm(d, axis=-1, keepdims=True)).astype(F32)
+    sc.B = B
+    return sc
+
+
+def test_anisotropic_grid_bit_exact():
+    from samplenerfro_amd import ops
+    sc = _aniso_scene()
+    np.testing.assert_array_equal(sc.table_d.cpu().numpy(), sc.table)
+    N = 53                                                                     # odd node count, B = 37 (ragged quads/waves)
+    pos, dirs, dist, n, g, vox = R.path_sampler(sc.o, sc.d, sc.table, sc.ndim, sc.nmin, sc.nmax, 0.2, 6.0, N, return_idx=True)
+    pd, dr, ior, vx = [x.cpu().numpy() for x in ops.march(sc.table_d, sc.spec, T(sc.o), T(sc.d), 0.2, 6.0, N, want_ior=True, want_vox=True)]
+    np.testing.assert_array_equal(vx.transpose(1, 0, 2), vox)
+    np.testing.assert_array_equal(pd[..., :3].transpose(1, 0, 2), pos)
+    np.testing.assert_array_equal(pd[..., 3].T, dist)
+    np.testing.assert_array_equal(dr[..., :3].transpose(1, 0, 2), dirs)
+    np.testing.assert_array_equal(ior.transpose(1, 0, 2), np.concatenate([n, g], -1))
+    assert (vox[..., 0] != vox[..., 2]).any()                                   # the three axes really differ
+
+
+@pytest.mark.parametrize("B,S,F,P", [(1, 3, 1, 2), (5, 3, 0, 1), (67, 9, 31, 24), (300, 16, 16, 4)])
+def test_model_ragged_shapes(B, S, F, P):
+    """Minimum sample counts, single ray, batch sizes that fill neither a quad-wave nor an MLP tile, P = 24 (glass.yaml)."""
+    from samplenerfro_amd import models, prng
+    from samplenerfro_amd.utils import Rays
+    sc = Scene(B=B, seed=31 + B)
+    pf = syn.init_params_flat(4, fine=F > 0, bias_scale=0.05)
+    model = models.NerfModel(ndim=sc.ndim, nmin=sc.nmin, nmax=sc.nmax, grid=T(sc.grid), near=0.2 if P == 24 else 2.0,
+                             far=14.0 if P == 24 else 6.0, num_coarse_samples=S, num_fine_samples=F, num_path_samples=P)
+    variables = models.make_variables({k: T(v) for k, v in pf.items()})
+    taps = {}
+    ret, _ = model.apply(variables, prng.PRNGKey(B), prng.PRNGKey(1), Rays(T(sc.o), None, T(sc.d), None), False, taps=taps)
+    cfg = R.ModelConfig(sc.ndim, sc.nmin, sc.nmax, near=model.near, far=model.far, num_coarse_samples=S, num_fine_samples=F, num_path_samples=P)
+    oret, _ = R.nerf_forward(cfg, syn.params_tree(pf), sc.table, sc.o, sc.d, taps["jitter"])
+    for g, o in zip(ret, oret):
+        assert tuple(g[0].shape) == (B, 3)
+        assert np.abs(g[0].cpu().numpy() - o[0]).max() < 1e-4
+        assert np.abs(g[2].cpu().numpy() - o[2]).max() < 1e-4
+
+
+def test_model_randomized_white_bkgd_sparsity():
+    """randomized=True (stratified u per ray from the host PRNG), white_bkgd, online sparsity loss."""
+    from samplenerfro_amd import models, prng
+    from samplenerfro_amd.utils import Rays
+    sc = Scene(B=96, seed=41)
+    S, F, P = 12, 20, 3
+    pf = syn.init_params_flat(6, fine=True, bias_scale=0.05)
+    model = models.NerfModel(ndim=sc.ndim, nmin=sc.nmin, nmax=sc.nmax, grid=T(sc.grid), num_coarse_samples=S, num_fine_samples=F,
+                             num_path_samples=P, white_bkgd=True, use_online_sparsity=True, use_fine_sparsity=True)
+    variables = models.make_variables({k: T(v) for k, v in pf.items()})
+    taps = {}
+    k0, k1 = prng.PRNGKey(11), prng.PRNGKey(12)
+    ret, loss_sp = model.apply(variables, k0, k1, Rays(T(sc.o), None, T(sc.d), None), True, taps=taps)
+    u = taps["u"].cpu().numpy().T                                   # [B, F], the reference layout
+    assert u.shape == (sc.B, F) and np.all(np.diff(u, axis=1) > 0) and u.min() >= 0 and u.max() < 1
+    assert np.all(u >= np.arange(F) / F - 1e-7) and np.all(u < (np.arange(F) + 1) / F)      # one draw per stratum
+    ret2, _ = model.apply(variables, k0, k1, Rays(T(sc.o), None, T(sc.d), None), True)       # same keys -> same draws
+    assert torch.equal(ret[1][0], ret2[1][0])
+    cfg = R.ModelConfig(sc.ndim, sc.nmin, sc.nmax, num_coarse_samples=S, num_fine_samples=F, num_path_samples=P, white_bkgd=True,
+                        use_online_sparsity=True, use_fine_sparsity=True)
+    oret, oloss_sp = R.nerf_forward(cfg, syn.params_tree(pf), sc.table, sc.o, sc.d, taps["jitter"], u_fine=u)
+    for g, o in zip(ret, oret):
+        assert np.abs(g[0].cpu().numpy() - o[0]).max() < 1e-4
+    assert abs(float(loss_sp) - float(oloss_sp)) < 1e-4 * max(1.0, abs(float(oloss_sp)))
+
+
+def test_construct_nerf_surface():
+    from samplenerfro_amd import models, prng, utils
+    sc = Scene(B=64, seed=3)
+    flags = utils.default_flags(num_coarse_samples=8, num_fine_samples=8, num_path_samples=3, white_bkgd=False, use_online_sparsity=False,
+                                config="configs/example")
+    model, variables = models.construct_nerf(prng.PRNGKey(20200823), None, flags, ndim=sc.ndim, nmin=sc.nmin, nmax=sc.nmax, grid=T(sc.grid))
+    assert set(variables["params"]) == {"coarse_mlp", "fine_mlp", "bkgd_mlp", "path_sampler"}
+    assert variables["params"]["coarse_mlp"]["Dense_10"]["kernel"].shape == (283, 128)
+    ret, loss_sp = model.apply(variables, prng.PRNGKey(1), prng.PRNGKey(2), utils.Rays(T(sc.o), None, T(sc.d), None), False)
+    assert len(ret) == 2 and loss_sp == 0.0 and torch.isfinite(ret[1][0]).all()
+    env = model.apply(variables, T(sc.d), method=model.forward_envmap)
+    assert env.shape == (64, 3) and float(env.min()) > -0.0011 and float(env.max()) < 1.0011
+    # updating the flat buffer in place (what an optimiser does) is picked up by the next call (weights are repacked)
+    variables["flat"]["coarse_mlp"].mul_(0.5)
+    ret2, _ = model.apply(variables, prng.PRNGKey(1), prng.PRNGKey(2), utils.Rays(T(sc.o), None, T(sc.d), None), False)
+    assert not torch.equal(ret[0][0], ret2[0][0])
