@@ -348,7 +348,8 @@ __device__ __forceinline__ void kstep_mfma(f32x16 (&acc0)[8], f32x16 (&acc1)[8],
   }
 #define RNERF_TILE(T)                                                                                     \
   if constexpr (T < NT) {                                                                                 \
-    const uint4 ah = fh[T % FRAG_DEPTH], al = fl[T % FRAG_DEPTH];                                         \
+    uint4 ah = fh[T % FRAG_DEPTH], al = fl[T % FRAG_DEPTH];                                               \
+    if constexpr (NOREAD) { asm volatile("" : "+v"(ah.x), "+v"(al.x)); }  /* ablation: opaque, so tiles are not CSE'd */ \
     tile_mfma<PREC, FIRST, (T & 7), W>(acc0[T], acc1[T], ah, al, b, work);                                \
     if constexpr (T + FRAG_DEPTH < NT && !NOREAD) {                                                       \
       fh[T % FRAG_DEPTH] = a[((T + FRAG_DEPTH) * PP::NP) * 64];                                           \
