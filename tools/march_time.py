@@ -1,7 +1,7 @@
 """Profiling helper (not part of the product): time the march kernel for several grid sizes."""
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from samplenerfro_amd import ops, _lib, synthetic as syn
 dev = torch.device("cuda:0")
 B, N = 4096, 1536

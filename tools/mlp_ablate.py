@@ -1,7 +1,7 @@
 """Profiling helper (not part of the product): time the PE+NerfMLP kernel alone, optionally under RNERF_MLP_DEBUG ablations."""
 import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from samplenerfro_amd import ops, _lib, synthetic as syn
 prec = sys.argv[1] if len(sys.argv) > 1 else "f16x3"
 S, B = 128, 4096
