@@ -116,11 +116,13 @@ int rnerf_bkgd_forward(const float* params, const float* dirs, int32_t dir_strid
 /* ---- V1: activations + alpha compositing.  Replaces rgb/sigma activation (rnerf/models.py:334-338) and
  * model_utils.volumetric_rendering (rnerf/model_utils.py:247-309).  Row addressing as rnerf_nerfmlp_forward.
  * bkgd: float[B][3].  Outputs: rgb float[B][3], dist float[B], acc float[B], trans float[B],
- * trans_bkgd float[B][3]; weights (nullable) float[S][B]; alpha (nullable) float[S][B]. */
+ * trans_bkgd float[B][3]; weights (nullable) float[S][B]; alpha (nullable) float[S][B].
+ * mask_mode / bbox (host double[6] = min xyz, max xyz): the bd_cut_dist masks of rnerf/models.py:479-524 — 0 none,
+ * 1: density_delta *= mask_bbox (1 up to the last sample inside the box), 2: density_delta *= 1 - mask_bbox. */
 int rnerf_composite(const float* raw, const float* rows_pd, const float* rows_dr, const int32_t* node_of_sample,
                     int32_t S, int32_t B, const float* bkgd, int white_bkgd, double rgb_padding, double sigma_bias,
                     float* rgb, float* dist, float* acc, float* trans, float* trans_bkgd, float* weights,
-                    float* alpha, void* stream);
+                    float* alpha, int mask_mode, const double* bbox, void* stream);
 
 /* ---- S1 + S2: PDF resampling along the bent path.  Replaces sorted_piecewise_constant_pdf and sample_pdf
  * (rnerf/model_utils.py:312-435) as called at rnerf/models.py:371-384.

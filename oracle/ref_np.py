@@ -378,6 +378,7 @@ class ModelConfig:
         self.min_deg_point = min_deg_point; self.max_deg_point = max_deg_point; self.deg_view = deg_view
         self.white_bkgd = white_bkgd; self.rgb_padding = rgb_padding; self.sigma_bias = sigma_bias
         self.use_online_sparsity = use_online_sparsity; self.use_fine_sparsity = use_fine_sparsity
+        self.bd_cut_bbox = None   # [xmin,ymin,zmin,xmax,ymax,zmax] when NerfModel.bd_cut_dist is set (models.py:485-497)
 
     @property
     def num_samples(self):
@@ -433,6 +434,15 @@ def nerf_forward(cfg: ModelConfig, params: Dict, table, origins, viewdirs, jitte
         sigma = sigma_activation(raw_sigma, cfg.sigma_bias)
         comp_rgb, disp, acc, w_f, alpha_f, trans, trans_rgb_bkgd = volumetric_rendering(
             rgb, sigma, z_f, dir_f, cfg.white_bkgd, bkgd)                                    # :468-476 (coarse bkgd)
+        if getattr(cfg, "bd_cut_bbox", None) is not None:                                    # :479-524
+            bmin, bmax = cfg.bd_cut_bbox[:3], cfg.bd_cut_bbox[3:]
+            inside = np.ones(pos_f.shape[:2], bool)
+            for a in range(3):
+                inside &= (pos_f[..., a] >= dtype(bmin[a])) & (pos_f[..., a] <= dtype(bmax[a]))
+            mask_bbox = (np.cumsum(inside[:, ::-1], axis=-1) > 0)[:, ::-1]
+            trans = volumetric_rendering(rgb, sigma, z_f, dir_f, cfg.white_bkgd, None, mask_bbox=mask_bbox)[5]
+            behind = volumetric_rendering(rgb, sigma, z_f, dir_f, cfg.white_bkgd, bkgd, mask_bbox=(1.0 - mask_bbox))[0]
+            trans_rgb_bkgd = trans * behind
         if cfg.use_online_sparsity and cfg.use_fine_sparsity:                                # :526-530
             mask = np.sqrt(_sum3_sq(grad_f))[..., 0] > dtype(1e-6)
             loss_sp = loss_sp + (mask * safe_log(alpha_f)).sum() / (np.sum(mask) + 1)

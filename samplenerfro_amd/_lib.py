@@ -51,7 +51,7 @@ SIGNATURES = {
     "rnerf_nerfmlp_forward": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _i32, _i32, _vp, _vp]),
     "rnerf_bkgd_forward": (C.c_int, [_vp, _vp, _i32, _i64, _dbl, _vp, _vp]),
     "rnerf_composite": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, C.c_int, _dbl, _dbl,
-                                  _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+                                  _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.POINTER(C.c_double * 6), _vp]),
     "rnerf_loss_reduce": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
     "rnerf_composite_backward": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _dbl, _dbl, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl,
                                            _vp, _vp, C.c_int, _vp]),

@@ -22,10 +22,19 @@ __global__ void __launch_bounds__(64) composite_kernel(const float4* __restrict_
                                                        float pad, float sigma_bias, float* __restrict__ rgb_out,
                                                        float* __restrict__ dist_out, float* __restrict__ acc_out,
                                                        float* __restrict__ trans_out, float* __restrict__ trans_bkgd_out,
-                                                       float* __restrict__ weights, float* __restrict__ alpha_out) {
+                                                       float* __restrict__ weights, float* __restrict__ alpha_out,
+                                                       int mask_mode, float bx0, float by0, float bz0, float bx1, float by1, float bz1) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= B) return;
   auto rec = [&](int s) -> size_t { return (size_t)(node_of_sample ? node_of_sample[s] : s) * B + r; };
+  // mask_bbox = (cumsum(inside[::-1]) > 0)[::-1] (rnerf/models.py:498-503): 1 up to and including the LAST sample inside the
+  // box; mask_mode 1 uses it, mask_mode 2 uses 1 - mask (:505-523).
+  int last_in = -1;
+  if (mask_mode != 0)
+    for (int s = S - 1; s >= 0; --s) {
+      const float4 p = rows_pd[rec(s)];
+      if (p.x >= bx0 && p.x <= bx1 && p.y >= by0 && p.y <= by1 && p.z >= bz0 && p.z <= bz1) { last_in = s; break; }
+    }
   float cum = 0.f, sr = 0.f, sg = 0.f, sb = 0.f, acc = 0.f, wt = 0.f;
   size_t o = rec(0);
   float t_cur = rows_pd[o].w;
@@ -43,7 +52,8 @@ __global__ void __launch_bounds__(64) composite_kernel(const float4* __restrict_
     const float cr = fsub(fmul(sigmoidf_ref(rw.x), pad_scale), pad);   // models.py:334-335
     const float cg = fsub(fmul(sigmoidf_ref(rw.y), pad_scale), pad);
     const float cb = fsub(fmul(sigmoidf_ref(rw.z), pad_scale), pad);
-    const float dd = fmul(sigma, delta);                     // :272
+    float dd = fmul(sigma, delta);                           // :272
+    if (mask_mode != 0) dd = fmul(dd, ((s <= last_in) == (mask_mode == 1)) ? 1.0f : 0.0f);   // density_delta *= mask_bbox (:275-276)
     const float a = fsub(1.0f, expf(-dd));                   // :285
     const float T = expf(-cum);                              // :286-289
     const float w = fmul(a, T);                              // :296
@@ -297,14 +307,17 @@ using namespace rnerf;
 extern "C" int rnerf_composite(const float* raw, const float* rows_pd, const float* rows_dr,
                                const int32_t* node_of_sample, int32_t S, int32_t B, const float* bkgd, int white_bkgd,
                                double rgb_padding, double sigma_bias, float* rgb, float* dist, float* acc, float* trans,
-                               float* trans_bkgd, float* weights, float* alpha, void* stream) {
+                               float* trans_bkgd, float* weights, float* alpha, int mask_mode, const double* bbox, void* stream) {
   RNERF_CHECK_ARG(raw && rows_pd && rows_dr && rgb && dist && acc && trans && trans_bkgd, "rnerf_composite: null pointer");
+  RNERF_CHECK_ARG(mask_mode >= 0 && mask_mode <= 2 && (mask_mode == 0 || bbox), "rnerf_composite: mask_mode 1/2 needs a bbox");
+  float bb[6] = {0, 0, 0, 0, 0, 0};
+  if (mask_mode != 0) for (int i = 0; i < 6; ++i) bb[i] = (float)bbox[i];
   RNERF_CHECK_ARG(S >= 1 && B >= 1, "rnerf_composite: need S >= 1 and B >= 1");
   RNERF_CHECK_ARG((((uintptr_t)raw | (uintptr_t)rows_pd | (uintptr_t)rows_dr) & 15) == 0, "rnerf_composite: float4 buffers must be 16-byte aligned");
   hipLaunchKernelGGL(composite_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const float4*)raw,
                      (const float4*)rows_pd, (const float4*)rows_dr, node_of_sample, S, B, bkgd, white_bkgd,
                      (float)(1 + 2 * rgb_padding), (float)rgb_padding, (float)sigma_bias, rgb, dist, acc, trans, trans_bkgd,
-                     weights, alpha);
+                     weights, alpha, mask_mode, bb[0], bb[1], bb[2], bb[3], bb[4], bb[5]);
   RNERF_CHECK_LAUNCH();
   return RNERF_OK;
 }

@@ -176,6 +176,20 @@ class NerfModel:
         u = np.minimum(u, np.float32(1.0 - eps)).astype(np.float32)
         return torch.from_numpy(np.ascontiguousarray(u.T)).to(self.device)
 
+    def _bd_cut_bbox(self):
+        """The scene-name-specific box of rnerf/models.py:485-497."""
+        name = self.cfg_name or ""
+        nmin, nmax = list(self.nmin), list(self.nmax)
+        if "pen" in name:
+            nmax[1] -= 0.6
+        elif "ball" in name:
+            nmin, nmax = [-1, 0.03597, -1], [1, 2.03597, 1]
+        elif "glass" in name:
+            nmax[1] -= 0.7
+        else:
+            raise NotImplementedError("bd_cut_dist is defined for the pen / ball / glass configs only (rnerf/models.py:485-497)")
+        return nmin + nmax
+
     # ---- cross-batch pipelining ---------------------------------------------------------------------------------------------
     def prefetch_path(self, rays: Rays, sync_inputs: bool = True, reserve_cus: int = 32) -> "PathHandle":
         """March `rays` on a side stream so that it overlaps the MLP phase of the batch currently in flight.
@@ -265,8 +279,15 @@ class NerfModel:
                 g = path_ior[idx.long(), torch.arange(B, device=self.device)[None, :]][..., 1:4]
                 mask = (torch.sqrt((g * g).sum(-1)) > 1e-6).float()
                 loss_sp = loss_sp + (mask * torch.log(torch.clamp(alpha_f, min=1e-6))).sum() / (mask.sum() + 1)
-            if self.bd_cut_dist is not None:
-                raise NotImplementedError("bd_cut_dist (glass/pen/ball training masks, rnerf/models.py:479-524) is not built yet")
+            if self.bd_cut_dist is not None:                                              # rnerf/models.py:479-524
+                bbox = self._bd_cut_bbox()
+                # trans with the density kept only up to the last sample inside the box (rgb_bkgd=None)
+                _, _, _, trans, _, _, _ = ops.composite(raw_f, rows_pd, rows_dr, None, S, B, None, self.white_bkgd, self.rgb_padding,
+                                                        self.sigma_bias, want_weights=False, mask_mode=1, bbox=bbox)
+                # colour of everything BEHIND the box over the background, then attenuated by that trans
+                behind, _, _, _, _, _, _ = ops.composite(raw_f, rows_pd, rows_dr, None, S, B, bkgd, self.white_bkgd, self.rgb_padding,
+                                                         self.sigma_bias, want_weights=False, mask_mode=2, bbox=bbox)
+                trans_bkgd = trans * behind
             ret.append((rgb, dist, acc, trans, trans_bkgd))
             if taps is not None:
                 taps.update(rows_pd=rows_pd, rows_dr=rows_dr, idx_f=idx, raw_f=raw_f, weights_f=w_f, u=u)

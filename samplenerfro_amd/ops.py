@@ -118,7 +118,7 @@ def bkgd_forward(params_flat: torch.Tensor, dirs: torch.Tensor, rgb_padding: flo
 
 def composite(raw: torch.Tensor, rows_pd: torch.Tensor, rows_dr: torch.Tensor, node_of_sample: Optional[torch.Tensor],
               S: int, B: int, bkgd: Optional[torch.Tensor], white_bkgd: bool = False, rgb_padding: float = 0.001,
-              sigma_bias: float = -1.0, want_weights: bool = True, want_alpha: bool = False):
+              sigma_bias: float = -1.0, want_weights: bool = True, want_alpha: bool = False, mask_mode: int = 0, bbox=None):
     """V1: activations + volumetric_rendering (rnerf/models.py:334-349, rnerf/model_utils.py:247-309)."""
     lib = _lib.load()
     raw = _chk(raw, "raw"); dev = raw.device
@@ -133,7 +133,9 @@ def composite(raw: torch.Tensor, rows_pd: torch.Tensor, rows_dr: torch.Tensor, n
         bkgd = _chk(bkgd, "bkgd")
     check(lib.rnerf_composite(ptr(raw), ptr(rows_pd), ptr(rows_dr), ptr(node_of_sample), int(S), int(B), ptr(bkgd),
                               int(bool(white_bkgd)), float(rgb_padding), float(sigma_bias), ptr(rgb), ptr(dist), ptr(acc),
-                              ptr(trans), ptr(trans_bkgd), ptr(weights), ptr(alpha), current_stream()), "rnerf_composite")
+                              ptr(trans), ptr(trans_bkgd), ptr(weights), ptr(alpha), int(mask_mode),
+                              C.byref((C.c_double * 6)(*[float(v) for v in bbox])) if bbox is not None else None,
+                              current_stream()), "rnerf_composite")
     return rgb, dist, acc, trans, trans_bkgd, weights, alpha
 
 
