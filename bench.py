@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--rays", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", dest="pipeline", action="store_false", help="march and MLP of a step strictly in sequence")
+    ap.add_argument("--frame", action="store_true", help="also time one 800x800 full-frame render (ms/frame, BASELINE metric 2)")
     ap.add_argument("--reserve-cus", type=int, default=32, help="CUs kept free of MLP workgroups for the overlapped march")
     ap.add_argument("--cpu-rays", type=int, default=2048)
     args = ap.parse_args()
@@ -191,6 +192,29 @@ def main():
                 traffic[k.split("::")[-1].split("<")[0]] = 1024.0 * (v["FETCH_SIZE"]["mean"] + v["WRITE_SIZE"]["mean"])
     except Exception:
         traffic = {}
+    frame = None
+    if args.frame:
+        # ms/frame @ 800x800 (BASELINE.json metric 2): pinhole rays of the example camera looking at the volume, rendered in
+        # pipelined chunks; each rank renders its own full frame here (the sharded variant is distributed.render_image_sharded)
+        from samplenerfro_amd import utils as U
+        H = W = 800
+        focal = 0.5 * W / np.tan(0.5 * 0.6911112070083618)          # example_data/transforms_train.json camera_angle_x
+        jj, ii = np.meshgrid(np.arange(W, dtype=np.float32) + 0.5, np.arange(H, dtype=np.float32) + 0.5, indexing="xy")
+        dirs = np.stack([(jj - W * 0.5) / focal, -(ii - H * 0.5) / focal, -np.ones_like(jj)], -1)
+        c2w = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 4.0]], np.float32)                  # camera on +z at distance 4
+        d_w = dirs @ c2w[:3, :3].T
+        v_w = d_w / np.linalg.norm(d_w, axis=-1, keepdims=True)
+        o_w = np.broadcast_to(c2w[:3, 3], d_w.shape).copy()
+        fr = Rays(torch.from_numpy(o_w).to(device), None, torch.from_numpy(v_w.astype(np.float32)).to(device), None)
+        fn = lambda k0, k1, r, path=None: model.apply(variables, k0, k1, r, False, path=path)
+        chunk = 8192 * 4
+        U.render_image(fn, fr, key, False, chunk=chunk, model=model)
+        barrier()
+        t1 = time.perf_counter()
+        rgb_img, _, _ = U.render_image(fn, fr, key, False, chunk=chunk, model=model)
+        barrier()
+        frame = {"ms_per_frame": 1e3 * D.max_over_ranks(time.perf_counter() - t1, device), "height": H, "width": W, "samples": cfg["S"] + fine,
+                 "chunk": chunk, "finite": bool(torch.isfinite(rgb_img).all())}
     if rank == 0:
         total_rays = B * args.steps * world
         rows_per_ray = S + (S + fine if fine > 0 else 0)
@@ -210,6 +234,8 @@ def main():
                                "unit": "GB/s", "frac": march_achieved / PEAK_HBM, "traffic": traffic.get("march_kernel"), "avg_launch_ms": march_ms,
                                "algorithmic_bytes_per_launch": march_bytes},
         }
+        if frame is not None:
+            line["frame"] = frame
         if not args.no_cpu_baseline:
             cpu_rps, cpu_dt = cpu_baseline(cfg, pf, fine, args.cpu_rays, syn.SEED)
             line["cpu_baseline"] = {"value": cpu_rps, "unit": "rays/s", "cores": os.cpu_count(), "kind": "port",

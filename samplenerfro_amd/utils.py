@@ -79,11 +79,12 @@ def learning_rate_decay(step, lr_init, lr_final, max_steps, lr_delay_steps=0, lr
     return start_rate * delay_rate * log_lerp
 
 
-def render_image(render_fn: Callable, rays: Rays, rng, normalize_disp: bool, chunk: int = 8192):
+def render_image(render_fn: Callable, rays: Rays, rng, normalize_disp: bool, chunk: int = 8192, model=None):
     """rnerf/utils.py:331-389.  `render_fn(key_0, key_1, chunk_rays)` -> (ret, loss_sp); the fine tuple ret[-1] is kept.
 
     rays: Rays of [H, W, ...] tensors.  Returns (rgb [H,W,3], dist [H,W,1], acc [H,W,1]).  The same key pair is used for
-    every chunk (:350).  There is no device padding/sharding here: one process renders on one GPU; multi-GPU eval gives
+    every chunk (:350).  With `model=` the chunks are software-pipelined (march of chunk k+1 beside the MLP of chunk k) and
+    render_fn must accept `path=`.  There is no device padding/sharding here: one process renders on one GPU; multi-GPU eval gives
     each rank a contiguous block of rows and needs no collective (samplenerfro_amd.distributed.render_image_sharded).
     """
     height, width = rays[0].shape[:2]
@@ -91,10 +92,22 @@ def render_image(render_fn: Callable, rays: Rays, rng, normalize_disp: bool, chu
     rays = namedtuple_map(lambda r: None if r is None else r.reshape((num_rays, -1)), rays)
     _unused, key_0, key_1 = prng.split(rng, 3)
     results = []
-    for i in range(0, num_rays, chunk):
-        chunk_rays = namedtuple_map(lambda r: None if r is None else r[i:i + chunk], rays)
-        chunk_results = render_fn(key_0, key_1, chunk_rays)[0][-1]
-        results.append(chunk_results)
+    if model is not None:
+        # pipelined form: `render_fn(key_0, key_1, chunk_rays, path=handle)`; the march of chunk k+1 runs on the model's side
+        # stream while chunk k is in its MLP phase (NerfModel.prefetch_path)
+        starts = list(range(0, num_rays, chunk))
+        get = lambda i: namedtuple_map(lambda r: None if r is None else r[i:i + chunk], rays)
+        nxt_rays = get(starts[0]); handle = model.prefetch_path(nxt_rays, sync_inputs=True)
+        for k, i in enumerate(starts):
+            cur_rays, cur_handle = nxt_rays, handle
+            if k + 1 < len(starts):
+                nxt_rays = get(starts[k + 1]); handle = model.prefetch_path(nxt_rays, sync_inputs=False)
+            results.append(render_fn(key_0, key_1, cur_rays, path=cur_handle)[0][-1])
+    else:
+        for i in range(0, num_rays, chunk):
+            chunk_rays = namedtuple_map(lambda r: None if r is None else r[i:i + chunk], rays)
+            chunk_results = render_fn(key_0, key_1, chunk_rays)[0][-1]
+            results.append(chunk_results)
     rgb, distance, acc, _trans, _trans_rgb_bkgd = [torch.cat(r, dim=0) for r in zip(*results)]
     if normalize_disp:
         distance = (distance - distance.min()) / (distance.max() - distance.min())
