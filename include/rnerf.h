@@ -153,6 +153,26 @@ int rnerf_composite_backward(const float* raw, const float* rows_pd, const float
                              const float* pixels, const float* trans, const float* trans_bkgd, const float* sums,
                              double mse_scale, double bg_scale, float* d_raw, float* d_bkgd, int accumulate_bkgd, void* stream);
 
+/* ---- T1 (backward of P1+N1): gradient of the NerfMLP parameters, replacing jax.value_and_grad through
+ * NerfMLP.__call__ (train.py:164; rnerf/model_utils.py:30-90).  Three steps:
+ *   rnerf_nerfmlp_forward_train : as rnerf_nerfmlp_forward (precision f16x3 / bf16x3) and additionally keeps the hi-part
+ *       operands of every layer in `save` (rnerf_nerfmlp_save_bytes(S*B) bytes);
+ *   rnerf_nerfmlp_dgrad : d_raw float4[rows] (d loss / d raw rgb, sigma) -> dy (rnerf_nerfmlp_dy_bytes(rows) bytes), the
+ *       gradients w.r.t. every layer's pre-activation output; packed_bwd from rnerf_nerfmlp_pack_bwd (transposed weights);
+ *   rnerf_nerfmlp_wgrad : (save, dy) -> grads float[RNERF_NERFMLP_PARAMS] in the flat parameter order (every entry is
+ *       overwritten); workspace: rnerf_nerfmlp_wgrad_workspace_bytes() bytes. */
+size_t rnerf_nerfmlp_save_bytes(int64_t rows);
+size_t rnerf_nerfmlp_dy_bytes(int64_t rows);
+size_t rnerf_nerfmlp_bwd_packed_bytes(void);
+size_t rnerf_nerfmlp_wgrad_workspace_bytes(void);
+int rnerf_nerfmlp_forward_train(const void* packed, int precision, const float* rows_pd, const float* rows_dr,
+                                const int32_t* node_of_sample, int32_t S, int32_t B, float* out_raw, void* save, void* stream);
+int rnerf_nerfmlp_pack_bwd(const float* params, void* packed_bwd, void* stream);
+int rnerf_nerfmlp_dgrad(const void* packed_bwd, const void* packed_fwd, int fwd_precision, const void* save, const float* d_raw,
+                        int64_t rows, void* dy, void* stream);
+int rnerf_nerfmlp_wgrad(int fwd_precision, const void* save, const void* dy, int64_t rows, float* grads, void* workspace,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif

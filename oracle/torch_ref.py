@@ -43,3 +43,25 @@ def radiance_loss(levels, pixels, bg_weight=0.0, annealed_alpha=1.0):
         parts["loss_c"] = loss_c
         total = total + loss_c
     return total, parts
+
+
+NERF_MLP_SHAPES = [(63, 256), (256, 256), (256, 256), (256, 256), (256, 256), (319, 256), (256, 256), (256, 256),
+                   (256, 1), (256, 256), (283, 128), (128, 3)]
+
+
+def nerf_mlp(flat, x, cond):
+    """rnerf/model_utils.py:30-90 on a flat parameter vector (flax order). x [R,63], cond [R,27] -> raw [R,4] = (rgb, sigma)."""
+    ps, off = [], 0
+    for i, o in NERF_MLP_SHAPES:
+        ps.append((flat[off:off + i * o].view(i, o), flat[off + i * o:off + i * o + o]))
+        off += i * o + o
+    h = x
+    for i in range(8):
+        h = torch.relu(h @ ps[i][0] + ps[i][1])
+        if i == 4:
+            h = torch.cat([h, x], -1)
+    sigma = h @ ps[8][0] + ps[8][1]
+    bott = h @ ps[9][0] + ps[9][1]
+    v = torch.relu(torch.cat([bott, cond], -1) @ ps[10][0] + ps[10][1])
+    rgb = v @ ps[11][0] + ps[11][1]
+    return torch.cat([rgb, sigma], -1)

@@ -55,6 +55,14 @@ SIGNATURES = {
     "rnerf_loss_reduce": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
     "rnerf_composite_backward": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _dbl, _dbl, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl,
                                            _vp, _vp, C.c_int, _vp]),
+    "rnerf_nerfmlp_save_bytes": (C.c_size_t, [_i64]),
+    "rnerf_nerfmlp_dy_bytes": (C.c_size_t, [_i64]),
+    "rnerf_nerfmlp_bwd_packed_bytes": (C.c_size_t, []),
+    "rnerf_nerfmlp_wgrad_workspace_bytes": (C.c_size_t, []),
+    "rnerf_nerfmlp_forward_train": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
+    "rnerf_nerfmlp_pack_bwd": (C.c_int, [_vp, _vp, _vp]),
+    "rnerf_nerfmlp_dgrad": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _i64, _vp, _vp]),
+    "rnerf_nerfmlp_wgrad": (C.c_int, [C.c_int, _vp, _vp, _i64, _vp, _vp, _vp]),
     "rnerf_resample": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
 }
 

@@ -368,10 +368,17 @@ __device__ __forceinline__ void kstep_mfma(f32x16 (&acc0)[8], f32x16 (&acc1)[8],
 //               of m-tile 1 ([n-tile][4-register group][lane] float4) = 160 KiB for the X3 modes.
 // The previous layer's outputs become this layer's B operands JUST IN TIME, one k-step ahead of use: bias + ReLU +
 // hi/lo split of 8 values per lane per m-tile, issued in the shadow of the 48 MFMAs of the current k-step.
-template <int PREC, int dbg>
+// Saved-activation layout of the training forward (consumed by the dgrad / wgrad kernels): slot-major uint4[SAVE_SLOTS][R][2]
+// (R = rows padded to the 256-row tile), one uint4 = the 8 hi-part operand values lane (row, half h) fed to one k-step, i.e.
+// exactly the B operands of the forward MFMAs.  slot 0..3: position encoding; 4 + 16*(l-1) + s: input k-step s of MFMA layer
+// l = 1..9; 148..149: view encoding; 150..157: ReLU'd output of the view layer (= rgb head input).
+constexpr int SAVE_PE = 0, SAVE_L1 = 4, SAVE_VIEW = 148, SAVE_RGBIN = 150, SAVE_SLOTS = 158;
+
+template <int PREC, int dbg, bool TRAIN>
 __global__ void __launch_bounds__(256, 1)
 nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ rows_pd, const float4* __restrict__ rows_dr,
-                   const int* __restrict__ node_of_sample, int B, long long total_rows, int n_tiles, float4* __restrict__ out_raw) {
+                   const int* __restrict__ node_of_sample, int B, long long total_rows, int n_tiles, float4* __restrict__ out_raw,
+                   uint4* __restrict__ save, long long save_rows) {
   // dbg != 0: profiling ablations, only instantiated with -DRNERF_MLP_ABLATE (results are garbage):
   //   bit0 = skip the weight-stream loads, bit1 = skip ds_read + MFMA, bit2 = skip the barrier.
   // Compile-time on purpose: a runtime branch per k-step would split the scheduling region and stop the compiler from
@@ -411,6 +418,16 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
     }
 
     f32x16 acc0[8], acc1[8], prev0[8];
+
+    // training forward: keep the hi parts of the operands of slot q (see SAVE_* above); padded rows are written too
+    const long long srow0 = (long long)tile * 256 + wave * 64 + m;
+    auto save_ops = [&](int q, const KOps& o) {
+      if constexpr (TRAIN) {
+        uint4* dst = save + ((size_t)q * save_rows + srow0) * 2 + h;
+        dst[0] = o.h0;
+        dst[64] = o.h1;          // m-tile 1 = rows + 32
+      }
+    };
 
     // positional-encoding operands of k-step s (slot maps pe_feature / view_feature), for both m-tiles
     auto enc_ops = [&](const float4 (&v)[2], int s, int nsin) -> KOps {
@@ -501,6 +518,7 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
       KOps cur = enc_ops(pd, 0, 30);
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
+        save_ops(SAVE_PE + s, cur);
         SLAB_PREFETCH(true);   // glds first: it is a scheduling boundary, conversion + MFMAs must share the region after it
         KOps nxt = cur;
         if (s + 1 < 4) nxt = enc_ops(pd, s + 1, 30);
@@ -520,6 +538,7 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
       load_bias8(1, bias, bnext);
 #define RNERF_KSTEP(S)                                                                                              \
       {                                                                                                              \
+        save_ops(SAVE_L1 + 16 * (l - 1) + S, cur);                                                                   \
         float bnn[8];                                                                                                \
         if constexpr (S + 2 < 16) load_bias8(S + 2, bias, bnn);   /* consumed in the NEXT slab */                     \
         auto dma = [&]() { SLAB_PREFETCH(true); };                                                                   \
@@ -577,6 +596,8 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
       KOps c1 = prev_ops(1, bias, NEG_INF);
 #pragma unroll
       for (int sl = 0; sl < 8; ++sl) {
+        save_ops(SAVE_L1 + 16 * 8 + 2 * sl, c0);
+        save_ops(SAVE_L1 + 16 * 8 + 2 * sl + 1, c1);
         SLAB_PREFETCH(true);
         KOps n0 = c0, n1 = c1;
         if (sl + 1 < 8) { n0 = prev_ops(2 * sl + 2, bias, NEG_INF); n1 = prev_ops(2 * sl + 3, bias, NEG_INF); }
@@ -589,6 +610,8 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
         c0 = n0; c1 = n1;
       }
       // last slab of the tile (the two view-encoding k-steps): prefetch the first slab of the next tile (stream restarts)
+      save_ops(SAVE_VIEW, c0);
+      save_ops(SAVE_VIEW + 1, c1);
       if (has_next_tile) off = 0;
       SLAB_PREFETCH(has_next_tile);
       if (!(dbg & 2)) { kstep_mfma<PREC, 4, 0, false>(acc0, acc1, c0, smem + buf * SLAB, lane, nowork); kstep_mfma<PREC, 4, 1, false>(acc0, acc1, c1, smem + buf * SLAB, lane, nowork); }
@@ -600,7 +623,8 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
       const float* __restrict__ b9 = aux + AUX_BIAS + 256 * 9;
       float p0[3] = {0.f, 0.f, 0.f}, p1[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+      for (int t = 0; t < 4; ++t) {
+        float rv0[16], rv1[16];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int n = 32 * t + 8 * g + 4 * h;
@@ -613,8 +637,21 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
             const float v1 = fmaxf(fmaf(acc1[t][4 * g + i], INV_SCALE, bv[i]), 0.f);
             p0[0] = fmaf(v0, wrv[i], p0[0]); p0[1] = fmaf(v0, wgv[i], p0[1]); p0[2] = fmaf(v0, wbv[i], p0[2]);
             p1[0] = fmaf(v1, wrv[i], p1[0]); p1[1] = fmaf(v1, wgv[i], p1[1]); p1[2] = fmaf(v1, wbv[i], p1[2]);
+            rv0[4 * g + i] = v0; rv1[4 * g + i] = v1;
           }
         }
+        if constexpr (TRAIN) {   // rgb-head input (ReLU'd view-layer output) in operand-slot order: k-step 2t + half, slot j = reg & 7
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+            KOps o;
+            o.h0 = make_uint4(pack2<PP::F16>(rv0[8 * half], rv0[8 * half + 1]), pack2<PP::F16>(rv0[8 * half + 2], rv0[8 * half + 3]),
+                              pack2<PP::F16>(rv0[8 * half + 4], rv0[8 * half + 5]), pack2<PP::F16>(rv0[8 * half + 6], rv0[8 * half + 7]));
+            o.h1 = make_uint4(pack2<PP::F16>(rv1[8 * half], rv1[8 * half + 1]), pack2<PP::F16>(rv1[8 * half + 2], rv1[8 * half + 3]),
+                              pack2<PP::F16>(rv1[8 * half + 4], rv1[8 * half + 5]), pack2<PP::F16>(rv1[8 * half + 6], rv1[8 * half + 7]));
+            save_ops(SAVE_RGBIN + 2 * t + half, o);
+          }
+        }
+      }
       const float bsig = aux[AUX_BSIG];
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
@@ -633,6 +670,372 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
   }
   if constexpr ((dbg & 64) != 0) {
     if (lane == 0) out_raw[blockIdx.x * 4 + wave] = make_float4(prof_tot, prof_dma, prof_bar, prof_n);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// T1 (MLP part): backward of the NerfMLP.  Replaces jax.value_and_grad through NerfMLP.__call__ (train.py:164 /
+// rnerf/model_utils.py:30-90).
+//   dgrad chain (this kernel): the same transposed-chain engine as the forward, with the weights transposed:
+//       dX^T[k][row] = W[k][n] dY^T[n][row]   (A = W rows, B = dY in accumulator layout, bf16 hi/lo split -> 3 MFMAs)
+//   dY_{l-1} = dX_l * 1[X_l > 0] uses the operands saved by the training forward as the ReLU mask (a saved operand is the
+//   ReLU output; 0 <=> inactive).  Every dY_l (bf16 hi parts, the very B operands of the next dgrad layer) is written
+//   slot-major for the wgrad kernel:  slot 16*l + s (l = 0..8), 144 + s (l = 9, 8 k-steps), 152 = head grads
+//   (half 0: slot 0 = d raw_sigma, slots 1..3 = d raw_rgb).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int DY_L9 = 144, DY_HEADS = 152, DY_SLOTS = 153;
+constexpr int kBwdBlocks = 8 * 8 + 8 * 16 * 8;   // (k-steps over n) x (8 input-feature tiles): L9 then L8..L1
+
+// dgrad layer order: index 0 = MFMA layer 9 (Dense_10), 1 = layer 8 (Dense_9), 2..8 = layers 7..1 (Dense_7..Dense_1)
+__host__ __device__ constexpr int bwd_dense(int i) { return i == 0 ? 10 : (i == 1 ? 9 : 9 - i); }
+__host__ __device__ constexpr int bwd_blocks_before(int i) { return i == 0 ? 0 : 64 + (i - 1) * 128; }
+
+template <int PREC>
+__global__ void nerfmlp_pack_bwd_kernel(const float* __restrict__ params, char* __restrict__ packed) {
+  using PP = Prec<PREC>;
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= kBwdBlocks * 64) return;
+  const int blk = gid >> 6, lane = gid & 63;
+  int i = 0;
+  while (i < 8 && blk >= bwd_blocks_before(i + 1)) ++i;
+  const int rel = blk - bwd_blocks_before(i);
+  const int s = rel / 8, kt = rel % 8;
+  const int d = bwd_dense(i), out_dim = nerf_dense(d).out;
+  const int kf = 32 * kt + (lane & 31), h = lane >> 5;        // input feature (row of the Dense kernel), < 256 always
+  float w[8];
+  for (int j = 0; j < 8; ++j) {
+    const int n = prev_feature(s, h, j);
+    w[j] = n < out_dim ? params[nerf_koff(d) + kf * out_dim + n] * PP::WSCALE : 0.f;
+  }
+  uint32_t hi[4], lo[4];
+  for (int p = 0; p < 4; ++p) split2<PP::F16>(w[2 * p], w[2 * p + 1], hi[p], lo[p]);
+  uint4* dst = (uint4*)(packed + (size_t)blk * PP::NP * 1024);
+  dst[lane] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+  if (PP::NP == 2) dst[64 + lane] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+}
+
+template <int PREC>
+__global__ void __launch_bounds__(256, 1)
+nerfmlp_dgrad_kernel(const char* __restrict__ packed_bwd, const float* __restrict__ fwd_aux, const uint4* __restrict__ saved,
+                     long long save_rows, const float4* __restrict__ d_raw, long long total_rows, int n_tiles,
+                     uint4* __restrict__ dy) {
+  using PP = Prec<PREC>;
+  static_assert(!PP::F16, "gradients need the bf16 exponent range");
+  constexpr int SLAB = PP::SLAB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 31, h = lane >> 5;
+  float4* __restrict__ st1 = (float4*)(smem + 2 * SLAB + wave * 32768) + lane;
+  int buf = 0;
+  size_t off = 0;
+  NoWork nowork;
+  constexpr int dbg = 0;
+
+  if ((int)blockIdx.x < n_tiles) { issue_slab<SLAB>(packed_bwd, 0u, wave, lane); off = SLAB; }
+  slab_wait_dma();
+  __syncthreads();
+
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const bool has_next_tile = tile + (int)gridDim.x < n_tiles;
+    const long long srow0 = (long long)tile * 256 + wave * 64 + m;
+    float4 g[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const long long row = srow0 + 32 * mt;
+      g[mt] = row < total_rows ? d_raw[row] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    f32x16 acc0[8], acc1[8], prev0[8];
+
+    auto dy_store = [&](int q, const KOps& o) {
+      uint4* dst = dy + ((size_t)q * save_rows + srow0) * 2 + h;
+      dst[0] = o.h0;
+      dst[64] = o.h1;
+    };
+    auto saved_at = [&](int q, uint4& a, uint4& b) {
+      const uint4* src = saved + ((size_t)q * save_rows + srow0) * 2 + h;
+      a = src[0]; b = src[64];
+    };
+    // operands of k-step s from the state (prev0 / st1): x = (state + dsig * wadd) * 1[mask != 0]
+    auto grad_ops = [&](int s, bool use_mask, const uint4 mk0, const uint4 mk1, const float* __restrict__ wadd) -> KOps {
+      const float4 u0 = st1[((s >> 1) * 4 + 2 * (s & 1)) * 64], u1 = st1[((s >> 1) * 4 + 2 * (s & 1) + 1) * 64];
+      const float r1[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+      const uint32_t w0[4] = {mk0.x, mk0.y, mk0.z, mk0.w}, w1[4] = {mk1.x, mk1.y, mk1.z, mk1.w};
+      float x0[8], x1[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float a = prev0[s >> 1][8 * (s & 1) + j], b = r1[j];
+        if (wadd) { const float w = wadd[16 * s + 8 * (j >> 2) + 4 * h + (j & 3)]; a = fmaf(g[0].w, w, a); b = fmaf(g[1].w, w, b); }
+        if (use_mask) {
+          const uint32_t e0 = (j & 1) ? (w0[j >> 1] >> 16) : (w0[j >> 1] & 0xffffu);
+          const uint32_t e1 = (j & 1) ? (w1[j >> 1] >> 16) : (w1[j >> 1] & 0xffffu);
+          a = (e0 & 0x7fffu) ? a : 0.f;
+          b = (e1 & 0x7fffu) ? b : 0.f;
+        }
+        x0[j] = a; x1[j] = b;
+      }
+      KOps o;
+      split8<PREC>(x0, o.h0, o.l0);
+      split8<PREC>(x1, o.h1, o.l1);
+      return o;
+    };
+    auto layer_end = [&]() {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        prev0[t] = acc0[t];
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq)
+          st1[(t * 4 + rq) * 64] = make_float4(acc1[t][4 * rq], acc1[t][4 * rq + 1], acc1[t][4 * rq + 2], acc1[t][4 * rq + 3]);
+      }
+    };
+#define SLAB_PREFETCH(DO_NEXT)                                                                                       \
+  do { if (DO_NEXT) { issue_slab<SLAB>(packed_bwd + off, (unsigned)((buf ^ 1) * SLAB), wave, lane); off += SLAB; } } while (0)
+#define SLAB_DONE() do { slab_wait_dma(); __syncthreads(); buf ^= 1; } while (0)
+
+    // ---- head gradients: record them for the wgrad kernel, push d raw_rgb through the rgb head (Dense_11) into the state
+    {
+      KOps o;
+      float hz0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, hz1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (h == 0) { hz0[0] = g[0].w; hz0[1] = g[0].x; hz0[2] = g[0].y; hz0[3] = g[0].z; hz1[0] = g[1].w; hz1[1] = g[1].x; hz1[2] = g[1].y; hz1[3] = g[1].z; }
+      split8<PREC>(hz0, o.h0, o.l0);
+      split8<PREC>(hz1, o.h1, o.l1);
+      dy_store(DY_HEADS, o);
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float a = 0.f, b = 0.f;
+          if (t < 4) {
+            const int n = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const float wr = fwd_aux[AUX_WRGB + n], wg = fwd_aux[AUX_WRGB + 128 + n], wb = fwd_aux[AUX_WRGB + 256 + n];
+            a = g[0].x * wr + g[0].y * wg + g[0].z * wb;
+            b = g[1].x * wr + g[1].y * wg + g[1].z * wb;
+          }
+          acc0[t][r] = a; acc1[t][r] = b;
+        }
+      layer_end();
+    }
+
+    // ---- dgrad of MFMA layer 9 (Dense_10): k-steps over its 128 outputs; state masked by the saved rgb-head input
+    {
+      uint4 ma, mb;
+      saved_at(SAVE_RGBIN, ma, mb);
+      KOps cur = grad_ops(0, true, ma, mb, nullptr);
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        dy_store(DY_L9 + s, cur);
+        SLAB_PREFETCH(true);
+        KOps nxt = cur;
+        if (s + 1 < 8) { saved_at(SAVE_RGBIN + s + 1, ma, mb); nxt = grad_ops(s + 1, true, ma, mb, nullptr); }
+        if (s == 0) kstep_mfma<PREC, 8, 0, true>(acc0, acc1, cur, smem + buf * SLAB, lane, nowork);
+        else kstep_mfma<PREC, 8, 0, false>(acc0, acc1, cur, smem + buf * SLAB, lane, nowork);
+        SLAB_DONE();
+        cur = nxt;
+      }
+      layer_end();
+    }
+
+    // ---- dgrad of MFMA layers 8..1: dY_l = (dX_{l+1} [+ d sigma * w_sigma for l = 7]) * 1[X_{l+1} > 0]  (no mask for the bottleneck l = 8)
+#pragma unroll 1
+    for (int l = 8; l >= 1; --l) {
+      const bool use_mask = l != 8;
+      const float* __restrict__ wadd = (l == 7) ? fwd_aux + AUX_WSIG : nullptr;
+      const int mq = SAVE_L1 + 16 * l;          // saved input of layer l+1
+      uint4 ma = make_uint4(0, 0, 0, 0), mb = ma;
+      if (use_mask) saved_at(mq, ma, mb);
+      KOps cur = grad_ops(0, use_mask, ma, mb, wadd);
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        dy_store(16 * l + s, cur);
+        const bool last_of_tile = (l == 1 && s == 15);
+        if (last_of_tile) { if (has_next_tile) off = 0; SLAB_PREFETCH(has_next_tile); } else SLAB_PREFETCH(true);
+        KOps nxt = cur;
+        if (s + 1 < 16) { if (use_mask) saved_at(mq + s + 1, ma, mb); nxt = grad_ops(s + 1, use_mask, ma, mb, wadd); }
+        if (s == 0) kstep_mfma<PREC, 8, 0, true>(acc0, acc1, cur, smem + buf * SLAB, lane, nowork);
+        else kstep_mfma<PREC, 8, 0, false>(acc0, acc1, cur, smem + buf * SLAB, lane, nowork);
+        SLAB_DONE();
+        cur = nxt;
+      }
+      layer_end();
+    }
+
+    // ---- dY_0 = dX_1 * 1[X_1 > 0]: only recorded (layer 0's inputs are constants)
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      uint4 ma, mb;
+      saved_at(SAVE_L1 + s, ma, mb);
+      const KOps o = grad_ops(s, true, ma, mb, nullptr);
+      dy_store(s, o);
+    }
+#undef SLAB_PREFETCH
+#undef SLAB_DONE
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// wgrad: dW[k][n] = sum_rows X[row][k] * dY[row][n] for one (X slots, dY slots) job.  The saved tensors hold, per lane, 8
+// FEATURES of one ROW (the forward's B-operand layout); an MFMA contracts over the 8 values a lane holds, so both operands
+// must first be transposed to "lane = feature, slots = rows".  The transposition is itself done on the matrix cores:
+//     D = X_frag(k-step 2t) * I_lo + X_frag(k-step 2t+1) * I_hi        (A = the saved operand, B = a shifted identity)
+// puts feature 16a + 8h + j of the two k-steps in output LANE 16a+8h+j and the wave's 32 rows in the 16 accumulator
+// registers (exact: one non-zero product per output) -> repacked to bf16 they are wgrad operands.  Each wave transposes
+// its own 32 rows, publishes the fragments in LDS, and after a barrier accumulates its share of the dW tiles over the 128
+// rows of the workgroup.  Partials per workgroup are summed (and the slot permutation undone) by wgrad_reduce_kernel.
+// ------------------------------------------------------------------------------------------------------------------
+template <bool F16>
+__device__ __forceinline__ uint4 shifted_identity(int lane, int a) {   // B operand: 1 at slot (h, j) of column 16a + 8h + j
+  const int col = lane & 31, h = lane >> 5;
+  uint32_t w[4] = {0, 0, 0, 0};
+  if ((col >> 4) == a && ((col >> 3) & 1) == h) { const int j = col & 7; w[j >> 1] = (F16 ? 0x3C00u : 0x3F80u) << (16 * (j & 1)); }
+  return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+__device__ __forceinline__ void pack_rows_bf16(const f32x16& d, uint4& u0, uint4& u1) {
+  u0 = make_uint4(pack2<false>(d[0], d[1]), pack2<false>(d[2], d[3]), pack2<false>(d[4], d[5]), pack2<false>(d[6], d[7]));
+  u1 = make_uint4(pack2<false>(d[8], d[9]), pack2<false>(d[10], d[11]), pack2<false>(d[12], d[13]), pack2<false>(d[14], d[15]));
+}
+
+template <bool X_F16>
+__global__ void __launch_bounds__(256, 1)
+nerfmlp_wgrad_kernel(const uint4* __restrict__ saved, const uint4* __restrict__ dy, long long R, int qx, int KSx, int qd, int KSd,
+                     long long total_rows, int n_chunks, float* __restrict__ partial, float* __restrict__ partial_bias) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 31, h = lane >> 5;
+  const int KT = KSx >> 1, NT = (KSd + 1) >> 1;
+  uint4* myT = (uint4*)(smem + wave * 32768) + lane;       // slot*64: X^T fragments 0..15, dY^T fragments 16..31
+  const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const uint4 ixl = shifted_identity<X_F16>(lane, 0), ixh = shifted_identity<X_F16>(lane, 1);
+  const uint4 idl = shifted_identity<false>(lane, 0), idh = shifted_identity<false>(lane, 1);
+  const uint32_t one2 = (m == 0) ? 0x3F803F80u : 0u;
+  const uint4 ones = make_uint4(one2, one2, one2, one2);      // A operand whose row 0 is all ones: D[0][n] = sum over rows
+  f32x16 acc[2][8], accb[2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a) { accb[a] = zero;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc[a][b] = zero; }
+
+  for (int chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    const long long row = (long long)chunk * 128 + wave * 32 + m;
+    const bool ok = row < total_rows;
+    // ---- transpose this wave's 32 rows
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      if (t < KT) {
+        const uint4 a0 = saved[((size_t)(qx + 2 * t) * R + row) * 2 + h], a1 = saved[((size_t)(qx + 2 * t + 1) * R + row) * 2 + h];
+        f32x16 d = mfma16<X_F16>(a0, ixl, zero);
+        d = mfma16<X_F16>(a1, ixh, d);
+        uint4 u0, u1;
+        pack_rows_bf16(d, u0, u1);
+        myT[(2 * t) * 64] = u0; myT[(2 * t + 1) * 64] = u1;
+      }
+      if (t < NT) {
+        uint4 a0 = dy[((size_t)(qd + 2 * t) * R + row) * 2 + h];
+        uint4 a1 = (2 * t + 1 < KSd) ? dy[((size_t)(qd + 2 * t + 1) * R + row) * 2 + h] : make_uint4(0, 0, 0, 0);
+        if (!ok) { a0 = make_uint4(0, 0, 0, 0); a1 = a0; }       // padded rows carry replayed data: they must not contribute
+        f32x16 d = mfma16<false>(a0, idl, zero);
+        d = mfma16<false>(a1, idh, d);
+        uint4 u0, u1;
+        pack_rows_bf16(d, u0, u1);
+        myT[(16 + 2 * t) * 64] = u0; myT[(16 + 2 * t + 1) * 64] = u1;
+      }
+    }
+    __syncthreads();
+    // ---- accumulate this wave's dW tiles (k-tiles wave, wave+4; all n-tiles) over the 4 x 32 rows
+#pragma unroll 1
+    for (int v = 0; v < 4; ++v) {
+      const uint4* T = (const uint4*)(smem + v * 32768) + lane;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        uint4 b[8];
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) if (nt < NT) b[nt] = T[(16 + 2 * nt + u) * 64];
+#pragma unroll
+        for (int ki = 0; ki < 2; ++ki) {
+          const int kt = wave + 4 * ki;
+          if (kt < KT) {
+            const uint4 a = T[(2 * kt + u) * 64];
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) if (nt < NT) acc[ki][nt] = mfma16<false>(a, b[nt], acc[ki][nt]);
+          }
+        }
+#pragma unroll
+        for (int bi = 0; bi < 2; ++bi) {
+          const int nt = 2 * wave + bi;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) if (q == nt && nt < NT) accb[bi] = mfma16<false>(ones, b[q], accb[bi]);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // ---- per-workgroup partials: partial[g][KT*32][NT*32], partial_bias[g][NT*32]
+  const size_t ldn = (size_t)NT * 32;
+  float* pg = partial + (size_t)blockIdx.x * (size_t)KT * 32 * ldn;
+#pragma unroll
+  for (int ki = 0; ki < 2; ++ki) {
+    const int kt = wave + 4 * ki;
+    if (kt < KT) {
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) if (nt < NT) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+          pg[(size_t)(kt * 32 + i) * ldn + nt * 32 + m] = acc[ki][nt][r];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int bi = 0; bi < 2; ++bi) {
+    const int nt = 2 * wave + bi;
+    if (nt < NT && h == 0) partial_bias[(size_t)blockIdx.x * ldn + nt * 32 + m] = accb[bi][0];
+  }
+}
+
+// job description for the reduction: where the slot-ordered partial rows/columns land in the flat fp32 gradient buffer
+struct WgradJob {
+  int dense;      // Dense_k index in the flat parameter buffer
+  int xkind;      // 0 = position encoding slots, 1 = previous-layer slots, 2 = view encoding slots
+  int row_off;    // kernel row offset of this X block (256 for the concat parts)
+  int dkind;      // 0 = layer outputs (prev_feature order), 1 = sigma head (slot 0 of the head grads), 2 = rgb head (slots 1..3)
+  int KT, NT, write_bias;
+};
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ partial_bias, int n_wg, WgradJob job,
+                                    float* __restrict__ grads) {
+  const int ldn = job.NT * 32, rows = job.KT * 32;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int in_dim = nerf_dense(job.dense).in, out_dim = nerf_dense(job.dense).out;
+  auto out_feature = [&](int J) -> int {
+    const int nt = J >> 5, c = J & 31, a = c >> 4, hh = (c >> 3) & 1, j = c & 7;
+    if (job.dkind == 0) { const int n = prev_feature(2 * nt + a, hh, j); return n < out_dim ? n : -1; }
+    if (a != 0 || hh != 0 || nt != 0) return -1;
+    if (job.dkind == 1) return j == 0 ? 0 : -1;
+    return (j >= 1 && j <= 3) ? j - 1 : -1;
+  };
+  if (e < rows * ldn) {
+    const int I = e / ldn, J = e % ldn;
+    const int kt = I >> 5, c = I & 31, a = c >> 4, hh = (c >> 3) & 1, j = c & 7, s = 2 * kt + a;
+    int fin = job.xkind == 1 ? prev_feature(s, hh, j) : (job.xkind == 0 ? pe_feature(8 * s + j, hh) : view_feature(8 * s + j, hh));
+    const int fout = out_feature(J);
+    if (fin >= 0 && fout >= 0) {
+      fin += job.row_off;
+      if (fin < in_dim) {
+        float sum = 0.f;
+        for (int g = 0; g < n_wg; ++g) sum += partial[(size_t)g * rows * ldn + e];
+        grads[nerf_koff(job.dense) + fin * out_dim + fout] = sum;
+      }
+    }
+  }
+  if (job.write_bias && e < ldn) {
+    const int fout = out_feature(e);
+    if (fout >= 0) {
+      float sum = 0.f;
+      for (int g = 0; g < n_wg; ++g) sum += partial_bias[(size_t)g * ldn + e];
+      grads[nerf_boff(job.dense) + fout] = sum;
+    }
   }
 }
 
@@ -793,9 +1196,9 @@ static int mlp_debug_flags() {
   return v;
 }
 
-template <int PREC, int DBG>
+template <int PREC, int DBG, bool TRAIN = false>
 static int launch_fwd_dbg(const void* packed, const float* rows_pd, const float* rows_dr, const int32_t* node_of_sample, int32_t B,
-                          long long total_rows, float* out_raw, hipStream_t st);
+                          long long total_rows, float* out_raw, hipStream_t st, void* save = nullptr);
 
 template <int PREC>
 static int launch_fwd(const void* packed, const float* rows_pd, const float* rows_dr, const int32_t* node_of_sample, int32_t B,
@@ -821,9 +1224,9 @@ static int launch_fwd(const void* packed, const float* rows_pd, const float* row
   return launch_fwd_dbg<PREC, 0>(packed, rows_pd, rows_dr, node_of_sample, B, total_rows, out_raw, st);
 }
 
-template <int PREC, int DBG>
+template <int PREC, int DBG, bool TRAIN>
 static int launch_fwd_dbg(const void* packed, const float* rows_pd, const float* rows_dr, const int32_t* node_of_sample, int32_t B,
-                      long long total_rows, float* out_raw, hipStream_t st) {
+                      long long total_rows, float* out_raw, hipStream_t st, void* save) {
   using PP = Prec<PREC>;
   const int n_tiles = (int)((total_rows + 255) / 256);
   int dev = 0, cus = 0;
@@ -834,11 +1237,12 @@ static int launch_fwd_dbg(const void* packed, const float* rows_pd, const float*
   const size_t lds = 2 * (size_t)PP::SLAB + 4 * 32768;
   static bool attr_set = false;
   if (!attr_set) {
-    RNERF_CHECK_HIP(hipFuncSetAttribute((const void*)nerfmlp_fwd_kernel<PREC, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    RNERF_CHECK_HIP(hipFuncSetAttribute((const void*)nerfmlp_fwd_kernel<PREC, DBG, TRAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL((nerfmlp_fwd_kernel<PREC, DBG>), dim3(grid), dim3(256), lds, st, (const char*)packed, (const float4*)rows_pd,
-                     (const float4*)rows_dr, node_of_sample, B, total_rows, n_tiles, (float4*)out_raw);
+  hipLaunchKernelGGL((nerfmlp_fwd_kernel<PREC, DBG, TRAIN>), dim3(grid), dim3(256), lds, st, (const char*)packed, (const float4*)rows_pd,
+                     (const float4*)rows_dr, node_of_sample, B, total_rows, n_tiles, (float4*)out_raw, (uint4*)save,
+                     (long long)n_tiles * 256);
   RNERF_CHECK_LAUNCH();
   return RNERF_OK;
 }
@@ -858,6 +1262,119 @@ extern "C" int rnerf_nerfmlp_forward(const void* packed, int precision, const fl
     case RNERF_PREC_F16: return launch_fwd<RNERF_PREC_F16>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st);
     default: return launch_fwd<RNERF_PREC_BF16>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st);
   }
+}
+
+extern "C" size_t rnerf_nerfmlp_save_bytes(int64_t rows) {
+  const int64_t padded = (rows + 255) / 256 * 256;
+  return (size_t)SAVE_SLOTS * (size_t)padded * 2 * sizeof(uint4);
+}
+
+extern "C" int rnerf_nerfmlp_forward_train(const void* packed, int precision, const float* rows_pd, const float* rows_dr,
+                                           const int32_t* node_of_sample, int32_t S, int32_t B, float* out_raw, void* save,
+                                           void* stream) {
+  RNERF_CHECK_ARG(packed && rows_pd && rows_dr && out_raw && save, "rnerf_nerfmlp_forward_train: null pointer");
+  RNERF_CHECK_ARG(precision == RNERF_PREC_F16X3 || precision == RNERF_PREC_BF16X3, "rnerf_nerfmlp_forward_train: precision must be f16x3 or bf16x3");
+  RNERF_CHECK_ARG(S >= 1 && B >= 1, "rnerf_nerfmlp_forward_train: need S >= 1 and B >= 1");
+  RNERF_CHECK_ARG((((uintptr_t)packed | (uintptr_t)rows_pd | (uintptr_t)rows_dr | (uintptr_t)out_raw | (uintptr_t)save) & 15) == 0,
+                  "rnerf_nerfmlp_forward_train: buffers must be 16-byte aligned");
+  const long long total = (long long)S * B;
+  hipStream_t st = (hipStream_t)stream;
+  if (precision == RNERF_PREC_F16X3) return launch_fwd_dbg<RNERF_PREC_F16X3, 0, true>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, save);
+  return launch_fwd_dbg<RNERF_PREC_BF16X3, 0, true>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, save);
+}
+
+extern "C" size_t rnerf_nerfmlp_bwd_packed_bytes(void) { return (size_t)kBwdBlocks * 2 * 1024; }
+extern "C" size_t rnerf_nerfmlp_dy_bytes(int64_t rows) {
+  const int64_t padded = (rows + 255) / 256 * 256;
+  return (size_t)DY_SLOTS * (size_t)padded * 2 * sizeof(uint4);
+}
+
+extern "C" int rnerf_nerfmlp_pack_bwd(const float* params, void* packed_bwd, void* stream) {
+  RNERF_CHECK_ARG(params && packed_bwd, "rnerf_nerfmlp_pack_bwd: null pointer");
+  const int threads = kBwdBlocks * 64;
+  hipLaunchKernelGGL(nerfmlp_pack_bwd_kernel<RNERF_PREC_BF16X3>, dim3((threads + 255) / 256), dim3(256), 0, (hipStream_t)stream, params,
+                     (char*)packed_bwd);
+  RNERF_CHECK_LAUNCH();
+  return RNERF_OK;
+}
+
+extern "C" int rnerf_nerfmlp_dgrad(const void* packed_bwd, const void* packed_fwd, int fwd_precision, const void* save,
+                                   const float* d_raw, int64_t rows, void* dy, void* stream) {
+  RNERF_CHECK_ARG(packed_bwd && packed_fwd && save && d_raw && dy, "rnerf_nerfmlp_dgrad: null pointer");
+  RNERF_CHECK_ARG(fwd_precision == RNERF_PREC_F16X3 || fwd_precision == RNERF_PREC_BF16X3, "rnerf_nerfmlp_dgrad: forward precision must be f16x3 or bf16x3");
+  RNERF_CHECK_ARG(rows >= 1, "rnerf_nerfmlp_dgrad: rows must be >= 1");
+  using PB = Prec<RNERF_PREC_BF16X3>;
+  const size_t fwd_stream = fwd_precision == RNERF_PREC_F16X3 ? Prec<RNERF_PREC_F16X3>::STREAM_BYTES : Prec<RNERF_PREC_BF16X3>::STREAM_BYTES;
+  const float* fwd_aux = (const float*)((const char*)packed_fwd + fwd_stream);
+  const int n_tiles = (int)((rows + 255) / 256);
+  int dev = 0, cus = 0;
+  RNERF_CHECK_HIP(hipGetDevice(&dev));
+  RNERF_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  const int grid = n_tiles < cus ? n_tiles : cus;
+  const size_t lds = 2 * (size_t)PB::SLAB + 4 * 32768;
+  static bool attr_set = false;
+  if (!attr_set) {
+    RNERF_CHECK_HIP(hipFuncSetAttribute((const void*)nerfmlp_dgrad_kernel<RNERF_PREC_BF16X3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(nerfmlp_dgrad_kernel<RNERF_PREC_BF16X3>, dim3(grid), dim3(256), lds, (hipStream_t)stream, (const char*)packed_bwd, fwd_aux,
+                     (const uint4*)save, (long long)n_tiles * 256, (const float4*)d_raw, (long long)rows, n_tiles, (uint4*)dy);
+  RNERF_CHECK_LAUNCH();
+  return RNERF_OK;
+}
+
+// the 15 wgrad jobs of one NerfMLP: {x slot base, x k-steps, dy slot base, dy k-steps, job}
+struct WgradPlan { int qx, KSx, qd, KSd; WgradJob job; };
+static const WgradPlan kWgradPlan[15] = {
+    {SAVE_PE, 4, 0, 16, {0, 0, 0, 0, 2, 8, 1}},
+    {SAVE_L1 + 0, 16, 16, 16, {1, 1, 0, 0, 8, 8, 1}},   {SAVE_L1 + 16, 16, 32, 16, {2, 1, 0, 0, 8, 8, 1}},
+    {SAVE_L1 + 32, 16, 48, 16, {3, 1, 0, 0, 8, 8, 1}},  {SAVE_L1 + 48, 16, 64, 16, {4, 1, 0, 0, 8, 8, 1}},
+    {SAVE_L1 + 64, 16, 80, 16, {5, 1, 0, 0, 8, 8, 1}},  {SAVE_PE, 4, 80, 16, {5, 0, 256, 0, 2, 8, 0}},
+    {SAVE_L1 + 80, 16, 96, 16, {6, 1, 0, 0, 8, 8, 1}},  {SAVE_L1 + 96, 16, 112, 16, {7, 1, 0, 0, 8, 8, 1}},
+    {SAVE_L1 + 112, 16, 128, 16, {9, 1, 0, 0, 8, 8, 1}}, {SAVE_L1 + 112, 16, DY_HEADS, 1, {8, 1, 0, 1, 8, 1, 1}},
+    {SAVE_L1 + 128, 16, DY_L9, 8, {10, 1, 0, 0, 8, 4, 1}}, {SAVE_VIEW, 2, DY_L9, 8, {10, 2, 256, 0, 1, 4, 0}},
+    {SAVE_RGBIN, 8, DY_HEADS, 1, {11, 1, 0, 2, 4, 1, 1}},
+    {0, 0, 0, 0, {0, 0, 0, 0, 0, 0, 0}}};
+
+extern "C" size_t rnerf_nerfmlp_wgrad_workspace_bytes(void) {
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  return (size_t)cus * (256 * 256 + 256) * sizeof(float);
+}
+
+extern "C" int rnerf_nerfmlp_wgrad(int fwd_precision, const void* save, const void* dy, int64_t rows, float* grads, void* workspace,
+                                   void* stream) {
+  RNERF_CHECK_ARG(save && dy && grads && workspace, "rnerf_nerfmlp_wgrad: null pointer");
+  RNERF_CHECK_ARG(fwd_precision == RNERF_PREC_F16X3 || fwd_precision == RNERF_PREC_BF16X3, "rnerf_nerfmlp_wgrad: forward precision must be f16x3 or bf16x3");
+  RNERF_CHECK_ARG(rows >= 1, "rnerf_nerfmlp_wgrad: rows must be >= 1");
+  int dev = 0, cus = 0;
+  RNERF_CHECK_HIP(hipGetDevice(&dev));
+  RNERF_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  const long long R = (rows + 255) / 256 * 256;
+  const int n_chunks = (int)((rows + 127) / 128);
+  const int grid = n_chunks < cus ? n_chunks : cus;
+  float* partial = (float*)workspace;
+  float* partial_bias = partial + (size_t)cus * 256 * 256;
+  hipStream_t st = (hipStream_t)stream;
+  static bool attr_set = false;
+  if (!attr_set) {
+    RNERF_CHECK_HIP(hipFuncSetAttribute((const void*)nerfmlp_wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+    RNERF_CHECK_HIP(hipFuncSetAttribute((const void*)nerfmlp_wgrad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+    attr_set = true;
+  }
+  for (int i = 0; kWgradPlan[i].KSx != 0; ++i) {
+    const WgradPlan& p = kWgradPlan[i];
+    if (fwd_precision == RNERF_PREC_F16X3)
+      hipLaunchKernelGGL(nerfmlp_wgrad_kernel<true>, dim3(grid), dim3(256), 131072, st, (const uint4*)save, (const uint4*)dy, R, p.qx, p.KSx,
+                         p.qd, p.KSd, (long long)rows, n_chunks, partial, partial_bias);
+    else
+      hipLaunchKernelGGL(nerfmlp_wgrad_kernel<false>, dim3(grid), dim3(256), 131072, st, (const uint4*)save, (const uint4*)dy, R, p.qx, p.KSx,
+                         p.qd, p.KSd, (long long)rows, n_chunks, partial, partial_bias);
+    const int elems = p.job.KT * 32 * p.job.NT * 32;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((elems + 255) / 256), dim3(256), 0, st, partial, partial_bias, grid, p.job, grads);
+  }
+  RNERF_CHECK_LAUNCH();
+  return RNERF_OK;
 }
 
 extern "C" int rnerf_bkgd_forward(const float* params, const float* dirs, int32_t dir_stride, int64_t n, double rgb_padding,

@@ -191,3 +191,41 @@ def composite_backward(raw, rows_pd, rows_dr, node_of_sample, S: int, B: int, bk
                                        float(bg_scale), ptr(d_raw), ptr(d_bkgd), int(acc), current_stream()),
           "rnerf_composite_backward")
     return d_raw, d_bkgd
+
+
+def nerfmlp_forward_train(packed, precision: int, rows_pd, rows_dr, node_of_sample, S: int, B: int):
+    """Training forward: raw [S,B,4] + the saved operands (uint8 buffer) for the backward kernels."""
+    lib = _lib.load()
+    dev = rows_pd.device
+    out = torch.empty((S, B, 4), dtype=torch.float32, device=dev)
+    save = torch.empty(lib.rnerf_nerfmlp_save_bytes(S * B), dtype=torch.uint8, device=dev)
+    check(lib.rnerf_nerfmlp_forward_train(ptr(packed), int(precision), ptr(_chk(rows_pd, "rows_pd")), ptr(_chk(rows_dr, "rows_dr")),
+                                          ptr(node_of_sample), int(S), int(B), ptr(out), ptr(save), current_stream()),
+          "rnerf_nerfmlp_forward_train")
+    return out, save
+
+
+def nerfmlp_pack_bwd(params_flat: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    lib = _lib.load()
+    p = _chk(params_flat, "params_flat")
+    if out is None:
+        out = torch.empty(lib.rnerf_nerfmlp_bwd_packed_bytes(), dtype=torch.uint8, device=p.device)
+    check(lib.rnerf_nerfmlp_pack_bwd(ptr(p), ptr(out), current_stream()), "rnerf_nerfmlp_pack_bwd")
+    return out
+
+
+def nerfmlp_backward(packed_bwd, packed_fwd, precision: int, save, d_raw: torch.Tensor, rows: int,
+                     grads: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """d_raw [S,B,4] (d loss / d raw) -> flat fp32 gradient of the NerfMLP parameters (595844 floats)."""
+    lib = _lib.load()
+    dev = d_raw.device
+    dy = torch.empty(lib.rnerf_nerfmlp_dy_bytes(rows), dtype=torch.uint8, device=dev)
+    check(lib.rnerf_nerfmlp_dgrad(ptr(packed_bwd), ptr(packed_fwd), int(precision), ptr(save), ptr(_chk(d_raw, "d_raw")), int(rows), ptr(dy),
+                                  current_stream()), "rnerf_nerfmlp_dgrad")
+    if grads is None:
+        grads = torch.empty(_lib.NERFMLP_PARAMS, dtype=torch.float32, device=dev)
+    if workspace is None:
+        workspace = torch.empty(lib.rnerf_nerfmlp_wgrad_workspace_bytes(), dtype=torch.uint8, device=dev)
+    check(lib.rnerf_nerfmlp_wgrad(int(precision), ptr(save), ptr(dy), int(rows), ptr(grads), ptr(workspace), current_stream()),
+          "rnerf_nerfmlp_wgrad")
+    return grads

@@ -76,3 +76,45 @@ def test_loss_and_composite_backward(bg_weight):
         err = np.abs(g - ref).max() / scale
         print(f"max rel err {err:.2e} (scale {scale:.2e})")
         assert err < 5e-6
+
+
+@pytest.mark.parametrize("prec", ["f16x3", "bf16x3"])
+def test_nerfmlp_backward(prec):
+    """Flat parameter gradient of the NerfMLP (dgrad chain + wgrad on the matrix cores) vs torch.autograd in float64."""
+    from samplenerfro_amd import ops, synthetic as syn
+    rng = np.random.default_rng(9)
+    B, S = 83, 7                                   # 581 rows: ragged last 256-row tile and 128-row wgrad chunk
+    pf = syn.init_params_flat(12, fine=False, bias_scale=0.1)["coarse_mlp"]
+    pos = rng.uniform(-3, 3, (B, S, 3)).astype(F32)
+    dirs = R.safe_l2_normalize(rng.standard_normal((B, S, 3)).astype(F32))
+    pd = np.concatenate([pos, np.zeros((B, S, 1), F32)], -1).transpose(1, 0, 2)
+    dr = np.concatenate([dirs, np.zeros((B, S, 1), F32)], -1).transpose(1, 0, 2)
+    cot = (rng.standard_normal((S, B, 4)) * np.array([1e-3, 1e-3, 1e-3, 3e-4])).astype(F32)      # d loss / d raw
+    P = _lib.PRECISIONS[prec]
+    flat_d = T(pf)
+    packed = ops.nerfmlp_pack(flat_d, P)
+    raw, save = ops.nerfmlp_forward_train(packed, P, T(pd.astype(F32)), T(dr.astype(F32)), None, S, B)
+    raw_eval = ops.nerfmlp_forward(packed, P, T(pd.astype(F32)), T(dr.astype(F32)), None, S, B)
+    assert torch.equal(raw, raw_eval)                                   # saving activations must not change the outputs
+    grads = ops.nerfmlp_backward(ops.nerfmlp_pack_bwd(flat_d), packed, P, save, T(cot), S * B).cpu().numpy().astype(np.float64)
+    # reference
+    flat = torch.tensor(pf, dtype=torch.float64, requires_grad=True)
+    enc = torch.tensor(R.pos_enc(pos.transpose(1, 0, 2).reshape(-1, 3), 0, 10), dtype=torch.float64)
+    venc = torch.tensor(R.pos_enc(dirs.transpose(1, 0, 2).reshape(-1, 3), 0, 4), dtype=torch.float64)
+    out = TR.nerf_mlp(flat, enc, venc)
+    (out * torch.tensor(cot.reshape(-1, 4), dtype=torch.float64)).sum().backward()
+    ref = flat.grad.numpy()
+    assert np.abs(out.detach().numpy() - raw.cpu().numpy().reshape(-1, 4)).max() < 1e-4
+    off = 0
+    worst = 0.0
+    for k, (i, o) in enumerate(TR.NERF_MLP_SHAPES):
+        for name, n in (("kernel", i * o), ("bias", o)):
+            g, r = grads[off:off + n], ref[off:off + n]
+            off += n
+            scale = np.abs(r).max()
+            err = np.abs(g - r).max() / scale
+            cos = float(g @ r / (np.linalg.norm(g) * np.linalg.norm(r) + 1e-300))
+            worst = max(worst, err)
+            # bf16 operands in wgrad (8-bit mantissa, unbiased rounding over 581 rows): 1.5e-2 of the largest entry
+            assert err < 1.5e-2 and cos > 0.9995, f"Dense_{k} {name}: rel err {err:.3e}, cos {cos:.6f}"
+    print(f"[{prec}] worst relative gradient error over the 24 tensors: {worst:.2e}")
