@@ -173,6 +173,18 @@ int rnerf_nerfmlp_dgrad(const void* packed_bwd, const void* packed_fwd, int fwd_
 int rnerf_nerfmlp_wgrad(int fwd_precision, const void* save, const void* dy, int64_t rows, float* grads, void* workspace,
                         void* stream);
 
+/* ---- T1 (backward of P1+N2): the background MLP, exact fp32 on the matrix cores like its forward.
+ * rnerf_bkgd_forward_train = rnerf_bkgd_forward + `save` (rnerf_bkgd_save_bytes(n) bytes).
+ * rnerf_bkgd_backward: d_out float[n][3] (d loss / d activated bkgd colour) -> ACCUMULATES into grads
+ * float[RNERF_BKGDMLP_PARAMS] (the caller zeroes it once per step: the per-ray bkgd and the env-map patch, train.py:127-130,
+ * both add to it); dy: scratch of rnerf_bkgd_dy_bytes(n) bytes. */
+size_t rnerf_bkgd_save_bytes(int64_t n);
+size_t rnerf_bkgd_dy_bytes(int64_t n);
+int rnerf_bkgd_forward_train(const float* params, const float* dirs, int32_t dir_stride, int64_t n, double rgb_padding,
+                             float* out_rgb, void* save, void* stream);
+int rnerf_bkgd_backward(const float* params, const void* save, const float* d_out, int64_t n, double rgb_padding, void* dy,
+                        float* grads, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -65,3 +65,21 @@ def nerf_mlp(flat, x, cond):
     v = torch.relu(torch.cat([bott, cond], -1) @ ps[10][0] + ps[10][1])
     rgb = v @ ps[11][0] + ps[11][1]
     return torch.cat([rgb, sigma], -1)
+
+
+BKGD_MLP_SHAPES = [(27, 128), (128, 128), (128, 128), (155, 128), (128, 3)]
+
+
+def bkgd_mlp(flat, enc, rgb_padding=0.001):
+    """rnerf/model_utils.py:93-140 as built at rnerf/models.py:116-118 + rgb activation (:336-337). enc [n,27] -> [n,3]."""
+    ps, off = [], 0
+    for i, o in BKGD_MLP_SHAPES:
+        ps.append((flat[off:off + i * o].view(i, o), flat[off + i * o:off + i * o + o]))
+        off += i * o + o
+    h = enc
+    for i in range(4):
+        h = torch.relu(h @ ps[i][0] + ps[i][1])
+        if i == 2:
+            h = torch.cat([h, enc], -1)
+    raw = h @ ps[4][0] + ps[4][1]
+    return torch.sigmoid(raw) * (1 + 2 * rgb_padding) - rgb_padding

@@ -1090,8 +1090,14 @@ __device__ __forceinline__ void small_dir_layer(f32x16 (&acc)[4], const float (&
   }
 }
 
+// save (training forward), fp32 row-major: [enc: n x 28][X1: n x 128][X2][X3][X4][out: n x 3]  (X_k = ReLU'd input of Dense_k)
+__host__ __device__ constexpr size_t bkgd_save_floats(long long n) { return (size_t)n * (28 + 4 * 128 + 3); }
+__host__ __device__ constexpr size_t bkgd_dy_floats(long long n) { return (size_t)n * (4 * 128 + 4); }   // [dY0..dY3: n x 128][d raw: n x 4]
+
+template <bool TRAIN>
 __global__ void __launch_bounds__(64) bkgd_fwd_kernel(const float* __restrict__ params, const float* __restrict__ dirs, int dir_stride,
-                                                      long long n, float pad_scale, float pad, float* __restrict__ out_rgb) {
+                                                      long long n, float pad_scale, float pad, float* __restrict__ out_rgb,
+                                                      float* __restrict__ save) {
   const int lane = threadIdx.x & 63, m = lane & 31, h = lane >> 5;
   long long row = (long long)blockIdx.x * 32 + m;
   const bool ok = row < n;
@@ -1108,6 +1114,25 @@ __global__ void __launch_bounds__(64) bkgd_fwd_kernel(const float* __restrict__ 
   }
   enc[12] = h ? v2 : v0;
   enc[13] = h ? 0.f : v1;
+  auto save_x = [&](int k, const f32x16 (&xx)[4]) {     // X_k[row][f], f = 32t + 8g + 4h + i
+    if constexpr (TRAIN) {
+      if (ok) {
+        float* dst = save + (size_t)n * 28 + (size_t)(k - 1) * n * 128 + (size_t)row * 128;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            *(float4*)(dst + 32 * t + 8 * g + 4 * h) = make_float4(xx[t][4 * g], xx[t][4 * g + 1], xx[t][4 * g + 2], xx[t][4 * g + 3]);
+      }
+    }
+  };
+  if constexpr (TRAIN) {
+    if (ok) {
+#pragma unroll
+      for (int q = 0; q < 14; ++q) { const int f = h ? dir_feature(q, 1) : dir_feature(q, 0); if (f >= 0) save[(size_t)row * 28 + f] = enc[q]; }
+      if (h == 1) save[(size_t)row * 28 + 27] = 0.f;
+    }
+  }
 
   f32x16 acc[4], x[4];
   // Dense_0: 27 -> 128, ReLU
@@ -1117,6 +1142,7 @@ __global__ void __launch_bounds__(64) bkgd_fwd_kernel(const float* __restrict__ 
   for (int t = 0; t < 4; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) x[t][r] = fmaxf(acc[t][r], 0.f);
+  save_x(1, x);
   // Dense_1, Dense_2: 128 -> 128, ReLU
 #pragma unroll 1
   for (int l = 1; l <= 2; ++l) {
@@ -1126,12 +1152,20 @@ __global__ void __launch_bounds__(64) bkgd_fwd_kernel(const float* __restrict__ 
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) x[t][r] = fmaxf(acc[t][r], 0.f);
+    save_x(l + 1, x);
   }
   // Dense_3: [x(128), inputs(27)] -> 128, ReLU  (skip concat after i == 2, rnerf/model_utils.py:131-132)
   small_init_bias(acc, params + bkgd_boff(3), h);
   small_prev_layer(acc, x, params + bkgd_koff(3), m, h);
   small_dir_layer(acc, enc, params + bkgd_koff(3) + 128 * 128, m, h);
   // Dense_4: 128 -> 3 on the VALU, then sigmoid*(1+2p)-p (rnerf/models.py:336-337)
+  if constexpr (TRAIN) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) x[t][r] = fmaxf(acc[t][r], 0.f);
+    save_x(4, x);
+  }
   float o[3] = {0.f, 0.f, 0.f};
   const float* __restrict__ k4 = params + bkgd_koff(4);
 #pragma unroll
@@ -1147,7 +1181,123 @@ __global__ void __launch_bounds__(64) bkgd_fwd_kernel(const float* __restrict__ 
     o[c] = o[c] + __shfl_xor(o[c], 32) + params[bkgd_boff(4) + c];
     o[c] = fsub(fmul(fdiv(1.0f, fadd(1.0f, expf(-o[c]))), pad_scale), pad);
   }
-  if (ok && h == 0) { out_rgb[3 * row] = o[0]; out_rgb[3 * row + 1] = o[1]; out_rgb[3 * row + 2] = o[2]; }
+  if (ok && h == 0) {
+    out_rgb[3 * row] = o[0]; out_rgb[3 * row + 1] = o[1]; out_rgb[3 * row + 2] = o[2];
+    if constexpr (TRAIN) { float* so = save + (size_t)n * (28 + 4 * 128) + (size_t)row * 3; so[0] = o[0]; so[1] = o[1]; so[2] = o[2]; }
+  }
+}
+
+// ---- backward of the background MLP (exact fp32 on v_mfma_f32_32x32x2_f32, as the forward) --------------------------------
+// dgrad chain: dX^T[k][row] = W[k][n] dY^T[n][row] with the accumulator registers as B operands; ReLU masks from the saved X_k.
+__device__ __forceinline__ void small_prev_layer_T(f32x16 (&acc)[4], const f32x16 (&x)[4], const float* __restrict__ kern, int m, int h) {
+#pragma unroll
+  for (int ts = 0; ts < 4; ++ts)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int f = 32 * ts + (r & 3) + 8 * (r >> 2) + 4 * h;   // output feature n this half holds in x[ts][r]
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(kern[(32 * t + m) * 128 + f], x[ts][r], acc[t], 0, 0, 0);
+    }
+}
+
+__global__ void __launch_bounds__(64) bkgd_dgrad_kernel(const float* __restrict__ params, const float* __restrict__ save,
+                                                        const float* __restrict__ d_out, long long n, float pad_scale, float pad,
+                                                        float* __restrict__ dy) {
+  const int lane = threadIdx.x & 63, m = lane & 31, h = lane >> 5;
+  long long row = (long long)blockIdx.x * 32 + m;
+  const bool ok = row < n;
+  if (!ok) row = n - 1;
+  const float* so = save + (size_t)n * (28 + 4 * 128) + (size_t)row * 3;
+  float draw[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float sg = (so[c] + pad) / pad_scale;                       // out = sigmoid(raw) * (1+2p) - p   (rnerf/models.py:336-337)
+    draw[c] = ok ? d_out[3 * row + c] * pad_scale * sg * (1.0f - sg) : 0.f;
+  }
+  float* dyraw = dy + (size_t)n * 4 * 128;
+  if (ok && h == 0) { dyraw[4 * row] = draw[0]; dyraw[4 * row + 1] = draw[1]; dyraw[4 * row + 2] = draw[2]; dyraw[4 * row + 3] = 0.f; }
+  auto Xk = [&](int k) -> const float* { return save + (size_t)n * 28 + (size_t)(k - 1) * n * 128 + (size_t)row * 128; };
+  auto store_dy = [&](int k, const f32x16 (&xx)[4]) {
+    if (ok) {
+      float* dst = dy + (size_t)k * n * 128 + (size_t)row * 128;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *(float4*)(dst + 32 * t + 8 * g + 4 * h) = make_float4(xx[t][4 * g], xx[t][4 * g + 1], xx[t][4 * g + 2], xx[t][4 * g + 3]);
+    }
+  };
+  auto mask_by = [&](int k, const f32x16 (&a)[4], f32x16 (&xx)[4]) {
+    const float* xs = Xk(k);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 v = *(const float4*)(xs + 32 * t + 8 * g + 4 * h);
+        xx[t][4 * g] = v.x > 0.f ? a[t][4 * g] : 0.f; xx[t][4 * g + 1] = v.y > 0.f ? a[t][4 * g + 1] : 0.f;
+        xx[t][4 * g + 2] = v.z > 0.f ? a[t][4 * g + 2] : 0.f; xx[t][4 * g + 3] = v.w > 0.f ? a[t][4 * g + 3] : 0.f;
+      }
+  };
+  const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  f32x16 acc[4], x[4];
+  // through Dense_4 (128 -> 3) on the VALU
+  const float* __restrict__ k4 = params + bkgd_koff(4);
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int f = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+      acc[t][r] = draw[0] * k4[f * 3] + draw[1] * k4[f * 3 + 1] + draw[2] * k4[f * 3 + 2];
+    }
+  mask_by(4, acc, x);
+  store_dy(3, x);                                   // dY_3
+#pragma unroll 1
+  for (int k = 3; k >= 1; --k) {                    // through Dense_k (only the first 128 input rows of Dense_3 carry gradient)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = zero;
+    small_prev_layer_T(acc, x, params + (k == 3 ? bkgd_koff(3) : (k == 2 ? bkgd_koff(2) : bkgd_koff(1))), m, h);
+    mask_by(k, acc, x);
+    store_dy(k - 1, x);                             // dY_{k-1}
+  }
+}
+
+// wgrad: dW[k][n] += sum_rows X[row][k] dY[row][n]; A = X (lane = k, the half picks one of 2 rows), B = dY: row-major fp32 needs
+// no transposition for the K=2 MFMA.  One wave = one k-tile x up to 4 n-tiles over a 512-row chunk; atomics into the flat grads.
+__global__ void __launch_bounds__(64) bkgd_wgrad_kernel(const float* __restrict__ X, int ldx, int kin, const float* __restrict__ dY, int ldy,
+                                                        int nout, long long n, float* __restrict__ gk, int out_dim, float* __restrict__ gb) {
+  const int lane = threadIdx.x & 63, m = lane & 31, h = lane >> 5;
+  const int kt = blockIdx.y, k = 32 * kt + m;
+  const long long r0 = (long long)blockIdx.x * 512, r1 = r0 + 512 < n ? r0 + 512 : n;
+  const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  f32x16 acc[4] = {zero, zero, zero, zero}, accb[4] = {zero, zero, zero, zero};
+  const int NT = (nout + 31) / 32;
+  const float onesA = m == 0 ? 1.f : 0.f;
+  for (long long r = r0; r < r1; r += 2) {
+    const long long rr = r + h;
+    const bool ok = rr < r1;
+    const float a = (ok && k < kin) ? X[(size_t)rr * ldx + k] : 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+      if (nt < NT) {
+        const int nn = 32 * nt + m;
+        const float b = (ok && nn < nout) ? dY[(size_t)rr * ldy + nn] : 0.f;
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[nt], 0, 0, 0);
+        if (gb && kt == 0) accb[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(onesA, b, accb[nt], 0, 0, 0);
+      }
+  }
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+    if (nt < NT) {
+      const int nn = 32 * nt + m;
+      if (nn < nout) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ki = 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (ki < kin) atomicAdd(gk + (size_t)ki * out_dim + nn, acc[nt][r]);
+        }
+        if (gb && kt == 0 && h == 0) atomicAdd(gb + nn, accb[nt][0]);
+      }
+    }
 }
 
 }  // namespace rnerf
@@ -1382,8 +1532,48 @@ extern "C" int rnerf_bkgd_forward(const float* params, const float* dirs, int32_
   RNERF_CHECK_ARG(params && dirs && out_rgb, "rnerf_bkgd_forward: null pointer");
   RNERF_CHECK_ARG(dir_stride >= 3, "rnerf_bkgd_forward: dir_stride must be >= 3");
   RNERF_CHECK_ARG(n >= 1, "rnerf_bkgd_forward: n must be >= 1");
-  hipLaunchKernelGGL(bkgd_fwd_kernel, dim3((unsigned)((n + 31) / 32)), dim3(64), 0, (hipStream_t)stream, params, dirs, dir_stride,
-                     (long long)n, (float)(1 + 2 * rgb_padding), (float)rgb_padding, out_rgb);
+  hipLaunchKernelGGL(bkgd_fwd_kernel<false>, dim3((unsigned)((n + 31) / 32)), dim3(64), 0, (hipStream_t)stream, params, dirs, dir_stride,
+                     (long long)n, (float)(1 + 2 * rgb_padding), (float)rgb_padding, out_rgb, (float*)nullptr);
+  RNERF_CHECK_LAUNCH();
+  return RNERF_OK;
+}
+
+extern "C" size_t rnerf_bkgd_save_bytes(int64_t n) { return bkgd_save_floats(n) * sizeof(float); }
+extern "C" size_t rnerf_bkgd_dy_bytes(int64_t n) { return bkgd_dy_floats(n) * sizeof(float); }
+
+extern "C" int rnerf_bkgd_forward_train(const float* params, const float* dirs, int32_t dir_stride, int64_t n, double rgb_padding,
+                                        float* out_rgb, void* save, void* stream) {
+  RNERF_CHECK_ARG(params && dirs && out_rgb && save, "rnerf_bkgd_forward_train: null pointer");
+  RNERF_CHECK_ARG(dir_stride >= 3 && n >= 1, "rnerf_bkgd_forward_train: need dir_stride >= 3 and n >= 1");
+  hipLaunchKernelGGL(bkgd_fwd_kernel<true>, dim3((unsigned)((n + 31) / 32)), dim3(64), 0, (hipStream_t)stream, params, dirs, dir_stride,
+                     (long long)n, (float)(1 + 2 * rgb_padding), (float)rgb_padding, out_rgb, (float*)save);
+  RNERF_CHECK_LAUNCH();
+  return RNERF_OK;
+}
+
+extern "C" int rnerf_bkgd_backward(const float* params, const void* save, const float* d_out, int64_t n, double rgb_padding, void* dy,
+                                   float* grads, void* stream) {
+  RNERF_CHECK_ARG(params && save && d_out && dy && grads, "rnerf_bkgd_backward: null pointer");
+  RNERF_CHECK_ARG(n >= 1, "rnerf_bkgd_backward: n must be >= 1");
+  hipStream_t st = (hipStream_t)stream;
+  const float* sv = (const float*)save;
+  float* dyf = (float*)dy;
+  hipLaunchKernelGGL(bkgd_dgrad_kernel, dim3((unsigned)((n + 31) / 32)), dim3(64), 0, st, params, sv, d_out, (long long)n,
+                     (float)(1 + 2 * rgb_padding), (float)rgb_padding, dyf);
+  const unsigned chunks = (unsigned)((n + 511) / 512);
+  const float* enc = sv;
+  auto Xk = [&](int k) { return sv + (size_t)n * 28 + (size_t)(k - 1) * n * 128; };
+  auto dYk = [&](int k) { return dyf + (size_t)k * n * 128; };
+  const float* draw = dyf + (size_t)n * 4 * 128;
+#define WG(X, LDX, KIN, DY, LDY, NOUT, GK, OUTD, GB)                                                                          \
+  hipLaunchKernelGGL(bkgd_wgrad_kernel, dim3(chunks, ((KIN) + 31) / 32), dim3(64), 0, st, X, LDX, KIN, DY, LDY, NOUT, (long long)n, GK, OUTD, GB)
+  WG(enc, 28, 27, dYk(0), 128, 128, grads + bkgd_koff(0), 128, grads + bkgd_boff(0));
+  WG(Xk(1), 128, 128, dYk(1), 128, 128, grads + bkgd_koff(1), 128, grads + bkgd_boff(1));
+  WG(Xk(2), 128, 128, dYk(2), 128, 128, grads + bkgd_koff(2), 128, grads + bkgd_boff(2));
+  WG(Xk(3), 128, 128, dYk(3), 128, 128, grads + bkgd_koff(3), 128, grads + bkgd_boff(3));
+  WG(enc, 28, 27, dYk(3), 128, 128, grads + bkgd_koff(3) + 128 * 128, 128, (float*)nullptr);
+  WG(Xk(4), 128, 128, draw, 4, 3, grads + bkgd_koff(4), 3, grads + bkgd_boff(4));
+#undef WG
   RNERF_CHECK_LAUNCH();
   return RNERF_OK;
 }

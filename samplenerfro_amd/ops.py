@@ -229,3 +229,24 @@ def nerfmlp_backward(packed_bwd, packed_fwd, precision: int, save, d_raw: torch.
     check(lib.rnerf_nerfmlp_wgrad(int(precision), ptr(save), ptr(dy), int(rows), ptr(grads), ptr(workspace), current_stream()),
           "rnerf_nerfmlp_wgrad")
     return grads
+
+
+def bkgd_forward_train(params_flat: torch.Tensor, dirs: torch.Tensor, rgb_padding: float = 0.001):
+    lib = _lib.load()
+    p = _chk(params_flat, "params_flat"); d = _chk(dirs, "dirs")
+    n = d.shape[0]
+    out = torch.empty((n, 3), dtype=torch.float32, device=d.device)
+    save = torch.empty(lib.rnerf_bkgd_save_bytes(n), dtype=torch.uint8, device=d.device)
+    check(lib.rnerf_bkgd_forward_train(ptr(p), ptr(d), int(d.shape[-1]), n, float(rgb_padding), ptr(out), ptr(save), current_stream()),
+          "rnerf_bkgd_forward_train")
+    return out, save
+
+
+def bkgd_backward(params_flat: torch.Tensor, save: torch.Tensor, d_out: torch.Tensor, grads: torch.Tensor, rgb_padding: float = 0.001):
+    """Accumulates d loss / d params of the background MLP into `grads` (56963 floats)."""
+    lib = _lib.load()
+    n = d_out.shape[0]
+    dy = torch.empty(lib.rnerf_bkgd_dy_bytes(n), dtype=torch.uint8, device=d_out.device)
+    check(lib.rnerf_bkgd_backward(ptr(_chk(params_flat, "params_flat")), ptr(save), ptr(_chk(d_out, "d_out")), n, float(rgb_padding), ptr(dy),
+                                  ptr(_chk(grads, "grads")), current_stream()), "rnerf_bkgd_backward")
+    return grads

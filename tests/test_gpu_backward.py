@@ -118,3 +118,31 @@ def test_nerfmlp_backward(prec):
             # bf16 operands in wgrad (8-bit mantissa, unbiased rounding over 581 rows): 1.5e-2 of the largest entry
             assert err < 1.5e-2 and cos > 0.9995, f"Dense_{k} {name}: rel err {err:.3e}, cos {cos:.6f}"
     print(f"[{prec}] worst relative gradient error over the 24 tensors: {worst:.2e}")
+
+
+def test_bkgd_mlp_backward():
+    from samplenerfro_amd import ops, synthetic as syn
+    rng = np.random.default_rng(10)
+    n = 1237                                       # ragged: 32-row waves, 512-row wgrad chunks
+    pf = syn.init_params_flat(13, fine=False, bias_scale=0.1)["bkgd_mlp"]
+    dirs = R.safe_l2_normalize(rng.standard_normal((n, 3)).astype(F32))
+    cot = (rng.standard_normal((n, 3)) * 1e-2).astype(F32)
+    flat_d = T(pf)
+    out, save = ops.bkgd_forward_train(flat_d, T(dirs))
+    assert torch.equal(out, ops.bkgd_forward(flat_d, T(dirs)))
+    grads = torch.zeros(_lib.BKGDMLP_PARAMS, device="cuda:0")
+    ops.bkgd_backward(flat_d, save, T(cot), grads)
+    ops.bkgd_backward(flat_d, save, T(cot), grads)                     # accumulates: twice the gradient
+    g = grads.cpu().numpy().astype(np.float64) / 2
+    flat = torch.tensor(pf, dtype=torch.float64, requires_grad=True)
+    o = TR.bkgd_mlp(flat, torch.tensor(R.pos_enc(dirs, 0, 4), dtype=torch.float64))
+    (o * torch.tensor(cot, dtype=torch.float64)).sum().backward()
+    ref = flat.grad.numpy()
+    assert np.abs(o.detach().numpy() - out.cpu().numpy()).max() < 5e-6
+    off = 0
+    for k, (i, oo) in enumerate(TR.BKGD_MLP_SHAPES):
+        for name, cnt in (("kernel", i * oo), ("bias", oo)):
+            a, b = g[off:off + cnt], ref[off:off + cnt]
+            off += cnt
+            err = np.abs(a - b).max() / np.abs(b).max()
+            assert err < 2e-5, f"bkgd Dense_{k} {name}: rel err {err:.3e}"      # exact-fp32 MFMA chain + fp32 atomics
