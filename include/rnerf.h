@@ -135,6 +135,11 @@ int rnerf_resample(const float* path_pd, const float* path_dr, int32_t num_nodes
                    int32_t S, const float* weights, const float* u, int32_t u_per_ray, int32_t num_fine, float* rows_pd,
                    float* rows_dr, int32_t* node_idx, float* scratch, void* stream);
 
+/* ---- S1 (randomized=True): the stratified uniform draws of sorted_piecewise_constant_pdf, rnerf/model_utils.py:345-354:
+ * u = min(arange(F)/F + jax.random.uniform(key, [B,F], maxval=1/F-eps), 1-eps) with jax's threefry2x32 bit stream.
+ * key: HOST uint32[2]; u: device float[num_fine][B] (the layout rnerf_resample takes with u_per_ray = 1). */
+int rnerf_stratified_u(const uint32_t* key, int32_t B, int32_t num_fine, float* u, void* stream);
+
 /* ---- T1 (loss): the reductions of train_step.loss_fn (train.py:89-92,105) for stage "radiance*".
  * rgb_c (nullable, N_f == 0), rgb_f: float[B][3]; trans_f: float[B]; trans_bkgd_f, pixels: float[B][3].
  * sums: float[4] (device) = { sum (rgb_f-pix)^2, sum (rgb_c-pix)^2, sum mask*|trans_bkgd_f-pix|, sum mask },

@@ -348,6 +348,48 @@ extern "C" int rnerf_resample(const float* path_pd, const float* path_dr, int32_
   return RNERF_OK;
 }
 
+// The stratified draws of sorted_piecewise_constant_pdf (rnerf/model_utils.py:345-354) on the device:
+// u[b][f] = min(f*s + uniform(key, [B,F], maxval = s - eps)[b][f], 1 - eps), written sample-major float[F][B].
+// jax.random.uniform -> threefry2x32-20 over the counters 0..B*F-1 split in two halves (x0 = first half, x1 = second half).
+__device__ __forceinline__ unsigned rotl32(unsigned x, int r) { return (x << r) | (x >> (32 - r)); }
+__global__ void __launch_bounds__(256) stratified_u_kernel(unsigned k0, unsigned k1, int B, int F, float s, float maxval, float one_m_eps,
+                                                           float* __restrict__ u) {
+  const long long size = (long long)B * F, half = (size + 1) / 2;
+  const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= half) return;
+  const unsigned ks[3] = {k0, k1, k0 ^ k1 ^ 0x1BD11BDAu};
+  unsigned x0 = (unsigned)j + ks[0];
+  unsigned x1 = (j + half < size ? (unsigned)(j + half) : 0u) + ks[1];
+  const int rot[2][4] = {{13, 15, 26, 6}, {17, 29, 16, 24}};
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { x0 += x1; x1 = rotl32(x1, rot[i & 1][q]); x1 ^= x0; }
+    x0 += ks[(i + 1) % 3];
+    x1 += ks[(i + 2) % 3] + (unsigned)(i + 1);
+  }
+  auto put = [&](long long e, unsigned bits) {
+    const int b = (int)(e / F), f = (int)(e % F);
+    const float fl = fsub(__uint_as_float((bits >> 9) | 0x3F800000u), 1.0f);
+    const float r = fmaxf(0.0f, fadd(fmul(fl, maxval), 0.0f));
+    u[(size_t)f * B + b] = fminf(fadd(fmul((float)f, s), r), one_m_eps);
+  };
+  put(j, x0);
+  if (j + half < size) put(j + half, x1);
+}
+
+extern "C" int rnerf_stratified_u(const uint32_t* key, int32_t B, int32_t num_fine, float* u, void* stream) {
+  RNERF_CHECK_ARG(key && u, "rnerf_stratified_u: null pointer");
+  RNERF_CHECK_ARG(B >= 1 && num_fine >= 1, "rnerf_stratified_u: need B >= 1 and num_fine >= 1");
+  const double eps = 1.1920928955078125e-07;
+  const double s = 1.0 / num_fine;
+  const long long half = ((long long)B * num_fine + 1) / 2;
+  hipLaunchKernelGGL(stratified_u_kernel, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, (hipStream_t)stream, key[0], key[1], B, num_fine,
+                     (float)s, (float)(s - eps), (float)(1.0 - eps), u);
+  RNERF_CHECK_LAUNCH();
+  return RNERF_OK;
+}
+
 extern "C" int rnerf_loss_reduce(const float* rgb_c, const float* rgb_f, const float* trans_f, const float* trans_bkgd_f,
                                  const float* pixels, int32_t B, float* sums, void* stream) {
   RNERF_CHECK_ARG(rgb_f && trans_f && trans_bkgd_f && pixels && sums, "rnerf_loss_reduce: null pointer");

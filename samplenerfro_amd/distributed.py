@@ -60,6 +60,10 @@ def allreduce_mean_(buffers: Sequence[torch.Tensor], extra: Optional[torch.Tenso
     if w == 1:
         return
     parts = [b.reshape(-1) for b in buffers] + ([extra.reshape(-1)] if extra is not None else [])
+    if len(parts) == 1 and parts[0].is_contiguous():             # the train step keeps gradients + stats in one buffer already
+        dist.all_reduce(parts[0], op=dist.ReduceOp.SUM)
+        parts[0] /= w
+        return
     flat = torch.cat(parts)
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     flat /= w

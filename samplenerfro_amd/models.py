@@ -170,11 +170,15 @@ class NerfModel:
                 u = np.linspace(0.0, 1.0 - float(np.finfo(np.float32).eps), F).astype(np.float32)
                 self._u_lin = torch.from_numpy(u).to(self.device)
             return self._u_lin
+        return ops.stratified_u(np.asarray(key, np.uint32), batch, F, self.device)
+
+    def make_u_host(self, key, batch: int) -> np.ndarray:
+        """numpy form of the randomized branch (what rnerf_stratified_u computes on the device); [F, B]."""
+        F = self.num_fine_samples
         eps = float(np.finfo(np.float32).eps)
         s = 1.0 / F
         u = (np.arange(F, dtype=np.float32) * np.float32(s))[None, :] + prng.uniform(key, (batch, F), maxval=s - eps)
-        u = np.minimum(u, np.float32(1.0 - eps)).astype(np.float32)
-        return torch.from_numpy(np.ascontiguousarray(u.T)).to(self.device)
+        return np.ascontiguousarray(np.minimum(u, np.float32(1.0 - eps)).astype(np.float32).T)
 
     def _bd_cut_bbox(self):
         """The scene-name-specific box of rnerf/models.py:485-497."""
@@ -223,8 +227,11 @@ class NerfModel:
 
     def forward(self, variables, rng_0, rng_1, rays: Rays, randomized: bool, annealed_alpha: float = 1.0, *,
                 jitter=None, u_fine: Optional[torch.Tensor] = None, taps: Optional[dict] = None,
-                path: Optional["PathHandle"] = None):
-        """NerfModel.__call__ (rnerf/models.py:220-535)."""
+                path: Optional["PathHandle"] = None, ctx: Optional[dict] = None):
+        """NerfModel.__call__ (rnerf/models.py:220-535).
+
+        ctx: a dict to fill with what the backward pass needs (samplenerfro_amd.train); the MLPs then run their training
+        forward, which also stores the MFMA operands of every layer."""
         origins, viewdirs = rays.origins, rays.viewdirs                                   # rnerf/models.py:235-236
         if origins.dim() != 2 or origins.shape[-1] != 3:
             raise ValueError("rays.origins must be [B, 3]")
@@ -251,8 +258,18 @@ class NerfModel:
         jit = self._jitter_dev(jitter)
         last = int(np.asarray(jitter)[-1])
         # bkgd from the LAST coarse sample's direction (rnerf/models.py:303)
-        bkgd = ops.bkgd_forward(self._flat(variables, "bkgd_mlp", BKGD_MLP_SHAPES).detach(), path_dr[last], self.rgb_padding)
-        raw_c = ops.nerfmlp_forward(self._packed_weights(variables, "coarse_mlp"), self.precision, path_pd, path_dr, jit, Nc, B)
+        bkgd_flat = self._flat(variables, "bkgd_mlp", BKGD_MLP_SHAPES).detach()
+        if ctx is None:
+            bkgd = ops.bkgd_forward(bkgd_flat, path_dr[last], self.rgb_padding)
+            raw_c = ops.nerfmlp_forward(self._packed_weights(variables, "coarse_mlp"), self.precision, path_pd, path_dr, jit, Nc, B)
+        else:
+            if self.bd_cut_dist is not None or self.white_bkgd or self.use_online_sparsity:
+                raise NotImplementedError("training backward: bd_cut_dist masks / white_bkgd / online sparsity are not built "
+                                          "(the sparsity terms carry annealing_rate = 0.0 in train.py:156)")
+            bkgd, ctx["save_bkgd"] = ops.bkgd_forward_train(bkgd_flat, path_dr[last], self.rgb_padding)
+            raw_c, ctx["save_c"] = ops.nerfmlp_forward_train(self._packed_weights(variables, "coarse_mlp"), self.precision, path_pd,
+                                                            path_dr, jit, Nc, B)
+            ctx.update(path_pd=path_pd, path_dr=path_dr, jit=jit, raw_c=raw_c, bkgd=bkgd, B=B)
         rgb, dist, acc, trans, trans_bkgd, weights, alpha = ops.composite(
             raw_c, path_pd, path_dr, jit, Nc, B, bkgd, self.white_bkgd, self.rgb_padding, self.sigma_bias,
             want_weights=True, want_alpha=self.use_online_sparsity)
@@ -271,7 +288,12 @@ class NerfModel:
             fine_sp = self.use_online_sparsity and self.use_fine_sparsity
             rows_pd, rows_dr, idx = ops.resample(path_pd, path_dr, jit, weights, u, Nf, want_idx=(taps is not None) or fine_sp)
             S = Nc + Nf
-            raw_f = ops.nerfmlp_forward(self._packed_weights(variables, "fine_mlp"), self.precision, rows_pd, rows_dr, None, S, B)
+            if ctx is None:
+                raw_f = ops.nerfmlp_forward(self._packed_weights(variables, "fine_mlp"), self.precision, rows_pd, rows_dr, None, S, B)
+            else:
+                raw_f, ctx["save_f"] = ops.nerfmlp_forward_train(self._packed_weights(variables, "fine_mlp"), self.precision, rows_pd,
+                                                                rows_dr, None, S, B)
+                ctx.update(rows_pd=rows_pd, rows_dr=rows_dr, raw_f=raw_f)
             rgb, dist, acc, trans, trans_bkgd, w_f, alpha_f = ops.composite(
                 raw_f, rows_pd, rows_dr, None, S, B, bkgd, self.white_bkgd, self.rgb_padding, self.sigma_bias,
                 want_weights=taps is not None, want_alpha=self.use_online_sparsity and self.use_fine_sparsity)
@@ -295,8 +317,12 @@ class NerfModel:
 
     __call__ = forward
 
-    def forward_envmap(self, variables, viewdirs: torch.Tensor) -> torch.Tensor:
+    def forward_envmap(self, variables, viewdirs: torch.Tensor, ctx: Optional[dict] = None) -> torch.Tensor:
         """rnerf/models.py:181-191: bkgd colour for arbitrary view directions [M,3] -> [M,3]."""
+        if ctx is not None:
+            out, ctx["save_env"] = ops.bkgd_forward_train(self._flat(variables, "bkgd_mlp", BKGD_MLP_SHAPES).detach(), viewdirs,
+                                                          self.rgb_padding)
+            return out
         return ops.bkgd_forward(self._flat(variables, "bkgd_mlp", BKGD_MLP_SHAPES).detach(), viewdirs, self.rgb_padding)
 
 

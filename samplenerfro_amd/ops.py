@@ -250,3 +250,13 @@ def bkgd_backward(params_flat: torch.Tensor, save: torch.Tensor, d_out: torch.Te
     check(lib.rnerf_bkgd_backward(ptr(_chk(params_flat, "params_flat")), ptr(save), ptr(_chk(d_out, "d_out")), n, float(rgb_padding), ptr(dy),
                                   ptr(_chk(grads, "grads")), current_stream()), "rnerf_bkgd_backward")
     return grads
+
+
+def stratified_u(key, B: int, num_fine: int, device) -> torch.Tensor:
+    """S1 randomized draws on the device (rnerf/model_utils.py:345-354) -> u [num_fine, B]."""
+    import ctypes as C
+    lib = _lib.load()
+    k = (C.c_uint32 * 2)(int(key[0]), int(key[1]))
+    u = torch.empty((num_fine, B), dtype=torch.float32, device=device)
+    check(lib.rnerf_stratified_u(C.cast(k, C.c_void_p), int(B), int(num_fine), ptr(u), current_stream()), "rnerf_stratified_u")
+    return u

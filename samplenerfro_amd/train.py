@@ -1,0 +1,207 @@
+"""Host-side mirror of the reference's training step (train.py:58-183) for the radiance stages.
+
+    state = TrainState.create(model, variables, flags)
+    state, stats, rng = train_step(model, rng, state, batch, flags)
+
+`jax.value_and_grad(loss_fn)` is replaced by explicit backward kernels in librnerf.so, in reverse order of the forward:
+
+    loss reductions (rnerf_loss_reduce)                     train.py:89-92,105
+    compositing + activations backward, fine then coarse    rnerf_composite_backward
+    NerfMLP dgrad + wgrad on the matrix cores               rnerf_nerfmlp_dgrad / rnerf_nerfmlp_wgrad
+    background MLP backward (per-ray bkgd + env-map patch)  rnerf_bkgd_backward
+
+No gradient flows through the resampling (lax.stop_gradient, rnerf/model_utils.py:407-411), the marched path (the
+path_sampler parameters are labelled "zero" in the radiance stages, train.py:286-293) or trans * stop_gradient(rgb_bkgd)
+(rnerf/model_utils.py:309).  The terms scaled by annealing_rate are identically zero (train.py:156 sets it to 0.0).
+
+`jax.lax.pmean` (train.py:166-167) is ONE all-reduce (RCCL when the process group is nccl) over a single flat buffer
+holding every gradient and the stats vector.  The optimiser (optax.adam behind multi_transform, train.py:312-317) is
+plain torch arithmetic on that flat buffer: weights and optimiser state stay on the PyTorch side of the boundary.
+"""
+from __future__ import annotations
+
+import math
+from typing import Any, Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib, distributed, ops, prng
+from .models import BKGD_MLP_SHAPES, NERF_MLP_SHAPES, NerfModel, make_variables
+from .utils import Rays, Stats, learning_rate_decay
+
+_N_STATS = 8        # loss, loss_c, loss_bg, loss_bg_smooth, weight_l2, (3 spare)
+
+
+class TrainState:
+    """flax TrainState (step, params, opt_state) with every trained parameter in ONE flat fp32 buffer.
+
+    Segments in order: coarse_mlp, fine_mlp (if N_f > 0), bkgd_mlp — the "adam_lr_scheduler" labels of train.py:286-293;
+    path_sampler/so3_mlp is labelled "zero" and stays outside.  variables["flat"][name] are views into `theta`, so an
+    optimiser step is visible to the kernels without copies (the MFMA operand streams are re-packed lazily, keyed on the
+    buffer version)."""
+
+    def __init__(self, step, theta, mu, nu, variables, segments, lr_fn):
+        self.step, self.theta, self.mu, self.nu = step, theta, mu, nu
+        self.variables, self.segments, self.lr_fn = variables, segments, lr_fn
+        self.grads = torch.zeros(theta.numel() + _N_STATS, dtype=torch.float32, device=theta.device)   # + the stats vector
+        self.frozen_sq: Optional[torch.Tensor] = None
+
+    @classmethod
+    def create(cls, model: NerfModel, variables: Dict[str, Any], flags) -> "TrainState":
+        names = ["coarse_mlp"] + (["fine_mlp"] if model.num_fine_samples > 0 else []) + ["bkgd_mlp"]
+        shapes = {"coarse_mlp": NERF_MLP_SHAPES, "fine_mlp": NERF_MLP_SHAPES, "bkgd_mlp": BKGD_MLP_SHAPES}
+        parts = [model._flat(variables, n, shapes[n]).detach().reshape(-1).float() for n in names]
+        theta = torch.cat(parts).contiguous()
+        segments, off = {}, 0
+        flat = dict(variables.get("flat", {}))
+        for n, p in zip(names, parts):
+            segments[n] = (off, off + p.numel())
+            flat[n] = theta[off:off + p.numel()]
+            off += p.numel()
+        new_vars = make_variables(flat)
+        lr_fn = lambda count: learning_rate_decay(count, flags.lr_init, flags.lr_final, flags.max_steps, flags.lr_delay_steps,
+                                                  flags.lr_delay_mult)
+        return cls(0, theta, torch.zeros_like(theta), torch.zeros_like(theta), new_vars, segments, lr_fn)
+
+    def grad_view(self, name: str) -> torch.Tensor:
+        lo, hi = self.segments[name]
+        return self.grads[lo:hi]
+
+    def apply_gradients(self, grads: torch.Tensor, b1: float = 0.9, b2: float = 0.999, eps: float = 1e-8) -> "TrainState":
+        """optax.adam(learning_rate=schedule): scale_by_adam then scale_by_schedule(count) with count = updates so far."""
+        count = self.step
+        lr = self.lr_fn(count)
+        t = count + 1
+        self.mu.mul_(b1).add_(grads, alpha=1 - b1)
+        self.nu.mul_(b2).addcmul_(grads, grads, value=1 - b2)
+        denom = (self.nu / (1 - b2 ** t)).sqrt_().add_(eps)
+        self.theta.addcdiv_(self.mu, denom, value=-lr / (1 - b1 ** t))
+        self.step = t
+        return self
+
+    def state_dict(self) -> Dict[str, Any]:
+        return {"step": self.step, "theta": self.theta, "mu": self.mu, "nu": self.nu}
+
+    def load_state_dict(self, d: Dict[str, Any]) -> None:
+        self.step = int(d["step"])
+        for k in ("theta", "mu", "nu"):
+            getattr(self, k).copy_(d[k])
+
+
+def _bwd_packed(model: NerfModel, state: TrainState, name: str) -> torch.Tensor:
+    """The transposed (dgrad) weight stream of one NerfMLP, re-packed when the parameters changed."""
+    cache = model.__dict__.setdefault("_packed_bwd", {})
+    flat = state.variables["flat"][name]
+    ent = cache.get(name)
+    if ent is None or ent[0] != flat.data_ptr() or ent[1] != flat._version:
+        buf = ops.nerfmlp_pack_bwd(flat, ent[2] if ent is not None else None)
+        cache[name] = (flat.data_ptr(), flat._version, buf)
+    return cache[name][2]
+
+
+def env_smooth_loss_and_grad(rgb_env: torch.Tensor, scale: float):
+    """train.py:130: mean(0.5*dv^2 + 0.5*dh^2) over the [ps-1, ps, 3] / [ps, ps-1, 3] differences; returns (loss, d loss/d rgb_env * scale)."""
+    ps = rgb_env.shape[0]
+    dv = rgb_env[1:, :] - rgb_env[:-1, :]
+    dh = rgb_env[:, 1:] - rgb_env[:, :-1]
+    m = float((ps - 1) * ps * rgb_env.shape[-1])
+    loss = (0.5 * (dv * dv).sum() + 0.5 * (dh * dh).sum()) / m
+    g = torch.zeros_like(rgb_env)
+    k = scale / m
+    g[1:, :] += dv * k; g[:-1, :] -= dv * k
+    g[:, 1:] += dh * k; g[:, :-1] -= dh * k
+    return loss, g
+
+
+def train_step(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], flags, *, jitter=None, u_fine=None,
+               taps: Optional[dict] = None):
+    """One optimisation step (train.py:58-183).  batch: {"rays": Rays of [B,3], "pixels": [B,>=3], "annealed_alpha": float,
+    "env_rays": Rays with viewdirs [ps,ps,3] (when bg_smooth_weight > 0)}.  Returns (state, stats, rng); the Stats fields are
+    0-dim device tensors (no host synchronisation inside the step)."""
+    if not (flags.stage.startswith("radiance")):
+        raise NotImplementedError("train_step: only the radiance stages are built (SURVEY.md §8f)")
+    if flags.beta_weight > 0 or flags.sparsity_weight > 0:
+        pass        # both are multiplied by annealing_rate = 0.0 (train.py:156): no contribution to loss or gradient
+    rng, key_0, key_1 = prng.split(np.asarray(rng, np.uint32), 3)
+    annealed = float(np.asarray(batch["annealed_alpha"]).reshape(-1)[0])
+    rays: Rays = batch["rays"]
+    pixels = batch["pixels"][..., :3].contiguous()
+    variables = state.variables
+    prec = model.precision
+    Nc, Nf = model.num_coarse_samples, model.num_fine_samples
+    ctx: Dict[str, Any] = {}
+    ret, _loss_sp = model.apply(variables, key_0, key_1, rays, flags.randomized, annealed, jitter=jitter, u_fine=u_fine, ctx=ctx)
+    B = ctx["B"]
+    rgb_f, _, _, trans_f, tb_f = ret[-1]
+    rgb_c = ret[0][0] if len(ret) > 1 else None
+    sums = ops.loss_reduce(rgb_c, rgb_f, trans_f, tb_f, pixels)
+    bg_on = 1.0 if (flags.bg_weight > 0 and annealed > 0) else 0.0
+    mse_scale = 2.0 / (3.0 * B)
+
+    G = state.grads
+    G.zero_()
+    # ---- backward: last level first ---------------------------------------------------------------------------------------
+    if Nf > 0:
+        d_raw_f, d_bkgd = ops.composite_backward(ctx["raw_f"], ctx["rows_pd"], ctx["rows_dr"], None, Nc + Nf, B, ctx["bkgd"], rgb_f, pixels,
+                                                 trans_f, tb_f, sums, mse_scale, flags.bg_weight * bg_on, rgb_padding=model.rgb_padding,
+                                                 sigma_bias=model.sigma_bias)
+        ops.nerfmlp_backward(_bwd_packed(model, state, "fine_mlp"), model._packed_weights(variables, "fine_mlp"), prec, ctx["save_f"],
+                             d_raw_f, (Nc + Nf) * B, grads=state.grad_view("fine_mlp"))
+        d_raw_c, d_bkgd = ops.composite_backward(ctx["raw_c"], ctx["path_pd"], ctx["path_dr"], ctx["jit"], Nc, B, ctx["bkgd"], rgb_c, pixels,
+                                                 None, None, None, mse_scale, 0.0, d_bkgd=d_bkgd, rgb_padding=model.rgb_padding,
+                                                 sigma_bias=model.sigma_bias)
+    else:
+        d_raw_c, d_bkgd = ops.composite_backward(ctx["raw_c"], ctx["path_pd"], ctx["path_dr"], ctx["jit"], Nc, B, ctx["bkgd"], rgb_f, pixels,
+                                                 trans_f, tb_f, sums, mse_scale, flags.bg_weight * bg_on, rgb_padding=model.rgb_padding,
+                                                 sigma_bias=model.sigma_bias)
+    ops.nerfmlp_backward(_bwd_packed(model, state, "coarse_mlp"), model._packed_weights(variables, "coarse_mlp"), prec, ctx["save_c"],
+                         d_raw_c, Nc * B, grads=state.grad_view("coarse_mlp"))
+    bk_flat = variables["flat"]["bkgd_mlp"]
+    g_bk = state.grad_view("bkgd_mlp")
+    ops.bkgd_backward(bk_flat, ctx["save_bkgd"], d_bkgd, g_bk, model.rgb_padding)
+    # ---- env-map smoothness (train.py:127-132) ------------------------------------------------------------------------------
+    loss_bg_smooth = None
+    if flags.bg_smooth_weight > 0:
+        ev = batch["env_rays"].viewdirs
+        ps = ev.shape[0]
+        ectx: Dict[str, Any] = {}
+        rgb_env = model.forward_envmap(variables, ev.reshape(-1, 3).contiguous(), ctx=ectx).reshape(ps, ps, -1)
+        on = 1.0 if annealed > 0 else 0.0
+        loss_bg_smooth, g_env = env_smooth_loss_and_grad(rgb_env, flags.bg_smooth_weight * on)
+        loss_bg_smooth = loss_bg_smooth * on
+        if on:
+            ops.bkgd_backward(bk_flat, ectx["save_env"], g_env.reshape(-1, 3).contiguous(), g_bk, model.rgb_padding)
+    # ---- weight_l2 over ALL variables, the frozen path_sampler included (train.py:147-153) ----------------------------------
+    n_theta = state.theta.numel()
+    if state.frozen_sq is None:
+        so3 = variables.get("flat", {}).get("so3_mlp")
+        state.frozen_sq = ((so3 * so3).sum() if so3 is not None else torch.zeros((), device=state.theta.device),
+                           so3.numel() if so3 is not None else 0)
+    n_all = n_theta + state.frozen_sq[1]
+    weight_l2 = ((state.theta * state.theta).sum() + state.frozen_sq[0]) / n_all
+    if flags.weight_decay_mult > 0:
+        G[:n_theta].add_(state.theta, alpha=2.0 * flags.weight_decay_mult / n_all)
+    # ---- stats ride in the tail of the gradient buffer: one all-reduce for both (train.py:166-167) ---------------------------
+    st = G[n_theta:]
+    st[0] = sums[0] / (3.0 * B)
+    st[1] = sums[1] / (3.0 * B) if rgb_c is not None else 0.0
+    st[2] = bg_on * sums[2] / (sums[3] + 1.0)
+    if loss_bg_smooth is not None:
+        st[3] = loss_bg_smooth
+    st[4] = weight_l2
+    distributed.allreduce_mean_([G])
+    grads = G[:n_theta]
+    if flags.grad_max_val > 0:                                                            # train.py:169-172
+        grads.clamp_(-flags.grad_max_val, flags.grad_max_val)
+    if flags.grad_max_norm > 0:                                                           # train.py:174-180
+        norm = torch.sqrt((grads * grads).sum())
+        grads.mul_(torch.clamp(flags.grad_max_norm / (1e-7 + norm), max=1.0))
+    if taps is not None:
+        taps.update(grads=grads.clone(), sums=sums, ctx=ctx)
+    state.apply_gradients(grads)
+    k = -10.0 / math.log(10.0)
+    stats = Stats(loss=st[0], psnr=k * torch.log(st[0]), loss_c=st[1], psnr_c=(k * torch.log(st[1]) if rgb_c is not None else 0.0),
+                  weight_l2=st[4], loss_sp=0.0, loss_nrm=0.0, annealing_rate=annealed, coarse_alpha_target=0.0, fine_alpha_target=0.0,
+                  loss_bg=flags.bg_weight * st[2], loss_bg_c=0.0, loss_bg_smooth=st[3])
+    return state, stats, rng

@@ -76,3 +76,42 @@ def test_two_rank_render_and_allreduce(tmp_path):
     ref = utils.render_image(fake_render_fn, rays, prng.PRNGKey(3), False, chunk=7)
     for f, r in zip(full, ref):
         assert torch.equal(f, r.reshape(f.shape))
+
+
+def _adam_worker(rank, world, port, tmp):
+    """Data-parallel optimiser step: per-rank gradients -> one all-reduce (mean) -> identical Adam updates on every rank."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    D.init("gloo")
+    from samplenerfro_amd.train import TrainState, _N_STATS
+    n = 1001
+    theta = torch.linspace(-1, 1, n)
+    state = TrainState(0, theta.clone(), torch.zeros(n), torch.zeros(n), {}, {"all": (0, n)}, lambda c: 1e-2)
+    for step in range(3):
+        g = torch.Generator().manual_seed(100 * step + rank)
+        state.grads[:n] = torch.randn(n, generator=g)
+        state.grads[n:] = float(rank)                                # the stats tail
+        D.allreduce_mean_([state.grads])
+        assert torch.allclose(state.grads[n:], torch.full((_N_STATS,), (world - 1) / 2.0))
+        state.apply_gradients(state.grads[:n])
+    torch.save(state.theta.clone(), f"{tmp}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_two_rank_data_parallel_adam(tmp_path):
+    world, n = 2, 1001
+    port = _free_port()
+    base = str(tmp_path / "theta")
+    mp.spawn(_adam_worker, args=(world, port, base), nprocs=world, join=True)
+    t0, t1 = torch.load(base + ".0"), torch.load(base + ".1")
+    assert torch.equal(t0, t1)                                       # replicas stay bit-identical
+    # float64 optax.adam on the mean gradient
+    th = np.linspace(-1, 1, n); mu = np.zeros(n); nu = np.zeros(n)
+    for step in range(3):
+        gs = [torch.randn(n, generator=torch.Generator().manual_seed(100 * step + r)).numpy().astype(np.float64) for r in range(world)]
+        g = sum(gs) / world
+        mu = 0.9 * mu + 0.1 * g; nu = 0.999 * nu + 0.001 * g * g
+        t = step + 1
+        th = th - 1e-2 * (mu / (1 - 0.9 ** t)) / (np.sqrt(nu / (1 - 0.999 ** t)) + 1e-8)
+    assert np.abs(t0.numpy() - th).max() < 1e-5
