@@ -55,7 +55,7 @@ def build_scene(cfg, device, precision, fine):
     return model, variables, pf
 
 
-def cpu_baseline(cfg, pf, fine, sample_rays, seed):
+def cpu_baseline(cfg, pf, fine, sample_rays, seed, train=False):
     """The oracle (numpy fp32 restatement, multi-threaded BLAS for the matmuls) on a bounded sample of the workload."""
     from oracle import ref_np as R
     from samplenerfro_amd import synthetic as syn
@@ -76,10 +76,46 @@ def cpu_baseline(cfg, pf, fine, sample_rays, seed):
                        num_fine_samples=fine, num_path_samples=cfg["P"])
     jitter = np.arange(0, mc.num_samples, cfg["P"]) + (cfg["P"] // 2)
     params = syn.params_tree(pf)
+    if train:
+        return cpu_train_step(R, mc, pf, params, table, o, d, jitter, cfg, fine, seed)
     t0 = time.perf_counter()
     R.nerf_forward(mc, params, table, o, d, jitter)
     dt = time.perf_counter() - t0
     return sample_rays / dt, dt
+
+
+def cpu_train_step(R, mc, pf, params, table, o, d, jitter, cfg, fine, seed):
+    """One optimisation step on the host cores: the oracle marches / samples (no gradient there), torch CPU fp32 autograd does
+    the differentiable part of train.py's loss_fn (oracle/torch_ref.py) and Adam.  Flat N_f = 0 workloads only."""
+    import torch
+    from oracle import torch_ref as TR
+    assert fine == 0, "cpu train baseline is written for the flat (N_f = 0) bench workloads"
+    B = o.shape[0]
+    rng = np.random.default_rng(seed)
+    pix = torch.from_numpy(rng.uniform(0, 1, (B, 3)).astype(np.float32))
+    ev = rng.standard_normal((128 * 128, 3)).astype(np.float32)
+    ev /= np.linalg.norm(ev, axis=-1, keepdims=True)
+    th = {k: torch.tensor(pf[k], dtype=torch.float32, requires_grad=True) for k in ("coarse_mlp", "bkgd_mlp")}
+    opt = torch.optim.Adam(list(th.values()), lr=5e-4)
+    t0 = time.perf_counter()
+    rp, rd, rdist, _, _ = R.path_sampler(o, d, table, mc.ndim, mc.nmin, mc.nmax, mc.near, mc.far, mc.num_samples, np.float32)   # [B,N,*]
+    jitter = np.asarray(jitter, np.int64)
+    pos, dirs, t = rp[:, jitter], rd[:, jitter], rdist[:, jitter]
+    S = pos.shape[1]
+    enc = torch.from_numpy(R.pos_enc(pos.reshape(-1, 3), 0, 10).astype(np.float32))
+    venc = torch.from_numpy(R.pos_enc(dirs.reshape(-1, 3), 0, 4).astype(np.float32))
+    raw = TR.nerf_mlp(th["coarse_mlp"], enc, venc).reshape(B, S, 4)
+    rgb, sigma = TR.activations(raw)
+    bk = TR.bkgd_mlp(th["bkgd_mlp"], torch.from_numpy(R.pos_enc(dirs[:, -1], 0, 4).astype(np.float32)))
+    comp, acc, w, trans, tb = TR.volumetric_rendering(rgb, sigma, torch.from_numpy(t.astype(np.float32)), torch.from_numpy(dirs.astype(np.float32)), bk)
+    loss, _ = TR.radiance_loss([(comp, trans, tb)], pix, 0.025, 0.5)
+    env = TR.bkgd_mlp(th["bkgd_mlp"], torch.from_numpy(R.pos_enc(ev, 0, 4).astype(np.float32))).reshape(128, 128, 3)
+    loss = loss + (0.5 * ((env[1:, :] - env[:-1, :]) ** 2).reshape(-1) + 0.5 * ((env[:, 1:] - env[:, :-1]) ** 2).reshape(-1)).mean()
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+    dt = time.perf_counter() - t0
+    return B / dt, dt
 
 
 def main():
@@ -95,8 +131,12 @@ def main():
     ap.add_argument("--no-pipeline", dest="pipeline", action="store_false", help="march and MLP of a step strictly in sequence")
     ap.add_argument("--frame", action="store_true", help="also time one 800x800 full-frame render (ms/frame, BASELINE metric 2)")
     ap.add_argument("--reserve-cus", type=int, default=32, help="CUs kept free of MLP workgroups for the overlapped march")
-    ap.add_argument("--cpu-rays", type=int, default=2048)
+    ap.add_argument("--cpu-rays", type=int, default=None, help="rays in the CPU baseline sample (default 2048 forward / 512 train)")
+    ap.add_argument("--mode", choices=["train", "forward"], default="train",
+                    help="train: the whole optimisation step (BASELINE metric 'rays/sec (train step)'); forward: the render pass only")
     args = ap.parse_args()
+    if args.cpu_rays is None:
+        args.cpu_rays = 2048 if args.mode == "forward" else 512
 
     import torch
     import torch.distributed as dist
@@ -126,13 +166,31 @@ def main():
     # Software pipeline across steps: the march of batch k+1 (latency-bound, no matrix cores) runs on a side stream
     # while the MLP/compositing phase of batch k (MFMA-bound) runs on the main stream.  Every step still does its whole
     # work inside the timed region (the first march is issued after the opening barrier).
-    state = {"h": None}
+    state = {"h": None, "rng": key}
+    train = args.mode == "train"
+    if train:
+        # the shipped configs' loss terms (configs/*.yaml): bg_weight 0.025, bg_smooth_weight 1.0 on a 128x128 env-map patch,
+        # randomized stratified resampling, Adam with the reference schedule; pixels are synthetic
+        from samplenerfro_amd import utils as U
+        from samplenerfro_amd.train import TrainState, train_step
+        flags = U.default_flags(num_coarse_samples=cfg["S"], num_fine_samples=fine, num_path_samples=cfg["P"], white_bkgd=False,
+                                bg_weight=0.025, bg_smooth_weight=1.0, bg_patch_size=128, use_online_sparsity=False, randomized=True,
+                                near=cfg["near"], far=cfg["far"], batch_size=B * world)
+        tstate = TrainState.create(model, variables, flags)
+        gen = np.random.default_rng(syn.SEED + 1000 + rank)
+        ev_d = gen.standard_normal((flags.bg_patch_size, flags.bg_patch_size, 3)).astype(np.float32)
+        ev_d /= np.linalg.norm(ev_d, axis=-1, keepdims=True)
+        batch = {"rays": rays, "pixels": torch.from_numpy(gen.uniform(0, 1, (B, 3)).astype(np.float32)).to(device), "annealed_alpha": 0.5,
+                 "env_rays": Rays(None, None, torch.from_numpy(ev_d).to(device), None)}
 
     def step(last=False):
         h = state["h"] if args.pipeline else None
         if args.pipeline and h is None:
             h = model.prefetch_path(rays, sync_inputs=False, reserve_cus=args.reserve_cus)
         state["h"] = model.prefetch_path(rays, sync_inputs=False, reserve_cus=args.reserve_cus) if (args.pipeline and not last) else None
+        if train:
+            _, stats, state["rng"] = train_step(model, state["rng"], tstate, batch, flags, path=h)
+            return [(stats.loss.reshape(1),)], None
         return model.apply(variables, key, key, rays, False, path=h)
 
     def barrier():
@@ -222,9 +280,10 @@ def main():
             "metric": "rays_per_sec", "value": total_rays / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32 (MLP on %s MFMA, fp32 accumulate)" % args.precision, "data": "synthetic",
-            "config": {"workload": f"{args.workload}: forward render pass, {B} rays/GPU x {S} coarse + {fine} fine samples, "
+            "config": {"workload": f"{args.workload}: {'train step (forward + backward + grad all-reduce + Adam)' if train else 'forward render pass'}, "
+                                   f"{B} rays/GPU x {S} coarse + {fine} fine samples, "
                                    f"P={cfg['P']} (N={N} eikonal steps), grid {cfg['G']}^3", "rays_per_gpu": B,
-                       "mlp_rows_per_ray": rows_per_ray, "precision": args.precision, "pass": "forward",
+                       "mlp_rows_per_ray": rows_per_ray, "precision": args.precision, "pass": args.mode,
                        "pipeline": "march(k+1) on a side stream overlaps MLP(k)" if args.pipeline else "none"},
             "roofline": {"kernel": "nerfmlp_fwd_kernel", "bound": "mfma", "achieved": mlp_achieved / 1e12, "peak": PEAK_MFMA_16BIT / 1e12,
                          "unit": "TFLOP/s", "frac": mlp_achieved / PEAK_MFMA_16BIT, "traffic": traffic.get("nerfmlp_fwd_kernel"),
@@ -237,10 +296,11 @@ def main():
         if frame is not None:
             line["frame"] = frame
         if not args.no_cpu_baseline:
-            cpu_rps, cpu_dt = cpu_baseline(cfg, pf, fine, args.cpu_rays, syn.SEED)
+            cpu_rps, cpu_dt = cpu_baseline(cfg, pf, fine, args.cpu_rays, syn.SEED, train)
+            what = ("one train step: numpy fp32 oracle for march/sampling + torch CPU fp32 autograd of train.py's loss_fn + Adam"
+                    if train else "one pass of the numpy fp32 oracle")
             line["cpu_baseline"] = {"value": cpu_rps, "unit": "rays/s", "cores": os.cpu_count(), "kind": "port",
-                                    "sample": f"{args.cpu_rays} rays of the same workload, one pass of the numpy fp32 oracle "
-                                              f"(threaded BLAS), {cpu_dt:.1f} s"}
+                                    "sample": f"{args.cpu_rays} rays of the same workload, {what} (threaded BLAS), {cpu_dt:.1f} s"}
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -895,90 +895,114 @@ __device__ __forceinline__ void pack_rows_bf16(const f32x16& d, uint4& u0, uint4
   u1 = make_uint4(pack2<false>(d[8], d[9]), pack2<false>(d[10], d[11]), pack2<false>(d[12], d[13]), pack2<false>(d[14], d[15]));
 }
 
-template <bool X_F16>
-__global__ void __launch_bounds__(256, 1)
-nerfmlp_wgrad_kernel(const uint4* __restrict__ saved, const uint4* __restrict__ dy, long long R, int qx, int KSx, int qd, int KSd,
-                     long long total_rows, int n_chunks, float* __restrict__ partial, float* __restrict__ partial_bias) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+// job description for the reduction: where the slot-ordered partial rows/columns land in the flat fp32 gradient buffer
+struct WgradJob {
+  int dense;      // Dense_k index in the flat parameter buffer
+  int xkind;      // 0 = position encoding slots, 1 = previous-layer slots, 2 = view encoding slots
+  int row_off;    // kernel row offset of this X block (256 for the concat parts)
+  int dkind;      // 0 = layer outputs (prev_feature order), 1 = sigma head (slot 0 of the head grads), 2 = rgb head (slots 1..3)
+  int KT, NT, write_bias;
+};
+// all jobs of one NerfMLP in ONE launch: workgroups [wg0[j], wg0[j+1]) belong to job j (shares proportional to its MFMA count)
+struct WgradTable {
+  int n;
+  int qx[16], KSx[16], qd[16], KSd[16], wg0[17];
+  long long poff[16], pboff[16];          // float offsets of the job's partial blocks in the workspace
+  WgradJob job[16];
+};
+
+// One job shape (KT k-tiles of X, KSd k-steps = ceil(KSd/2) n-tiles of dY) is a compile-time instance: with run-time shapes the
+// compiler guards every load with a branch and a vmcnt(0), which serialises the 32 loads of a chunk (measured: 21 us per chunk).
+template <bool X_F16, int KT, int KSd>
+__device__ __forceinline__ void wgrad_body(const uint4* __restrict__ saved, const uint4* __restrict__ dy, long long R, long long total_rows,
+                                           int n_chunks, float* __restrict__ pg, float* __restrict__ pbias, int qx, int qd, int g, int G,
+                                           char* smem) {
+  constexpr int NT = (KSd + 1) / 2, KI = (KT + 3) / 4, BI = (NT + 3) / 4;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = lane & 31, h = lane >> 5;
-  const int KT = KSx >> 1, NT = (KSd + 1) >> 1;
   uint4* myT = (uint4*)(smem + wave * 32768) + lane;       // slot*64: X^T fragments 0..15, dY^T fragments 16..31
   const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   const uint4 ixl = shifted_identity<X_F16>(lane, 0), ixh = shifted_identity<X_F16>(lane, 1);
   const uint4 idl = shifted_identity<false>(lane, 0), idh = shifted_identity<false>(lane, 1);
   const uint32_t one2 = (m == 0) ? 0x3F803F80u : 0u;
   const uint4 ones = make_uint4(one2, one2, one2, one2);      // A operand whose row 0 is all ones: D[0][n] = sum over rows
-  f32x16 acc[2][8], accb[2];
+  const uint4 z4 = make_uint4(0, 0, 0, 0);
+  f32x16 acc[KI][NT], accb[BI];
 #pragma unroll
-  for (int a = 0; a < 2; ++a) { accb[a] = zero;
+  for (int a = 0; a < KI; ++a)
 #pragma unroll
-    for (int b = 0; b < 8; ++b) acc[a][b] = zero; }
+    for (int b = 0; b < NT; ++b) acc[a][b] = zero;
+#pragma unroll
+  for (int b = 0; b < BI; ++b) accb[b] = zero;
 
-  for (int chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
-    const long long row = (long long)chunk * 128 + wave * 32 + m;
-    const bool ok = row < total_rows;
+  // register double buffer: the next chunk's operands are in flight while the current one is accumulated
+  uint4 xr[2 * KT], dr[2 * NT];
+  auto load_chunk = [&](int chunk) {
+    const size_t row2 = ((size_t)chunk * 128 + wave * 32 + m) * 2 + h;
+#pragma unroll
+    for (int t = 0; t < 2 * KT; ++t) xr[t] = saved[(size_t)(qx + t) * R * 2 + row2];
+#pragma unroll
+    for (int t = 0; t < 2 * NT; ++t) dr[t] = t < KSd ? dy[(size_t)(qd + t) * R * 2 + row2] : z4;
+  };
+  if (g < n_chunks) load_chunk(g);
+  for (int chunk = g; chunk < n_chunks; chunk += G) {
+    const bool ok = (long long)chunk * 128 + wave * 32 + m < total_rows;
     // ---- transpose this wave's 32 rows
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      if (t < KT) {
-        const uint4 a0 = saved[((size_t)(qx + 2 * t) * R + row) * 2 + h], a1 = saved[((size_t)(qx + 2 * t + 1) * R + row) * 2 + h];
-        f32x16 d = mfma16<X_F16>(a0, ixl, zero);
-        d = mfma16<X_F16>(a1, ixh, d);
-        uint4 u0, u1;
-        pack_rows_bf16(d, u0, u1);
-        myT[(2 * t) * 64] = u0; myT[(2 * t + 1) * 64] = u1;
-      }
-      if (t < NT) {
-        uint4 a0 = dy[((size_t)(qd + 2 * t) * R + row) * 2 + h];
-        uint4 a1 = (2 * t + 1 < KSd) ? dy[((size_t)(qd + 2 * t + 1) * R + row) * 2 + h] : make_uint4(0, 0, 0, 0);
-        if (!ok) { a0 = make_uint4(0, 0, 0, 0); a1 = a0; }       // padded rows carry replayed data: they must not contribute
-        f32x16 d = mfma16<false>(a0, idl, zero);
-        d = mfma16<false>(a1, idh, d);
-        uint4 u0, u1;
-        pack_rows_bf16(d, u0, u1);
-        myT[(16 + 2 * t) * 64] = u0; myT[(16 + 2 * t + 1) * 64] = u1;
-      }
+    for (int t = 0; t < KT; ++t) {
+      f32x16 d = mfma16<X_F16>(xr[2 * t], ixl, zero);
+      d = mfma16<X_F16>(xr[2 * t + 1], ixh, d);
+      uint4 u0, u1;
+      pack_rows_bf16(d, u0, u1);
+      myT[(2 * t) * 64] = u0; myT[(2 * t + 1) * 64] = u1;
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const uint4 a0 = ok ? dr[2 * t] : z4, a1 = ok ? dr[2 * t + 1] : z4;   // padded rows carry replayed data: they must not contribute
+      f32x16 d = mfma16<false>(a0, idl, zero);
+      d = mfma16<false>(a1, idh, d);
+      uint4 u0, u1;
+      pack_rows_bf16(d, u0, u1);
+      myT[(16 + 2 * t) * 64] = u0; myT[(16 + 2 * t + 1) * 64] = u1;
     }
     __syncthreads();
+    if (chunk + G < n_chunks) load_chunk(chunk + G);
     // ---- accumulate this wave's dW tiles (k-tiles wave, wave+4; all n-tiles) over the 4 x 32 rows
 #pragma unroll 1
     for (int v = 0; v < 4; ++v) {
       const uint4* T = (const uint4*)(smem + v * 32768) + lane;
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        uint4 b[8];
+        uint4 b[NT];
 #pragma unroll
-        for (int nt = 0; nt < 8; ++nt) if (nt < NT) b[nt] = T[(16 + 2 * nt + u) * 64];
+        for (int nt = 0; nt < NT; ++nt) b[nt] = T[(16 + 2 * nt + u) * 64];
 #pragma unroll
-        for (int ki = 0; ki < 2; ++ki) {
+        for (int ki = 0; ki < KI; ++ki) {
           const int kt = wave + 4 * ki;
           if (kt < KT) {
             const uint4 a = T[(2 * kt + u) * 64];
 #pragma unroll
-            for (int nt = 0; nt < 8; ++nt) if (nt < NT) acc[ki][nt] = mfma16<false>(a, b[nt], acc[ki][nt]);
+            for (int nt = 0; nt < NT; ++nt) acc[ki][nt] = mfma16<false>(a, b[nt], acc[ki][nt]);
           }
         }
 #pragma unroll
-        for (int bi = 0; bi < 2; ++bi) {
-          const int nt = 2 * wave + bi;
+        for (int bi = 0; bi < BI; ++bi) {                    // bias sums: n-tile wave + 4*bi
 #pragma unroll
-          for (int q = 0; q < 8; ++q) if (q == nt && nt < NT) accb[bi] = mfma16<false>(ones, b[q], accb[bi]);
+          for (int q = 0; q < NT; ++q) if (q == wave + 4 * bi) accb[bi] = mfma16<false>(ones, b[q], accb[bi]);
         }
       }
     }
     __syncthreads();
   }
-  // ---- per-workgroup partials: partial[g][KT*32][NT*32], partial_bias[g][NT*32]
-  const size_t ldn = (size_t)NT * 32;
-  float* pg = partial + (size_t)blockIdx.x * (size_t)KT * 32 * ldn;
+  // ---- per-workgroup partials: partial[KT*32][NT*32], partial_bias[NT*32]
+  constexpr size_t ldn = (size_t)NT * 32;
 #pragma unroll
-  for (int ki = 0; ki < 2; ++ki) {
+  for (int ki = 0; ki < KI; ++ki) {
     const int kt = wave + 4 * ki;
     if (kt < KT) {
 #pragma unroll
-      for (int nt = 0; nt < 8; ++nt) if (nt < NT) {
+      for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -988,23 +1012,42 @@ nerfmlp_wgrad_kernel(const uint4* __restrict__ saved, const uint4* __restrict__ 
     }
   }
 #pragma unroll
-  for (int bi = 0; bi < 2; ++bi) {
-    const int nt = 2 * wave + bi;
-    if (nt < NT && h == 0) partial_bias[(size_t)blockIdx.x * ldn + nt * 32 + m] = accb[bi][0];
+  for (int bi = 0; bi < BI; ++bi) {
+    const int nt = wave + 4 * bi;
+    if (nt < NT && h == 0) pbias[nt * 32 + m] = accb[bi][0];
   }
 }
 
-// job description for the reduction: where the slot-ordered partial rows/columns land in the flat fp32 gradient buffer
-struct WgradJob {
-  int dense;      // Dense_k index in the flat parameter buffer
-  int xkind;      // 0 = position encoding slots, 1 = previous-layer slots, 2 = view encoding slots
-  int row_off;    // kernel row offset of this X block (256 for the concat parts)
-  int dkind;      // 0 = layer outputs (prev_feature order), 1 = sigma head (slot 0 of the head grads), 2 = rgb head (slots 1..3)
-  int KT, NT, write_bias;
-};
+template <bool X_F16>
+__global__ void __launch_bounds__(256, 1)
+nerfmlp_wgrad_kernel(const uint4* __restrict__ saved, const uint4* __restrict__ dy, long long R, long long total_rows, int n_chunks,
+                     float* __restrict__ workspace, const WgradTable tab) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int j = 0;
+  while ((int)blockIdx.x >= tab.wg0[j + 1]) ++j;
+  const int qx = tab.qx[j], KSx = tab.KSx[j], qd = tab.qd[j], KSd = tab.KSd[j];
+  const int g = blockIdx.x - tab.wg0[j], G = tab.wg0[j + 1] - tab.wg0[j];
+  const int KT = KSx >> 1, NT = (KSd + 1) >> 1;
+  float* pg = workspace + tab.poff[j] + (size_t)g * (size_t)KT * 32 * NT * 32;
+  float* pb = workspace + tab.pboff[j] + (size_t)g * NT * 32;
+#define RNERF_WGRAD_CASE(KT_, KSD_)                                                                                                 \
+  if (KSx == 2 * (KT_) && KSd == (KSD_)) { wgrad_body<X_F16, KT_, KSD_>(saved, dy, R, total_rows, n_chunks, pg, pb, qx, qd, g, G, smem); return; }
+  RNERF_WGRAD_CASE(8, 16)      // hidden layer -> hidden layer
+  RNERF_WGRAD_CASE(2, 16)      // position encoding -> Dense_0 / Dense_5
+  RNERF_WGRAD_CASE(8, 1)       // -> sigma head
+  RNERF_WGRAD_CASE(8, 8)       // bottleneck -> view layer
+  RNERF_WGRAD_CASE(1, 8)       // view encoding -> view layer
+  RNERF_WGRAD_CASE(4, 1)       // view layer -> rgb head
+#undef RNERF_WGRAD_CASE
+  __builtin_trap();
+}
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ partial_bias, int n_wg, WgradJob job,
-                                    float* __restrict__ grads) {
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ workspace, const WgradTable tab, float* __restrict__ grads) {
+  const int jb = blockIdx.y;
+  const WgradJob job = tab.job[jb];
+  const int n_wg = tab.wg0[jb + 1] - tab.wg0[jb];
+  const float* __restrict__ partial = workspace + tab.poff[jb];
+  const float* __restrict__ partial_bias = workspace + tab.pboff[jb];
   const int ldn = job.NT * 32, rows = job.KT * 32;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   const int in_dim = nerf_dense(job.dense).in, out_dim = nerf_dense(job.dense).out;
@@ -1015,6 +1058,13 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, const flo
     if (job.dkind == 1) return j == 0 ? 0 : -1;
     return (j >= 1 && j <= 3) ? j - 1 : -1;
   };
+  auto sum_over = [&](const float* __restrict__ p, size_t stride) -> float {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int g = 0;
+    for (; g + 4 <= n_wg; g += 4) { s0 += p[(size_t)g * stride]; s1 += p[(size_t)(g + 1) * stride]; s2 += p[(size_t)(g + 2) * stride]; s3 += p[(size_t)(g + 3) * stride]; }
+    for (; g < n_wg; ++g) s0 += p[(size_t)g * stride];
+    return (s0 + s1) + (s2 + s3);
+  };
   if (e < rows * ldn) {
     const int I = e / ldn, J = e % ldn;
     const int kt = I >> 5, c = I & 31, a = c >> 4, hh = (c >> 3) & 1, j = c & 7, s = 2 * kt + a;
@@ -1022,20 +1072,12 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, const flo
     const int fout = out_feature(J);
     if (fin >= 0 && fout >= 0) {
       fin += job.row_off;
-      if (fin < in_dim) {
-        float sum = 0.f;
-        for (int g = 0; g < n_wg; ++g) sum += partial[(size_t)g * rows * ldn + e];
-        grads[nerf_koff(job.dense) + fin * out_dim + fout] = sum;
-      }
+      if (fin < in_dim) grads[nerf_koff(job.dense) + fin * out_dim + fout] = sum_over(partial + e, (size_t)rows * ldn);
     }
   }
   if (job.write_bias && e < ldn) {
     const int fout = out_feature(e);
-    if (fout >= 0) {
-      float sum = 0.f;
-      for (int g = 0; g < n_wg; ++g) sum += partial_bias[(size_t)g * ldn + e];
-      grads[nerf_boff(job.dense) + fout] = sum;
-    }
+    if (fout >= 0) grads[nerf_boff(job.dense) + fout] = sum_over(partial_bias + e, (size_t)ldn);
   }
 }
 
@@ -1092,7 +1134,8 @@ __device__ __forceinline__ void small_dir_layer(f32x16 (&acc)[4], const float (&
 
 // save (training forward), fp32 row-major: [enc: n x 28][X1: n x 128][X2][X3][X4][out: n x 3]  (X_k = ReLU'd input of Dense_k)
 __host__ __device__ constexpr size_t bkgd_save_floats(long long n) { return (size_t)n * (28 + 4 * 128 + 3); }
-__host__ __device__ constexpr size_t bkgd_dy_floats(long long n) { return (size_t)n * (4 * 128 + 4); }   // [dY0..dY3: n x 128][d raw: n x 4]
+// scratch: [dY0..dY3: n x 128][d raw: n x 4, padded to n x 128 so that dY_k = base + k*n*128][wgrad partials: chunks x params]
+__host__ __device__ constexpr size_t bkgd_dy_floats(long long n) { return (size_t)n * (5 * 128) + (size_t)((n + 255) / 256) * RNERF_BKGDMLP_PARAMS; }
 
 template <bool TRAIN>
 __global__ void __launch_bounds__(64) bkgd_fwd_kernel(const float* __restrict__ params, const float* __restrict__ dirs, int dir_stride,
@@ -1261,43 +1304,85 @@ __global__ void __launch_bounds__(64) bkgd_dgrad_kernel(const float* __restrict_
   }
 }
 
-// wgrad: dW[k][n] += sum_rows X[row][k] dY[row][n]; A = X (lane = k, the half picks one of 2 rows), B = dY: row-major fp32 needs
-// no transposition for the K=2 MFMA.  One wave = one k-tile x up to 4 n-tiles over a 512-row chunk; atomics into the flat grads.
-__global__ void __launch_bounds__(64) bkgd_wgrad_kernel(const float* __restrict__ X, int ldx, int kin, const float* __restrict__ dY, int ldy,
-                                                        int nout, long long n, float* __restrict__ gk, int out_dim, float* __restrict__ gb) {
-  const int lane = threadIdx.x & 63, m = lane & 31, h = lane >> 5;
-  const int kt = blockIdx.y, k = 32 * kt + m;
-  const long long r0 = (long long)blockIdx.x * 512, r1 = r0 + 512 < n ? r0 + 512 : n;
+// wgrad: dW[k][n] = sum_rows X[row][k] dY[row][n]; A = X (lane = k, the half picks one of 2 rows), B = dY: row-major fp32 needs
+// no transposition for the K=2 MFMA.  One launch covers every (Dense_k block, k-tile) "unit"; a workgroup = 256 rows (4 waves x 64
+// rows, summed through LDS) of one unit and writes its partial in flat-gradient layout; bkgd_wgrad_reduce_kernel adds them up.
+struct BkgdUnit { int xk, ldx, kin, kt, dk, ldy, nout, goff, out_dim, boff; };   // xk: 0 = enc, k = X_k; dk: 0..3 = dY_k, 4 = d raw
+__constant__ BkgdUnit kBkgdUnits[18] = {
+    {0, 28, 27, 0, 0, 128, 128, bkgd_koff(0), 128, bkgd_boff(0)},
+    {1, 128, 128, 0, 1, 128, 128, bkgd_koff(1), 128, bkgd_boff(1)}, {1, 128, 128, 1, 1, 128, 128, bkgd_koff(1), 128, -1},
+    {1, 128, 128, 2, 1, 128, 128, bkgd_koff(1), 128, -1},            {1, 128, 128, 3, 1, 128, 128, bkgd_koff(1), 128, -1},
+    {2, 128, 128, 0, 2, 128, 128, bkgd_koff(2), 128, bkgd_boff(2)}, {2, 128, 128, 1, 2, 128, 128, bkgd_koff(2), 128, -1},
+    {2, 128, 128, 2, 2, 128, 128, bkgd_koff(2), 128, -1},            {2, 128, 128, 3, 2, 128, 128, bkgd_koff(2), 128, -1},
+    {3, 128, 128, 0, 3, 128, 128, bkgd_koff(3), 128, bkgd_boff(3)}, {3, 128, 128, 1, 3, 128, 128, bkgd_koff(3), 128, -1},
+    {3, 128, 128, 2, 3, 128, 128, bkgd_koff(3), 128, -1},            {3, 128, 128, 3, 3, 128, 128, bkgd_koff(3), 128, -1},
+    {0, 28, 27, 0, 3, 128, 128, bkgd_koff(3) + 128 * 128, 128, -1},
+    {4, 128, 128, 0, 4, 4, 3, bkgd_koff(4), 3, bkgd_boff(4)},       {4, 128, 128, 1, 4, 4, 3, bkgd_koff(4), 3, -1},
+    {4, 128, 128, 2, 4, 4, 3, bkgd_koff(4), 3, -1},                  {4, 128, 128, 3, 4, 4, 3, bkgd_koff(4), 3, -1}};
+
+__global__ void __launch_bounds__(256) bkgd_wgrad_kernel(const float* __restrict__ save, const float* __restrict__ dy, long long n,
+                                                         float* __restrict__ partial) {
+  __shared__ float red[4][4][1024 + 32];            // [wave][n-tile][acc reg * 64 + lane] (+ the bias row)
+  const BkgdUnit u = kBkgdUnits[blockIdx.y];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 31, h = lane >> 5;
+  const float* __restrict__ X = u.xk == 0 ? save : save + (size_t)n * 28 + (size_t)(u.xk - 1) * n * 128;
+  const float* __restrict__ dY = dy + (size_t)u.dk * n * 128;
+  const int k = 32 * u.kt + m;
+  const bool bias = u.boff >= 0;
+  const int NT = (u.nout + 31) / 32;
   const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   f32x16 acc[4] = {zero, zero, zero, zero}, accb[4] = {zero, zero, zero, zero};
-  const int NT = (nout + 31) / 32;
   const float onesA = m == 0 ? 1.f : 0.f;
-  for (long long r = r0; r < r1; r += 2) {
-    const long long rr = r + h;
-    const bool ok = rr < r1;
-    const float a = (ok && k < kin) ? X[(size_t)rr * ldx + k] : 0.f;
+  const long long r0 = (long long)blockIdx.x * 256 + wave * 64;
+#pragma unroll 4
+  for (int i = 0; i < 32; ++i) {
+    const long long rr = r0 + 2 * i + h;
+    const bool ok = rr < n;
+    const float a = (ok && k < u.kin) ? X[(size_t)rr * u.ldx + k] : 0.f;
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
       if (nt < NT) {
         const int nn = 32 * nt + m;
-        const float b = (ok && nn < nout) ? dY[(size_t)rr * ldy + nn] : 0.f;
+        const float b = (ok && nn < u.nout) ? dY[(size_t)rr * u.ldy + nn] : 0.f;
         acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[nt], 0, 0, 0);
-        if (gb && kt == 0) accb[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(onesA, b, accb[nt], 0, 0, 0);
+        if (bias) accb[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(onesA, b, accb[nt], 0, 0, 0);
       }
   }
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt)
     if (nt < NT) {
-      const int nn = 32 * nt + m;
-      if (nn < nout) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int ki = 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * h;
-          if (ki < kin) atomicAdd(gk + (size_t)ki * out_dim + nn, acc[nt][r]);
-        }
-        if (gb && kt == 0 && h == 0) atomicAdd(gb + nn, accb[nt][0]);
-      }
+      for (int r = 0; r < 16; ++r) red[wave][nt][r * 64 + lane] = acc[nt][r];
+      if (h == 0) red[wave][nt][1024 + m] = accb[nt][0];
     }
+  __syncthreads();
+  const int nt = wave;                                // wave w sums n-tile w over the 4 waves
+  if (nt < NT) {
+    float* pg = partial + (size_t)blockIdx.x * RNERF_BKGDMLP_PARAMS;
+    const int nn = 32 * nt + m;
+    if (nn < u.nout) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ki = 32 * u.kt + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float v = red[0][nt][r * 64 + lane] + red[1][nt][r * 64 + lane] + red[2][nt][r * 64 + lane] + red[3][nt][r * 64 + lane];
+        if (ki < u.kin) pg[u.goff + ki * u.out_dim + nn] = v;
+      }
+      if (bias && h == 0) pg[u.boff + nn] = red[0][nt][1024 + m] + red[1][nt][1024 + m] + red[2][nt][1024 + m] + red[3][nt][1024 + m];
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) bkgd_wgrad_reduce_kernel(const float* __restrict__ partial, int chunks, float* __restrict__ grads) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= RNERF_BKGDMLP_PARAMS) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int c = 0;
+  for (; c + 4 <= chunks; c += 4) {
+    s0 += partial[(size_t)c * RNERF_BKGDMLP_PARAMS + e]; s1 += partial[(size_t)(c + 1) * RNERF_BKGDMLP_PARAMS + e];
+    s2 += partial[(size_t)(c + 2) * RNERF_BKGDMLP_PARAMS + e]; s3 += partial[(size_t)(c + 3) * RNERF_BKGDMLP_PARAMS + e];
+  }
+  for (; c < chunks; ++c) s0 += partial[(size_t)c * RNERF_BKGDMLP_PARAMS + e];
+  grads[e] += (s0 + s1) + (s2 + s3);
 }
 
 }  // namespace rnerf
@@ -1486,10 +1571,41 @@ static const WgradPlan kWgradPlan[15] = {
     {SAVE_RGBIN, 8, DY_HEADS, 1, {11, 1, 0, 2, 4, 1, 1}},
     {0, 0, 0, 0, {0, 0, 0, 0, 0, 0, 0}}};
 
-extern "C" size_t rnerf_nerfmlp_wgrad_workspace_bytes(void) {
+static size_t build_wgrad_table(int cus, WgradTable& t) {
+  int n = 0;
+  double cost[16], total = 0;
+  for (; kWgradPlan[n].KSx != 0; ++n) {
+    const WgradJob& jb = kWgradPlan[n].job;
+    cost[n] = 2.0 * jb.KT * jb.NT + 2 * (jb.KT + jb.NT) + 16;   // accumulate MFMAs + transposition MFMAs + a fixed part per chunk
+    total += cost[n];
+  }
+  t.n = n;
+  static const int mult = getenv("RNERF_WGRAD_MULT") ? atoi(getenv("RNERF_WGRAD_MULT")) : 4;
+  const int budget = mult * cus;                             // rounds of one-per-CU workgroups
+  size_t off = 0;
+  int wg = 0;
+  for (int i = 0; i < n; ++i) {
+    const WgradPlan& p = kWgradPlan[i];
+    int share = (int)(budget * cost[i] / total + 0.5);
+    if (share < 8) share = 8;
+    t.qx[i] = p.qx; t.KSx[i] = p.KSx; t.qd[i] = p.qd; t.KSd[i] = p.KSd; t.job[i] = p.job;
+    t.wg0[i] = wg; wg += share;
+    t.poff[i] = (long long)off; off += (size_t)share * p.job.KT * 32 * p.job.NT * 32;
+    t.pboff[i] = (long long)off; off += (size_t)share * p.job.NT * 32;
+  }
+  t.wg0[n] = wg;
+  return off;
+}
+
+static int device_cus() {
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  return (size_t)cus * (256 * 256 + 256) * sizeof(float);
+  return cus;
+}
+
+extern "C" size_t rnerf_nerfmlp_wgrad_workspace_bytes(void) {
+  WgradTable t;
+  return build_wgrad_table(device_cus(), t) * sizeof(float);
 }
 
 extern "C" int rnerf_nerfmlp_wgrad(int fwd_precision, const void* save, const void* dy, int64_t rows, float* grads, void* workspace,
@@ -1497,32 +1613,24 @@ extern "C" int rnerf_nerfmlp_wgrad(int fwd_precision, const void* save, const vo
   RNERF_CHECK_ARG(save && dy && grads && workspace, "rnerf_nerfmlp_wgrad: null pointer");
   RNERF_CHECK_ARG(fwd_precision == RNERF_PREC_F16X3 || fwd_precision == RNERF_PREC_BF16X3, "rnerf_nerfmlp_wgrad: forward precision must be f16x3 or bf16x3");
   RNERF_CHECK_ARG(rows >= 1, "rnerf_nerfmlp_wgrad: rows must be >= 1");
-  int dev = 0, cus = 0;
-  RNERF_CHECK_HIP(hipGetDevice(&dev));
-  RNERF_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-  const long long R = (rows + 255) / 256 * 256;
-  const int n_chunks = (int)((rows + 127) / 128);
-  const int grid = n_chunks < cus ? n_chunks : cus;
-  float* partial = (float*)workspace;
-  float* partial_bias = partial + (size_t)cus * 256 * 256;
-  hipStream_t st = (hipStream_t)stream;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static WgradTable tab;
+  static bool ready = false;
+  if (!ready) {
+    build_wgrad_table(device_cus(), tab);
     RNERF_CHECK_HIP(hipFuncSetAttribute((const void*)nerfmlp_wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
     RNERF_CHECK_HIP(hipFuncSetAttribute((const void*)nerfmlp_wgrad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
-    attr_set = true;
+    ready = true;
   }
-  for (int i = 0; kWgradPlan[i].KSx != 0; ++i) {
-    const WgradPlan& p = kWgradPlan[i];
-    if (fwd_precision == RNERF_PREC_F16X3)
-      hipLaunchKernelGGL(nerfmlp_wgrad_kernel<true>, dim3(grid), dim3(256), 131072, st, (const uint4*)save, (const uint4*)dy, R, p.qx, p.KSx,
-                         p.qd, p.KSd, (long long)rows, n_chunks, partial, partial_bias);
-    else
-      hipLaunchKernelGGL(nerfmlp_wgrad_kernel<false>, dim3(grid), dim3(256), 131072, st, (const uint4*)save, (const uint4*)dy, R, p.qx, p.KSx,
-                         p.qd, p.KSd, (long long)rows, n_chunks, partial, partial_bias);
-    const int elems = p.job.KT * 32 * p.job.NT * 32;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((elems + 255) / 256), dim3(256), 0, st, partial, partial_bias, grid, p.job, grads);
-  }
+  const long long R = (rows + 255) / 256 * 256;
+  const int n_chunks = (int)((rows + 127) / 128);
+  hipStream_t st = (hipStream_t)stream;
+  if (fwd_precision == RNERF_PREC_F16X3)
+    hipLaunchKernelGGL(nerfmlp_wgrad_kernel<true>, dim3(tab.wg0[tab.n]), dim3(256), 131072, st, (const uint4*)save, (const uint4*)dy, R,
+                       (long long)rows, n_chunks, (float*)workspace, tab);
+  else
+    hipLaunchKernelGGL(nerfmlp_wgrad_kernel<false>, dim3(tab.wg0[tab.n]), dim3(256), 131072, st, (const uint4*)save, (const uint4*)dy, R,
+                       (long long)rows, n_chunks, (float*)workspace, tab);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(256, tab.n), dim3(256), 0, st, (const float*)workspace, tab, grads);
   RNERF_CHECK_LAUNCH();
   return RNERF_OK;
 }
@@ -1560,20 +1668,11 @@ extern "C" int rnerf_bkgd_backward(const float* params, const void* save, const 
   float* dyf = (float*)dy;
   hipLaunchKernelGGL(bkgd_dgrad_kernel, dim3((unsigned)((n + 31) / 32)), dim3(64), 0, st, params, sv, d_out, (long long)n,
                      (float)(1 + 2 * rgb_padding), (float)rgb_padding, dyf);
-  const unsigned chunks = (unsigned)((n + 511) / 512);
-  const float* enc = sv;
-  auto Xk = [&](int k) { return sv + (size_t)n * 28 + (size_t)(k - 1) * n * 128; };
-  auto dYk = [&](int k) { return dyf + (size_t)k * n * 128; };
-  const float* draw = dyf + (size_t)n * 4 * 128;
-#define WG(X, LDX, KIN, DY, LDY, NOUT, GK, OUTD, GB)                                                                          \
-  hipLaunchKernelGGL(bkgd_wgrad_kernel, dim3(chunks, ((KIN) + 31) / 32), dim3(64), 0, st, X, LDX, KIN, DY, LDY, NOUT, (long long)n, GK, OUTD, GB)
-  WG(enc, 28, 27, dYk(0), 128, 128, grads + bkgd_koff(0), 128, grads + bkgd_boff(0));
-  WG(Xk(1), 128, 128, dYk(1), 128, 128, grads + bkgd_koff(1), 128, grads + bkgd_boff(1));
-  WG(Xk(2), 128, 128, dYk(2), 128, 128, grads + bkgd_koff(2), 128, grads + bkgd_boff(2));
-  WG(Xk(3), 128, 128, dYk(3), 128, 128, grads + bkgd_koff(3), 128, grads + bkgd_boff(3));
-  WG(enc, 28, 27, dYk(3), 128, 128, grads + bkgd_koff(3) + 128 * 128, 128, (float*)nullptr);
-  WG(Xk(4), 128, 128, draw, 4, 3, grads + bkgd_koff(4), 3, grads + bkgd_boff(4));
-#undef WG
+  const unsigned chunks = (unsigned)((n + 255) / 256);
+  float* partial = dyf + (size_t)n * 5 * 128;
+  hipLaunchKernelGGL(bkgd_wgrad_kernel, dim3(chunks, 18), dim3(256), 0, st, sv, (const float*)dyf, (long long)n, partial);
+  hipLaunchKernelGGL(bkgd_wgrad_reduce_kernel, dim3((RNERF_BKGDMLP_PARAMS + 255) / 256), dim3(256), 0, st, (const float*)partial, (int)chunks,
+                     grads);
   RNERF_CHECK_LAUNCH();
   return RNERF_OK;
 }

@@ -215,13 +215,17 @@ def nerfmlp_pack_bwd(params_flat: torch.Tensor, out: Optional[torch.Tensor] = No
 
 
 def nerfmlp_backward(packed_bwd, packed_fwd, precision: int, save, d_raw: torch.Tensor, rows: int,
-                     grads: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+                     grads: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None, dy: Optional[torch.Tensor] = None,
+                     stages: str = "dw") -> torch.Tensor:
     """d_raw [S,B,4] (d loss / d raw) -> flat fp32 gradient of the NerfMLP parameters (595844 floats)."""
     lib = _lib.load()
     dev = d_raw.device
-    dy = torch.empty(lib.rnerf_nerfmlp_dy_bytes(rows), dtype=torch.uint8, device=dev)
-    check(lib.rnerf_nerfmlp_dgrad(ptr(packed_bwd), ptr(packed_fwd), int(precision), ptr(save), ptr(_chk(d_raw, "d_raw")), int(rows), ptr(dy),
-                                  current_stream()), "rnerf_nerfmlp_dgrad")
+    dy = torch.empty(lib.rnerf_nerfmlp_dy_bytes(rows), dtype=torch.uint8, device=dev) if dy is None else dy
+    if "d" in stages:
+        check(lib.rnerf_nerfmlp_dgrad(ptr(packed_bwd), ptr(packed_fwd), int(precision), ptr(save), ptr(_chk(d_raw, "d_raw")), int(rows), ptr(dy),
+                                      current_stream()), "rnerf_nerfmlp_dgrad")
+    if "w" not in stages:
+        return dy
     if grads is None:
         grads = torch.empty(_lib.NERFMLP_PARAMS, dtype=torch.float32, device=dev)
     if workspace is None:

@@ -115,9 +115,10 @@ def env_smooth_loss_and_grad(rgb_env: torch.Tensor, scale: float):
 
 
 def train_step(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], flags, *, jitter=None, u_fine=None,
-               taps: Optional[dict] = None):
+               taps: Optional[dict] = None, path=None):
     """One optimisation step (train.py:58-183).  batch: {"rays": Rays of [B,3], "pixels": [B,>=3], "annealed_alpha": float,
-    "env_rays": Rays with viewdirs [ps,ps,3] (when bg_smooth_weight > 0)}.  Returns (state, stats, rng); the Stats fields are
+    "env_rays": Rays with viewdirs [ps,ps,3] (when bg_smooth_weight > 0)}.  path: an optional NerfModel.prefetch_path handle for
+    these rays (the march carries no gradient and does not read the trained parameters, so it may overlap the previous step).  Returns (state, stats, rng); the Stats fields are
     0-dim device tensors (no host synchronisation inside the step)."""
     if not (flags.stage.startswith("radiance")):
         raise NotImplementedError("train_step: only the radiance stages are built (SURVEY.md §8f)")
@@ -131,7 +132,7 @@ def train_step(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], 
     prec = model.precision
     Nc, Nf = model.num_coarse_samples, model.num_fine_samples
     ctx: Dict[str, Any] = {}
-    ret, _loss_sp = model.apply(variables, key_0, key_1, rays, flags.randomized, annealed, jitter=jitter, u_fine=u_fine, ctx=ctx)
+    ret, _loss_sp = model.apply(variables, key_0, key_1, rays, flags.randomized, annealed, jitter=jitter, u_fine=u_fine, ctx=ctx, path=path)
     B = ctx["B"]
     rgb_f, _, _, trans_f, tb_f = ret[-1]
     rgb_c = ret[0][0] if len(ret) > 1 else None
