@@ -237,9 +237,10 @@ __device__ __forceinline__ void split8(const float (&x)[8], uint4& hi, uint4& lo
 // ~5 independent VALU ops in that shadow).  hipcc does not build this interleave by itself (it emits the ~110 VALU ops as
 // one clump ahead of the 48 MFMAs and the matrix pipe idles), so the order is written out and pinned with sched_barrier.
 //   pair pi in [0,8): m-tile pi>>2, value pair pi&3 -> chunk 0: bias+scale+ReLU, chunk 1: hi + residual, chunk 2: lo
-template <int PREC, int S>
+template <int PREC, int S, bool MASK = false>
 struct PrevConv {
   using PP = Prec<PREC>;
+  uint32_t nz[2] = {0, 0};   // MASK (training forward): non-zero flags of the 8 hi values per m-tile, bits p and 16 + p for pair p
   const f32x16& p0;   // m-tile 0: the accumulator registers holding features 32*(S>>1) .. +31 of the previous layer
   float v1[8];        // m-tile 1: raw accumulator values of the 8 features of k-step S (from LDS)
   float b[8];         // fp32 bias of the producing layer
@@ -278,6 +279,11 @@ struct PrevConv {
     } else {
       if constexpr (PP::NP == 2) lo[mt][p] = pack2<PP::F16>(x0, x1);
       else lo[mt][p] = 0;
+      if constexpr (MASK) {   // post-ReLU values are non-negative: min(u16, 1) is the non-zero flag of each half
+        typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+        const u16x2 one = {1, 1};
+        nz[mt] |= __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, hi[mt][p]), one)) << p;
+      }
     }
   }
   __device__ __forceinline__ KOps result() const {
@@ -372,7 +378,19 @@ __device__ __forceinline__ void kstep_mfma(f32x16 (&acc0)[8], f32x16 (&acc1)[8],
 // (R = rows padded to the 256-row tile), one uint4 = the 8 hi-part operand values lane (row, half h) fed to one k-step, i.e.
 // exactly the B operands of the forward MFMAs.  slot 0..3: position encoding; 4 + 16*(l-1) + s: input k-step s of MFMA layer
 // l = 1..9; 148..149: view encoding; 150..157: ReLU'd output of the view layer (= rgb head input).
-constexpr int SAVE_PE = 0, SAVE_L1 = 4, SAVE_VIEW = 148, SAVE_RGBIN = 150, SAVE_SLOTS = 158;
+// slots 158..166: ReLU bit masks for the dgrad chain, one uint4 per (row, half) per mask set (set l-1 = the input of MFMA layer
+// l = 1..8, set 8 = the rgb-head input): byte s (written as soon as k-step s is converted: no register lives across the layer),
+// bit (j>>1) + 4*(j&1) of it <=> element j of k-step s is non-zero.
+constexpr int SAVE_PE = 0, SAVE_L1 = 4, SAVE_VIEW = 148, SAVE_RGBIN = 150, SAVE_SLOTS = 158, SAVE_MASK = 158, SAVE_TOTAL = 167;
+
+// non-zero flags of the 8 post-ReLU (non-negative) 16-bit values of one operand: bits 0..3 = even elements, 16..19 = odd elements
+__device__ __forceinline__ uint32_t nz_nibbles(const uint4& o) {
+  typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+  const u16x2 one = {1, 1};
+  auto f = [&](uint32_t w) -> uint32_t { return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, w), one)); };
+  return f(o.x) | (f(o.y) << 1) | (f(o.z) << 2) | (f(o.w) << 3);
+}
+__device__ __forceinline__ uint32_t nz_byte(uint32_t nib) { return (nib & 0xFu) | (nib >> 12); }   // even flags | odd flags << 4
 
 template <int PREC, int dbg, bool TRAIN>
 __global__ void __launch_bounds__(256, 1)
@@ -426,6 +444,19 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
         uint4* dst = save + ((size_t)q * save_rows + srow0) * 2 + h;
         dst[0] = o.h0;
         dst[64] = o.h1;          // m-tile 1 = rows + 32
+      }
+    };
+
+    uint32_t mw0 = 0, mw1 = 0;                                                // mask bytes of up to 4 k-steps, then one dword store
+    auto save_mask = [&](int set, int s, uint32_t nib0, uint32_t nib1) {      // nib: nz_nibbles() of the hi operands of k-step s
+      if constexpr (TRAIN) {
+        if ((s & 3) == 0) { mw0 = nz_byte(nib0); mw1 = nz_byte(nib1); }
+        else { mw0 |= nz_byte(nib0) << (8 * (s & 3)); mw1 |= nz_byte(nib1) << (8 * (s & 3)); }
+        if ((s & 3) == 3) {
+          uint32_t* dst = (uint32_t*)(save + ((size_t)(SAVE_MASK + set) * save_rows + srow0) * 2 + h) + (s >> 2);
+          dst[0] = mw0;
+          dst[64 * 4] = mw1;
+        }
       }
     };
 
@@ -539,17 +570,19 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
 #define RNERF_KSTEP(S)                                                                                              \
       {                                                                                                              \
         save_ops(SAVE_L1 + 16 * (l - 1) + S, cur);                                                                   \
+        if constexpr (TRAIN && S == 0) save_mask(l - 1, 0, nz_nibbles(cur.h0), nz_nibbles(cur.h1));                  \
         float bnn[8];                                                                                                \
         if constexpr (S + 2 < 16) load_bias8(S + 2, bias, bnn);   /* consumed in the NEXT slab */                     \
         auto dma = [&]() { SLAB_PREFETCH(true); };                                                                   \
         if constexpr (S + 1 < 16) {                                                                                  \
-          PrevConv<PREC, S + 1> cv(prev0[(S + 1) >> 1]);                                                             \
+          PrevConv<PREC, S + 1, TRAIN> cv(prev0[(S + 1) >> 1]);                                                      \
           cv.floor_v = 0.f;                                                                                          \
           _Pragma("unroll") for (int j = 0; j < 8; ++j) cv.b[j] = bnext[j];                                          \
           load_state8(S + 1, cv.v1);                                                                                 \
           if (dbg & 8) { kstep_mfma<PREC, 8, 0, S == 0, NoWork, (dbg & 16) != 0>(acc0, acc1, cur, smem + buf * SLAB, lane, nowork, dma); } \
-          else { if (!(dbg & 2)) kstep_mfma<PREC, 8, 0, S == 0, PrevConv<PREC, S + 1>, (dbg & 16) != 0, decltype(dma)>(acc0, acc1, cur, smem + buf * SLAB, lane, cv, dma);              \
-          cur = cv.result(); }                                                                                       \
+          else { if (!(dbg & 2)) kstep_mfma<PREC, 8, 0, S == 0, PrevConv<PREC, S + 1, TRAIN>, (dbg & 16) != 0, decltype(dma)>(acc0, acc1, cur, smem + buf * SLAB, lane, cv, dma);              \
+          cur = cv.result();                                                                                         \
+          save_mask(l - 1, S + 1, cv.nz[0], cv.nz[1]); }                                                             \
         } else {                                                                                                     \
           if (!(dbg & 2)) kstep_mfma<PREC, 8, 0, false>(acc0, acc1, cur, smem + buf * SLAB, lane, nowork, dma);      \
         }                                                                                                            \
@@ -649,6 +682,7 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
             o.h1 = make_uint4(pack2<PP::F16>(rv1[8 * half], rv1[8 * half + 1]), pack2<PP::F16>(rv1[8 * half + 2], rv1[8 * half + 3]),
                               pack2<PP::F16>(rv1[8 * half + 4], rv1[8 * half + 5]), pack2<PP::F16>(rv1[8 * half + 6], rv1[8 * half + 7]));
             save_ops(SAVE_RGBIN + 2 * t + half, o);
+            save_mask(8, 2 * t + half, nz_nibbles(o.h0), nz_nibbles(o.h1));
           }
         }
       }
@@ -748,29 +782,33 @@ nerfmlp_dgrad_kernel(const char* __restrict__ packed_bwd, const float* __restric
     f32x16 acc0[8], acc1[8], prev0[8];
 
     auto dy_store = [&](int q, const KOps& o) {
+#ifdef RNERF_DGRAD_NOSTORE
+      if (g[0].x != 12345.f) return;
+#endif
       uint4* dst = dy + ((size_t)q * save_rows + srow0) * 2 + h;
       dst[0] = o.h0;
       dst[64] = o.h1;
     };
-    auto saved_at = [&](int q, uint4& a, uint4& b) {
-      const uint4* src = saved + ((size_t)q * save_rows + srow0) * 2 + h;
+    // ReLU masks: one uint4 of non-zero flags per (row, half) per layer (SAVE_MASK), fetched one layer ahead
+    auto mask_at = [&](int set, uint4& a, uint4& b) {
+      const uint4* src = saved + ((size_t)(SAVE_MASK + set) * save_rows + srow0) * 2 + h;
       a = src[0]; b = src[64];
     };
     // operands of k-step s from the state (prev0 / st1): x = (state + dsig * wadd) * 1[mask != 0]
     auto grad_ops = [&](int s, bool use_mask, const uint4 mk0, const uint4 mk1, const float* __restrict__ wadd) -> KOps {
       const float4 u0 = st1[((s >> 1) * 4 + 2 * (s & 1)) * 64], u1 = st1[((s >> 1) * 4 + 2 * (s & 1) + 1) * 64];
       const float r1[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
-      const uint32_t w0[4] = {mk0.x, mk0.y, mk0.z, mk0.w}, w1[4] = {mk1.x, mk1.y, mk1.z, mk1.w};
+      const uint32_t w0 = (s >> 2) == 0 ? mk0.x : ((s >> 2) == 1 ? mk0.y : ((s >> 2) == 2 ? mk0.z : mk0.w));
+      const uint32_t w1 = (s >> 2) == 0 ? mk1.x : ((s >> 2) == 1 ? mk1.y : ((s >> 2) == 2 ? mk1.z : mk1.w));
       float x0[8], x1[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         float a = prev0[s >> 1][8 * (s & 1) + j], b = r1[j];
         if (wadd) { const float w = wadd[16 * s + 8 * (j >> 2) + 4 * h + (j & 3)]; a = fmaf(g[0].w, w, a); b = fmaf(g[1].w, w, b); }
         if (use_mask) {
-          const uint32_t e0 = (j & 1) ? (w0[j >> 1] >> 16) : (w0[j >> 1] & 0xffffu);
-          const uint32_t e1 = (j & 1) ? (w1[j >> 1] >> 16) : (w1[j >> 1] & 0xffffu);
-          a = (e0 & 0x7fffu) ? a : 0.f;
-          b = (e1 & 0x7fffu) ? b : 0.f;
+          const uint32_t bit = 1u << (8 * (s & 3) + (j >> 1) + 4 * (j & 1));
+          a = (w0 & bit) ? a : 0.f;
+          b = (w1 & bit) ? b : 0.f;
         }
         x0[j] = a; x1[j] = b;
       }
@@ -819,14 +857,14 @@ nerfmlp_dgrad_kernel(const char* __restrict__ packed_bwd, const float* __restric
     // ---- dgrad of MFMA layer 9 (Dense_10): k-steps over its 128 outputs; state masked by the saved rgb-head input
     {
       uint4 ma, mb;
-      saved_at(SAVE_RGBIN, ma, mb);
+      mask_at(8, ma, mb);
       KOps cur = grad_ops(0, true, ma, mb, nullptr);
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
         dy_store(DY_L9 + s, cur);
         SLAB_PREFETCH(true);
         KOps nxt = cur;
-        if (s + 1 < 8) { saved_at(SAVE_RGBIN + s + 1, ma, mb); nxt = grad_ops(s + 1, true, ma, mb, nullptr); }
+        if (s + 1 < 8) nxt = grad_ops(s + 1, true, ma, mb, nullptr);
         if (s == 0) kstep_mfma<PREC, 8, 0, true>(acc0, acc1, cur, smem + buf * SLAB, lane, nowork);
         else kstep_mfma<PREC, 8, 0, false>(acc0, acc1, cur, smem + buf * SLAB, lane, nowork);
         SLAB_DONE();
@@ -836,13 +874,13 @@ nerfmlp_dgrad_kernel(const char* __restrict__ packed_bwd, const float* __restric
     }
 
     // ---- dgrad of MFMA layers 8..1: dY_l = (dX_{l+1} [+ d sigma * w_sigma for l = 7]) * 1[X_{l+1} > 0]  (no mask for the bottleneck l = 8)
+    uint4 nma = make_uint4(0, 0, 0, 0), nmb = nma;      // mask of the NEXT iteration (set l-1), loaded a whole layer ahead
 #pragma unroll 1
     for (int l = 8; l >= 1; --l) {
       const bool use_mask = l != 8;
       const float* __restrict__ wadd = (l == 7) ? fwd_aux + AUX_WSIG : nullptr;
-      const int mq = SAVE_L1 + 16 * l;          // saved input of layer l+1
-      uint4 ma = make_uint4(0, 0, 0, 0), mb = ma;
-      if (use_mask) saved_at(mq, ma, mb);
+      const uint4 ma = nma, mb = nmb;            // set l = the ReLU mask of the input of layer l+1
+      mask_at(l - 1, nma, nmb);
       KOps cur = grad_ops(0, use_mask, ma, mb, wadd);
 #pragma unroll
       for (int s = 0; s < 16; ++s) {
@@ -850,7 +888,7 @@ nerfmlp_dgrad_kernel(const char* __restrict__ packed_bwd, const float* __restric
         const bool last_of_tile = (l == 1 && s == 15);
         if (last_of_tile) { if (has_next_tile) off = 0; SLAB_PREFETCH(has_next_tile); } else SLAB_PREFETCH(true);
         KOps nxt = cur;
-        if (s + 1 < 16) { if (use_mask) saved_at(mq + s + 1, ma, mb); nxt = grad_ops(s + 1, use_mask, ma, mb, wadd); }
+        if (s + 1 < 16) nxt = grad_ops(s + 1, use_mask, ma, mb, wadd);
         if (s == 0) kstep_mfma<PREC, 8, 0, true>(acc0, acc1, cur, smem + buf * SLAB, lane, nowork);
         else kstep_mfma<PREC, 8, 0, false>(acc0, acc1, cur, smem + buf * SLAB, lane, nowork);
         SLAB_DONE();
@@ -862,9 +900,7 @@ nerfmlp_dgrad_kernel(const char* __restrict__ packed_bwd, const float* __restric
     // ---- dY_0 = dX_1 * 1[X_1 > 0]: only recorded (layer 0's inputs are constants)
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
-      uint4 ma, mb;
-      saved_at(SAVE_L1 + s, ma, mb);
-      const KOps o = grad_ops(s, true, ma, mb, nullptr);
+      const KOps o = grad_ops(s, true, nma, nmb, nullptr);
       dy_store(s, o);
     }
 #undef SLAB_PREFETCH
@@ -1501,7 +1537,7 @@ extern "C" int rnerf_nerfmlp_forward(const void* packed, int precision, const fl
 
 extern "C" size_t rnerf_nerfmlp_save_bytes(int64_t rows) {
   const int64_t padded = (rows + 255) / 256 * 256;
-  return (size_t)SAVE_SLOTS * (size_t)padded * 2 * sizeof(uint4);
+  return (size_t)SAVE_TOTAL * (size_t)padded * 2 * sizeof(uint4);
 }
 
 extern "C" int rnerf_nerfmlp_forward_train(const void* packed, int precision, const float* rows_pd, const float* rows_dr,
