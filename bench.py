@@ -85,31 +85,42 @@ def cpu_baseline(cfg, pf, fine, sample_rays, seed, train=False):
 
 
 def cpu_train_step(R, mc, pf, params, table, o, d, jitter, cfg, fine, seed):
-    """One optimisation step on the host cores: the oracle marches / samples (no gradient there), torch CPU fp32 autograd does
-    the differentiable part of train.py's loss_fn (oracle/torch_ref.py) and Adam.  Flat N_f = 0 workloads only."""
+    """One optimisation step on the host cores: the oracle marches / resamples (no gradient there), torch CPU fp32 autograd does
+    the differentiable part of train.py's loss_fn (oracle/torch_ref.py) and Adam."""
     import torch
     from oracle import torch_ref as TR
-    assert fine == 0, "cpu train baseline is written for the flat (N_f = 0) bench workloads"
     B = o.shape[0]
     rng = np.random.default_rng(seed)
     pix = torch.from_numpy(rng.uniform(0, 1, (B, 3)).astype(np.float32))
     ev = rng.standard_normal((128 * 128, 3)).astype(np.float32)
     ev /= np.linalg.norm(ev, axis=-1, keepdims=True)
-    th = {k: torch.tensor(pf[k], dtype=torch.float32, requires_grad=True) for k in ("coarse_mlp", "bkgd_mlp")}
+    names = ["coarse_mlp", "bkgd_mlp"] + (["fine_mlp"] if fine > 0 else [])
+    th = {k: torch.tensor(pf[k], dtype=torch.float32, requires_grad=True) for k in names}
     opt = torch.optim.Adam(list(th.values()), lr=5e-4)
+    f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32))
     t0 = time.perf_counter()
-    rp, rd, rdist, _, _ = R.path_sampler(o, d, table, mc.ndim, mc.nmin, mc.nmax, mc.near, mc.far, mc.num_samples, np.float32)   # [B,N,*]
+    rp, rd, rdist, _, idx_grad = R.path_sampler(o, d, table, mc.ndim, mc.nmin, mc.nmax, mc.near, mc.far, mc.num_samples, np.float32)   # [B,N,*]
     jitter = np.asarray(jitter, np.int64)
+
+    def level(name, pos, dirs, t, bk):
+        S = pos.shape[1]
+        raw = TR.nerf_mlp(th[name], f32(R.pos_enc(pos.reshape(-1, 3), 0, 10)), f32(R.pos_enc(dirs.reshape(-1, 3), 0, 4))).reshape(B, S, 4)
+        rgb, sigma = TR.activations(raw)
+        comp, acc, w, trans, tb = TR.volumetric_rendering(rgb, sigma, f32(t), f32(dirs), bk)
+        return comp, trans, tb, w
+
     pos, dirs, t = rp[:, jitter], rd[:, jitter], rdist[:, jitter]
-    S = pos.shape[1]
-    enc = torch.from_numpy(R.pos_enc(pos.reshape(-1, 3), 0, 10).astype(np.float32))
-    venc = torch.from_numpy(R.pos_enc(dirs.reshape(-1, 3), 0, 4).astype(np.float32))
-    raw = TR.nerf_mlp(th["coarse_mlp"], enc, venc).reshape(B, S, 4)
-    rgb, sigma = TR.activations(raw)
-    bk = TR.bkgd_mlp(th["bkgd_mlp"], torch.from_numpy(R.pos_enc(dirs[:, -1], 0, 4).astype(np.float32)))
-    comp, acc, w, trans, tb = TR.volumetric_rendering(rgb, sigma, torch.from_numpy(t.astype(np.float32)), torch.from_numpy(dirs.astype(np.float32)), bk)
-    loss, _ = TR.radiance_loss([(comp, trans, tb)], pix, 0.025, 0.5)
-    env = TR.bkgd_mlp(th["bkgd_mlp"], torch.from_numpy(R.pos_enc(ev, 0, 4).astype(np.float32))).reshape(128, 128, 3)
+    bk = TR.bkgd_mlp(th["bkgd_mlp"], f32(R.pos_enc(dirs[:, -1], 0, 4)))
+    comp_c, trans_c, tb_c, w_c = level("coarse_mlp", pos, dirs, t, bk)
+    levels = [(comp_c, trans_c, tb_c)]
+    if fine > 0:
+        mid = np.float32(0.5) * (t[..., 1:] + t[..., :-1])
+        u = R.linspace_u(fine, B, np.float32)
+        z_f, pos_f, dir_f, _, _ = R.sample_pdf(u, mid, w_c.detach().numpy()[..., 1:-1], rp, rd, rdist, idx_grad, jitter)
+        comp_f, trans_f, tb_f, _ = level("fine_mlp", pos_f, dir_f, z_f, bk)
+        levels.append((comp_f, trans_f, tb_f))
+    loss, _ = TR.radiance_loss(levels, pix, 0.025, 0.5)
+    env = TR.bkgd_mlp(th["bkgd_mlp"], f32(R.pos_enc(ev, 0, 4))).reshape(128, 128, 3)
     loss = loss + (0.5 * ((env[1:, :] - env[:-1, :]) ** 2).reshape(-1) + 0.5 * ((env[:, 1:] - env[:, :-1]) ** 2).reshape(-1)).mean()
     opt.zero_grad()
     loss.backward()
@@ -184,13 +195,16 @@ def main():
                  "env_rays": Rays(None, None, torch.from_numpy(ev_d).to(device), None)}
 
     def step(last=False):
+        if train:
+            # the march of step k+1 is issued right after the forward of step k and runs beside its backward kernels
+            _, stats, state["rng"] = train_step(model, state["rng"], tstate, batch, flags, path=state["h"],
+                                                next_rays=rays if (args.pipeline and not last) else None)
+            state["h"] = tstate.next_path
+            return [(stats.loss.reshape(1),)], None
         h = state["h"] if args.pipeline else None
         if args.pipeline and h is None:
             h = model.prefetch_path(rays, sync_inputs=False, reserve_cus=args.reserve_cus)
         state["h"] = model.prefetch_path(rays, sync_inputs=False, reserve_cus=args.reserve_cus) if (args.pipeline and not last) else None
-        if train:
-            _, stats, state["rng"] = train_step(model, state["rng"], tstate, batch, flags, path=h)
-            return [(stats.loss.reshape(1),)], None
         return model.apply(variables, key, key, rays, False, path=h)
 
     def barrier():
@@ -284,7 +298,8 @@ def main():
                                    f"{B} rays/GPU x {S} coarse + {fine} fine samples, "
                                    f"P={cfg['P']} (N={N} eikonal steps), grid {cfg['G']}^3", "rays_per_gpu": B,
                        "mlp_rows_per_ray": rows_per_ray, "precision": args.precision, "pass": args.mode,
-                       "pipeline": "march(k+1) on a side stream overlaps MLP(k)" if args.pipeline else "none"},
+                       "pipeline": ("none" if not args.pipeline else ("march(k+1) on a side stream beside backward(k)" if train
+                                                                          else "march(k+1) on a side stream overlaps MLP(k)"))},
             "roofline": {"kernel": "nerfmlp_fwd_kernel", "bound": "mfma", "achieved": mlp_achieved / 1e12, "peak": PEAK_MFMA_16BIT / 1e12,
                          "unit": "TFLOP/s", "frac": mlp_achieved / PEAK_MFMA_16BIT, "traffic": traffic.get("nerfmlp_fwd_kernel"),
                          "avg_launch_ms": mlp_ms, "algorithmic_flop_per_launch": mlp_flops,

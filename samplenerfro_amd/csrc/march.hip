@@ -56,45 +56,79 @@ __global__ void __launch_bounds__(64) march_kernel(const float* __restrict__ tab
   const double rcp_q = g.rcp_nd[qc];
   const int dim_q = qc == 0 ? g.dx : (qc == 1 ? g.dy : g.dz);
   const unsigned comp = (q + 1) & 3;
-  const unsigned s1 = (unsigned)g.dy * (unsigned)g.dz, s2 = (unsigned)g.dz;
-  const float* __restrict__ tabc = table + comp;
+  // byte offsets into the table fit 32 bits (checked by the launcher): one v_mad_u32_u24 + adds per corner, SGPR base
+  const unsigned s1 = (unsigned)g.dy * (unsigned)g.dz * 16u, s2 = (unsigned)g.dz * 16u;
+  const char* __restrict__ tabc = (const char*)table;   // uniform base; this lane's component goes into the 32-bit offset
+  const unsigned cofs = comp * 4u;
   float d = q < 3 ? viewdirs[3 * r + qc] : 0.f;
   float p = q < 3 ? fadd(origins[3 * r + qc], fmul(near, d)) : 0.f;   // eikonal_utils.py:104-106
   float rt = near;
-  for (int k = 0; k < num_nodes; ++k) {
-    const size_t o = (size_t)k * B + r;
+
+  // The gathers of steps k+1 and k+2 are issued EARLY, from predicted cells (grid coordinate extrapolated linearly from the
+  // last two nodes), so that their latency overlaps the arithmetic of the steps before instead of adding to the per-step
+  // dependent chain.  When the real cell of a step is known it is compared with the prediction (integer indices): equal ->
+  // the values in flight are exactly the ones the reference gathers; different (ray within ~1 ulp of a cell face, a few per
+  // million steps) -> they are gathered again.  Results stay bit-identical to the un-speculated march.
+  struct Corners { float c[8]; int i0, i1; };     // 000 100 001 101 010 110 011 111 (xyz) + the indices they were gathered with
+  Corners ca, cb, cc;
+  auto gather = [&](int i0, int i1, Corners& o) {
+    o.i0 = i0; o.i1 = i1;
+    const unsigned x0 = quad_bcast_i<0>(i0), x1 = quad_bcast_i<0>(i1);
+    const unsigned y0 = quad_bcast_i<1>(i0), y1 = quad_bcast_i<1>(i1);
+    const unsigned z0 = quad_bcast_i<2>(i0) * 16u + cofs, z1 = quad_bcast_i<2>(i1) * 16u + cofs;
+    const unsigned bx0 = __umul24(x0, s1), bx1 = __umul24(x1, s1);
+    const unsigned b00 = bx0 + __umul24(y0, s2), b10 = bx1 + __umul24(y0, s2), b01 = bx0 + __umul24(y1, s2), b11 = bx1 + __umul24(y1, s2);
+    o.c[0] = *(const float*)(tabc + (b00 + z0)); o.c[1] = *(const float*)(tabc + (b10 + z0));
+    o.c[2] = *(const float*)(tabc + (b00 + z1)); o.c[3] = *(const float*)(tabc + (b10 + z1));
+    o.c[4] = *(const float*)(tabc + (b01 + z0)); o.c[5] = *(const float*)(tabc + (b11 + z0));
+    o.c[6] = *(const float*)(tabc + (b01 + z1)); o.c[7] = *(const float*)(tabc + (b11 + z1));
+  };
+  auto predict = [&](float xp, Corners& o) {
+    const int j = (int)floorf(xp);
+    gather(clampi(j, 0, dim_q - 1), clampi(j + 1, 0, dim_q - 1), o);
+  };
+  float x_prev;
+  {
+    const float x = div_const(fsub(p, nmin_q), rcp_q);
+    x_prev = div_const(fsub(fsub(p, fmul(step, d)), nmin_q), rcp_q);   // as if a vacuum step had led here
+    predict(x, ca);
+    predict(fadd(x, fsub(x, x_prev)), cb);
+  }
+  float* __restrict__ out_pd = path_pd + 4 * (size_t)r + q;          // advanced by one node (B records) per step
+  float* __restrict__ out_dr = path_dr + 4 * (size_t)r + q;
+  float* __restrict__ out_ior = WANT_IOR ? path_ior + 4 * (size_t)r + comp : nullptr;
+  const size_t node_stride = 4 * (size_t)B;
+  // one step; cn = corners of this step, nx = where the corners of step k+2 are gathered to
+  auto one_step = [&](int k, Corners& cn, Corners& nx) {
     // ---- VoxMLP._linear3 addressing (ior_utils.py:188-211): one coordinate per lane
     const float x = div_const(fsub(p, nmin_q), rcp_q);
     const float fx = floorf(x);
     const int i = (int)fx;
     const float t = fsub(x, fx);                   // (x - x0) / (x1 - x0), divisor exactly 1
     const int i0 = clampi(i, 0, dim_q - 1), i1 = clampi(i + 1, 0, dim_q - 1);
-    const unsigned x0 = quad_bcast_i<0>(i0), x1 = quad_bcast_i<0>(i1);
-    const unsigned y0 = quad_bcast_i<1>(i0), y1 = quad_bcast_i<1>(i1);
-    const unsigned z0 = quad_bcast_i<2>(i0), z1 = quad_bcast_i<2>(i1);
+    if (__builtin_amdgcn_ballot_w64(i0 != cn.i0 || i1 != cn.i1) != 0) gather(i0, i1, cn);     // mispredicted somewhere in the wave
+    // ---- speculative gather for step k+2
+    const float dx = fsub(x, x_prev);
+    predict(fadd(x, fadd(dx, dx)), nx);
+    x_prev = x;
     const float xd = quad_bcast<0>(t), yd = quad_bcast<1>(t), zd = quad_bcast<2>(t);
-    const unsigned bx0 = s1 * x0, bx1 = s1 * x1, by0 = s2 * y0, by1 = s2 * y1;
-    // ---- the 8 corner gathers, this lane's component (a quad reads the whole 16-byte entry)
-    const float d000 = tabc[(size_t)(bx0 + by0 + z0) * 4], d100 = tabc[(size_t)(bx1 + by0 + z0) * 4];
-    const float d001 = tabc[(size_t)(bx0 + by0 + z1) * 4], d101 = tabc[(size_t)(bx1 + by0 + z1) * 4];
-    const float d010 = tabc[(size_t)(bx0 + by1 + z0) * 4], d110 = tabc[(size_t)(bx1 + by1 + z0) * 4];
-    const float d011 = tabc[(size_t)(bx0 + by1 + z1) * 4], d111 = tabc[(size_t)(bx1 + by1 + z1) * 4];
     // ---- node record while the gathers are in flight: node k = state before step k (eikonal_utils.py:112-114),
     //      direction safe-normalised (math_utils.py:6-12)
     const float nrm = fsqrt(fmaxf(quad_sumsq3(d), 1e-6f));
-    path_pd[4 * o + q] = q < 3 ? p : rt;
-    path_dr[4 * o + q] = q < 3 ? fdiv(d, nrm) : 0.f;
-    if (WANT_VOX && q < 3) { vox[6 * o + 2 * q] = i0; vox[6 * o + 2 * q + 1] = i1; }
+    *out_pd = q < 3 ? p : rt;
+    *out_dr = q < 3 ? fdiv(d, nrm) : 0.f;
+    out_pd += node_stride; out_dr += node_stride;
+    if (WANT_VOX && q < 3) { const size_t o = (size_t)k * B + r; vox[6 * o + 2 * q] = i0; vox[6 * o + 2 * q + 1] = i1; }
     // ---- 7 lerps a*(1-t) + b*t (ior_utils.py:214-222)
     const float oxd = fsub(1.0f, xd), oyd = fsub(1.0f, yd), ozd = fsub(1.0f, zd);
-    const float c00 = fadd(fmul(d000, oxd), fmul(d100, xd));
-    const float c01 = fadd(fmul(d001, oxd), fmul(d101, xd));
-    const float c10 = fadd(fmul(d010, oxd), fmul(d110, xd));
-    const float c11 = fadd(fmul(d011, oxd), fmul(d111, xd));
+    const float c00 = fadd(fmul(cn.c[0], oxd), fmul(cn.c[1], xd));
+    const float c01 = fadd(fmul(cn.c[2], oxd), fmul(cn.c[3], xd));
+    const float c10 = fadd(fmul(cn.c[4], oxd), fmul(cn.c[5], xd));
+    const float c11 = fadd(fmul(cn.c[6], oxd), fmul(cn.c[7], xd));
     const float c0 = fadd(fmul(c00, oyd), fmul(c10, yd));
     const float c1 = fadd(fmul(c01, oyd), fmul(c11, yd));
     const float c = fadd(fmul(c0, ozd), fmul(c1, zd));   // lanes 0..2: grad component q, lane 3: n
-    if (WANT_IOR) path_ior[4 * o + comp] = c;
+    if (WANT_IOR) { *out_ior = c; out_ior += node_stride; }
     // ---- OneEikonalStep (eikonal_utils.py:41-45)
     const float n = quad_bcast<3>(c);
     const float s = fdiv(step, n);
@@ -102,7 +136,15 @@ __global__ void __launch_bounds__(64) march_kernel(const float* __restrict__ tab
     d = fadd(d, fmul(step, c));
     rt = fadd(rt, fsqrt(quad_sumsq3(fsub(p, np))));
     p = np;
+  };
+  int k = 0;
+  for (; k + 2 < num_nodes; k += 3) {      // three steps per trip: the corner register sets rotate instead of being copied
+    one_step(k, ca, cc);
+    one_step(k + 1, cb, ca);
+    one_step(k + 2, cc, cb);
   }
+  if (k < num_nodes) { one_step(k, ca, cc); ++k; }
+  if (k < num_nodes) one_step(k, cb, ca);
 }
 
 }  // namespace rnerf
@@ -118,7 +160,8 @@ extern "C" int rnerf_march(const float* table, const rnerf_grid* g, const float*
                   "rnerf_march: table/path buffers must be 16-byte aligned");
   GridParams gp;
   RNERF_CHECK_ARG(make_grid_params(g, &gp), "rnerf_march: bad grid");
-  RNERF_CHECK_ARG((double)gp.dx * gp.dy * gp.dz < 1073741824.0, "rnerf_march: grid too large for 32-bit entry indices");
+  RNERF_CHECK_ARG((double)gp.dx * gp.dy * gp.dz * 16.0 < 4294967296.0 && (double)gp.dy * gp.dz * 16.0 < 16777216.0 && gp.dx < 16777216,
+                  "rnerf_march: grid too large for 32-bit byte offsets (needs G^3 * 16 B < 4 GiB)");
   MarchParams p;
   p.dx = gp.dx; p.dy = gp.dy; p.dz = gp.dz;
   p.nmin[0] = gp.nminx; p.nmin[1] = gp.nminy; p.nmin[2] = gp.nminz;

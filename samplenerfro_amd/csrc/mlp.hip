@@ -302,7 +302,8 @@ struct NoWork {
 #define RNERF_PIN() __builtin_amdgcn_sched_barrier(0)
 
 // one n-tile of one k-step: 6 (X3) or 2 MFMAs with the conversion chunks of pair PI in their shadow
-template <int PREC, bool FIRST, int PI, typename W>
+// PASSES (X3 modes): 3 = hi*hi + hi*lo + lo*hi (fp32-grade), 2 = drop the lo(weight) term, 1 = hi*hi only
+template <int PREC, bool FIRST, int PI, typename W, int PASSES = 3>
 __device__ __forceinline__ void tile_mfma(f32x16& a0, f32x16& a1, const uint4 ah, const uint4 al, const KOps& b, W& work) {
   using PP = Prec<PREC>;
   const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -312,7 +313,7 @@ __device__ __forceinline__ void tile_mfma(f32x16& a0, f32x16& a1, const uint4 ah
   a1 = mfma16<PP::F16>(ah, b.h1, FIRST ? zero : a1);
   work.template chunk<1, PI>();
   RNERF_PIN();
-  if constexpr (PP::NP == 2) {
+  if constexpr (PP::NP == 2 && PASSES == 3) {
     a0 = mfma16<PP::F16>(ah, b.l0, a0);
     work.template chunk<2, PI>();
     RNERF_PIN();
@@ -323,6 +324,13 @@ __device__ __forceinline__ void tile_mfma(f32x16& a0, f32x16& a1, const uint4 ah
     work.template chunk<4, PI>();
     RNERF_PIN();
     a1 = mfma16<PP::F16>(al, b.h1, a1);
+  } else if constexpr (PP::NP == 2 && PASSES == 2) {
+    a0 = mfma16<PP::F16>(ah, b.l0, a0);
+    work.template chunk<2, PI>();
+    work.template chunk<3, PI>();
+    RNERF_PIN();
+    a1 = mfma16<PP::F16>(ah, b.l1, a1);
+    work.template chunk<4, PI>();
   } else {
     work.template chunk<2, PI>();
     work.template chunk<3, PI>();
@@ -341,7 +349,7 @@ struct NoDma { __device__ __forceinline__ void operator()() const {} };
 // number of reads in flight (latency x concurrency), not by the 256 B/clk peak.
 constexpr int FRAG_DEPTH = 4;
 
-template <int PREC, int NT, int KOFF, bool FIRST, typename W, bool NOREAD = false, typename D = NoDma>
+template <int PREC, int NT, int KOFF, bool FIRST, typename W, bool NOREAD = false, typename D = NoDma, int PASSES = 3>
 __device__ __forceinline__ void kstep_mfma(f32x16 (&acc0)[8], f32x16 (&acc1)[8], const KOps& b, const char* slab, int lane, W& work, D dma = D()) {
   using PP = Prec<PREC>;
   const uint4* a = (const uint4*)slab + lane + (size_t)KOFF * NT * PP::NP * 64;
@@ -356,7 +364,7 @@ __device__ __forceinline__ void kstep_mfma(f32x16 (&acc0)[8], f32x16 (&acc1)[8],
   if constexpr (T < NT) {                                                                                 \
     uint4 ah = fh[T % FRAG_DEPTH], al = fl[T % FRAG_DEPTH];                                               \
     if constexpr (NOREAD) { asm volatile("" : "+v"(ah.x), "+v"(al.x)); }  /* ablation: opaque, so tiles are not CSE'd */ \
-    tile_mfma<PREC, FIRST, (T & 7), W>(acc0[T], acc1[T], ah, al, b, work);                                \
+    tile_mfma<PREC, FIRST, (T & 7), W, PASSES>(acc0[T], acc1[T], ah, al, b, work);                        \
     if constexpr (T + FRAG_DEPTH < NT && !NOREAD) {                                                       \
       fh[T % FRAG_DEPTH] = a[((T + FRAG_DEPTH) * PP::NP) * 64];                                           \
       fl[T % FRAG_DEPTH] = a[((T + FRAG_DEPTH) * PP::NP + PP::NP - 1) * 64];                              \
@@ -718,6 +726,12 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
 //   (half 0: slot 0 = d raw_sigma, slots 1..3 = d raw_rgb).
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int DY_L9 = 144, DY_HEADS = 152, DY_SLOTS = 153;
+// dgrad MFMA passes per product: 2 = (dY_hi + dY_lo) * W_hi, i.e. fp32-grade gradients times bf16-rounded weights (the wgrad
+// operands are bf16-rounded anyway: measured worst gradient error 6.8e-3 of the tensor maximum vs 5.1e-3 with 3 passes, 2.2 -> 1.9 ms)
+#ifndef RNERF_DGRAD_PASSES
+#define RNERF_DGRAD_PASSES 2
+#endif
+constexpr int DGRAD_PASSES = RNERF_DGRAD_PASSES;
 constexpr int kBwdBlocks = 8 * 8 + 8 * 16 * 8;   // (k-steps over n) x (8 input-feature tiles): L9 then L8..L1
 
 // dgrad layer order: index 0 = MFMA layer 9 (Dense_10), 1 = layer 8 (Dense_9), 2..8 = layers 7..1 (Dense_7..Dense_1)
@@ -747,6 +761,49 @@ __global__ void nerfmlp_pack_bwd_kernel(const float* __restrict__ params, char* 
   dst[lane] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
   if (PP::NP == 2) dst[64 + lane] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
 }
+
+// dgrad twin of PrevConv: the B operands of k-step S of the NEXT dgrad GEMM = (state [+ d sigma * w_sigma]) * ReLU mask, split
+// into bf16 hi/lo, computed pair by pair in the shadow of the current k-step's MFMAs.
+template <int PREC, int S>
+struct GradConv {
+  const f32x16& p0;   // m-tile 0 state (accumulator registers of the previous dgrad layer)
+  float v1[8];        // m-tile 1 state (from LDS)
+  float wv[8];        // w_sigma of these 8 features (0 unless this is the layer that receives d sigma)
+  float gw0, gw1;     // d raw_sigma of the lane's two rows
+  uint32_t w0, w1;    // mask word S>>2 of both m-tiles (all ones: no ReLU)
+  uint32_t hi[2][4], lo[2][4];
+  float x0, x1;
+  __device__ __forceinline__ GradConv(const f32x16& p) : p0(p) {}
+  template <int C, int PI>
+  __device__ __forceinline__ void chunk() {
+    constexpr int mt = PI >> 2, p = PI & 3;
+    constexpr uint32_t bit0 = 1u << (8 * (S & 3) + p), bit1 = 1u << (8 * (S & 3) + p + 4);     // elements 2p, 2p+1
+    if constexpr (C == 0) {
+      const float r0 = mt == 0 ? p0[8 * (S & 1) + 2 * p] : v1[2 * p];
+      const float r1 = mt == 0 ? p0[8 * (S & 1) + 2 * p + 1] : v1[2 * p + 1];
+      x0 = fmaf(mt == 0 ? gw0 : gw1, wv[2 * p], r0);
+      x1 = fmaf(mt == 0 ? gw0 : gw1, wv[2 * p + 1], r1);
+    } else if constexpr (C == 1) {
+      const uint32_t w = mt == 0 ? w0 : w1;
+      x0 = (w & bit0) ? x0 : 0.f;
+      x1 = (w & bit1) ? x1 : 0.f;
+    } else if constexpr (C == 2) {
+      hi[mt][p] = pack2<false>(x0, x1);
+    } else if constexpr (C == 3) {
+      float ha, hb;
+      unpack2<false>(hi[mt][p], ha, hb);
+      x0 -= ha; x1 -= hb;
+    } else {
+      lo[mt][p] = pack2<false>(x0, x1);
+    }
+  }
+  __device__ __forceinline__ KOps result() const {
+    KOps o;
+    o.h0 = make_uint4(hi[0][0], hi[0][1], hi[0][2], hi[0][3]); o.l0 = make_uint4(lo[0][0], lo[0][1], lo[0][2], lo[0][3]);
+    o.h1 = make_uint4(hi[1][0], hi[1][1], hi[1][2], hi[1][3]); o.l1 = make_uint4(lo[1][0], lo[1][1], lo[1][2], lo[1][3]);
+    return o;
+  }
+};
 
 template <int PREC>
 __global__ void __launch_bounds__(256, 1)
@@ -859,16 +916,33 @@ nerfmlp_dgrad_kernel(const char* __restrict__ packed_bwd, const float* __restric
       uint4 ma, mb;
       mask_at(8, ma, mb);
       KOps cur = grad_ops(0, true, ma, mb, nullptr);
-#pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        dy_store(DY_L9 + s, cur);
-        SLAB_PREFETCH(true);
-        KOps nxt = cur;
-        if (s + 1 < 8) nxt = grad_ops(s + 1, true, ma, mb, nullptr);
-        if (s == 0) kstep_mfma<PREC, 8, 0, true>(acc0, acc1, cur, smem + buf * SLAB, lane, nowork);
-        else kstep_mfma<PREC, 8, 0, false>(acc0, acc1, cur, smem + buf * SLAB, lane, nowork);
-        SLAB_DONE();
-        cur = nxt;
+#define RNERF_DG_KSTEP(S, NSTEPS, SLOT0, PREFETCH_STMT)                                                                       \
+      {                                                                                                                         \
+        dy_store((SLOT0) + S, cur);                                                                                             \
+        PREFETCH_STMT;                                                                                                          \
+        if constexpr (S + 1 < NSTEPS) {                                                                                         \
+          GradConv<PREC, S + 1> cv(prev0[(S + 1) >> 1]);                                                                        \
+          {                                                                                                                     \
+            const float4 u0 = st1[(((S + 1) >> 1) * 4 + 2 * ((S + 1) & 1)) * 64], u1 = st1[(((S + 1) >> 1) * 4 + 2 * ((S + 1) & 1) + 1) * 64]; \
+            cv.v1[0] = u0.x; cv.v1[1] = u0.y; cv.v1[2] = u0.z; cv.v1[3] = u0.w; cv.v1[4] = u1.x; cv.v1[5] = u1.y; cv.v1[6] = u1.z; cv.v1[7] = u1.w; \
+          }                                                                                                                     \
+          _Pragma("unroll") for (int j = 0; j < 8; ++j) cv.wv[j] = wadd ? wadd[16 * (S + 1) + 8 * (j >> 2) + 4 * h + (j & 3)] : 0.f; \
+          cv.gw0 = g[0].w; cv.gw1 = g[1].w;                                                                                     \
+          cv.w0 = ((S + 1) >> 2) == 0 ? ma.x : (((S + 1) >> 2) == 1 ? ma.y : (((S + 1) >> 2) == 2 ? ma.z : ma.w));             \
+          cv.w1 = ((S + 1) >> 2) == 0 ? mb.x : (((S + 1) >> 2) == 1 ? mb.y : (((S + 1) >> 2) == 2 ? mb.z : mb.w));             \
+          kstep_mfma<PREC, 8, 0, S == 0, GradConv<PREC, S + 1>, false, NoDma, DGRAD_PASSES>(acc0, acc1, cur, smem + buf * SLAB, lane, cv); \
+          cur = cv.result();                                                                                                    \
+        } else {                                                                                                                \
+          kstep_mfma<PREC, 8, 0, false, NoWork, false, NoDma, DGRAD_PASSES>(acc0, acc1, cur, smem + buf * SLAB, lane, nowork);  \
+        }                                                                                                                       \
+        SLAB_DONE();                                                                                                            \
+      }
+      {
+        const float* __restrict__ wadd = nullptr;
+        RNERF_DG_KSTEP(0, 8, DY_L9, SLAB_PREFETCH(true)) RNERF_DG_KSTEP(1, 8, DY_L9, SLAB_PREFETCH(true))
+        RNERF_DG_KSTEP(2, 8, DY_L9, SLAB_PREFETCH(true)) RNERF_DG_KSTEP(3, 8, DY_L9, SLAB_PREFETCH(true))
+        RNERF_DG_KSTEP(4, 8, DY_L9, SLAB_PREFETCH(true)) RNERF_DG_KSTEP(5, 8, DY_L9, SLAB_PREFETCH(true))
+        RNERF_DG_KSTEP(6, 8, DY_L9, SLAB_PREFETCH(true)) RNERF_DG_KSTEP(7, 8, DY_L9, SLAB_PREFETCH(true))
       }
       layer_end();
     }
@@ -879,23 +953,22 @@ nerfmlp_dgrad_kernel(const char* __restrict__ packed_bwd, const float* __restric
     for (int l = 8; l >= 1; --l) {
       const bool use_mask = l != 8;
       const float* __restrict__ wadd = (l == 7) ? fwd_aux + AUX_WSIG : nullptr;
-      const uint4 ma = nma, mb = nmb;            // set l = the ReLU mask of the input of layer l+1
+      uint4 ma = nma, mb = nmb;                  // set l = the ReLU mask of the input of layer l+1
+      if (!use_mask) { ma = make_uint4(~0u, ~0u, ~0u, ~0u); mb = ma; }
       mask_at(l - 1, nma, nmb);
-      KOps cur = grad_ops(0, use_mask, ma, mb, wadd);
-#pragma unroll
-      for (int s = 0; s < 16; ++s) {
-        dy_store(16 * l + s, cur);
-        const bool last_of_tile = (l == 1 && s == 15);
-        if (last_of_tile) { if (has_next_tile) off = 0; SLAB_PREFETCH(has_next_tile); } else SLAB_PREFETCH(true);
-        KOps nxt = cur;
-        if (s + 1 < 16) nxt = grad_ops(s + 1, use_mask, ma, mb, wadd);
-        if (s == 0) kstep_mfma<PREC, 8, 0, true>(acc0, acc1, cur, smem + buf * SLAB, lane, nowork);
-        else kstep_mfma<PREC, 8, 0, false>(acc0, acc1, cur, smem + buf * SLAB, lane, nowork);
-        SLAB_DONE();
-        cur = nxt;
-      }
+      KOps cur = grad_ops(0, true, ma, mb, wadd);
+      const int slot0 = 16 * l;
+#define RNERF_DG_PF(S) do { if ((S) == 15 && l == 1) { if (has_next_tile) off = 0; SLAB_PREFETCH(has_next_tile); } else SLAB_PREFETCH(true); } while (0)
+      RNERF_DG_KSTEP(0, 16, slot0, RNERF_DG_PF(0)) RNERF_DG_KSTEP(1, 16, slot0, RNERF_DG_PF(1)) RNERF_DG_KSTEP(2, 16, slot0, RNERF_DG_PF(2))
+      RNERF_DG_KSTEP(3, 16, slot0, RNERF_DG_PF(3)) RNERF_DG_KSTEP(4, 16, slot0, RNERF_DG_PF(4)) RNERF_DG_KSTEP(5, 16, slot0, RNERF_DG_PF(5))
+      RNERF_DG_KSTEP(6, 16, slot0, RNERF_DG_PF(6)) RNERF_DG_KSTEP(7, 16, slot0, RNERF_DG_PF(7)) RNERF_DG_KSTEP(8, 16, slot0, RNERF_DG_PF(8))
+      RNERF_DG_KSTEP(9, 16, slot0, RNERF_DG_PF(9)) RNERF_DG_KSTEP(10, 16, slot0, RNERF_DG_PF(10)) RNERF_DG_KSTEP(11, 16, slot0, RNERF_DG_PF(11))
+      RNERF_DG_KSTEP(12, 16, slot0, RNERF_DG_PF(12)) RNERF_DG_KSTEP(13, 16, slot0, RNERF_DG_PF(13)) RNERF_DG_KSTEP(14, 16, slot0, RNERF_DG_PF(14))
+      RNERF_DG_KSTEP(15, 16, slot0, RNERF_DG_PF(15))
+#undef RNERF_DG_PF
       layer_end();
     }
+#undef RNERF_DG_KSTEP
 
     // ---- dY_0 = dX_1 * 1[X_1 > 0]: only recorded (layer 0's inputs are constants)
 #pragma unroll

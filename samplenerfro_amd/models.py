@@ -206,7 +206,8 @@ class NerfModel:
             self._side = torch.cuda.Stream(device=self.device)
             lib = _lib.load()
             cus = lib.rnerf_device_cus()
-            _lib.check(lib.rnerf_set_mlp_workgroup_limit(max(cus - int(reserve_cus), 1)), "rnerf_set_mlp_workgroup_limit")
+            if reserve_cus > 0:
+                _lib.check(lib.rnerf_set_mlp_workgroup_limit(max(cus - int(reserve_cus), 1)), "rnerf_set_mlp_workgroup_limit")
         cur = torch.cuda.current_stream()
         if sync_inputs:
             self._side.wait_stream(cur)

@@ -1,7 +1,7 @@
 """Host-side mirror of the reference's training step (train.py:58-183) for the radiance stages.
 
     state = TrainState.create(model, variables, flags)
-    state, stats, rng = train_step(model, rng, state, batch, flags)
+    state, stats, rng = train_step(model, rng, state, batch)          # same call as train.py:58
 
 `jax.value_and_grad(loss_fn)` is replaced by explicit backward kernels in librnerf.so, in reverse order of the forward:
 
@@ -41,11 +41,13 @@ class TrainState:
     optimiser step is visible to the kernels without copies (the MFMA operand streams are re-packed lazily, keyed on the
     buffer version)."""
 
-    def __init__(self, step, theta, mu, nu, variables, segments, lr_fn):
+    def __init__(self, step, theta, mu, nu, variables, segments, lr_fn, flags=None):
         self.step, self.theta, self.mu, self.nu = step, theta, mu, nu
+        self.flags = flags
         self.variables, self.segments, self.lr_fn = variables, segments, lr_fn
         self.grads = torch.zeros(theta.numel() + _N_STATS, dtype=torch.float32, device=theta.device)   # + the stats vector
         self.frozen_sq: Optional[torch.Tensor] = None
+        self.next_path = None          # PathHandle of the next step's rays when train_step was given next_rays
 
     @classmethod
     def create(cls, model: NerfModel, variables: Dict[str, Any], flags) -> "TrainState":
@@ -62,7 +64,7 @@ class TrainState:
         new_vars = make_variables(flat)
         lr_fn = lambda count: learning_rate_decay(count, flags.lr_init, flags.lr_final, flags.max_steps, flags.lr_delay_steps,
                                                   flags.lr_delay_mult)
-        return cls(0, theta, torch.zeros_like(theta), torch.zeros_like(theta), new_vars, segments, lr_fn)
+        return cls(0, theta, torch.zeros_like(theta), torch.zeros_like(theta), new_vars, segments, lr_fn, flags)
 
     def grad_view(self, name: str) -> torch.Tensor:
         lo, hi = self.segments[name]
@@ -114,12 +116,15 @@ def env_smooth_loss_and_grad(rgb_env: torch.Tensor, scale: float):
     return loss, g
 
 
-def train_step(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], flags, *, jitter=None, u_fine=None,
-               taps: Optional[dict] = None, path=None):
+def train_step(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], flags=None, *, jitter=None, u_fine=None,
+               taps: Optional[dict] = None, path=None, next_rays: Optional[Rays] = None):
     """One optimisation step (train.py:58-183).  batch: {"rays": Rays of [B,3], "pixels": [B,>=3], "annealed_alpha": float,
     "env_rays": Rays with viewdirs [ps,ps,3] (when bg_smooth_weight > 0)}.  path: an optional NerfModel.prefetch_path handle for
-    these rays (the march carries no gradient and does not read the trained parameters, so it may overlap the previous step).  Returns (state, stats, rng); the Stats fields are
+    these rays (the march carries no gradient and does not read the trained parameters, so it may overlap the previous step);
+    next_rays: the rays of the NEXT step — their march is issued on the model's side stream right after this step's forward, so
+    that it runs beside the backward kernels; the handle is left in state.next_path.  Returns (state, stats, rng); the Stats fields are
     0-dim device tensors (no host synchronisation inside the step)."""
+    flags = state.flags if flags is None else flags           # the reference reads the global FLAGS (train.py:52)
     if not (flags.stage.startswith("radiance")):
         raise NotImplementedError("train_step: only the radiance stages are built (SURVEY.md §8f)")
     if flags.beta_weight > 0 or flags.sparsity_weight > 0:
@@ -134,6 +139,7 @@ def train_step(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], 
     ctx: Dict[str, Any] = {}
     ret, _loss_sp = model.apply(variables, key_0, key_1, rays, flags.randomized, annealed, jitter=jitter, u_fine=u_fine, ctx=ctx, path=path)
     B = ctx["B"]
+    next_path = model.prefetch_path(next_rays, sync_inputs=True, reserve_cus=0) if next_rays is not None else None
     rgb_f, _, _, trans_f, tb_f = ret[-1]
     rgb_c = ret[0][0] if len(ret) > 1 else None
     sums = ops.loss_reduce(rgb_c, rgb_f, trans_f, tb_f, pixels)
@@ -205,4 +211,5 @@ def train_step(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], 
     stats = Stats(loss=st[0], psnr=k * torch.log(st[0]), loss_c=st[1], psnr_c=(k * torch.log(st[1]) if rgb_c is not None else 0.0),
                   weight_l2=st[4], loss_sp=0.0, loss_nrm=0.0, annealing_rate=annealed, coarse_alpha_target=0.0, fine_alpha_target=0.0,
                   loss_bg=flags.bg_weight * st[2], loss_bg_c=0.0, loss_bg_smooth=st[3])
+    state.next_path = next_path
     return state, stats, rng

@@ -126,7 +126,7 @@ def test_training_reduces_the_loss():
     rng = np.array([3, 4], np.uint32)
     losses = []
     for _ in range(40):
-        state, stats, rng = train_step(model, rng, state, batch, flags)
+        state, stats, rng = train_step(model, rng, state, batch)          # the reference's call signature (train.py:58)
         losses.append(float(stats.loss))
     assert losses[-1] < 0.6 * losses[0], losses[::8]
 
