@@ -139,15 +139,16 @@ def main():
     ap.add_argument("--precision", default="f16x3")
     ap.add_argument("--rays", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-pipeline", dest="pipeline", action="store_false", help="march and MLP of a step strictly in sequence")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="issue the march of step k+1 on a side stream beside step k (default: every step runs its stages in sequence)")
     ap.add_argument("--frame", action="store_true", help="also time one 800x800 full-frame render (ms/frame, BASELINE metric 2)")
     ap.add_argument("--reserve-cus", type=int, default=32, help="CUs kept free of MLP workgroups for the overlapped march")
-    ap.add_argument("--cpu-rays", type=int, default=None, help="rays in the CPU baseline sample (default 2048 forward / 512 train)")
+    ap.add_argument("--cpu-rays", type=int, default=None, help="rays in the CPU baseline sample (default 8192 forward / 1536 train)")
     ap.add_argument("--mode", choices=["train", "forward"], default="train",
                     help="train: the whole optimisation step (BASELINE metric 'rays/sec (train step)'); forward: the render pass only")
     args = ap.parse_args()
     if args.cpu_rays is None:
-        args.cpu_rays = 2048 if args.mode == "forward" else 512
+        args.cpu_rays = 8192 if args.mode == "forward" else 1536
 
     import torch
     import torch.distributed as dist
@@ -254,16 +255,67 @@ def main():
     march_bytes = B * (N * 128 + 24)
     march_achieved = march_bytes / (march_ms * 1e-3)
 
+    # ---- training kernels, each alone with HIP events on the launch stream
+    train_kernels = []
+    if train:
+        lib = _lib.load()
+        rows = S * B
+        pbwd = ops.nerfmlp_pack_bwd(variables["flat"]["coarse_mlp"])
+        raw_t, save_t = ops.nerfmlp_forward_train(packed, model.precision, path_pd, path_dr, jit, S, B)
+        d_raw = torch.randn((S, B, 4), device=device) * 1e-3
+        dy_t = torch.empty(lib.rnerf_nerfmlp_dy_bytes(rows), dtype=torch.uint8, device=device)
+        ws_t = torch.empty(lib.rnerf_nerfmlp_wgrad_workspace_bytes(), dtype=torch.uint8, device=device)
+        g_t = torch.empty(_lib.NERFMLP_PARAMS, device=device)
+
+        def timed(fn):
+            fn(); torch.cuda.synchronize()
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+            e[0].record()
+            for i in range(reps):
+                fn(); e[i + 1].record()
+            torch.cuda.synchronize()
+            return float(np.mean([e[i].elapsed_time(e[i + 1]) for i in range(reps)]))
+
+        jp = jit.data_ptr()
+        t_f = timed(lambda: lib.rnerf_nerfmlp_forward_train(packed.data_ptr(), model.precision, path_pd.data_ptr(), path_dr.data_ptr(), jp, S, B,
+                                                            raw_t.data_ptr(), save_t.data_ptr(), _lib.current_stream()))
+        t_d = timed(lambda: ops.nerfmlp_backward(pbwd, packed, model.precision, save_t, d_raw, rows, dy=dy_t, stages="d"))
+        t_w = timed(lambda: ops.nerfmlp_backward(pbwd, packed, model.precision, save_t, d_raw, rows, grads=g_t, workspace=ws_t, dy=dy_t, stages="w"))
+        R_pad = (rows + 255) // 256 * 256
+        wgrad_bytes = (8 * 32 + 2 * 20 + 17 + 24 + 10 + 9) * R_pad * 32        # sum over the 14 jobs of (X slots + dY slots) x R x 32 B
+        for name, ms, flop, bound, byt in (("nerfmlp_fwd_kernel<train>", t_f, MLP_FLOP_PER_ROW * rows, "mfma", None),
+                                           ("nerfmlp_dgrad_kernel", t_d, 2 * 557696 * rows, "mfma", None),
+                                           ("nerfmlp_wgrad_kernel", t_w, MLP_FLOP_PER_ROW * rows, "hbm", wgrad_bytes)):
+            if bound == "mfma":
+                train_kernels.append({"kernel": name, "bound": "mfma", "achieved": flop / (ms * 1e-3) / 1e12, "peak": PEAK_MFMA_16BIT / 1e12,
+                                      "unit": "TFLOP/s", "frac": flop / (ms * 1e-3) / PEAK_MFMA_16BIT, "avg_launch_ms": ms,
+                                      "algorithmic_flop_per_launch": flop})
+            else:
+                train_kernels.append({"kernel": name, "bound": "hbm", "achieved": byt / (ms * 1e-3) / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
+                                      "frac": byt / (ms * 1e-3) / PEAK_HBM, "avg_launch_ms": ms, "algorithmic_bytes_per_launch": byt,
+                                      "algorithmic_flop_per_launch": flop})
+        del raw_t, save_t, dy_t, ws_t
+
     # HBM bytes per launch from the committed rocprofv3 --pmc passes of this very command (profiles/);
     # PMC counters cannot be collected from inside the process, so `traffic` is null when no matching profile exists.
     traffic = {}
     try:
         if args.workload == "ship_straight" and fine == 0 and B == 4096:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01", "b_pmc_hbm_traffic.json")))["counters"]
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01", "c_pmc_%s.json" % args.mode)))["counters"]
             for k, v in pm.items():
-                traffic[k.split("::")[-1].split("<")[0]] = 1024.0 * (v["FETCH_SIZE"]["mean"] + v["WRITE_SIZE"]["mean"])
+                # KiB -> bytes; wide (16 B/lane) streaming reads are reported at half their size on gfx950 (MI355X_MICROARCH.md, HBM):
+                # doubled for the MLP kernels (weight DMA / saved-operand streams); the march's 4-byte gathers stay as reported
+                ff = 2.0 if "nerfmlp" in k else 1.0
+                name = k.split("::")[-1]
+                traffic[name] = 1024.0 * (ff * v["FETCH_SIZE"]["mean"] + v["WRITE_SIZE"]["mean"])
     except Exception:
         traffic = {}
+
+    def traffic_of(prefix):
+        for k, v in traffic.items():
+            if k.startswith(prefix):
+                return v
+        return None
     frame = None
     if args.frame:
         # ms/frame @ 800x800 (BASELINE.json metric 2): pinhole rays of the example camera looking at the volume, rendered in
@@ -301,13 +353,20 @@ def main():
                        "pipeline": ("none" if not args.pipeline else ("march(k+1) on a side stream beside backward(k)" if train
                                                                           else "march(k+1) on a side stream overlaps MLP(k)"))},
             "roofline": {"kernel": "nerfmlp_fwd_kernel", "bound": "mfma", "achieved": mlp_achieved / 1e12, "peak": PEAK_MFMA_16BIT / 1e12,
-                         "unit": "TFLOP/s", "frac": mlp_achieved / PEAK_MFMA_16BIT, "traffic": traffic.get("nerfmlp_fwd_kernel"),
+                         "unit": "TFLOP/s", "frac": mlp_achieved / PEAK_MFMA_16BIT, "traffic": traffic_of("nerfmlp_fwd_kernel<1, 0, false>"),
                          "avg_launch_ms": mlp_ms, "algorithmic_flop_per_launch": mlp_flops,
                          "mfma_issue_frac": (3 if "x3" in args.precision else 1) * mlp_achieved / PEAK_MFMA_16BIT},
             "roofline_march": {"kernel": "march_kernel", "bound": "hbm", "achieved": march_achieved / 1e9, "peak": PEAK_HBM / 1e9,
-                               "unit": "GB/s", "frac": march_achieved / PEAK_HBM, "traffic": traffic.get("march_kernel"), "avg_launch_ms": march_ms,
+                               "unit": "GB/s", "frac": march_achieved / PEAK_HBM, "traffic": traffic_of("march_kernel"), "avg_launch_ms": march_ms,
                                "algorithmic_bytes_per_launch": march_bytes},
         }
+        if train:
+            # the dominant kernel of a train step is the training forward (the forward + the operand/mask stores for the backward)
+            for tk, pref in zip(train_kernels, ("nerfmlp_fwd_kernel<1, 0, true>", "nerfmlp_dgrad_kernel", "nerfmlp_wgrad_kernel")):
+                tk["traffic"] = traffic_of(pref)
+            line["roofline_forward_kernel"] = line["roofline"]
+            line["roofline"] = max(train_kernels, key=lambda t: t["avg_launch_ms"])
+            line["roofline_train_kernels"] = train_kernels
         if frame is not None:
             line["frame"] = frame
         if not args.no_cpu_baseline:

@@ -387,8 +387,8 @@ __device__ __forceinline__ void kstep_mfma(f32x16 (&acc0)[8], f32x16 (&acc1)[8],
 // exactly the B operands of the forward MFMAs.  slot 0..3: position encoding; 4 + 16*(l-1) + s: input k-step s of MFMA layer
 // l = 1..9; 148..149: view encoding; 150..157: ReLU'd output of the view layer (= rgb head input).
 // slots 158..166: ReLU bit masks for the dgrad chain, one uint4 per (row, half) per mask set (set l-1 = the input of MFMA layer
-// l = 1..8, set 8 = the rgb-head input): byte s (written as soon as k-step s is converted: no register lives across the layer),
-// bit (j>>1) + 4*(j&1) of it <=> element j of k-step s is non-zero.
+// l = 1..8, set 8 = the rgb-head input), stored word-major uint32[9][4][R][2]: word w holds k-steps 4w..4w+3 (written as soon as
+// they are converted: no register lives across the layer), byte s&3, bit (j>>1) + 4*(j&1) <=> element j of k-step s is non-zero.
 constexpr int SAVE_PE = 0, SAVE_L1 = 4, SAVE_VIEW = 148, SAVE_RGBIN = 150, SAVE_SLOTS = 158, SAVE_MASK = 158, SAVE_TOTAL = 167;
 
 // non-zero flags of the 8 post-ReLU (non-negative) 16-bit values of one operand: bits 0..3 = even elements, 16..19 = odd elements
@@ -460,10 +460,10 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
       if constexpr (TRAIN) {
         if ((s & 3) == 0) { mw0 = nz_byte(nib0); mw1 = nz_byte(nib1); }
         else { mw0 |= nz_byte(nib0) << (8 * (s & 3)); mw1 |= nz_byte(nib1) << (8 * (s & 3)); }
-        if ((s & 3) == 3) {
-          uint32_t* dst = (uint32_t*)(save + ((size_t)(SAVE_MASK + set) * save_rows + srow0) * 2 + h) + (s >> 2);
+        if ((s & 3) == 3) {      // word-major: a wave's 64 dwords are contiguous (full-line writes)
+          uint32_t* dst = (uint32_t*)(save + (size_t)SAVE_MASK * save_rows * 2) + ((size_t)(set * 4 + (s >> 2)) * save_rows + srow0) * 2 + h;
           dst[0] = mw0;
-          dst[64 * 4] = mw1;
+          dst[64] = mw1;
         }
       }
     };
@@ -848,8 +848,10 @@ nerfmlp_dgrad_kernel(const char* __restrict__ packed_bwd, const float* __restric
     };
     // ReLU masks: one uint4 of non-zero flags per (row, half) per layer (SAVE_MASK), fetched one layer ahead
     auto mask_at = [&](int set, uint4& a, uint4& b) {
-      const uint4* src = saved + ((size_t)(SAVE_MASK + set) * save_rows + srow0) * 2 + h;
-      a = src[0]; b = src[64];
+      const uint32_t* src = (const uint32_t*)(saved + (size_t)SAVE_MASK * save_rows * 2) + ((size_t)(set * 4) * save_rows + srow0) * 2 + h;
+      const size_t ws = (size_t)save_rows * 2;
+      a = make_uint4(src[0], src[ws], src[2 * ws], src[3 * ws]);
+      b = make_uint4(src[64], src[ws + 64], src[2 * ws + 64], src[3 * ws + 64]);
     };
     // operands of k-step s from the state (prev0 / st1): x = (state + dsig * wadd) * 1[mask != 0]
     auto grad_ops = [&](int s, bool use_mask, const uint4 mk0, const uint4 mk1, const float* __restrict__ wadd) -> KOps {
