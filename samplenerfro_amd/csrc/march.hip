@@ -115,8 +115,13 @@ __global__ void __launch_bounds__(64) march_kernel(const float* __restrict__ tab
     // ---- node record while the gathers are in flight: node k = state before step k (eikonal_utils.py:112-114),
     //      direction safe-normalised (math_utils.py:6-12)
     const float nrm = fsqrt(fmaxf(quad_sumsq3(d), 1e-6f));
+#ifdef RNERF_MARCH_NT
+    __builtin_nontemporal_store(q < 3 ? p : rt, out_pd);
+    __builtin_nontemporal_store(q < 3 ? fdiv(d, nrm) : 0.f, out_dr);
+#else
     *out_pd = q < 3 ? p : rt;
     *out_dr = q < 3 ? fdiv(d, nrm) : 0.f;
+#endif
     out_pd += node_stride; out_dr += node_stride;
     if (WANT_VOX && q < 3) { const size_t o = (size_t)k * B + r; vox[6 * o + 2 * q] = i0; vox[6 * o + 2 * q + 1] = i1; }
     // ---- 7 lerps a*(1-t) + b*t (ior_utils.py:214-222)

@@ -219,6 +219,22 @@ __device__ __forceinline__ void issue_slab(const char* __restrict__ gsrc, unsign
 // B operands of one k-step for the wave's two 32-row m-tiles
 struct KOps { uint4 h0, l0, h1, l1; };
 
+// streaming accesses of the training tensors (written once, read once by a later kernel): keep them out of the L2 working set
+#ifdef RNERF_NO_NT
+__device__ __forceinline__ void stream_store(uint4* p, const uint4 v) { *p = v; }
+__device__ __forceinline__ uint4 stream_load(const uint4* p) { return *p; }
+#else
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void stream_store(uint4* p, const uint4 v) {
+  u32x4_t t = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(t, (u32x4_t*)p);
+}
+__device__ __forceinline__ uint4 stream_load(const uint4* p) {
+  const u32x4_t t = __builtin_nontemporal_load((const u32x4_t*)p);
+  return make_uint4(t.x, t.y, t.z, t.w);
+}
+#endif
+
 template <int PREC>
 __device__ __forceinline__ void split8(const float (&x)[8], uint4& hi, uint4& lo) {
   using PP = Prec<PREC>;
@@ -450,8 +466,8 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
     auto save_ops = [&](int q, const KOps& o) {
       if constexpr (TRAIN) {
         uint4* dst = save + ((size_t)q * save_rows + srow0) * 2 + h;
-        dst[0] = o.h0;
-        dst[64] = o.h1;          // m-tile 1 = rows + 32
+        stream_store(dst, o.h0);
+        stream_store(dst + 64, o.h1);          // m-tile 1 = rows + 32
       }
     };
 
@@ -462,8 +478,8 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
         else { mw0 |= nz_byte(nib0) << (8 * (s & 3)); mw1 |= nz_byte(nib1) << (8 * (s & 3)); }
         if ((s & 3) == 3) {      // word-major: a wave's 64 dwords are contiguous (full-line writes)
           uint32_t* dst = (uint32_t*)(save + (size_t)SAVE_MASK * save_rows * 2) + ((size_t)(set * 4 + (s >> 2)) * save_rows + srow0) * 2 + h;
-          dst[0] = mw0;
-          dst[64] = mw1;
+          __builtin_nontemporal_store(mw0, dst);
+          __builtin_nontemporal_store(mw1, dst + 64);
         }
       }
     };
@@ -843,15 +859,17 @@ nerfmlp_dgrad_kernel(const char* __restrict__ packed_bwd, const float* __restric
       if (g[0].x != 12345.f) return;
 #endif
       uint4* dst = dy + ((size_t)q * save_rows + srow0) * 2 + h;
-      dst[0] = o.h0;
-      dst[64] = o.h1;
+      stream_store(dst, o.h0);
+      stream_store(dst + 64, o.h1);
     };
     // ReLU masks: one uint4 of non-zero flags per (row, half) per layer (SAVE_MASK), fetched one layer ahead
     auto mask_at = [&](int set, uint4& a, uint4& b) {
       const uint32_t* src = (const uint32_t*)(saved + (size_t)SAVE_MASK * save_rows * 2) + ((size_t)(set * 4) * save_rows + srow0) * 2 + h;
       const size_t ws = (size_t)save_rows * 2;
-      a = make_uint4(src[0], src[ws], src[2 * ws], src[3 * ws]);
-      b = make_uint4(src[64], src[ws + 64], src[2 * ws + 64], src[3 * ws + 64]);
+#define RNERF_NTL(P) __builtin_nontemporal_load(P)
+      a = make_uint4(RNERF_NTL(src), RNERF_NTL(src + ws), RNERF_NTL(src + 2 * ws), RNERF_NTL(src + 3 * ws));
+      b = make_uint4(RNERF_NTL(src + 64), RNERF_NTL(src + ws + 64), RNERF_NTL(src + 2 * ws + 64), RNERF_NTL(src + 3 * ws + 64));
+#undef RNERF_NTL
     };
     // operands of k-step s from the state (prev0 / st1): x = (state + dsig * wadd) * 1[mask != 0]
     auto grad_ops = [&](int s, bool use_mask, const uint4 mk0, const uint4 mk1, const float* __restrict__ wadd) -> KOps {
@@ -1052,9 +1070,9 @@ __device__ __forceinline__ void wgrad_body(const uint4* __restrict__ saved, cons
   auto load_chunk = [&](int chunk) {
     const size_t row2 = ((size_t)chunk * 128 + wave * 32 + m) * 2 + h;
 #pragma unroll
-    for (int t = 0; t < 2 * KT; ++t) xr[t] = saved[(size_t)(qx + t) * R * 2 + row2];
+    for (int t = 0; t < 2 * KT; ++t) xr[t] = stream_load(saved + (size_t)(qx + t) * R * 2 + row2);
 #pragma unroll
-    for (int t = 0; t < 2 * NT; ++t) dr[t] = t < KSd ? dy[(size_t)(qd + t) * R * 2 + row2] : z4;
+    for (int t = 0; t < 2 * NT; ++t) dr[t] = t < KSd ? stream_load(dy + (size_t)(qd + t) * R * 2 + row2) : z4;
   };
   if (g < n_chunks) load_chunk(g);
   for (int chunk = g; chunk < n_chunks; chunk += G) {
