@@ -158,8 +158,15 @@ class NerfModel:
         if t is None:
             if len(self._jit_cache) > 64:
                 self._jit_cache.clear()
-            t = torch.from_numpy(j).to(self.device)
+            # pinned staging + asynchronous copy: a pageable H2D copy would block the host until the stream drains, i.e. once
+            # per training step (the jitter is redrawn every step); the cache keeps the pinned buffer alive until it is evicted
+            pin = torch.from_numpy(j).pin_memory()
+            t = pin.to(self.device, non_blocking=True)
             self._jit_cache[k] = t
+            self._jit_pins = getattr(self, "_jit_pins", {})
+            if len(self._jit_pins) > 64:
+                self._jit_pins.clear()
+            self._jit_pins[k] = pin
         return t
 
     def make_u(self, key, batch: int, randomized: bool):

@@ -190,9 +190,11 @@ def train_step(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], 
     if flags.weight_decay_mult > 0:
         G[:n_theta].add_(state.theta, alpha=2.0 * flags.weight_decay_mult / n_all)
     # ---- stats ride in the tail of the gradient buffer: one all-reduce for both (train.py:166-167) ---------------------------
+    # (only device tensors are assigned: `st[i] = python_float` is a synchronising host-to-device copy; G.zero_() cleared the rest)
     st = G[n_theta:]
     st[0] = sums[0] / (3.0 * B)
-    st[1] = sums[1] / (3.0 * B) if rgb_c is not None else 0.0
+    if rgb_c is not None:
+        st[1] = sums[1] / (3.0 * B)
     st[2] = bg_on * sums[2] / (sums[3] + 1.0)
     if loss_bg_smooth is not None:
         st[3] = loss_bg_smooth
