@@ -15,16 +15,29 @@ def activations(raw, rgb_padding=0.001, sigma_bias=-1.0):
     return rgb, sigma
 
 
-def volumetric_rendering(rgb, sigma, t_vals, dirs, bkgd):
-    """rgb [B,S,3], sigma [B,S], t_vals [B,S], dirs [B,S,3], bkgd [B,3] -> comp_rgb, acc, weights, trans [B,1], trans*sg(bkgd)."""
+def volumetric_rendering(rgb, sigma, t_vals, dirs, bkgd, mask=None):
+    """rgb [B,S,3], sigma [B,S], t_vals [B,S], dirs [B,S,3], bkgd [B,3] -> comp_rgb, acc, weights, trans [B,1], trans*sg(bkgd).
+    mask [B,S]: density_delta *= mask_bbox (rnerf/model_utils.py:275-276)."""
     t_dists = torch.cat([t_vals[..., 1:] - t_vals[..., :-1], torch.full_like(t_vals[..., :1], 1e-3)], -1)
     delta = t_dists * torch.linalg.norm(dirs, dim=-1)
     dd = sigma * delta
+    if mask is not None:
+        dd = dd * mask
     alpha = 1 - torch.exp(-dd)
     trans = torch.exp(-torch.cat([torch.zeros_like(dd[..., :1]), torch.cumsum(dd, -1)], -1))
     weights = alpha * trans[..., :-1]
     comp = (weights[..., None] * rgb).sum(-2) + trans[..., -1:] * bkgd
     return comp, weights.sum(-1), weights, trans[..., -1:], trans[..., -1:] * bkgd.detach()
+
+
+def bd_cut_pair(rgb, sigma, t_vals, dirs, bkgd, pos, bbox):
+    """rnerf/models.py:498-524: (trans, trans_rgb_bkgd) of the last level when bd_cut_dist is set.  pos [B,S,3], bbox = min xyz + max xyz."""
+    lo = torch.tensor(bbox[:3], dtype=pos.dtype); hi = torch.tensor(bbox[3:], dtype=pos.dtype)
+    inside = ((pos >= lo) & (pos <= hi)).all(-1).to(rgb.dtype)
+    m = (torch.flip(torch.cumsum(torch.flip(inside, [-1]), -1), [-1]) > 0).to(rgb.dtype)
+    _, _, _, trans, _ = volumetric_rendering(rgb, sigma, t_vals, dirs, torch.ones_like(bkgd), mask=m)
+    behind, _, _, _, _ = volumetric_rendering(rgb, sigma, t_vals, dirs, bkgd, mask=1.0 - m)
+    return trans, trans * behind
 
 
 def radiance_loss(levels, pixels, bg_weight=0.0, annealed_alpha=1.0):

@@ -120,23 +120,40 @@ __global__ void __launch_bounds__(64) composite_bwd_kernel(const float4* __restr
                                                            float sigma_bias, const float* __restrict__ rgb, const float* __restrict__ pix,
                                                            const float* __restrict__ trans, const float* __restrict__ tb,
                                                            const float* __restrict__ sums, float mse_scale, float bg_scale,
-                                                           float4* __restrict__ d_raw, float* __restrict__ d_bkgd, int accumulate_bkgd) {
+                                                           float4* __restrict__ d_raw, float* __restrict__ d_bkgd, int accumulate_bkgd,
+                                                           int bd_cut, float bx0, float by0, float bz0, float bx1, float by1, float bz1) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= B) return;
   auto rec = [&](int s) -> size_t { return (size_t)(node_of_sample ? node_of_sample[s] : s) * B + r; };
   float gC[3], bk[3], gTB[3] = {0.f, 0.f, 0.f};
   float GT = 0.f;
+  // bd_cut (rnerf/models.py:479-524): the loss_bg pair is trans_A = exp(-sum_{s <= L} dd_s) (L = last sample inside the box) and
+  // trans_A * C_B with C_B = composite of the samples s > L over bkgd (NOT stop-gradient there: rgb_bkgd=bkgd, :514-523).
+  int last_in = -1;
+  float gA = 0.f, gCB[3] = {0.f, 0.f, 0.f}, GTB = 0.f;
   for (int c = 0; c < 3; ++c) {
     bk[c] = bkgd[3 * r + c];
     gC[c] = mse_scale * (rgb[3 * r + c] - pix[3 * r + c]);
     GT += gC[c] * bk[c];
   }
+  if (bd_cut)
+    for (int s = S - 1; s >= 0; --s) {
+      const float4 p = rows_pd[rec(s)];
+      if (p.x >= bx0 && p.x <= bx1 && p.y >= by0 && p.y <= by1 && p.z >= bz0 && p.z <= bz1) { last_in = s; break; }
+    }
+  float trA = 1.f;
   if (bg_scale != 0.f && trans[r] > 0.5f) {
     const float inv = bg_scale / (sums[3] + 1.0f);
+    trA = trans[r];
     for (int c = 0; c < 3; ++c) {
       const float d = tb[3 * r + c] - pix[3 * r + c];
       gTB[c] = d > 0.f ? inv : (d < 0.f ? -inv : 0.f);
-      GT += gTB[c] * bk[c];
+      if (!bd_cut) GT += gTB[c] * bk[c];                   // d (trans * stop_gradient(bkgd)) / d trans
+      else {
+        gA += gTB[c] * (tb[3 * r + c] / trA);                // d / d trans_A  (C_B = trans_rgb_bkgd / trans_A, trans_A > 0.5 here)
+        gCB[c] = gTB[c] * trA;                               // d / d C_B
+        GTB += gCB[c] * bk[c];
+      }
     }
   }
   // forward sweep: total optical depth
@@ -151,11 +168,12 @@ __global__ void __launch_bounds__(64) composite_bwd_kernel(const float4* __restr
     sg_out = fdiv(1.0f, fadd(1.0f, expf(-x)));             // d softplus / dx
     return fmul(softplusf_ref(x), delta_out);
   };
-  float cum = 0.f;
-  for (int s = 0; s < S; ++s) { float a, b; cum = fadd(cum, dd_at(s, a, b)); }
-  const float TS = expf(-cum);
+  float cum = 0.f, cumB = 0.f;
+  for (int s = 0; s < S; ++s) { float a, b; const float dd = dd_at(s, a, b); cum = fadd(cum, dd); if (bd_cut && s > last_in) cumB = fadd(cumB, dd); }
+  const float TS = expf(-cum), TBS = expf(-cumB);
   float suffix = 0.f;          // sum_{j>s} (gC . c_j) w_j
   float cum_after = cum;
+  float suffixB = 0.f, cumB_after = cumB;
   for (int s = S - 1; s >= 0; --s) {
     float sgp, delta;
     const float dd = dd_at(s, sgp, delta);
@@ -167,18 +185,34 @@ __global__ void __launch_bounds__(64) composite_bwd_kernel(const float4* __restr
     const float sr = sigmoidf_ref(rw.x), sgn = sigmoidf_ref(rw.y), sb = sigmoidf_ref(rw.z);
     const float cr = sr * pad_scale - pad, cg = sgn * pad_scale - pad, cb = sb * pad_scale - pad;
     const float gcc = gC[0] * cr + gC[1] * cg + gC[2] * cb;
-    const float g_dd = gcc * T_next - suffix - GT * TS;
+    float g_dd = gcc * T_next - suffix - GT * TS;
+    float gr = gC[0] * w, gg = gC[1] * w, gb = gC[2] * w;
+    if (bd_cut) {
+      if (s > last_in) {                                     // the chain behind the box
+        const float TB_next = expf(-cumB_after);
+        const float cumB_before = fsub(cumB_after, dd);
+        const float TB_s = (s == last_in + 1) ? 1.0f : expf(-cumB_before);
+        const float wB = fmul(fsub(1.0f, expf(-dd)), TB_s);
+        const float gccB = gCB[0] * cr + gCB[1] * cg + gCB[2] * cb;
+        g_dd += gccB * TB_next - suffixB - GTB * TBS;
+        gr += gCB[0] * wB; gg += gCB[1] * wB; gb += gCB[2] * wB;
+        suffixB += gccB * wB;
+        cumB_after = cumB_before;
+      } else {
+        g_dd -= gA * trA;                                    // d trans_A / d dd_s = -trans_A
+      }
+    }
     float4 o;
-    o.x = gC[0] * w * pad_scale * sr * (1.0f - sr);
-    o.y = gC[1] * w * pad_scale * sgn * (1.0f - sgn);
-    o.z = gC[2] * w * pad_scale * sb * (1.0f - sb);
+    o.x = gr * pad_scale * sr * (1.0f - sr);
+    o.y = gg * pad_scale * sgn * (1.0f - sgn);
+    o.z = gb * pad_scale * sb * (1.0f - sb);
     o.w = g_dd * delta * sgp;
     d_raw[(size_t)s * B + r] = o;
     suffix += gcc * w;
     cum_after = cum_before;
   }
   for (int c = 0; c < 3; ++c) {
-    const float g = gC[c] * TS;
+    const float g = gC[c] * TS + (bd_cut ? gCB[c] * TBS : 0.f);
     if (accumulate_bkgd) d_bkgd[3 * r + c] += g; else d_bkgd[3 * r + c] = g;
   }
 }
@@ -406,7 +440,7 @@ extern "C" int rnerf_composite_backward(const float* raw, const float* rows_pd, 
                                         int32_t S, int32_t B, const float* bkgd, double rgb_padding, double sigma_bias,
                                         const float* rgb, const float* pixels, const float* trans, const float* trans_bkgd,
                                         const float* sums, double mse_scale, double bg_scale, float* d_raw, float* d_bkgd,
-                                        int accumulate_bkgd, void* stream) {
+                                        int accumulate_bkgd, const double* bd_cut_bbox, void* stream) {
   RNERF_CHECK_ARG(raw && rows_pd && rows_dr && bkgd && rgb && pixels && d_raw && d_bkgd, "rnerf_composite_backward: null pointer");
   RNERF_CHECK_ARG(bg_scale == 0.0 || (trans && trans_bkgd && sums), "rnerf_composite_backward: bg term needs trans, trans_bkgd and sums");
   RNERF_CHECK_ARG(S >= 1 && B >= 1, "rnerf_composite_backward: need S >= 1 and B >= 1");
@@ -415,7 +449,9 @@ extern "C" int rnerf_composite_backward(const float* raw, const float* rows_pd, 
   hipLaunchKernelGGL(composite_bwd_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const float4*)raw,
                      (const float4*)rows_pd, (const float4*)rows_dr, node_of_sample, S, B, bkgd, (float)(1 + 2 * rgb_padding),
                      (float)rgb_padding, (float)sigma_bias, rgb, pixels, trans, trans_bkgd, sums, (float)mse_scale, (float)bg_scale,
-                     (float4*)d_raw, d_bkgd, accumulate_bkgd);
+                     (float4*)d_raw, d_bkgd, accumulate_bkgd, bd_cut_bbox != nullptr, bd_cut_bbox ? (float)bd_cut_bbox[0] : 0.f,
+                     bd_cut_bbox ? (float)bd_cut_bbox[1] : 0.f, bd_cut_bbox ? (float)bd_cut_bbox[2] : 0.f, bd_cut_bbox ? (float)bd_cut_bbox[3] : 0.f,
+                     bd_cut_bbox ? (float)bd_cut_bbox[4] : 0.f, bd_cut_bbox ? (float)bd_cut_bbox[5] : 0.f);
   RNERF_CHECK_LAUNCH();
   return RNERF_OK;
 }

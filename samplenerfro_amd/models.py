@@ -271,9 +271,9 @@ class NerfModel:
             bkgd = ops.bkgd_forward(bkgd_flat, path_dr[last], self.rgb_padding)
             raw_c = ops.nerfmlp_forward(self._packed_weights(variables, "coarse_mlp"), self.precision, path_pd, path_dr, jit, Nc, B)
         else:
-            if self.bd_cut_dist is not None or self.white_bkgd or self.use_online_sparsity:
-                raise NotImplementedError("training backward: bd_cut_dist masks / white_bkgd / online sparsity are not built "
-                                          "(the sparsity terms carry annealing_rate = 0.0 in train.py:156)")
+            if self.white_bkgd or self.use_online_sparsity:
+                raise NotImplementedError("training backward: white_bkgd / online sparsity are not built (every shipped yaml sets "
+                                          "white_bkgd false; the sparsity terms carry annealing_rate = 0.0 in train.py:156)")
             bkgd, ctx["save_bkgd"] = ops.bkgd_forward_train(bkgd_flat, path_dr[last], self.rgb_padding)
             raw_c, ctx["save_c"] = ops.nerfmlp_forward_train(self._packed_weights(variables, "coarse_mlp"), self.precision, path_pd,
                                                             path_dr, jit, Nc, B)
@@ -318,6 +318,8 @@ class NerfModel:
                 behind, _, _, _, _, _, _ = ops.composite(raw_f, rows_pd, rows_dr, None, S, B, bkgd, self.white_bkgd, self.rgb_padding,
                                                          self.sigma_bias, want_weights=False, mask_mode=2, bbox=bbox)
                 trans_bkgd = trans * behind
+                if ctx is not None:
+                    ctx["bd_cut_bbox"] = bbox
             ret.append((rgb, dist, acc, trans, trans_bkgd))
             if taps is not None:
                 taps.update(rows_pd=rows_pd, rows_dr=rows_dr, idx_f=idx, raw_f=raw_f, weights_f=w_f, u=u)

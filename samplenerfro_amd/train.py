@@ -152,7 +152,7 @@ def train_step(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], 
     if Nf > 0:
         d_raw_f, d_bkgd = ops.composite_backward(ctx["raw_f"], ctx["rows_pd"], ctx["rows_dr"], None, Nc + Nf, B, ctx["bkgd"], rgb_f, pixels,
                                                  trans_f, tb_f, sums, mse_scale, flags.bg_weight * bg_on, rgb_padding=model.rgb_padding,
-                                                 sigma_bias=model.sigma_bias)
+                                                 sigma_bias=model.sigma_bias, bd_cut_bbox=ctx.get("bd_cut_bbox"))
         ops.nerfmlp_backward(_bwd_packed(model, state, "fine_mlp"), model._packed_weights(variables, "fine_mlp"), prec, ctx["save_f"],
                              d_raw_f, (Nc + Nf) * B, grads=state.grad_view("fine_mlp"))
         d_raw_c, d_bkgd = ops.composite_backward(ctx["raw_c"], ctx["path_pd"], ctx["path_dr"], ctx["jit"], Nc, B, ctx["bkgd"], rgb_c, pixels,

@@ -23,9 +23,10 @@ def _level(rng, B, S):
     return t, dirs, pos, raw
 
 
-@pytest.mark.parametrize("bg_weight", [0.0, 0.025])
-def test_loss_and_composite_backward(bg_weight):
+@pytest.mark.parametrize("bg_weight,bd_cut", [(0.0, False), (0.025, False), (0.05, True)])
+def test_loss_and_composite_backward(bg_weight, bd_cut):
     from samplenerfro_amd import ops
+    bbox = [-0.8, -0.6, -0.9, 0.7, 0.9, 0.8] if bd_cut else None      # ~1/3 of the N(0,1) positions fall inside
     rng = np.random.default_rng(3)
     B, Sc, Sf = 300, 12, 29
     tc, dc, pc, rawc = _level(rng, B, Sc)
@@ -43,6 +44,9 @@ def test_loss_and_composite_backward(bg_weight):
     for r_, t_, d_ in ((rc, tc, dc), (rf, tf, df)):
         rgb, sig = TR.activations(r_)
         comp, acc, w, tr, tb = TR.volumetric_rendering(rgb, sig, torch.tensor(t_, dtype=torch.float64), torch.tensor(d_, dtype=torch.float64), bkt)
+        if bd_cut and r_ is rf:          # rnerf/models.py:479-524 replaces the last level's (trans, trans_rgb_bkgd)
+            tr, tb = TR.bd_cut_pair(rgb, sig, torch.tensor(t_, dtype=torch.float64), torch.tensor(d_, dtype=torch.float64), bkt,
+                                    torch.tensor(pf_, dtype=torch.float64), bbox)
         levels.append((comp, tr, tb))
     total, parts = TR.radiance_loss(levels, px, bg_weight=bg_weight)
     total.backward()
@@ -55,7 +59,11 @@ def test_loss_and_composite_backward(bg_weight):
     pdc, drc = rows(pc, dc, tc); pdf, drf = rows(pf_, df, tf)
     rawc_d, rawf_d, bk_d, pix_d = T(rawc.transpose(1, 0, 2)), T(rawf.transpose(1, 0, 2)), T(bk), T(pix)
     oc = ops.composite(rawc_d, pdc, drc, None, Sc, B, bk_d)
-    of = ops.composite(rawf_d, pdf, drf, None, Sf, B, bk_d)
+    of = list(ops.composite(rawf_d, pdf, drf, None, Sf, B, bk_d))
+    if bd_cut:
+        of[3] = ops.composite(rawf_d, pdf, drf, None, Sf, B, None, want_weights=False, mask_mode=1, bbox=bbox)[3]
+        behind = ops.composite(rawf_d, pdf, drf, None, Sf, B, bk_d, want_weights=False, mask_mode=2, bbox=bbox)[0]
+        of[4] = of[3][:, None] * behind if of[3].dim() == 1 else of[3] * behind
     sums = ops.loss_reduce(oc[0], of[0], of[3], of[4], pix_d)
     s = sums.cpu().numpy().astype(np.float64)
     loss_f, loss_c = s[0] / (3 * B), s[1] / (3 * B)
@@ -67,7 +75,7 @@ def test_loss_and_composite_backward(bg_weight):
     mse_scale = 2.0 / (3 * B)
     d_raw_c, d_bk = ops.composite_backward(rawc_d, pdc, drc, None, Sc, B, bk_d, oc[0], pix_d, mse_scale=mse_scale)
     d_raw_f, d_bk = ops.composite_backward(rawf_d, pdf, drf, None, Sf, B, bk_d, of[0], pix_d, trans=of[3], trans_bkgd=of[4],
-                                           sums=sums, mse_scale=mse_scale, bg_scale=bg_weight, d_bkgd=d_bk)
+                                           sums=sums, mse_scale=mse_scale, bg_scale=bg_weight, d_bkgd=d_bk, bd_cut_bbox=bbox)
     gc = d_raw_c.cpu().numpy().transpose(1, 0, 2); gf = d_raw_f.cpu().numpy().transpose(1, 0, 2)
     # fp32 kernels vs the float64 autograd: 2e-6 relative to the largest gradient entry
     for g, ref in ((gc, rc.grad.numpy()), (gf, rf.grad.numpy()), (d_bk.cpu().numpy(), bkt.grad.numpy())):

@@ -16,7 +16,7 @@ def T(a):
     return torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
 
 
-def _setup(Nf, seed=5, B=96):
+def _setup(Nf, seed=5, B=96, bd_cut=False):
     from samplenerfro_amd import models, synthetic as syn, utils
     from samplenerfro_amd.train import TrainState
     G = 24
@@ -24,6 +24,8 @@ def _setup(Nf, seed=5, B=96):
     flags = utils.default_flags(num_coarse_samples=8, num_fine_samples=Nf, num_path_samples=4, white_bkgd=False, bg_weight=0.025,
                                 bg_smooth_weight=1.0, bg_patch_size=8, use_online_sparsity=False, lr_delay_steps=0, max_steps=1000,
                                 weight_decay_mult=1e-3, near=2.0, far=6.0)
+    if bd_cut:                                     # configs/glass.gin:13 — the loss_bg pair comes from the two masked composites
+        flags.config, flags.bd_cut_dist = "glass", 6.0
     model, variables = models.construct_nerf(np.array([0, 7], np.uint32), None, flags, [G] * 3, [-1.5] * 3, [1.5] * 3, T(grid))
     pf = syn.init_params_flat(seed, fine=Nf > 0, bias_scale=0.1)
     for k in ("coarse_mlp", "fine_mlp", "bkgd_mlp"):
@@ -57,7 +59,10 @@ def _reference_grads(model, state, batch, flags, taps, ev, theta0):
         raw = TR.nerf_mlp(th[seg[name][0]:seg[name][1]], enc, venc).reshape(B, S, 4)
         rgb, sigma = TR.activations(raw, model.rgb_padding, model.sigma_bias)
         t = pd[..., 3].permute(1, 0).double()
-        comp, acc, w, trans, tb = TR.volumetric_rendering(rgb, sigma, t, torch.tensor(dirs, dtype=torch.float64).reshape(B, S, 3), bk)
+        dirs_t = torch.tensor(dirs, dtype=torch.float64).reshape(B, S, 3)
+        comp, acc, w, trans, tb = TR.volumetric_rendering(rgb, sigma, t, dirs_t, bk)
+        if name == "fine_mlp" and model.bd_cut_dist is not None:
+            trans, tb = TR.bd_cut_pair(rgb, sigma, t, dirs_t, bk, torch.tensor(pos, dtype=torch.float64).reshape(B, S, 3), model._bd_cut_bbox())
         return comp, trans, tb
 
     path_pd, path_dr = ctx["path_pd"].cpu(), ctx["path_dr"].cpu()
@@ -78,10 +83,10 @@ def _reference_grads(model, state, batch, flags, taps, ev, theta0):
     return th.grad.numpy(), {k: float(v.detach()) for k, v in parts.items()}
 
 
-@pytest.mark.parametrize("Nf", [12, 0])
-def test_train_step_gradients_and_adam(Nf):
+@pytest.mark.parametrize("Nf,bd_cut", [(12, False), (0, False), (12, True)])
+def test_train_step_gradients_and_adam(Nf, bd_cut):
     from samplenerfro_amd.train import train_step
-    model, state, batch, flags, ev = _setup(Nf)
+    model, state, batch, flags, ev = _setup(Nf, bd_cut=bd_cut)
     theta0 = state.theta.cpu().numpy().astype(np.float64)
     rng = np.array([1, 2], np.uint32)
     taps = {}
