@@ -153,12 +153,13 @@ int rnerf_loss_reduce(const float* rgb_c, const float* rgb_f, const float* trans
  * that carries loss_bg (the last one), 0 otherwise (then trans/trans_bkgd/sums may be NULL).
  * d_raw: float4[S][B]; d_bkgd: float[B][3] gradient w.r.t. the activated background colour (accumulated if
  * accumulate_bkgd != 0: both levels composite over the coarse pass's bkgd, rnerf/models.py:468-476).
+ * white_bkgd: comp_rgb carried the + (1 - acc) term of rnerf/model_utils.py:307-308.
  * bd_cut_bbox (nullable, host double[6] = min xyz, max xyz): the level's trans / trans_bkgd are the bd_cut_dist pair of
  * rnerf/models.py:479-524 (trans = mask_mode-1 transmittance, trans_bkgd = trans * mask_mode-2 colour over bkgd). */
 int rnerf_composite_backward(const float* raw, const float* rows_pd, const float* rows_dr, const int32_t* node_of_sample,
                              int32_t S, int32_t B, const float* bkgd, double rgb_padding, double sigma_bias, const float* rgb,
                              const float* pixels, const float* trans, const float* trans_bkgd, const float* sums,
-                             double mse_scale, double bg_scale, float* d_raw, float* d_bkgd, int accumulate_bkgd,
+                             double mse_scale, double bg_scale, float* d_raw, float* d_bkgd, int accumulate_bkgd, int white_bkgd,
                              const double* bd_cut_bbox, void* stream);
 
 /* ---- T1 (backward of P1+N1): gradient of the NerfMLP parameters, replacing jax.value_and_grad through

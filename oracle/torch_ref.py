@@ -15,7 +15,7 @@ def activations(raw, rgb_padding=0.001, sigma_bias=-1.0):
     return rgb, sigma
 
 
-def volumetric_rendering(rgb, sigma, t_vals, dirs, bkgd, mask=None):
+def volumetric_rendering(rgb, sigma, t_vals, dirs, bkgd, mask=None, white_bkgd=False):
     """rgb [B,S,3], sigma [B,S], t_vals [B,S], dirs [B,S,3], bkgd [B,3] -> comp_rgb, acc, weights, trans [B,1], trans*sg(bkgd).
     mask [B,S]: density_delta *= mask_bbox (rnerf/model_utils.py:275-276)."""
     t_dists = torch.cat([t_vals[..., 1:] - t_vals[..., :-1], torch.full_like(t_vals[..., :1], 1e-3)], -1)
@@ -27,6 +27,8 @@ def volumetric_rendering(rgb, sigma, t_vals, dirs, bkgd, mask=None):
     trans = torch.exp(-torch.cat([torch.zeros_like(dd[..., :1]), torch.cumsum(dd, -1)], -1))
     weights = alpha * trans[..., :-1]
     comp = (weights[..., None] * rgb).sum(-2) + trans[..., -1:] * bkgd
+    if white_bkgd:
+        comp = comp + (1.0 - weights.sum(-1)[..., None])
     return comp, weights.sum(-1), weights, trans[..., -1:], trans[..., -1:] * bkgd.detach()
 
 

@@ -121,10 +121,12 @@ __global__ void __launch_bounds__(64) composite_bwd_kernel(const float4* __restr
                                                            const float* __restrict__ trans, const float* __restrict__ tb,
                                                            const float* __restrict__ sums, float mse_scale, float bg_scale,
                                                            float4* __restrict__ d_raw, float* __restrict__ d_bkgd, int accumulate_bkgd,
-                                                           int bd_cut, float bx0, float by0, float bz0, float bx1, float by1, float bz1) {
+                                                           int bd_cut, float bx0, float by0, float bz0, float bx1, float by1, float bz1,
+                                                           int white_bkgd) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= B) return;
   auto rec = [&](int s) -> size_t { return (size_t)(node_of_sample ? node_of_sample[s] : s) * B + r; };
+  const float wb1 = white_bkgd ? 1.0f : 0.0f;       // comp_rgb += 1 - acc (model_utils.py:307-308): every weight also carries -1 per channel
   float gC[3], bk[3], gTB[3] = {0.f, 0.f, 0.f};
   float GT = 0.f;
   // bd_cut (rnerf/models.py:479-524): the loss_bg pair is trans_A = exp(-sum_{s <= L} dd_s) (L = last sample inside the box) and
@@ -184,7 +186,7 @@ __global__ void __launch_bounds__(64) composite_bwd_kernel(const float4* __restr
     const float4 rw = raw[(size_t)s * B + r];
     const float sr = sigmoidf_ref(rw.x), sgn = sigmoidf_ref(rw.y), sb = sigmoidf_ref(rw.z);
     const float cr = sr * pad_scale - pad, cg = sgn * pad_scale - pad, cb = sb * pad_scale - pad;
-    const float gcc = gC[0] * cr + gC[1] * cg + gC[2] * cb;
+    const float gcc = gC[0] * (cr - wb1) + gC[1] * (cg - wb1) + gC[2] * (cb - wb1);
     float g_dd = gcc * T_next - suffix - GT * TS;
     float gr = gC[0] * w, gg = gC[1] * w, gb = gC[2] * w;
     if (bd_cut) {
@@ -440,7 +442,7 @@ extern "C" int rnerf_composite_backward(const float* raw, const float* rows_pd, 
                                         int32_t S, int32_t B, const float* bkgd, double rgb_padding, double sigma_bias,
                                         const float* rgb, const float* pixels, const float* trans, const float* trans_bkgd,
                                         const float* sums, double mse_scale, double bg_scale, float* d_raw, float* d_bkgd,
-                                        int accumulate_bkgd, const double* bd_cut_bbox, void* stream) {
+                                        int accumulate_bkgd, int white_bkgd, const double* bd_cut_bbox, void* stream) {
   RNERF_CHECK_ARG(raw && rows_pd && rows_dr && bkgd && rgb && pixels && d_raw && d_bkgd, "rnerf_composite_backward: null pointer");
   RNERF_CHECK_ARG(bg_scale == 0.0 || (trans && trans_bkgd && sums), "rnerf_composite_backward: bg term needs trans, trans_bkgd and sums");
   RNERF_CHECK_ARG(S >= 1 && B >= 1, "rnerf_composite_backward: need S >= 1 and B >= 1");
@@ -451,7 +453,7 @@ extern "C" int rnerf_composite_backward(const float* raw, const float* rows_pd, 
                      (float)rgb_padding, (float)sigma_bias, rgb, pixels, trans, trans_bkgd, sums, (float)mse_scale, (float)bg_scale,
                      (float4*)d_raw, d_bkgd, accumulate_bkgd, bd_cut_bbox != nullptr, bd_cut_bbox ? (float)bd_cut_bbox[0] : 0.f,
                      bd_cut_bbox ? (float)bd_cut_bbox[1] : 0.f, bd_cut_bbox ? (float)bd_cut_bbox[2] : 0.f, bd_cut_bbox ? (float)bd_cut_bbox[3] : 0.f,
-                     bd_cut_bbox ? (float)bd_cut_bbox[4] : 0.f, bd_cut_bbox ? (float)bd_cut_bbox[5] : 0.f);
+                     bd_cut_bbox ? (float)bd_cut_bbox[4] : 0.f, bd_cut_bbox ? (float)bd_cut_bbox[5] : 0.f, white_bkgd);
   RNERF_CHECK_LAUNCH();
   return RNERF_OK;
 }

@@ -271,9 +271,9 @@ class NerfModel:
             bkgd = ops.bkgd_forward(bkgd_flat, path_dr[last], self.rgb_padding)
             raw_c = ops.nerfmlp_forward(self._packed_weights(variables, "coarse_mlp"), self.precision, path_pd, path_dr, jit, Nc, B)
         else:
-            if self.white_bkgd or self.use_online_sparsity:
-                raise NotImplementedError("training backward: white_bkgd / online sparsity are not built (every shipped yaml sets "
-                                          "white_bkgd false; the sparsity terms carry annealing_rate = 0.0 in train.py:156)")
+            if self.use_online_sparsity:
+                raise NotImplementedError("training with use_online_sparsity: the term carries annealing_rate = 0.0 (train.py:156), i.e. "
+                                          "no gradient; run the model with use_online_sparsity=False (every shipped yaml does)")
             bkgd, ctx["save_bkgd"] = ops.bkgd_forward_train(bkgd_flat, path_dr[last], self.rgb_padding)
             raw_c, ctx["save_c"] = ops.nerfmlp_forward_train(self._packed_weights(variables, "coarse_mlp"), self.precision, path_pd,
                                                             path_dr, jit, Nc, B)

@@ -177,7 +177,7 @@ def loss_reduce(rgb_c: Optional[torch.Tensor], rgb_f: torch.Tensor, trans_f: tor
 
 def composite_backward(raw, rows_pd, rows_dr, node_of_sample, S: int, B: int, bkgd, rgb, pixels, trans=None, trans_bkgd=None,
                        sums=None, mse_scale: float = 0.0, bg_scale: float = 0.0, d_bkgd: Optional[torch.Tensor] = None,
-                       rgb_padding: float = 0.001, sigma_bias: float = -1.0, bd_cut_bbox=None):
+                       rgb_padding: float = 0.001, sigma_bias: float = -1.0, bd_cut_bbox=None, white_bkgd: bool = False):
     """T1: backward of activations + volumetric_rendering for one level. -> d_raw [S,B,4], d_bkgd [B,3] (accumulated if given)."""
     lib = _lib.load()
     dev = raw.device
@@ -188,7 +188,7 @@ def composite_backward(raw, rows_pd, rows_dr, node_of_sample, S: int, B: int, bk
     check(lib.rnerf_composite_backward(ptr(_chk(raw, "raw")), ptr(rows_pd), ptr(rows_dr), ptr(node_of_sample), int(S), int(B),
                                        ptr(_chk(bkgd, "bkgd")), float(rgb_padding), float(sigma_bias), ptr(_chk(rgb, "rgb")),
                                        ptr(_chk(pixels, "pixels")), ptr(trans), ptr(trans_bkgd), ptr(sums), float(mse_scale),
-                                       float(bg_scale), ptr(d_raw), ptr(d_bkgd), int(acc),
+                                       float(bg_scale), ptr(d_raw), ptr(d_bkgd), int(acc), int(bool(white_bkgd)),
                                        None if bd_cut_bbox is None else (C.c_double * 6)(*[float(v) for v in bd_cut_bbox]), current_stream()),
           "rnerf_composite_backward")
     return d_raw, d_bkgd

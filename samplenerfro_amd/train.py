@@ -152,16 +152,16 @@ def train_step(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], 
     if Nf > 0:
         d_raw_f, d_bkgd = ops.composite_backward(ctx["raw_f"], ctx["rows_pd"], ctx["rows_dr"], None, Nc + Nf, B, ctx["bkgd"], rgb_f, pixels,
                                                  trans_f, tb_f, sums, mse_scale, flags.bg_weight * bg_on, rgb_padding=model.rgb_padding,
-                                                 sigma_bias=model.sigma_bias, bd_cut_bbox=ctx.get("bd_cut_bbox"))
+                                                 sigma_bias=model.sigma_bias, bd_cut_bbox=ctx.get("bd_cut_bbox"), white_bkgd=model.white_bkgd)
         ops.nerfmlp_backward(_bwd_packed(model, state, "fine_mlp"), model._packed_weights(variables, "fine_mlp"), prec, ctx["save_f"],
                              d_raw_f, (Nc + Nf) * B, grads=state.grad_view("fine_mlp"))
         d_raw_c, d_bkgd = ops.composite_backward(ctx["raw_c"], ctx["path_pd"], ctx["path_dr"], ctx["jit"], Nc, B, ctx["bkgd"], rgb_c, pixels,
                                                  None, None, None, mse_scale, 0.0, d_bkgd=d_bkgd, rgb_padding=model.rgb_padding,
-                                                 sigma_bias=model.sigma_bias)
+                                                 sigma_bias=model.sigma_bias, white_bkgd=model.white_bkgd)
     else:
         d_raw_c, d_bkgd = ops.composite_backward(ctx["raw_c"], ctx["path_pd"], ctx["path_dr"], ctx["jit"], Nc, B, ctx["bkgd"], rgb_f, pixels,
                                                  trans_f, tb_f, sums, mse_scale, flags.bg_weight * bg_on, rgb_padding=model.rgb_padding,
-                                                 sigma_bias=model.sigma_bias)
+                                                 sigma_bias=model.sigma_bias, white_bkgd=model.white_bkgd)
     ops.nerfmlp_backward(_bwd_packed(model, state, "coarse_mlp"), model._packed_weights(variables, "coarse_mlp"), prec, ctx["save_c"],
                          d_raw_c, Nc * B, grads=state.grad_view("coarse_mlp"))
     bk_flat = variables["flat"]["bkgd_mlp"]

@@ -23,8 +23,8 @@ def _level(rng, B, S):
     return t, dirs, pos, raw
 
 
-@pytest.mark.parametrize("bg_weight,bd_cut", [(0.0, False), (0.025, False), (0.05, True)])
-def test_loss_and_composite_backward(bg_weight, bd_cut):
+@pytest.mark.parametrize("bg_weight,bd_cut,white", [(0.0, False, False), (0.025, False, False), (0.05, True, False), (0.025, False, True)])
+def test_loss_and_composite_backward(bg_weight, bd_cut, white):
     from samplenerfro_amd import ops
     bbox = [-0.8, -0.6, -0.9, 0.7, 0.9, 0.8] if bd_cut else None      # ~1/3 of the N(0,1) positions fall inside
     rng = np.random.default_rng(3)
@@ -43,7 +43,8 @@ def test_loss_and_composite_backward(bg_weight, bd_cut):
     levels = []
     for r_, t_, d_ in ((rc, tc, dc), (rf, tf, df)):
         rgb, sig = TR.activations(r_)
-        comp, acc, w, tr, tb = TR.volumetric_rendering(rgb, sig, torch.tensor(t_, dtype=torch.float64), torch.tensor(d_, dtype=torch.float64), bkt)
+        comp, acc, w, tr, tb = TR.volumetric_rendering(rgb, sig, torch.tensor(t_, dtype=torch.float64), torch.tensor(d_, dtype=torch.float64), bkt,
+                                                       white_bkgd=white)
         if bd_cut and r_ is rf:          # rnerf/models.py:479-524 replaces the last level's (trans, trans_rgb_bkgd)
             tr, tb = TR.bd_cut_pair(rgb, sig, torch.tensor(t_, dtype=torch.float64), torch.tensor(d_, dtype=torch.float64), bkt,
                                     torch.tensor(pf_, dtype=torch.float64), bbox)
@@ -58,8 +59,8 @@ def test_loss_and_composite_backward(bg_weight, bd_cut):
         return T(pd.astype(F32)), T(dr.astype(F32))
     pdc, drc = rows(pc, dc, tc); pdf, drf = rows(pf_, df, tf)
     rawc_d, rawf_d, bk_d, pix_d = T(rawc.transpose(1, 0, 2)), T(rawf.transpose(1, 0, 2)), T(bk), T(pix)
-    oc = ops.composite(rawc_d, pdc, drc, None, Sc, B, bk_d)
-    of = list(ops.composite(rawf_d, pdf, drf, None, Sf, B, bk_d))
+    oc = ops.composite(rawc_d, pdc, drc, None, Sc, B, bk_d, white)
+    of = list(ops.composite(rawf_d, pdf, drf, None, Sf, B, bk_d, white))
     if bd_cut:
         of[3] = ops.composite(rawf_d, pdf, drf, None, Sf, B, None, want_weights=False, mask_mode=1, bbox=bbox)[3]
         behind = ops.composite(rawf_d, pdf, drf, None, Sf, B, bk_d, want_weights=False, mask_mode=2, bbox=bbox)[0]
@@ -73,9 +74,9 @@ def test_loss_and_composite_backward(bg_weight, bd_cut):
         assert s[3] >= 40
         np.testing.assert_allclose(s[2] / (s[3] + 1), parts["loss_bg"].item(), rtol=5e-6)
     mse_scale = 2.0 / (3 * B)
-    d_raw_c, d_bk = ops.composite_backward(rawc_d, pdc, drc, None, Sc, B, bk_d, oc[0], pix_d, mse_scale=mse_scale)
+    d_raw_c, d_bk = ops.composite_backward(rawc_d, pdc, drc, None, Sc, B, bk_d, oc[0], pix_d, mse_scale=mse_scale, white_bkgd=white)
     d_raw_f, d_bk = ops.composite_backward(rawf_d, pdf, drf, None, Sf, B, bk_d, of[0], pix_d, trans=of[3], trans_bkgd=of[4],
-                                           sums=sums, mse_scale=mse_scale, bg_scale=bg_weight, d_bkgd=d_bk, bd_cut_bbox=bbox)
+                                           sums=sums, mse_scale=mse_scale, bg_scale=bg_weight, d_bkgd=d_bk, bd_cut_bbox=bbox, white_bkgd=white)
     gc = d_raw_c.cpu().numpy().transpose(1, 0, 2); gf = d_raw_f.cpu().numpy().transpose(1, 0, 2)
     # fp32 kernels vs the float64 autograd: 2e-6 relative to the largest gradient entry
     for g, ref in ((gc, rc.grad.numpy()), (gf, rf.grad.numpy()), (d_bk.cpu().numpy(), bkt.grad.numpy())):
