@@ -373,7 +373,13 @@ def main():
             cpu_rps, cpu_dt = cpu_baseline(cfg, pf, fine, args.cpu_rays, syn.SEED, train)
             what = ("one train step: numpy fp32 oracle for march/sampling + torch CPU fp32 autograd of train.py's loss_fn + Adam"
                     if train else "one pass of the numpy fp32 oracle")
-            line["cpu_baseline"] = {"value": cpu_rps, "unit": "rays/s", "cores": os.cpu_count(), "kind": "port",
+            try:      # threads actually used by the heavy part: torch intra-op threads (train) / the BLAS pool behind numpy (forward)
+                from threadpoolctl import threadpool_info
+                blas = max([int(t.get("num_threads", 1)) for t in threadpool_info() if t.get("user_api") == "blas"] or [1])
+            except Exception:
+                blas = os.cpu_count()
+            used = torch.get_num_threads() if train else blas
+            line["cpu_baseline"] = {"value": cpu_rps, "unit": "rays/s", "cores": used, "host_cpus": os.cpu_count(), "kind": "port",
                                     "sample": f"{args.cpu_rays} rays of the same workload, {what} (threaded BLAS), {cpu_dt:.1f} s"}
         print(json.dumps(line))
     if world > 1:

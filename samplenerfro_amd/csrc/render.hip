@@ -36,35 +36,48 @@ __global__ void __launch_bounds__(64) composite_kernel(const float4* __restrict_
       if (p.x >= bx0 && p.x <= bx1 && p.y >= by0 && p.y <= by1 && p.z >= bz0 && p.z <= bz1) { last_in = s; break; }
     }
   float cum = 0.f, sr = 0.f, sg = 0.f, sb = 0.f, acc = 0.f, wt = 0.f;
-  size_t o = rec(0);
-  float t_cur = rows_pd[o].w;
-  const float t0 = t_cur;
-  float t_last = t_cur;
-  for (int s = 0; s < S; ++s) {
-    const float4 d = rows_dr[o];
-    const float4 rw = raw[(size_t)s * B + r];
-    float t_next = 0.f, tdist = 1e-3f;                      // model_utils.py:265-268
-    size_t o_next = o;
-    if (s + 1 < S) { o_next = rec(s + 1); t_next = rows_pd[o_next].w; tdist = fsub(t_next, t_cur); }
-    const float nrm = fsqrt(fadd(fadd(fmul(d.x, d.x), fmul(d.y, d.y)), fmul(d.z, d.z)));
-    const float delta = fmul(tdist, nrm);                    // :270
-    const float sigma = softplusf_ref(fadd(rw.w, sigma_bias));   // models.py:338
-    const float cr = fsub(fmul(sigmoidf_ref(rw.x), pad_scale), pad);   // models.py:334-335
-    const float cg = fsub(fmul(sigmoidf_ref(rw.y), pad_scale), pad);
-    const float cb = fsub(fmul(sigmoidf_ref(rw.z), pad_scale), pad);
-    float dd = fmul(sigma, delta);                           // :272
-    if (mask_mode != 0) dd = fmul(dd, ((s <= last_in) == (mask_mode == 1)) ? 1.0f : 0.0f);   // density_delta *= mask_bbox (:275-276)
-    const float a = fsub(1.0f, expf(-dd));                   // :285
-    const float T = expf(-cum);                              // :286-289
-    const float w = fmul(a, T);                              // :296
-    sr = fadd(sr, fmul(w, cr)); sg = fadd(sg, fmul(w, cg)); sb = fadd(sb, fmul(w, cb));
-    acc = fadd(acc, w);
-    wt = fadd(wt, fmul(w, t_cur));
-    cum = fadd(cum, dd);
-    if (weights) weights[(size_t)s * B + r] = w;
-    if (alpha_out) alpha_out[(size_t)s * B + r] = a;
-    t_last = t_cur;
-    t_cur = t_next; o = o_next;
+  const float t0 = rows_pd[rec(0)].w;
+  float t_last = t0;
+  // The recurrence over samples is serial (and kept in the reference's summation order), but its inputs are not: the records of
+  // CH samples are fetched together, so one memory round trip serves CH steps instead of one.
+  constexpr int CH = 8;
+  for (int s0 = 0; s0 < S; s0 += CH) {
+    float4 dv[CH], rv[CH];
+    float tv[CH + 1];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int s = s0 + i < S ? s0 + i : S - 1;
+      const size_t o = rec(s);
+      dv[i] = rows_dr[o]; rv[i] = raw[(size_t)s * B + r]; tv[i] = rows_pd[o].w;
+    }
+    tv[CH] = s0 + CH < S ? rows_pd[rec(s0 + CH)].w : 0.f;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int s = s0 + i;
+      if (s < S) {
+        const float4 d = dv[i], rw = rv[i];
+        const float t_cur = tv[i];
+        const float tdist = (s + 1 < S) ? fsub(tv[i + 1], t_cur) : 1e-3f;   // model_utils.py:265-268
+        const float nrm = fsqrt(fadd(fadd(fmul(d.x, d.x), fmul(d.y, d.y)), fmul(d.z, d.z)));
+        const float delta = fmul(tdist, nrm);                    // :270
+        const float sigma = softplusf_ref(fadd(rw.w, sigma_bias));   // models.py:338
+        const float cr = fsub(fmul(sigmoidf_ref(rw.x), pad_scale), pad);   // models.py:334-335
+        const float cg = fsub(fmul(sigmoidf_ref(rw.y), pad_scale), pad);
+        const float cb = fsub(fmul(sigmoidf_ref(rw.z), pad_scale), pad);
+        float dd = fmul(sigma, delta);                           // :272
+        if (mask_mode != 0) dd = fmul(dd, ((s <= last_in) == (mask_mode == 1)) ? 1.0f : 0.0f);   // density_delta *= mask_bbox (:275-276)
+        const float a = fsub(1.0f, expf(-dd));                   // :285
+        const float T = expf(-cum);                              // :286-289
+        const float w = fmul(a, T);                              // :296
+        sr = fadd(sr, fmul(w, cr)); sg = fadd(sg, fmul(w, cg)); sb = fadd(sb, fmul(w, cb));
+        acc = fadd(acc, w);
+        wt = fadd(wt, fmul(w, t_cur));
+        cum = fadd(cum, dd);
+        if (weights) weights[(size_t)s * B + r] = w;
+        if (alpha_out) alpha_out[(size_t)s * B + r] = a;
+        t_last = t_cur;
+      }
+    }
   }
   const float Tl = expf(-cum);
   float br = 1.f, bg = 1.f, bb = 1.f;                       // rgb_bkgd=None -> ones (:301)
@@ -158,60 +171,92 @@ __global__ void __launch_bounds__(64) composite_bwd_kernel(const float4* __restr
       }
     }
   }
-  // forward sweep: total optical depth
-  auto dd_at = [&](int s, float& sg_out, float& delta_out) -> float {
-    const size_t o = rec(s);
-    const float4 d = rows_dr[o];
-    const float t_cur = rows_pd[o].w;
-    const float tdist = (s + 1 < S) ? fsub(rows_pd[rec(s + 1)].w, t_cur) : 1e-3f;
+  // Both sweeps fetch the records of CH samples together (one memory round trip per CH serial steps, as in the forward kernel).
+  constexpr int CH = 8;
+  auto dd_of = [&](const float4 d, float t_cur, float t_next, bool last, float raw_w, float& sg_out, float& delta_out) -> float {
+    const float tdist = last ? 1e-3f : fsub(t_next, t_cur);
     const float nrm = fsqrt(fadd(fadd(fmul(d.x, d.x), fmul(d.y, d.y)), fmul(d.z, d.z)));
     delta_out = fmul(tdist, nrm);
-    const float x = fadd(raw[(size_t)s * B + r].w, sigma_bias);
+    const float x = fadd(raw_w, sigma_bias);
     sg_out = fdiv(1.0f, fadd(1.0f, expf(-x)));             // d softplus / dx
     return fmul(softplusf_ref(x), delta_out);
   };
+  // forward sweep: total optical depth
   float cum = 0.f, cumB = 0.f;
-  for (int s = 0; s < S; ++s) { float a, b; const float dd = dd_at(s, a, b); cum = fadd(cum, dd); if (bd_cut && s > last_in) cumB = fadd(cumB, dd); }
+  for (int s0 = 0; s0 < S; s0 += CH) {
+    float4 dv[CH]; float rw[CH], tv[CH + 1];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int s = s0 + i < S ? s0 + i : S - 1;
+      const size_t o = rec(s);
+      dv[i] = rows_dr[o]; tv[i] = rows_pd[o].w; rw[i] = raw[(size_t)s * B + r].w;
+    }
+    tv[CH] = s0 + CH < S ? rows_pd[rec(s0 + CH)].w : 0.f;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int s = s0 + i;
+      if (s < S) {
+        float a, b2;
+        const float dd = dd_of(dv[i], tv[i], tv[i + 1], s + 1 >= S, rw[i], a, b2);
+        cum = fadd(cum, dd);
+        if (bd_cut && s > last_in) cumB = fadd(cumB, dd);
+      }
+    }
+  }
   const float TS = expf(-cum), TBS = expf(-cumB);
   float suffix = 0.f;          // sum_{j>s} (gC . c_j) w_j
   float cum_after = cum;
   float suffixB = 0.f, cumB_after = cumB;
-  for (int s = S - 1; s >= 0; --s) {
-    float sgp, delta;
-    const float dd = dd_at(s, sgp, delta);
-    const float T_next = expf(-cum_after);
-    const float cum_before = fsub(cum_after, dd);
-    const float T_s = (s == 0) ? 1.0f : expf(-cum_before);
-    const float w = fmul(fsub(1.0f, expf(-dd)), T_s);
-    const float4 rw = raw[(size_t)s * B + r];
-    const float sr = sigmoidf_ref(rw.x), sgn = sigmoidf_ref(rw.y), sb = sigmoidf_ref(rw.z);
-    const float cr = sr * pad_scale - pad, cg = sgn * pad_scale - pad, cb = sb * pad_scale - pad;
-    const float gcc = gC[0] * (cr - wb1) + gC[1] * (cg - wb1) + gC[2] * (cb - wb1);
-    float g_dd = gcc * T_next - suffix - GT * TS;
-    float gr = gC[0] * w, gg = gC[1] * w, gb = gC[2] * w;
-    if (bd_cut) {
-      if (s > last_in) {                                     // the chain behind the box
-        const float TB_next = expf(-cumB_after);
-        const float cumB_before = fsub(cumB_after, dd);
-        const float TB_s = (s == last_in + 1) ? 1.0f : expf(-cumB_before);
-        const float wB = fmul(fsub(1.0f, expf(-dd)), TB_s);
-        const float gccB = gCB[0] * cr + gCB[1] * cg + gCB[2] * cb;
-        g_dd += gccB * TB_next - suffixB - GTB * TBS;
-        gr += gCB[0] * wB; gg += gCB[1] * wB; gb += gCB[2] * wB;
-        suffixB += gccB * wB;
-        cumB_after = cumB_before;
-      } else {
-        g_dd -= gA * trA;                                    // d trans_A / d dd_s = -trans_A
+  for (int s1 = S - 1; s1 >= 0; s1 -= CH) {               // reverse sweep over chunks [s1-CH+1, s1]
+    float4 dv[CH], rv[CH]; float tv[CH + 1];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {                          // i = 0 is sample s1, i = 1 is s1 - 1, ...
+      const int s = s1 - i >= 0 ? s1 - i : 0;
+      const size_t o = rec(s);
+      dv[i] = rows_dr[o]; tv[i + 1] = rows_pd[o].w; rv[i] = raw[(size_t)s * B + r];
+    }
+    tv[0] = s1 + 1 < S ? rows_pd[rec(s1 + 1)].w : 0.f;      // depth of the sample after s1
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int s = s1 - i;
+      if (s >= 0) {
+        float sgp, delta;
+        const float4 rw = rv[i];
+        const float dd = dd_of(dv[i], tv[i + 1], tv[i], s + 1 >= S, rw.w, sgp, delta);
+        const float T_next = expf(-cum_after);
+        const float cum_before = fsub(cum_after, dd);
+        const float T_s = (s == 0) ? 1.0f : expf(-cum_before);
+        const float w = fmul(fsub(1.0f, expf(-dd)), T_s);
+        const float sr = sigmoidf_ref(rw.x), sgn = sigmoidf_ref(rw.y), sb = sigmoidf_ref(rw.z);
+        const float cr = sr * pad_scale - pad, cg = sgn * pad_scale - pad, cb = sb * pad_scale - pad;
+        const float gcc = gC[0] * (cr - wb1) + gC[1] * (cg - wb1) + gC[2] * (cb - wb1);
+        float g_dd = gcc * T_next - suffix - GT * TS;
+        float gr = gC[0] * w, gg = gC[1] * w, gb = gC[2] * w;
+        if (bd_cut) {
+          if (s > last_in) {                                     // the chain behind the box
+            const float TB_next = expf(-cumB_after);
+            const float cumB_before = fsub(cumB_after, dd);
+            const float TB_s = (s == last_in + 1) ? 1.0f : expf(-cumB_before);
+            const float wB = fmul(fsub(1.0f, expf(-dd)), TB_s);
+            const float gccB = gCB[0] * cr + gCB[1] * cg + gCB[2] * cb;
+            g_dd += gccB * TB_next - suffixB - GTB * TBS;
+            gr += gCB[0] * wB; gg += gCB[1] * wB; gb += gCB[2] * wB;
+            suffixB += gccB * wB;
+            cumB_after = cumB_before;
+          } else {
+            g_dd -= gA * trA;                                    // d trans_A / d dd_s = -trans_A
+          }
+        }
+        float4 o;
+        o.x = gr * pad_scale * sr * (1.0f - sr);
+        o.y = gg * pad_scale * sgn * (1.0f - sgn);
+        o.z = gb * pad_scale * sb * (1.0f - sb);
+        o.w = g_dd * delta * sgp;
+        d_raw[(size_t)s * B + r] = o;
+        suffix += gcc * w;
+        cum_after = cum_before;
       }
     }
-    float4 o;
-    o.x = gr * pad_scale * sr * (1.0f - sr);
-    o.y = gg * pad_scale * sgn * (1.0f - sgn);
-    o.z = gb * pad_scale * sb * (1.0f - sb);
-    o.w = g_dd * delta * sgp;
-    d_raw[(size_t)s * B + r] = o;
-    suffix += gcc * w;
-    cum_after = cum_before;
   }
   for (int c = 0; c < 3; ++c) {
     const float g = gC[c] * TS + (bd_cut ? gCB[c] * TBS : 0.f);
