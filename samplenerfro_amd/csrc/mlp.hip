@@ -1042,6 +1042,9 @@ struct WgradTable {
 
 // One job shape (KT k-tiles of X, KSd k-steps = ceil(KSd/2) n-tiles of dY) is a compile-time instance: with run-time shapes the
 // compiler guards every load with a branch and a vmcnt(0), which serialises the 32 loads of a chunk (measured: 21 us per chunk).
+#ifndef RNERF_WG_ABL
+#define RNERF_WG_ABL 0     // profiling ablations (results are garbage): 1 = no accumulate phase, 2 = operands fetched once, 3 = no transposition
+#endif
 template <bool X_F16, int KT, int KSd>
 __device__ __forceinline__ void wgrad_body(const uint4* __restrict__ saved, const uint4* __restrict__ dy, long long R, long long total_rows,
                                            int n_chunks, float* __restrict__ pg, float* __restrict__ pbias, int qx, int qd, int g, int G,
@@ -1079,7 +1082,7 @@ __device__ __forceinline__ void wgrad_body(const uint4* __restrict__ saved, cons
     const bool ok = (long long)chunk * 128 + wave * 32 + m < total_rows;
     // ---- transpose this wave's 32 rows
 #pragma unroll
-    for (int t = 0; t < KT; ++t) {
+    for (int t = 0; t < (RNERF_WG_ABL == 3 ? 0 : KT); ++t) {
       f32x16 d = mfma16<X_F16>(xr[2 * t], ixl, zero);
       d = mfma16<X_F16>(xr[2 * t + 1], ixh, d);
       uint4 u0, u1;
@@ -1087,7 +1090,7 @@ __device__ __forceinline__ void wgrad_body(const uint4* __restrict__ saved, cons
       myT[(2 * t) * 64] = u0; myT[(2 * t + 1) * 64] = u1;
     }
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
+    for (int t = 0; t < (RNERF_WG_ABL == 3 ? 0 : NT); ++t) {
       const uint4 a0 = ok ? dr[2 * t] : z4, a1 = ok ? dr[2 * t + 1] : z4;   // padded rows carry replayed data: they must not contribute
       f32x16 d = mfma16<false>(a0, idl, zero);
       d = mfma16<false>(a1, idh, d);
@@ -1096,10 +1099,12 @@ __device__ __forceinline__ void wgrad_body(const uint4* __restrict__ saved, cons
       myT[(16 + 2 * t) * 64] = u0; myT[(16 + 2 * t + 1) * 64] = u1;
     }
     __syncthreads();
+#if RNERF_WG_ABL != 2
     if (chunk + G < n_chunks) load_chunk(chunk + G);
+#endif
     // ---- accumulate this wave's dW tiles (k-tiles wave, wave+4; all n-tiles) over the 4 x 32 rows
 #pragma unroll 1
-    for (int v = 0; v < 4; ++v) {
+    for (int v = 0; v < (RNERF_WG_ABL == 1 ? 0 : 4); ++v) {
       const uint4* T = (const uint4*)(smem + v * 32768) + lane;
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
