@@ -140,6 +140,13 @@ int rnerf_resample(const float* path_pd, const float* path_dr, int32_t num_nodes
  * key: HOST uint32[2]; u: device float[num_fine][B] (the layout rnerf_resample takes with u_per_ray = 1). */
 int rnerf_stratified_u(const uint32_t* key, int32_t B, int32_t num_fine, float* u, void* stream);
 
+/* ---- pinhole ray generation on the device.  Replaces Dataset._generate_rays (rnerf/datasets.py:216-242, Blender
+ * model: opencv = 0, fx = fy = focal, cx = W/2, cy = H/2) and the OpenCV variant (:486-518: opencv = 1, fx, fy, cx, cy from cam_mat),
+ * for rows [row0, row0+rows) of one view.  camtoworld: HOST float[3][4] (row-major, rotation | translation).
+ * origins / directions (nullable) / viewdirs: device float[rows][W][3]. */
+int rnerf_generate_rays(const float* camtoworld, int32_t opencv, double fx, double fy, double cx, double cy, double pixel_center,
+                        int32_t W, int32_t row0, int32_t rows, float* origins, float* directions, float* viewdirs, void* stream);
+
 /* ---- T1 (loss): the reductions of train_step.loss_fn (train.py:89-92,105) for stage "radiance*".
  * rgb_c (nullable, N_f == 0), rgb_f: float[B][3]; trans_f: float[B]; trans_bkgd_f, pixels: float[B][3].
  * sums: float[4] (device) = { sum (rgb_f-pix)^2, sum (rgb_c-pix)^2, sum mask*|trans_bkgd_f-pix|, sum mask },

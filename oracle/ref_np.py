@@ -507,3 +507,24 @@ def init_params(seed=0, fine=True, bias_scale=0.0, dtype=F32):
     if fine:
         p["fine_mlp"] = init_mlp(rng, NERF_MLP_SHAPES, bias_scale, dtype)
     return p
+
+
+# ----------------------------------------------------------------------------
+# ray generation                  (rnerf/datasets.py:216-242, :486-518)
+# ----------------------------------------------------------------------------
+def generate_rays(camtoworld, h, w, focal=None, cam_mat=None, pixel_center=True):
+    """Dataset._generate_rays for ONE view, fp32 like the reference's numpy code. -> origins, directions, viewdirs [h,w,3]."""
+    pc = F32(0.5 if pixel_center else 0.0)
+    c2w = np.asarray(camtoworld, F32)
+    if cam_mat is None:      # Blender (:216-242)
+        x, y = np.meshgrid(np.arange(w, dtype=F32) + pc, np.arange(h, dtype=F32) + pc, indexing="xy")
+        cam = np.stack([(x - F32(w * 0.5)) / F32(focal), -(y - F32(h * 0.5)) / F32(focal), -np.ones_like(x)], axis=-1)
+    else:                    # OpenCV (:486-518)
+        x, y = np.meshgrid(np.arange(w, dtype=F32), np.arange(h, dtype=F32), indexing="xy")
+        cam = np.stack([(x - F32(cam_mat[0][2]) + pc) / F32(cam_mat[0][0]), (y - F32(cam_mat[1][2]) + pc) / F32(cam_mat[1][1]),
+                        np.ones_like(x)], axis=-1)
+    prod = cam[..., None, :] * c2w[None, None, :3, :3]
+    directions = _seqsum(prod, axis=-1)
+    origins = np.broadcast_to(c2w[None, None, :3, -1], directions.shape).astype(F32)
+    viewdirs = directions / np.sqrt(_seqsum(directions * directions, axis=-1, keepdims=True))
+    return origins, directions.astype(F32), viewdirs.astype(F32)

@@ -63,6 +63,7 @@ SIGNATURES = {
     "rnerf_nerfmlp_pack_bwd": (C.c_int, [_vp, _vp, _vp]),
     "rnerf_nerfmlp_dgrad": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _i64, _vp, _vp]),
     "rnerf_nerfmlp_wgrad": (C.c_int, [C.c_int, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "rnerf_generate_rays": (C.c_int, [_vp, _i32, _dbl, _dbl, _dbl, _dbl, _dbl, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "rnerf_stratified_u": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
     "rnerf_bkgd_save_bytes": (C.c_size_t, [_i64]),
     "rnerf_bkgd_dy_bytes": (C.c_size_t, [_i64]),

@@ -471,6 +471,50 @@ extern "C" int rnerf_stratified_u(const uint32_t* key, int32_t B, int32_t num_fi
   return RNERF_OK;
 }
 
+// Pinhole ray generation for rows [row0, row0 + rows) of one H x W view (rnerf/datasets.py:216-242 Blender, :486-518 OpenCV), in
+// the reference's fp32 op order: one thread per pixel, no host->device ray traffic for full-frame evaluation.
+struct RayCam { float r[9]; float t[3]; float fx, fy, cx, cy, pc; int opencv; };
+__global__ void __launch_bounds__(256) generate_rays_kernel(RayCam c, int W, int row0, long long n, float* __restrict__ origins,
+                                                            float* __restrict__ directions, float* __restrict__ viewdirs) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int col = (int)(i % W), row = row0 + (int)(i / W);
+  float cam[3];
+  if (!c.opencv) {        // x = arange(w) + pc; ((x - w/2) / focal, -(y - h/2) / focal, -1)        (cx, cy hold w/2, h/2)
+    cam[0] = fdiv(fsub(fadd((float)col, c.pc), c.cx), c.fx);
+    cam[1] = -fdiv(fsub(fadd((float)row, c.pc), c.cy), c.fy);
+    cam[2] = -1.0f;
+  } else {                // ((x - cx + pc) / fx, (y - cy + pc) / fy, 1)
+    cam[0] = fdiv(fadd(fsub((float)col, c.cx), c.pc), c.fx);
+    cam[1] = fdiv(fadd(fsub((float)row, c.cy), c.pc), c.fy);
+    cam[2] = 1.0f;
+  }
+  float d[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) d[k] = fadd(fadd(fmul(cam[0], c.r[3 * k]), fmul(cam[1], c.r[3 * k + 1])), fmul(cam[2], c.r[3 * k + 2]));
+  const float nrm = fsqrt(fadd(fadd(fmul(d[0], d[0]), fmul(d[1], d[1])), fmul(d[2], d[2])));
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    origins[3 * i + k] = c.t[k];
+    if (directions) directions[3 * i + k] = d[k];
+    viewdirs[3 * i + k] = fdiv(d[k], nrm);
+  }
+}
+
+extern "C" int rnerf_generate_rays(const float* camtoworld, int32_t opencv, double fx, double fy, double cx, double cy, double pixel_center,
+                                   int32_t W, int32_t row0, int32_t rows, float* origins, float* directions, float* viewdirs, void* stream) {
+  RNERF_CHECK_ARG(camtoworld && origins && viewdirs, "rnerf_generate_rays: null pointer");
+  RNERF_CHECK_ARG(W >= 1 && rows >= 1 && row0 >= 0, "rnerf_generate_rays: need W >= 1, rows >= 1, row0 >= 0");
+  RayCam c;
+  for (int k = 0; k < 3; ++k) { for (int j = 0; j < 3; ++j) c.r[3 * k + j] = camtoworld[4 * k + j]; c.t[k] = camtoworld[4 * k + 3]; }
+  c.fx = (float)fx; c.fy = (float)fy; c.cx = (float)cx; c.cy = (float)cy; c.pc = (float)pixel_center; c.opencv = opencv;
+  const long long n = (long long)rows * W;
+  hipLaunchKernelGGL(generate_rays_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, c, W, row0, n, origins, directions,
+                     viewdirs);
+  RNERF_CHECK_LAUNCH();
+  return RNERF_OK;
+}
+
 extern "C" int rnerf_loss_reduce(const float* rgb_c, const float* rgb_f, const float* trans_f, const float* trans_bkgd_f,
                                  const float* pixels, int32_t B, float* sums, void* stream) {
   RNERF_CHECK_ARG(rgb_f && trans_f && trans_bkgd_f && pixels && sums, "rnerf_loss_reduce: null pointer");

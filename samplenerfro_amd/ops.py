@@ -265,3 +265,25 @@ def stratified_u(key, B: int, num_fine: int, device) -> torch.Tensor:
     u = torch.empty((num_fine, B), dtype=torch.float32, device=device)
     check(lib.rnerf_stratified_u(C.cast(k, C.c_void_p), int(B), int(num_fine), ptr(u), current_stream()), "rnerf_stratified_u")
     return u
+
+
+def generate_rays(camtoworld, H: int, W: int, device, focal: Optional[float] = None, cam_mat=None, pixel_center: bool = True,
+                  rows: Optional[Tuple[int, int]] = None, want_directions: bool = False):
+    """Dataset._generate_rays on the device (rnerf/datasets.py:216-242 with `focal`, :486-518 with `cam_mat`).
+    -> (origins, directions | None, viewdirs), each [rows, W, 3] for image rows [rows[0], rows[1])."""
+    import numpy as np
+    lib = _lib.load()
+    c2w = np.ascontiguousarray(np.asarray(camtoworld, np.float32)[:3, :4])
+    r0, r1 = rows if rows is not None else (0, H)
+    n = r1 - r0
+    o = torch.empty((n, W, 3), dtype=torch.float32, device=device)
+    v = torch.empty_like(o)
+    d = torch.empty_like(o) if want_directions else None
+    pc = 0.5 if pixel_center else 0.0
+    if cam_mat is None:
+        args = (0, float(focal), float(focal), W * 0.5, H * 0.5)
+    else:
+        args = (1, float(cam_mat[0][0]), float(cam_mat[1][1]), float(cam_mat[0][2]), float(cam_mat[1][2]))
+    check(lib.rnerf_generate_rays(c2w.ctypes.data_as(C.c_void_p), args[0], args[1], args[2], args[3], args[4], pc, int(W), int(r0), int(n),
+                                  ptr(o), ptr(d), ptr(v), current_stream()), "rnerf_generate_rays")
+    return o, d, v
