@@ -274,7 +274,15 @@ class NerfModel:
             if self.use_online_sparsity:
                 raise NotImplementedError("training with use_online_sparsity: the term carries annealing_rate = 0.0 (train.py:156), i.e. "
                                           "no gradient; run the model with use_online_sparsity=False (every shipped yaml does)")
-            bkgd, ctx["save_bkgd"] = ops.bkgd_forward_train(bkgd_flat, path_dr[last], self.rgb_padding)
+            env = ctx.get("env_dirs")
+            if env is None:
+                bkgd, ctx["save_bkgd"] = ops.bkgd_forward_train(bkgd_flat, path_dr[last], self.rgb_padding)
+            else:
+                # the env-map patch of train.py:127-130 rides in the same launch: rows [0, B) = the rays' last coarse direction,
+                # rows [B, B + M) = the patch directions; one training forward, later one backward, for both
+                both = torch.cat([path_dr[last][:, :3], env], 0)
+                out, ctx["save_bkgd"] = ops.bkgd_forward_train(bkgd_flat, both, self.rgb_padding)
+                bkgd, ctx["rgb_env"] = out[:B], out[B:]
             raw_c, ctx["save_c"] = ops.nerfmlp_forward_train(self._packed_weights(variables, "coarse_mlp"), self.precision, path_pd,
                                                             path_dr, jit, Nc, B)
             ctx.update(path_pd=path_pd, path_dr=path_dr, jit=jit, raw_c=raw_c, bkgd=bkgd, B=B)

@@ -137,6 +137,9 @@ def train_step(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], 
     prec = model.precision
     Nc, Nf = model.num_coarse_samples, model.num_fine_samples
     ctx: Dict[str, Any] = {}
+    if flags.bg_smooth_weight > 0:
+        ev = batch["env_rays"].viewdirs
+        ctx["env_dirs"] = ev.reshape(-1, 3)
     ret, _loss_sp = model.apply(variables, key_0, key_1, rays, flags.randomized, annealed, jitter=jitter, u_fine=u_fine, ctx=ctx, path=path)
     B = ctx["B"]
     next_path = model.prefetch_path(next_rays, sync_inputs=True, reserve_cus=0) if next_rays is not None else None
@@ -166,19 +169,15 @@ def train_step(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], 
                          d_raw_c, Nc * B, grads=state.grad_view("coarse_mlp"))
     bk_flat = variables["flat"]["bkgd_mlp"]
     g_bk = state.grad_view("bkgd_mlp")
-    ops.bkgd_backward(bk_flat, ctx["save_bkgd"], d_bkgd, g_bk, model.rgb_padding)
-    # ---- env-map smoothness (train.py:127-132) ------------------------------------------------------------------------------
+    # ---- env-map smoothness (train.py:127-132): its rows went through the background MLP together with the rays' rows
     loss_bg_smooth = None
     if flags.bg_smooth_weight > 0:
-        ev = batch["env_rays"].viewdirs
-        ps = ev.shape[0]
-        ectx: Dict[str, Any] = {}
-        rgb_env = model.forward_envmap(variables, ev.reshape(-1, 3).contiguous(), ctx=ectx).reshape(ps, ps, -1)
+        ps = batch["env_rays"].viewdirs.shape[0]
         on = 1.0 if annealed > 0 else 0.0
-        loss_bg_smooth, g_env = env_smooth_loss_and_grad(rgb_env, flags.bg_smooth_weight * on)
+        loss_bg_smooth, g_env = env_smooth_loss_and_grad(ctx["rgb_env"].reshape(ps, ps, -1), flags.bg_smooth_weight * on)
         loss_bg_smooth = loss_bg_smooth * on
-        if on:
-            ops.bkgd_backward(bk_flat, ectx["save_env"], g_env.reshape(-1, 3).contiguous(), g_bk, model.rgb_padding)
+        d_bkgd = torch.cat([d_bkgd, g_env.reshape(-1, 3)], 0)
+    ops.bkgd_backward(bk_flat, ctx["save_bkgd"], d_bkgd, g_bk, model.rgb_padding)
     # ---- weight_l2 over ALL variables, the frozen path_sampler included (train.py:147-153) ----------------------------------
     n_theta = state.theta.numel()
     if state.frozen_sq is None:
