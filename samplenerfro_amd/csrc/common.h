@@ -120,4 +120,22 @@ __device__ __forceinline__ float4 trilinear(const float4* __restrict__ tab, cons
   return trilinear_finish(c);
 }
 
+// ---- quad helpers: 4 consecutive lanes cooperate on one ray (march, compositing) -------------------------------------------
+template <int SRC>
+__device__ __forceinline__ int quad_bcast_i(int v) {   // value of lane SRC of this lane's quad (DPP quad_perm, no LDS)
+  return __builtin_amdgcn_update_dpp(0, v, SRC * 0x55, 0xF, 0xF, true);
+}
+template <int SRC>
+__device__ __forceinline__ float quad_bcast(float v) {
+  return __builtin_bit_cast(float, quad_bcast_i<SRC>(__builtin_bit_cast(int, v)));
+}
+// value of the NEXT lane of the quad (lane 3 keeps its own)
+__device__ __forceinline__ float quad_next(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 1 | (2 << 2) | (3 << 4) | (3 << 6), 0xF, 0xF, true));
+}
+// value of the PREVIOUS lane of the quad (lane 0 keeps its own)
+__device__ __forceinline__ float quad_prev(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0 | (0 << 2) | (1 << 4) | (2 << 6), 0xF, 0xF, true));
+}
+
 }  // namespace rnerf

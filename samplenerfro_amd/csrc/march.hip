@@ -10,15 +10,6 @@
 
 namespace rnerf {
 
-// ---- quad helpers: 4 consecutive lanes cooperate on one ray --------------------------------------------------------------
-template <int SRC>
-__device__ __forceinline__ int quad_bcast_i(int v) {   // value of lane SRC of this lane's quad (DPP quad_perm, no LDS)
-  return __builtin_amdgcn_update_dpp(0, v, SRC * 0x55, 0xF, 0xF, true);
-}
-template <int SRC>
-__device__ __forceinline__ float quad_bcast(float v) {
-  return __builtin_bit_cast(float, quad_bcast_i<SRC>(__builtin_bit_cast(int, v)));
-}
 // (a0*a0 + a1*a1) + a2*a2 over the three coordinate lanes, in the reference's summation order
 __device__ __forceinline__ float quad_sumsq3(float a) {
   const float a2 = fmul(a, a);

@@ -15,6 +15,10 @@ __device__ __forceinline__ float sigmoidf_ref(float x) { return fdiv(1.0f, fadd(
 // jax.nn.softplus = logaddexp(x, 0) = max(x,0) + log1p(exp(-|x|))
 __device__ __forceinline__ float softplusf_ref(float x) { return fadd(fmaxf(x, 0.f), log1pf(expf(-fabsf(x)))); }
 
+// Four lanes (a DPP quad) per ray: lane q owns samples 4j + q.  Everything that does not depend on the running optical depth
+// (activations: 3 sigmoids + softplus, segment length, alpha) is computed by the four lanes at once; the recurrence itself —
+// cum += dd and the five ordered accumulations — is replayed in SAMPLE ORDER through quad broadcasts, so every sum is built
+// by the same sequence of individually rounded additions as the one-lane loop (and the reference's cumsum order).
 __global__ void __launch_bounds__(64) composite_kernel(const float4* __restrict__ raw, const float4* __restrict__ rows_pd,
                                                        const float4* __restrict__ rows_dr,
                                                        const int* __restrict__ node_of_sample, int S, int B,
@@ -24,61 +28,78 @@ __global__ void __launch_bounds__(64) composite_kernel(const float4* __restrict_
                                                        float* __restrict__ trans_out, float* __restrict__ trans_bkgd_out,
                                                        float* __restrict__ weights, float* __restrict__ alpha_out,
                                                        int mask_mode, float bx0, float by0, float bz0, float bx1, float by1, float bz1) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= B) return;
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int q = gid & 3;
+  int r = gid >> 2;
+  const bool live = r < B;
+  if (!live) r = B - 1;            // surplus quads replay the last ray (DPP needs whole quads); their stores are suppressed
   auto rec = [&](int s) -> size_t { return (size_t)(node_of_sample ? node_of_sample[s] : s) * B + r; };
+  const int G = (S + 3) >> 2;
   // mask_bbox = (cumsum(inside[::-1]) > 0)[::-1] (rnerf/models.py:498-503): 1 up to and including the LAST sample inside the
   // box; mask_mode 1 uses it, mask_mode 2 uses 1 - mask (:505-523).
   int last_in = -1;
-  if (mask_mode != 0)
-    for (int s = S - 1; s >= 0; --s) {
-      const float4 p = rows_pd[rec(s)];
-      if (p.x >= bx0 && p.x <= bx1 && p.y >= by0 && p.y <= by1 && p.z >= bz0 && p.z <= bz1) { last_in = s; break; }
-    }
-  float cum = 0.f, sr = 0.f, sg = 0.f, sb = 0.f, acc = 0.f, wt = 0.f;
-  const float t0 = rows_pd[rec(0)].w;
-  float t_last = t0;
-  // The recurrence over samples is serial (and kept in the reference's summation order), but its inputs are not: the records of
-  // CH samples are fetched together, so one memory round trip serves CH steps instead of one.
-  constexpr int CH = 8;
-  for (int s0 = 0; s0 < S; s0 += CH) {
-    float4 dv[CH], rv[CH];
-    float tv[CH + 1];
-#pragma unroll
-    for (int i = 0; i < CH; ++i) {
-      const int s = s0 + i < S ? s0 + i : S - 1;
-      const size_t o = rec(s);
-      dv[i] = rows_dr[o]; rv[i] = raw[(size_t)s * B + r]; tv[i] = rows_pd[o].w;
-    }
-    tv[CH] = s0 + CH < S ? rows_pd[rec(s0 + CH)].w : 0.f;
-#pragma unroll
-    for (int i = 0; i < CH; ++i) {
-      const int s = s0 + i;
+  if (mask_mode != 0) {
+    for (int j = G - 1; j >= 0; --j) {
+      const int s = 4 * j + q;
       if (s < S) {
-        const float4 d = dv[i], rw = rv[i];
-        const float t_cur = tv[i];
-        const float tdist = (s + 1 < S) ? fsub(tv[i + 1], t_cur) : 1e-3f;   // model_utils.py:265-268
-        const float nrm = fsqrt(fadd(fadd(fmul(d.x, d.x), fmul(d.y, d.y)), fmul(d.z, d.z)));
-        const float delta = fmul(tdist, nrm);                    // :270
-        const float sigma = softplusf_ref(fadd(rw.w, sigma_bias));   // models.py:338
-        const float cr = fsub(fmul(sigmoidf_ref(rw.x), pad_scale), pad);   // models.py:334-335
-        const float cg = fsub(fmul(sigmoidf_ref(rw.y), pad_scale), pad);
-        const float cb = fsub(fmul(sigmoidf_ref(rw.z), pad_scale), pad);
-        float dd = fmul(sigma, delta);                           // :272
-        if (mask_mode != 0) dd = fmul(dd, ((s <= last_in) == (mask_mode == 1)) ? 1.0f : 0.0f);   // density_delta *= mask_bbox (:275-276)
-        const float a = fsub(1.0f, expf(-dd));                   // :285
-        const float T = expf(-cum);                              // :286-289
-        const float w = fmul(a, T);                              // :296
-        sr = fadd(sr, fmul(w, cr)); sg = fadd(sg, fmul(w, cg)); sb = fadd(sb, fmul(w, cb));
-        acc = fadd(acc, w);
-        wt = fadd(wt, fmul(w, t_cur));
-        cum = fadd(cum, dd);
-        if (weights) weights[(size_t)s * B + r] = w;
-        if (alpha_out) alpha_out[(size_t)s * B + r] = a;
-        t_last = t_cur;
+        const float4 p = rows_pd[rec(s)];
+        if (p.x >= bx0 && p.x <= bx1 && p.y >= by0 && p.y <= by1 && p.z >= bz0 && p.z <= bz1) { last_in = s; break; }
       }
     }
+    last_in = max(max(quad_bcast_i<0>(last_in), quad_bcast_i<1>(last_in)), max(quad_bcast_i<2>(last_in), quad_bcast_i<3>(last_in)));
   }
+  float cum = 0.f, sr = 0.f, sg = 0.f, sb = 0.f, acc = 0.f, wt = 0.f;
+  const float t0 = rows_pd[rec(0)].w;
+  const float t_last = rows_pd[rec(S - 1)].w;
+  struct Rec { float4 d, rw; float t; };
+  auto load = [&](int j) -> Rec {
+    int s = 4 * j + q;
+    if (s > S - 1) s = S - 1;
+    const size_t o = rec(s);
+    Rec x;
+    x.d = rows_dr[o]; x.rw = raw[(size_t)s * B + r]; x.t = rows_pd[o].w;
+    return x;
+  };
+  // ordered accumulation of the four lanes' products: (((a + p0) + p1) + p2) + p3
+  auto acc4 = [&](float a, float p) -> float {
+    return fadd(fadd(fadd(fadd(a, quad_bcast<0>(p)), quad_bcast<1>(p)), quad_bcast<2>(p)), quad_bcast<3>(p));
+  };
+  Rec cur = load(0);
+  for (int j = 0; j < G; ++j) {
+    const Rec nxt = load(j + 1 < G ? j + 1 : j);                // the next group's records are in flight during this group's arithmetic
+    const int s = 4 * j + q;
+    const bool valid = s < S;
+    const float4 d = cur.d, rw = cur.rw;
+    const float t_cur = cur.t;
+    const float t_up = quad_next(t_cur), t_grp = quad_bcast<0>(nxt.t);
+    const float t_next = q < 3 ? t_up : t_grp;
+    const float tdist = (s + 1 < S) ? fsub(t_next, t_cur) : 1e-3f;   // model_utils.py:265-268
+    const float nrm = fsqrt(fadd(fadd(fmul(d.x, d.x), fmul(d.y, d.y)), fmul(d.z, d.z)));
+    const float delta = fmul(tdist, nrm);                    // :270
+    const float sigma = softplusf_ref(fadd(rw.w, sigma_bias));   // models.py:338
+    const float cr = fsub(fmul(sigmoidf_ref(rw.x), pad_scale), pad);   // models.py:334-335
+    const float cg = fsub(fmul(sigmoidf_ref(rw.y), pad_scale), pad);
+    const float cb = fsub(fmul(sigmoidf_ref(rw.z), pad_scale), pad);
+    float dd = fmul(sigma, delta);                           // :272
+    if (mask_mode != 0) dd = fmul(dd, ((s <= last_in) == (mask_mode == 1)) ? 1.0f : 0.0f);   // density_delta *= mask_bbox (:275-276)
+    if (!valid) dd = 0.f;                                    // padding lanes of the last group: alpha = 0, weight = 0
+    const float a = fsub(1.0f, expf(-dd));                   // :285
+    // optical depth before each of the four samples, in order
+    const float c1 = fadd(cum, quad_bcast<0>(dd)), c2 = fadd(c1, quad_bcast<1>(dd)), c3 = fadd(c2, quad_bcast<2>(dd));
+    const float my_cum = q == 0 ? cum : (q == 1 ? c1 : (q == 2 ? c2 : c3));
+    cum = fadd(c3, quad_bcast<3>(dd));
+    const float T = expf(-my_cum);                           // :286-289
+    const float w = fmul(a, T);                              // :296
+    sr = acc4(sr, fmul(w, cr)); sg = acc4(sg, fmul(w, cg)); sb = acc4(sb, fmul(w, cb));
+    acc = acc4(acc, w);
+    wt = acc4(wt, fmul(w, t_cur));
+    if (valid && live) {
+      if (weights) weights[(size_t)s * B + r] = w;
+      if (alpha_out) alpha_out[(size_t)s * B + r] = a;
+    }
+    cur = nxt;
+  }
+  if (q != 0 || !live) return;
   const float Tl = expf(-cum);
   float br = 1.f, bg = 1.f, bb = 1.f;                       // rgb_bkgd=None -> ones (:301)
   if (bkgd) {
@@ -395,7 +416,7 @@ extern "C" int rnerf_composite(const float* raw, const float* rows_pd, const flo
   if (mask_mode != 0) for (int i = 0; i < 6; ++i) bb[i] = (float)bbox[i];
   RNERF_CHECK_ARG(S >= 1 && B >= 1, "rnerf_composite: need S >= 1 and B >= 1");
   RNERF_CHECK_ARG((((uintptr_t)raw | (uintptr_t)rows_pd | (uintptr_t)rows_dr) & 15) == 0, "rnerf_composite: float4 buffers must be 16-byte aligned");
-  hipLaunchKernelGGL(composite_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const float4*)raw,
+  hipLaunchKernelGGL(composite_kernel, dim3((B + 15) / 16), dim3(64), 0, (hipStream_t)stream, (const float4*)raw,
                      (const float4*)rows_pd, (const float4*)rows_dr, node_of_sample, S, B, bkgd, white_bkgd,
                      (float)(1 + 2 * rgb_padding), (float)rgb_padding, (float)sigma_bias, rgb, dist, acc, trans, trans_bkgd,
                      weights, alpha, mask_mode, bb[0], bb[1], bb[2], bb[3], bb[4], bb[5]);
