@@ -157,8 +157,13 @@ __global__ void __launch_bounds__(64) composite_bwd_kernel(const float4* __restr
                                                            float4* __restrict__ d_raw, float* __restrict__ d_bkgd, int accumulate_bkgd,
                                                            int bd_cut, float bx0, float by0, float bz0, float bx1, float by1, float bz1,
                                                            int white_bkgd) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= B) return;
+  // four lanes per ray, lane q owns samples 4j + q (see composite_kernel): the ordered chains run through quad broadcasts
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int q = gid & 3;
+  int r = gid >> 2;
+  const bool live = r < B;
+  if (!live) r = B - 1;
+  const int G = (S + 3) >> 2;
   auto rec = [&](int s) -> size_t { return (size_t)(node_of_sample ? node_of_sample[s] : s) * B + r; };
   const float wb1 = white_bkgd ? 1.0f : 0.0f;       // comp_rgb += 1 - acc (model_utils.py:307-308): every weight also carries -1 per channel
   float gC[3], bk[3], gTB[3] = {0.f, 0.f, 0.f};
@@ -172,11 +177,16 @@ __global__ void __launch_bounds__(64) composite_bwd_kernel(const float4* __restr
     gC[c] = mse_scale * (rgb[3 * r + c] - pix[3 * r + c]);
     GT += gC[c] * bk[c];
   }
-  if (bd_cut)
-    for (int s = S - 1; s >= 0; --s) {
-      const float4 p = rows_pd[rec(s)];
-      if (p.x >= bx0 && p.x <= bx1 && p.y >= by0 && p.y <= by1 && p.z >= bz0 && p.z <= bz1) { last_in = s; break; }
+  if (bd_cut) {
+    for (int j = G - 1; j >= 0; --j) {
+      const int s = 4 * j + q;
+      if (s < S) {
+        const float4 p = rows_pd[rec(s)];
+        if (p.x >= bx0 && p.x <= bx1 && p.y >= by0 && p.y <= by1 && p.z >= bz0 && p.z <= bz1) { last_in = s; break; }
+      }
     }
+    last_in = max(max(quad_bcast_i<0>(last_in), quad_bcast_i<1>(last_in)), max(quad_bcast_i<2>(last_in), quad_bcast_i<3>(last_in)));
+  }
   float trA = 1.f;
   if (bg_scale != 0.f && trans[r] > 0.5f) {
     const float inv = bg_scale / (sums[3] + 1.0f);
@@ -192,93 +202,111 @@ __global__ void __launch_bounds__(64) composite_bwd_kernel(const float4* __restr
       }
     }
   }
-  // Both sweeps fetch the records of CH samples together (one memory round trip per CH serial steps, as in the forward kernel).
-  constexpr int CH = 8;
-  auto dd_of = [&](const float4 d, float t_cur, float t_next, bool last, float raw_w, float& sg_out, float& delta_out) -> float {
-    const float tdist = last ? 1e-3f : fsub(t_next, t_cur);
-    const float nrm = fsqrt(fadd(fadd(fmul(d.x, d.x), fmul(d.y, d.y)), fmul(d.z, d.z)));
-    delta_out = fmul(tdist, nrm);
-    const float x = fadd(raw_w, sigma_bias);
-    sg_out = fdiv(1.0f, fadd(1.0f, expf(-x)));             // d softplus / dx
-    return fmul(softplusf_ref(x), delta_out);
+  struct Rec { float4 d, rw; float t; };
+  auto load = [&](int j) -> Rec {
+    int s = 4 * j + q;
+    if (s > S - 1) s = S - 1;
+    const size_t o = rec(s);
+    Rec x;
+    x.d = rows_dr[o]; x.rw = raw[(size_t)s * B + r]; x.t = rows_pd[o].w;
+    return x;
   };
-  // forward sweep: total optical depth
+  // dd of this lane's sample (0 for the padding lanes of the last group), d softplus/dx and the segment length
+  auto dd_of = [&](const Rec& c, int s, float t_next, float& sg_out, float& delta_out) -> float {
+    const float tdist = (s + 1 < S) ? fsub(t_next, c.t) : 1e-3f;
+    const float nrm = fsqrt(fadd(fadd(fmul(c.d.x, c.d.x), fmul(c.d.y, c.d.y)), fmul(c.d.z, c.d.z)));
+    delta_out = fmul(tdist, nrm);
+    const float x = fadd(c.rw.w, sigma_bias);
+    sg_out = fdiv(1.0f, fadd(1.0f, expf(-x)));             // d softplus / dx
+    return s < S ? fmul(softplusf_ref(x), delta_out) : 0.f;
+  };
+  // forward sweep: total optical depth, summed in sample order
   float cum = 0.f, cumB = 0.f;
-  for (int s0 = 0; s0 < S; s0 += CH) {
-    float4 dv[CH]; float rw[CH], tv[CH + 1];
-#pragma unroll
-    for (int i = 0; i < CH; ++i) {
-      const int s = s0 + i < S ? s0 + i : S - 1;
-      const size_t o = rec(s);
-      dv[i] = rows_dr[o]; tv[i] = rows_pd[o].w; rw[i] = raw[(size_t)s * B + r].w;
-    }
-    tv[CH] = s0 + CH < S ? rows_pd[rec(s0 + CH)].w : 0.f;
-#pragma unroll
-    for (int i = 0; i < CH; ++i) {
-      const int s = s0 + i;
-      if (s < S) {
-        float a, b2;
-        const float dd = dd_of(dv[i], tv[i], tv[i + 1], s + 1 >= S, rw[i], a, b2);
-        cum = fadd(cum, dd);
-        if (bd_cut && s > last_in) cumB = fadd(cumB, dd);
-      }
+  {
+    Rec cur = load(0);
+    for (int j = 0; j < G; ++j) {
+      const Rec nxt = load(j + 1 < G ? j + 1 : j);
+      const int s = 4 * j + q;
+      const float t_up = quad_next(cur.t), t_grp = quad_bcast<0>(nxt.t);
+      float a, b2;
+      const float dd = dd_of(cur, s, q < 3 ? t_up : t_grp, a, b2);
+      const float ddB = (bd_cut && s > last_in) ? dd : 0.f;
+      cum = fadd(fadd(fadd(fadd(cum, quad_bcast<0>(dd)), quad_bcast<1>(dd)), quad_bcast<2>(dd)), quad_bcast<3>(dd));
+      cumB = fadd(fadd(fadd(fadd(cumB, quad_bcast<0>(ddB)), quad_bcast<1>(ddB)), quad_bcast<2>(ddB)), quad_bcast<3>(ddB));
+      cur = nxt;
     }
   }
   const float TS = expf(-cum), TBS = expf(-cumB);
   float suffix = 0.f;          // sum_{j>s} (gC . c_j) w_j
   float cum_after = cum;
   float suffixB = 0.f, cumB_after = cumB;
-  for (int s1 = S - 1; s1 >= 0; s1 -= CH) {               // reverse sweep over chunks [s1-CH+1, s1]
-    float4 dv[CH], rv[CH]; float tv[CH + 1];
-#pragma unroll
-    for (int i = 0; i < CH; ++i) {                          // i = 0 is sample s1, i = 1 is s1 - 1, ...
-      const int s = s1 - i >= 0 ? s1 - i : 0;
-      const size_t o = rec(s);
-      dv[i] = rows_dr[o]; tv[i + 1] = rows_pd[o].w; rv[i] = raw[(size_t)s * B + r];
-    }
-    tv[0] = s1 + 1 < S ? rows_pd[rec(s1 + 1)].w : 0.f;      // depth of the sample after s1
-#pragma unroll
-    for (int i = 0; i < CH; ++i) {
-      const int s = s1 - i;
-      if (s >= 0) {
-        float sgp, delta;
-        const float4 rw = rv[i];
-        const float dd = dd_of(dv[i], tv[i + 1], tv[i], s + 1 >= S, rw.w, sgp, delta);
-        const float T_next = expf(-cum_after);
-        const float cum_before = fsub(cum_after, dd);
-        const float T_s = (s == 0) ? 1.0f : expf(-cum_before);
-        const float w = fmul(fsub(1.0f, expf(-dd)), T_s);
-        const float sr = sigmoidf_ref(rw.x), sgn = sigmoidf_ref(rw.y), sb = sigmoidf_ref(rw.z);
-        const float cr = sr * pad_scale - pad, cg = sgn * pad_scale - pad, cb = sb * pad_scale - pad;
-        const float gcc = gC[0] * (cr - wb1) + gC[1] * (cg - wb1) + gC[2] * (cb - wb1);
-        float g_dd = gcc * T_next - suffix - GT * TS;
-        float gr = gC[0] * w, gg = gC[1] * w, gb = gC[2] * w;
-        if (bd_cut) {
-          if (s > last_in) {                                     // the chain behind the box
-            const float TB_next = expf(-cumB_after);
-            const float cumB_before = fsub(cumB_after, dd);
-            const float TB_s = (s == last_in + 1) ? 1.0f : expf(-cumB_before);
-            const float wB = fmul(fsub(1.0f, expf(-dd)), TB_s);
-            const float gccB = gCB[0] * cr + gCB[1] * cg + gCB[2] * cb;
-            g_dd += gccB * TB_next - suffixB - GTB * TBS;
-            gr += gCB[0] * wB; gg += gCB[1] * wB; gb += gCB[2] * wB;
-            suffixB += gccB * wB;
-            cumB_after = cumB_before;
-          } else {
-            g_dd -= gA * trA;                                    // d trans_A / d dd_s = -trans_A
-          }
+  // a chain that runs from the group's LAST sample to its first: x3 = v - b3, x2 = x3 - b2, ...; `mine` = value before this lane's
+  // own term (lane 3: v), `out` = value after all four
+  auto chain_sub = [&](float v, float term, float& mine_after, float& mine_before) -> float {
+    const float x3 = fsub(v, quad_bcast<3>(term)), x2 = fsub(x3, quad_bcast<2>(term)), x1 = fsub(x2, quad_bcast<1>(term));
+    const float x0 = fsub(x1, quad_bcast<0>(term));
+    mine_after = q == 3 ? v : (q == 2 ? x3 : (q == 1 ? x2 : x1));
+    mine_before = q == 3 ? x3 : (q == 2 ? x2 : (q == 1 ? x1 : x0));
+    return x0;
+  };
+  auto chain_add = [&](float v, float term, float& mine) -> float {       // suffix sums: lane 3 sees v, lane 2 v + p3, ...
+    const float y3 = v + quad_bcast<3>(term), y2 = y3 + quad_bcast<2>(term), y1 = y2 + quad_bcast<1>(term);
+    mine = q == 3 ? v : (q == 2 ? y3 : (q == 1 ? y2 : y1));
+    return y1 + quad_bcast<0>(term);
+  };
+  {
+    Rec cur = load(G - 1);
+    float t_first_of_next = 0.f;                            // depth of sample 4(j+1): lane 0 of the group processed before
+    for (int j = G - 1; j >= 0; --j) {
+      const Rec nxt = load(j > 0 ? j - 1 : 0);
+      const int s = 4 * j + q;
+      const bool valid = s < S;
+      const float t_up = quad_next(cur.t);
+      float sgp, delta;
+      const float dd = dd_of(cur, s, q < 3 ? t_up : t_first_of_next, sgp, delta);
+      t_first_of_next = quad_bcast<0>(cur.t);
+      float my_after, my_before;
+      cum_after = chain_sub(cum_after, dd, my_after, my_before);
+      const float T_next = expf(-my_after);
+      const float T_s = (s == 0) ? 1.0f : expf(-my_before);
+      const float a1 = fsub(1.0f, expf(-dd));
+      const float w = fmul(a1, T_s);
+      const float4 rw = cur.rw;
+      const float sr = sigmoidf_ref(rw.x), sgn = sigmoidf_ref(rw.y), sb = sigmoidf_ref(rw.z);
+      const float cr = sr * pad_scale - pad, cg = sgn * pad_scale - pad, cb = sb * pad_scale - pad;
+      const float gcc = gC[0] * (cr - wb1) + gC[1] * (cg - wb1) + gC[2] * (cb - wb1);
+      float my_suffix;
+      suffix = chain_add(suffix, valid ? gcc * w : 0.f, my_suffix);
+      float g_dd = gcc * T_next - my_suffix - GT * TS;
+      float gr = gC[0] * w, gg = gC[1] * w, gb = gC[2] * w;
+      if (bd_cut) {
+        const bool behind = s > last_in;                       // the chain behind the box
+        float myB_after, myB_before, my_suffixB;
+        cumB_after = chain_sub(cumB_after, (behind && valid) ? dd : 0.f, myB_after, myB_before);
+        const float TB_next = expf(-myB_after);
+        const float TB_s = (s == last_in + 1) ? 1.0f : expf(-myB_before);
+        const float wB = fmul(a1, TB_s);
+        const float gccB = gCB[0] * cr + gCB[1] * cg + gCB[2] * cb;
+        suffixB = chain_add(suffixB, (behind && valid) ? gccB * wB : 0.f, my_suffixB);
+        if (behind) {
+          g_dd += gccB * TB_next - my_suffixB - GTB * TBS;
+          gr += gCB[0] * wB; gg += gCB[1] * wB; gb += gCB[2] * wB;
+        } else {
+          g_dd -= gA * trA;                                    // d trans_A / d dd_s = -trans_A
         }
+      }
+      if (valid && live) {
         float4 o;
         o.x = gr * pad_scale * sr * (1.0f - sr);
         o.y = gg * pad_scale * sgn * (1.0f - sgn);
         o.z = gb * pad_scale * sb * (1.0f - sb);
         o.w = g_dd * delta * sgp;
         d_raw[(size_t)s * B + r] = o;
-        suffix += gcc * w;
-        cum_after = cum_before;
       }
+      cur = nxt;
     }
   }
+  if (q != 0 || !live) return;
   for (int c = 0; c < 3; ++c) {
     const float g = gC[c] * TS + (bd_cut ? gCB[c] * TBS : 0.f);
     if (accumulate_bkgd) d_bkgd[3 * r + c] += g; else d_bkgd[3 * r + c] = g;
@@ -558,7 +586,7 @@ extern "C" int rnerf_composite_backward(const float* raw, const float* rows_pd, 
   RNERF_CHECK_ARG(S >= 1 && B >= 1, "rnerf_composite_backward: need S >= 1 and B >= 1");
   RNERF_CHECK_ARG((((uintptr_t)raw | (uintptr_t)rows_pd | (uintptr_t)rows_dr | (uintptr_t)d_raw) & 15) == 0,
                   "rnerf_composite_backward: float4 buffers must be 16-byte aligned");
-  hipLaunchKernelGGL(composite_bwd_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const float4*)raw,
+  hipLaunchKernelGGL(composite_bwd_kernel, dim3((B + 15) / 16), dim3(64), 0, (hipStream_t)stream, (const float4*)raw,
                      (const float4*)rows_pd, (const float4*)rows_dr, node_of_sample, S, B, bkgd, (float)(1 + 2 * rgb_padding),
                      (float)rgb_padding, (float)sigma_bias, rgb, pixels, trans, trans_bkgd, sums, (float)mse_scale, (float)bg_scale,
                      (float4*)d_raw, d_bkgd, accumulate_bkgd, bd_cut_bbox != nullptr, bd_cut_bbox ? (float)bd_cut_bbox[0] : 0.f,
