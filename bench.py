@@ -84,6 +84,32 @@ def cpu_baseline(cfg, pf, fine, sample_rays, seed, train=False):
     return sample_rays / dt, dt
 
 
+def parity_vs_oracle(model, pf, cfg, fine, device, n_rays=256):
+    """BASELINE metric 'PSNR vs ref' / max-abs error: the GPU path against the fp32 oracle on a small sample of the SAME workload
+    (same table, initial weights, rays, jitter).  The oracle is the checker here, never the thing measured."""
+    import torch
+    from oracle import ref_np as R
+    from samplenerfro_amd import models, synthetic as syn
+    from samplenerfro_amd.utils import Rays
+    G, ext = cfg["G"], cfg["extent"]
+    ndim, nmin, nmax = [G] * 3, [-ext] * 3, [ext] * 3
+    table = model.table.cpu().numpy().reshape(-1, 4)
+    o, d = syn.sphere_rays(n_rays, seed=syn.SEED + 7)
+    mc = R.ModelConfig(ndim, nmin, nmax, near=cfg["near"], far=cfg["far"], num_coarse_samples=cfg["S"], num_fine_samples=fine,
+                       num_path_samples=cfg["P"])
+    jitter = np.arange(0, mc.num_samples, cfg["P"]) + (cfg["P"] // 2)
+    oret, _ = R.nerf_forward(mc, syn.params_tree(pf), table, o, d, jitter)
+    del table
+    fresh = models.make_variables({k: torch.from_numpy(v).to(device) for k, v in pf.items()})
+    rays = Rays(torch.from_numpy(o).to(device), None, torch.from_numpy(d).to(device), None)
+    key = np.array([0, 1], np.uint32)
+    ret, _ = model.apply(fresh, key, key, rays, False, jitter=jitter)
+    rgb = ret[-1][0].cpu().numpy().astype(np.float64); dist = ret[-1][1].cpu().numpy().astype(np.float64)
+    mse = float(((rgb - oret[-1][0]) ** 2).mean())
+    return {"rays": n_rays, "max_abs_rgb": float(np.abs(rgb - oret[-1][0]).max()), "max_abs_dist": float(np.abs(dist - oret[-1][1]).max()),
+            "psnr_db_vs_oracle": (-10.0 * np.log10(mse)) if mse > 0 else float("inf")}
+
+
 def cpu_train_step(R, mc, pf, params, table, o, d, jitter, cfg, fine, seed):
     """One optimisation step on the host cores: the oracle marches / resamples (no gradient there), torch CPU fp32 autograd does
     the differentiable part of train.py's loss_fn (oracle/torch_ref.py) and Adam."""
@@ -375,6 +401,7 @@ def main():
             except Exception:
                 blas = os.cpu_count()
             used = torch.get_num_threads() if train else blas
+            line["parity"] = parity_vs_oracle(model, pf, cfg, fine, device)
             line["cpu_baseline"] = {"value": cpu_rps, "unit": "rays/s", "cores": used, "host_cpus": os.cpu_count(), "kind": "port",
                                     "sample": f"{args.cpu_rays} rays of the same workload, {what} (threaded BLAS), {cpu_dt:.1f} s"}
         print(json.dumps(line))
