@@ -59,6 +59,7 @@ typedef struct rnerf_grid {
  * row-major followed by bias[out]).  NerfMLP: rnerf/model_utils.py:30-90, MLP: :93-140. */
 #define RNERF_NERFMLP_PARAMS 595844
 #define RNERF_BKGDMLP_PARAMS 56963
+#define RNERF_SO3MLP_PARAMS 65411   /* so3_mlp: 60->128->128->128(+60)->128->3 (rnerf/ior_utils.py:148-152) */
 
 const char* rnerf_last_error(void);
 int rnerf_version(void);
@@ -139,6 +140,19 @@ int rnerf_resample(const float* path_pd, const float* path_dr, int32_t num_nodes
  * u = min(arange(F)/F + jax.random.uniform(key, [B,F], maxval=1/F-eps), 1-eps) with jax's threefry2x32 bit stream.
  * key: HOST uint32[2]; u: device float[num_fine][B] (the layout rnerf_resample takes with u_per_ray = 1). */
 int rnerf_stratified_u(const uint32_t* key, int32_t B, int32_t num_fine, float* u, void* stream);
+
+/* ---- G4 + P2: VoxMLP.__call__ (rnerf/ior_utils.py:269-312, shipped gin: annealed, use_residual, use_direct_output):
+ * (n, grad n) by trilinear lookup and pred_grad = grad n rotated (Rodrigues) by the axis-angle so3_mlp(annealed_pos_enc(x)).
+ * so3_params: device float[RNERF_SO3MLP_PARAMS] (flax order); window10: HOST float[10] = cosine_easing_window(0, 9, 10,
+ * annealed_alpha * 10) (rnerf/model_utils.py:218-233); pts: device float[n][3]; out4: float4[n] = (n, grad n); pred_grad: float[n][3]. */
+int rnerf_so3_query(const float* table, const rnerf_grid* g, const float* so3_params, const float* window10, const float* pts,
+                    int64_t n, float* out4, float* pred_grad, void* stream);
+
+/* ---- E1/E2 with stage "all*": the march with grad = where(|grad n| > 1e-3, pred_grad, grad n) (rnerf/eikonal_utils.py:34-39).
+ * Outputs as rnerf_march (path_ior nullable). */
+int rnerf_march_all(const float* table, const rnerf_grid* g, const float* so3_params, const float* window10, const float* origins,
+                    const float* viewdirs, int32_t B, double near, double far, int32_t num_nodes, float* path_pd, float* path_dr,
+                    float* path_ior, void* stream);
 
 /* ---- pinhole ray generation on the device.  Replaces Dataset._generate_rays (rnerf/datasets.py:216-242, Blender
  * model: opencv = 0, fx = fy = focal, cx = W/2, cy = H/2) and the OpenCV variant (:486-518: opencv = 1, fx, fy, cx, cy from cam_mat),

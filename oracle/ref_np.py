@@ -131,9 +131,28 @@ def safe_l2_normalize(x, eps=1e-6):
 # ----------------------------------------------------------------------------
 # E1/E2: eikonal march                       (rnerf/eikonal_utils.py:29-49,100-124)
 # ----------------------------------------------------------------------------
+def vox_mlp_call(table, so3_params, pts, ndim, nmin, nmax, annealed_alpha=1.0, dtype=F32, max_deg_point=10):
+    """VoxMLP.__call__ (rnerf/ior_utils.py:269-312) with the shipped gin settings (annealed, use_residual, use_direct_output):
+    -> (n [B,1], grad n [B,3], pred_grad [B,3]); pred_grad = grad n rotated by the axis-angle so3_mlp(annealed_pos_enc(x))."""
+    ret = linear3(table, pts, ndim, nmin, nmax, dtype)
+    n, g = ret[:, :1], ret[:, 1:]
+    enc = annealed_pos_enc(np.asarray(pts, dtype)[:, None], 0, max_deg_point, dtype(annealed_alpha) * dtype(max_deg_point), dtype)   # :283
+    raw = simple_mlp(so3_params, enc)[:, 0]
+    theta = safe_l2_norm(raw)                                               # :305-312
+    e = raw / theta
+    a = safe_l2_norm(g)
+    v = g / a
+    cos_t, sin_t = np.cos(theta).astype(dtype), np.sin(theta).astype(dtype)
+    cross = np.stack([e[:, 1] * v[:, 2] - e[:, 2] * v[:, 1], e[:, 2] * v[:, 0] - e[:, 0] * v[:, 2], e[:, 0] * v[:, 1] - e[:, 1] * v[:, 0]], -1)
+    dot = _seqsum(e * v, axis=-1, keepdims=True)
+    pred = a * (cos_t * v + sin_t * cross + (dtype(1) - cos_t) * dot * e)
+    return n, g, pred.astype(dtype)
+
+
 def path_sampler(origins, viewdirs, table, ndim, nmin, nmax, near: float, far: float,
-                 num_samples: int, dtype=F32, return_idx: bool = False):
-    """PathSampler.__call__ with stage="radiance" (grad = table gradient).
+                 num_samples: int, dtype=F32, return_idx: bool = False, so3_params=None, annealed_alpha=1.0):
+    """PathSampler.__call__ with stage="radiance" (grad = table gradient), or stage="all" when so3_params is given
+    (grad = where(|grad n| > 1e-3, pred_grad, grad n), rnerf/eikonal_utils.py:34-39).
 
     Returns (ray_pos [B,N,3], ray_dir [B,N,3] normalised, ray_dist [B,N], idx_data [B,N,1], idx_grad [B,N,3])
     (+ voxel idx [B,N,6] when return_idx).  step_size as models.py:122.
@@ -157,6 +176,9 @@ def path_sampler(origins, viewdirs, table, ndim, nmin, nmax, near: float, far: f
             ret = linear3(table, rp, ndim, nmin, nmax, dtype)
         n = ret[:, :1]; g = ret[:, 1:]
         idx_data[:, k] = n; idx_grad[:, k] = g                           # :115-116 (not shifted)
+        if so3_params is not None:                                       # stage "all" (:34-39)
+            _, _, pred = vox_mlp_call(table, so3_params, rp, ndim, nmin, nmax, annealed_alpha, dtype)
+            g = np.where(np.sqrt(_sum3_sq(g)) > dtype(1e-3), pred, g)
         next_rp = rp + step / n * rd                                     # :41
         next_rd = rd + step * g                                          # :42
         dlt = rp - next_rp
@@ -399,7 +421,8 @@ def nerf_forward(cfg: ModelConfig, params: Dict, table, origins, viewdirs, jitte
     """
     N = cfg.num_samples
     ray_pos, ray_dir, ray_dist, idx_data, idx_grad = path_sampler(
-        origins, viewdirs, table, cfg.ndim, cfg.nmin, cfg.nmax, cfg.near, cfg.far, N, dtype)
+        origins, viewdirs, table, cfg.ndim, cfg.nmin, cfg.nmax, cfg.near, cfg.far, N, dtype,
+        so3_params=getattr(cfg, "so3_params", None), annealed_alpha=getattr(cfg, "annealed_alpha", 1.0))   # stage "all" when set
     jitter = np.asarray(jitter, np.int64)
     ray_pos_c = ray_pos[:, jitter]; ray_dir_c = ray_dir[:, jitter]; ray_dist_c = ray_dist[:, jitter]
     idx_grad_c = idx_grad[:, jitter]

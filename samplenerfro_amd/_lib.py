@@ -15,6 +15,7 @@ PREC_F32, PREC_F16X3, PREC_BF16X3, PREC_F16, PREC_BF16 = 0, 1, 2, 3, 4
 PRECISIONS = {"f16x3": PREC_F16X3, "bf16x3": PREC_BF16X3, "f16": PREC_F16, "bf16": PREC_BF16}
 NERFMLP_PARAMS = 595844
 BKGDMLP_PARAMS = 56963
+SO3MLP_PARAMS = 65411
 
 
 class RnerfError(RuntimeError):
@@ -63,6 +64,8 @@ SIGNATURES = {
     "rnerf_nerfmlp_pack_bwd": (C.c_int, [_vp, _vp, _vp]),
     "rnerf_nerfmlp_dgrad": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _i64, _vp, _vp]),
     "rnerf_nerfmlp_wgrad": (C.c_int, [C.c_int, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "rnerf_so3_query": (C.c_int, [_vp, _GP, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "rnerf_march_all": (C.c_int, [_vp, _GP, _vp, _vp, _vp, _vp, _i32, _dbl, _dbl, _i32, _vp, _vp, _vp, _vp]),
     "rnerf_generate_rays": (C.c_int, [_vp, _i32, _dbl, _dbl, _dbl, _dbl, _dbl, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "rnerf_stratified_u": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
     "rnerf_bkgd_save_bytes": (C.c_size_t, [_i64]),

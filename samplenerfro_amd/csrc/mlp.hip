@@ -1364,6 +1364,155 @@ __global__ void __launch_bounds__(64) bkgd_fwd_kernel(const float* __restrict__ 
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// G4 / P2 / E1 (stage "all"): so3_mlp = MLP(128, 4, skip 2, out 3) on annealed_pos_enc(x) (rnerf/ior_utils.py:148-152, :283;
+// rnerf/model_utils.py:236-245), the Rodrigues rotation of grad n by that axis-angle (ior_utils.py:305-312), and the march
+// that uses it (rnerf/eikonal_utils.py:34-39).  Same exact-fp32 MFMA chain as the background MLP; one wave = 32 points.
+// ------------------------------------------------------------------------------------------------------------------
+__host__ __device__ constexpr DenseShape so3_dense(int d) {
+  constexpr DenseShape t[5] = {{60, 128}, {128, 128}, {128, 128}, {188, 128}, {128, 3}};
+  return t[d];
+}
+__host__ __device__ constexpr int so3_koff(int d) {
+  int o = 0;
+  for (int i = 0; i < d; ++i) o += so3_dense(i).in * so3_dense(i).out + so3_dense(i).out;
+  return o;
+}
+__host__ __device__ constexpr int so3_boff(int d) { return so3_koff(d) + so3_dense(d).in * so3_dense(d).out; }
+static_assert(so3_koff(5) == RNERF_SO3MLP_PARAMS, "so3 MLP parameter count");
+
+struct So3Window { float w[10]; };   // cosine_easing_window(0, 9, 10, annealed_alpha * 10), computed by the host (model_utils.py:218-233)
+
+// K=2 steps over the 60 annealed features: step p, half h -> feature 2p + h = 6d + 3*is_cos + c with d = p / 3 for both halves
+__device__ __forceinline__ void so3_enc_layer(f32x16 (&acc)[4], const float (&enc)[30], const float* __restrict__ kern, int m, int h) {
+#pragma unroll
+  for (int p = 0; p < 30; ++p) {
+    const int f = 2 * p + h;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(kern[f * 128 + 32 * t + m], enc[p], acc[t], 0, 0, 0);
+  }
+}
+
+// raw axis-angle of one point per lane pair (lanes m and m + 32 hold the same point); all 64 lanes must call it
+__device__ __forceinline__ void so3_eval(const float* __restrict__ params, float px, float py, float pz, const So3Window& win, int m, int h,
+                                         float (&raw)[3]) {
+  float enc[30];
+  const float HALF_PI = 1.5707963705062866f;
+#pragma unroll
+  for (int p = 0; p < 30; ++p) {
+    const int d = p / 3, k = p % 3;
+    const float x = k == 0 ? (h ? py : px) : (k == 1 ? (h ? px : pz) : (h ? pz : py));
+    const float phase = k == 0 ? 0.f : (k == 1 ? (h ? HALF_PI : 0.f) : HALF_PI);
+    const float xb = fmul(x, (float)(1 << d));
+    enc[p] = fmul(sinf(k == 0 ? xb : fadd(xb, phase)), win.w[d]);
+  }
+  f32x16 acc[4], x[4];
+  small_init_bias(acc, params + so3_boff(0), h);
+  so3_enc_layer(acc, enc, params + so3_koff(0), m, h);
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x[t][r] = fmaxf(acc[t][r], 0.f);
+#pragma unroll 1
+  for (int l = 1; l <= 2; ++l) {
+    small_init_bias(acc, params + (l == 1 ? so3_boff(1) : so3_boff(2)), h);
+    small_prev_layer(acc, x, params + (l == 1 ? so3_koff(1) : so3_koff(2)), m, h);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) x[t][r] = fmaxf(acc[t][r], 0.f);
+  }
+  small_init_bias(acc, params + so3_boff(3), h);                     // Dense_3: [x(128), inputs(60)] (skip concat after i == 2)
+  small_prev_layer(acc, x, params + so3_koff(3), m, h);
+  so3_enc_layer(acc, enc, params + so3_koff(3) + 128 * 128, m, h);
+  float o[3] = {0.f, 0.f, 0.f};
+  const float* __restrict__ k4 = params + so3_koff(4);
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float v = fmaxf(acc[t][r], 0.f);
+      const int f = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+      o[0] = fmaf(v, k4[f * 3 + 0], o[0]); o[1] = fmaf(v, k4[f * 3 + 1], o[1]); o[2] = fmaf(v, k4[f * 3 + 2], o[2]);
+    }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) raw[c] = o[c] + __shfl_xor(o[c], 32) + params[so3_boff(4) + c];
+}
+
+// pred_grad = a (cos(t) v + sin(t) e x v + (1 - cos(t)) (e . v) e),  e = raw / |raw|, v = g / |g| with safe norms (ior_utils.py:305-312)
+__device__ __forceinline__ void so3_rotate(const float (&raw)[3], const float (&g)[3], float (&pred)[3]) {
+  const float theta = fsqrt(fmaxf(fadd(fadd(fmul(raw[0], raw[0]), fmul(raw[1], raw[1])), fmul(raw[2], raw[2])), 1e-6f));
+  const float e[3] = {fdiv(raw[0], theta), fdiv(raw[1], theta), fdiv(raw[2], theta)};
+  const float a = fsqrt(fmaxf(fadd(fadd(fmul(g[0], g[0]), fmul(g[1], g[1])), fmul(g[2], g[2])), 1e-6f));
+  const float v[3] = {fdiv(g[0], a), fdiv(g[1], a), fdiv(g[2], a)};
+  const float ct = cosf(theta), st = sinf(theta);
+  const float cr[3] = {fsub(fmul(e[1], v[2]), fmul(e[2], v[1])), fsub(fmul(e[2], v[0]), fmul(e[0], v[2])), fsub(fmul(e[0], v[1]), fmul(e[1], v[0]))};
+  const float dot = fadd(fadd(fmul(e[0], v[0]), fmul(e[1], v[1])), fmul(e[2], v[2]));
+  const float k = fmul(fsub(1.0f, ct), dot);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) pred[c] = fmul(a, fadd(fadd(fmul(ct, v[c]), fmul(st, cr[c])), fmul(k, e[c])));
+}
+
+// G4: VoxMLP.__call__ for arbitrary points -> (n, grad n) and pred_grad
+__global__ void __launch_bounds__(64) so3_query_kernel(const float4* __restrict__ table, GridParams gp, const float* __restrict__ params,
+                                                       So3Window win, const float* __restrict__ pts, long long n, float4* __restrict__ out4,
+                                                       float* __restrict__ pred_out) {
+  const int lane = threadIdx.x & 63, m = lane & 31, h = lane >> 5;
+  long long row = (long long)blockIdx.x * 32 + m;
+  const bool ok = row < n;
+  if (!ok) row = n - 1;
+  const float px = pts[3 * row], py = pts[3 * row + 1], pz = pts[3 * row + 2];
+  const float4 c = trilinear(table, gp, px, py, pz, nullptr);
+  float raw[3], pred[3];
+  so3_eval(params, px, py, pz, win, m, h, raw);
+  const float g[3] = {c.y, c.z, c.w};
+  so3_rotate(raw, g, pred);
+  if (ok && h == 0) { out4[row] = c; pred_out[3 * row] = pred[0]; pred_out[3 * row + 1] = pred[1]; pred_out[3 * row + 2] = pred[2]; }
+}
+
+// E1/E2 with stage "all": one wave = 32 rays (both lane halves carry the ray state; the MLP needs the whole wave), the so3 MLP is
+// evaluated at every node.  Weights stream from L2 (262 KB per step per wave).
+__global__ void __launch_bounds__(64) march_all_kernel(const float4* __restrict__ table, GridParams gp, const float* __restrict__ params,
+                                                       So3Window win, const float* __restrict__ origins, const float* __restrict__ viewdirs,
+                                                       int B, float near, float step, int num_nodes, float4* __restrict__ path_pd,
+                                                       float4* __restrict__ path_dr, float4* __restrict__ path_ior) {
+  const int lane = threadIdx.x & 63, m = lane & 31, h = lane >> 5;
+  int r = blockIdx.x * 32 + m;
+  const bool ok = r < B;
+  if (!ok) r = B - 1;
+  float d[3] = {viewdirs[3 * r], viewdirs[3 * r + 1], viewdirs[3 * r + 2]};
+  float p[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) p[c] = fadd(origins[3 * r + c], fmul(near, d[c]));   // eikonal_utils.py:104-106
+  float rt = near;
+  for (int k = 0; k < num_nodes; ++k) {
+    const float4 c = trilinear(table, gp, p[0], p[1], p[2], nullptr);
+    if (ok && h == 0) {
+      const size_t o = (size_t)k * B + r;
+      const float nrm = fsqrt(fmaxf(fadd(fadd(fmul(d[0], d[0]), fmul(d[1], d[1])), fmul(d[2], d[2])), 1e-6f));
+      path_pd[o] = make_float4(p[0], p[1], p[2], rt);
+      path_dr[o] = make_float4(fdiv(d[0], nrm), fdiv(d[1], nrm), fdiv(d[2], nrm), 0.f);
+      if (path_ior) path_ior[o] = c;
+    }
+    float raw[3], pred[3];
+    so3_eval(params, p[0], p[1], p[2], win, m, h, raw);
+    const float g[3] = {c.y, c.z, c.w};
+    so3_rotate(raw, g, pred);
+    const bool use = fsqrt(fadd(fadd(fmul(g[0], g[0]), fmul(g[1], g[1])), fmul(g[2], g[2]))) > 1e-3f;   // eikonal_utils.py:35
+    const float s = fdiv(step, c.x);
+    float dl2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const float np = fadd(p[q], fmul(s, d[q]));
+      d[q] = fadd(d[q], fmul(step, use ? pred[q] : g[q]));
+      const float dl = fsub(p[q], np);
+      dl2 = q == 0 ? fmul(dl, dl) : fadd(dl2, fmul(dl, dl));
+      p[q] = np;
+    }
+    rt = fadd(rt, fsqrt(dl2));
+  }
+}
+
 // ---- backward of the background MLP (exact fp32 on v_mfma_f32_32x32x2_f32, as the forward) --------------------------------
 // dgrad chain: dX^T[k][row] = W[k][n] dY^T[n][row] with the accumulator registers as B operands; ReLU masks from the saved X_k.
 __device__ __forceinline__ void small_prev_layer_T(f32x16 (&acc)[4], const f32x16 (&x)[4], const float* __restrict__ kern, int m, int h) {
@@ -1807,6 +1956,36 @@ extern "C" int rnerf_bkgd_backward(const float* params, const void* save, const 
   hipLaunchKernelGGL(bkgd_wgrad_kernel, dim3(chunks, 18), dim3(256), 0, st, sv, (const float*)dyf, (long long)n, partial);
   hipLaunchKernelGGL(bkgd_wgrad_reduce_kernel, dim3((RNERF_BKGDMLP_PARAMS + 255) / 256), dim3(256), 0, st, (const float*)partial, (int)chunks,
                      grads);
+  RNERF_CHECK_LAUNCH();
+  return RNERF_OK;
+}
+
+extern "C" int rnerf_so3_query(const float* table, const rnerf_grid* g, const float* so3_params, const float* window10, const float* pts,
+                               int64_t n, float* out4, float* pred_grad, void* stream) {
+  RNERF_CHECK_ARG(table && g && so3_params && window10 && pts && out4 && pred_grad, "rnerf_so3_query: null pointer");
+  RNERF_CHECK_ARG(n >= 1, "rnerf_so3_query: n must be >= 1");
+  GridParams gp;
+  RNERF_CHECK_ARG(make_grid_params(g, &gp), "rnerf_so3_query: bad grid");
+  So3Window w;
+  for (int i = 0; i < 10; ++i) w.w[i] = window10[i];
+  hipLaunchKernelGGL(so3_query_kernel, dim3((unsigned)((n + 31) / 32)), dim3(64), 0, (hipStream_t)stream, (const float4*)table, gp, so3_params, w,
+                     pts, (long long)n, (float4*)out4, pred_grad);
+  RNERF_CHECK_LAUNCH();
+  return RNERF_OK;
+}
+
+extern "C" int rnerf_march_all(const float* table, const rnerf_grid* g, const float* so3_params, const float* window10, const float* origins,
+                               const float* viewdirs, int32_t B, double near, double far, int32_t num_nodes, float* path_pd, float* path_dr,
+                               float* path_ior, void* stream) {
+  RNERF_CHECK_ARG(table && g && so3_params && window10 && origins && viewdirs && path_pd && path_dr, "rnerf_march_all: null pointer");
+  RNERF_CHECK_ARG(B > 0 && num_nodes >= 2, "rnerf_march_all: need B > 0 and num_nodes >= 2");
+  GridParams gp;
+  RNERF_CHECK_ARG(make_grid_params(g, &gp), "rnerf_march_all: bad grid");
+  So3Window w;
+  for (int i = 0; i < 10; ++i) w.w[i] = window10[i];
+  const float stepf = (float)((far - near) / (num_nodes - 1));  // models.py:122
+  hipLaunchKernelGGL(march_all_kernel, dim3((unsigned)((B + 31) / 32)), dim3(64), 0, (hipStream_t)stream, (const float4*)table, gp, so3_params, w,
+                     origins, viewdirs, B, (float)near, stepf, num_nodes, (float4*)path_pd, (float4*)path_dr, (float4*)path_ior);
   RNERF_CHECK_LAUNCH();
   return RNERF_OK;
 }

@@ -76,8 +76,8 @@ class NerfModel:
                  use_fine_sparsity=False, net_depth=8, net_width=256, net_depth_condition=1, net_width_condition=128,
                  skip_layer=4, num_rgb_channels=3, num_sigma_channels=1, legacy_posenc_order=False, lindisp=False,
                  precision="f16x3", device=None, **unused):
-        if not stage.startswith("radiance"):
-            raise NotImplementedError(f"stage={stage!r}: only the radiance stages are built (so3_mlp in the march is SURVEY §8f N3)")
+        if not (stage.startswith("radiance") or stage.startswith("all")):
+            raise NotImplementedError(f"stage={stage!r}: the radiance* and all* stages are built (forward; training only for radiance*)")
         if (net_depth, net_width, net_depth_condition, net_width_condition, skip_layer) != (8, 256, 1, 128, 4):
             raise NotImplementedError("the HIP NerfMLP kernel is specialised for the reference's 8x256 / skip 4 / 1x128 network")
         if (min_deg_point, max_deg_point, deg_view) != (0, 10, 4) or legacy_posenc_order or not use_viewdirs:
@@ -127,7 +127,8 @@ class NerfModel:
     def _flat(self, variables, name: str, shapes) -> torch.Tensor:
         f = variables.get("flat", {}).get(name)
         if f is None:
-            f = tree_to_flat(variables["params"][name], shapes, self.device)
+            tree = (variables["params"]["path_sampler"]["scan"]["idx_model"]["so3_mlp"] if name == "so3_mlp" else variables["params"][name])
+            f = tree_to_flat(tree, shapes, self.device)
             variables.setdefault("flat", {})[name] = f
         return f
 
@@ -209,6 +210,8 @@ class NerfModel:
         kernel is MFMA-bound and owns whole CUs.  `reserve_cus` CUs are kept free of MLP workgroups so both can run at
         once.  Pass the handle to `apply(..., path=handle)` (same rays).  sync_inputs=False skips the wait on the current
         stream when the ray tensors are known to be complete already (e.g. slices of a resident image)."""
+        if not self.stage.startswith("radiance"):
+            raise NotImplementedError("prefetch_path: the all* march depends on the so3_mlp parameters; call apply() without a handle")
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.device)
             lib = _lib.load()
@@ -258,6 +261,9 @@ class NerfModel:
                     t.record_stream(cur)
             if want_ior and path_ior is None:
                 raise ValueError("path handle lacks the IoR record (prefetch it from a model with the same options)")
+        elif self.stage.startswith("all"):                                                # so3_mlp bends the gradient (eikonal_utils.py:34-39)
+            path_pd, path_dr, path_ior = ops.march_all(self.table, self.spec, self._flat(variables, "so3_mlp", SO3_MLP_SHAPES).detach(),
+                                                       origins, viewdirs, self.near, self.far, N, annealed_alpha, want_ior=want_ior)
         else:
             path_pd, path_dr, path_ior, _ = ops.march(self.table, self.spec, origins, viewdirs, self.near, self.far, N,
                                                       want_ior=want_ior)
@@ -271,6 +277,8 @@ class NerfModel:
             bkgd = ops.bkgd_forward(bkgd_flat, path_dr[last], self.rgb_padding)
             raw_c = ops.nerfmlp_forward(self._packed_weights(variables, "coarse_mlp"), self.precision, path_pd, path_dr, jit, Nc, B)
         else:
+            if not self.stage.startswith("radiance"):
+                raise NotImplementedError("training is built for the radiance* stages (all*: back-propagation through the march, SURVEY §8f N3)")
             if self.use_online_sparsity:
                 raise NotImplementedError("training with use_online_sparsity: the term carries annealing_rate = 0.0 (train.py:156), i.e. "
                                           "no gradient; run the model with use_online_sparsity=False (every shipped yaml does)")

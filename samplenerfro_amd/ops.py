@@ -287,3 +287,40 @@ def generate_rays(camtoworld, H: int, W: int, device, focal: Optional[float] = N
     check(lib.rnerf_generate_rays(c2w.ctypes.data_as(C.c_void_p), args[0], args[1], args[2], args[3], args[4], pc, int(W), int(r0), int(n),
                                   ptr(o), ptr(d), ptr(v), current_stream()), "rnerf_generate_rays")
     return o, d, v
+
+
+def so3_window(annealed_alpha: float, max_deg_point: int = 10):
+    """cosine_easing_window(0, max_deg-1, max_deg, annealed_alpha * max_deg) in fp32 (rnerf/model_utils.py:218-233, ior_utils.py:283)."""
+    import numpy as np
+    f = np.float32
+    bands = np.linspace(0, max_deg_point - 1, max_deg_point).astype(f)
+    x = np.clip(f(annealed_alpha) * f(max_deg_point) - bands, f(0), f(1))
+    return np.ascontiguousarray((f(0.5) * (f(1) + np.cos(f(np.pi) * x + f(np.pi)))).astype(f))
+
+
+def so3_query(table: torch.Tensor, spec: Grid, so3_flat: torch.Tensor, pts: torch.Tensor, annealed_alpha: float = 1.0):
+    """G4 + P2: VoxMLP.__call__ (rnerf/ior_utils.py:269-312). pts [n,3] -> (out [n,4] = (n, grad n), pred_grad [n,3])."""
+    lib = _lib.load()
+    p = _chk(pts, "pts")
+    n = p.shape[0]
+    out = torch.empty((n, 4), dtype=torch.float32, device=p.device)
+    pred = torch.empty((n, 3), dtype=torch.float32, device=p.device)
+    w = so3_window(annealed_alpha)
+    check(lib.rnerf_so3_query(ptr(table), C.byref(spec), ptr(_chk(so3_flat, "so3_flat")), w.ctypes.data_as(C.c_void_p), ptr(p), n, ptr(out),
+                              ptr(pred), current_stream()), "rnerf_so3_query")
+    return out, pred
+
+
+def march_all(table: torch.Tensor, spec: Grid, so3_flat: torch.Tensor, origins: torch.Tensor, viewdirs: torch.Tensor, near: float, far: float,
+              num_nodes: int, annealed_alpha: float = 1.0, want_ior: bool = False):
+    """E1/E2 with stage "all*" (rnerf/eikonal_utils.py:34-39). -> path_pd [N,B,4], path_dr [N,B,4], ior?"""
+    lib = _lib.load()
+    o = _chk(origins, "origins"); v = _chk(viewdirs, "viewdirs")
+    B = o.shape[0]
+    pd = torch.empty((num_nodes, B, 4), dtype=torch.float32, device=o.device)
+    dr = torch.empty_like(pd)
+    ior = torch.empty_like(pd) if want_ior else None
+    w = so3_window(annealed_alpha)
+    check(lib.rnerf_march_all(ptr(table), C.byref(spec), ptr(_chk(so3_flat, "so3_flat")), w.ctypes.data_as(C.c_void_p), ptr(o), ptr(v), B,
+                              float(near), float(far), int(num_nodes), ptr(pd), ptr(dr), ptr(ior), current_stream()), "rnerf_march_all")
+    return pd, dr, ior

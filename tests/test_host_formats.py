@@ -71,6 +71,6 @@ def test_flags_and_lr_schedule():
 
 def test_model_rejects_unbuilt_options():
     with pytest.raises(NotImplementedError):
-        models.NerfModel(ndim=[4] * 3, nmin=[-1] * 3, nmax=[1] * 3, grid=np.ones((4, 4, 4), np.float32), stage="all", device="cpu")
+        models.NerfModel(ndim=[4] * 3, nmin=[-1] * 3, nmax=[1] * 3, grid=np.ones((4, 4, 4), np.float32), stage="ior", device="cpu")
     with pytest.raises(NotImplementedError):
         models.NerfModel(ndim=[4] * 3, nmin=[-1] * 3, nmax=[1] * 3, grid=np.ones((4, 4, 4), np.float32), sh_deg=2, device="cpu")
