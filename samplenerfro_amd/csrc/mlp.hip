@@ -1494,11 +1494,14 @@ __global__ void __launch_bounds__(64) march_all_kernel(const float4* __restrict_
       path_dr[o] = make_float4(fdiv(d[0], nrm), fdiv(d[1], nrm), fdiv(d[2], nrm), 0.f);
       if (path_ior) path_ior[o] = c;
     }
-    float raw[3], pred[3];
-    so3_eval(params, p[0], p[1], p[2], win, m, h, raw);
     const float g[3] = {c.y, c.z, c.w};
-    so3_rotate(raw, g, pred);
     const bool use = fsqrt(fadd(fadd(fmul(g[0], g[0]), fmul(g[1], g[1])), fmul(g[2], g[2]))) > 1e-3f;   // eikonal_utils.py:35
+    float pred[3] = {0.f, 0.f, 0.f};
+    if (__builtin_amdgcn_ballot_w64(use) != 0) {     // pred_grad is only selected where |grad n| > 1e-3: outside the object's boundary
+      float raw[3];                                   // shell no ray of the wave needs the MLP (wave-uniform branch, same results)
+      so3_eval(params, p[0], p[1], p[2], win, m, h, raw);
+      so3_rotate(raw, g, pred);
+    }
     const float s = fdiv(step, c.x);
     float dl2 = 0.f;
 #pragma unroll
