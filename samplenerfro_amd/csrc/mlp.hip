@@ -20,6 +20,7 @@
 #include "common.h"
 
 #include <stdlib.h>
+#include <type_traits>
 
 namespace rnerf {
 
@@ -1620,20 +1621,32 @@ __global__ void __launch_bounds__(256) bkgd_wgrad_kernel(const float* __restrict
   f32x16 acc[4] = {zero, zero, zero, zero}, accb[4] = {zero, zero, zero, zero};
   const float onesA = m == 0 ? 1.f : 0.f;
   const long long r0 = (long long)blockIdx.x * 256 + wave * 64;
-#pragma unroll 4
-  for (int i = 0; i < 32; ++i) {
-    const long long rr = r0 + 2 * i + h;
-    const bool ok = rr < n;
-    const float a = (ok && k < u.kin) ? X[(size_t)rr * u.ldx + k] : 0.f;
+  // unconditional loads from clamped addresses + selects: with run-time predicates around the loads hipcc emits a branch and a
+  // vmcnt(0) per load, which serialises them; the n-tile count and the bias row are compile-time instances
+  const int kc = k < u.kin ? k : u.kin - 1;
+  auto rows = [&](auto nt_c, auto bias_c) {
+    constexpr int NTC = decltype(nt_c)::value;
+    constexpr bool BIAS = decltype(bias_c)::value;
+#pragma unroll 8
+    for (int i = 0; i < 32; ++i) {
+      const long long rr = r0 + 2 * i + h;
+      const bool ok = rr < n;
+      const size_t rc = (size_t)(ok ? rr : n - 1);
+      const float av = X[rc * u.ldx + kc];
+      const float a = (ok && k < u.kin) ? av : 0.f;
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-      if (nt < NT) {
+      for (int nt = 0; nt < NTC; ++nt) {
         const int nn = 32 * nt + m;
-        const float b = (ok && nn < u.nout) ? dY[(size_t)rr * u.ldy + nn] : 0.f;
+        const float bv = dY[rc * u.ldy + (nn < u.nout ? nn : u.nout - 1)];
+        const float b = (ok && nn < u.nout) ? bv : 0.f;
         acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[nt], 0, 0, 0);
-        if (bias) accb[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(onesA, b, accb[nt], 0, 0, 0);
+        if constexpr (BIAS) accb[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(onesA, b, accb[nt], 0, 0, 0);
       }
-  }
+    }
+  };
+  using I1 = std::integral_constant<int, 1>; using I4 = std::integral_constant<int, 4>;
+  if (NT == 4) { if (bias) rows(I4{}, std::true_type{}); else rows(I4{}, std::false_type{}); }
+  else { if (bias) rows(I1{}, std::true_type{}); else rows(I1{}, std::false_type{}); }
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt)
     if (nt < NT) {
