@@ -348,6 +348,13 @@ __device__ __forceinline__ void tile_mfma(f32x16& a0, f32x16& a1, const uint4 ah
     RNERF_PIN();
     a1 = mfma16<PP::F16>(ah, b.l1, a1);
     work.template chunk<4, PI>();
+  } else if constexpr (PP::NP == 2 && PASSES == 22) {      // (W_hi + W_lo) * x_hi: the operand is a single 16-bit part
+    a0 = mfma16<PP::F16>(al, b.h0, a0);
+    work.template chunk<2, PI>();
+    work.template chunk<3, PI>();
+    RNERF_PIN();
+    a1 = mfma16<PP::F16>(al, b.h1, a1);
+    work.template chunk<4, PI>();
   } else {
     work.template chunk<2, PI>();
     work.template chunk<3, PI>();
@@ -743,10 +750,11 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
 //   (half 0: slot 0 = d raw_sigma, slots 1..3 = d raw_rgb).
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int DY_L9 = 144, DY_HEADS = 152, DY_SLOTS = 153;
-// dgrad MFMA passes per product: 2 = (dY_hi + dY_lo) * W_hi, i.e. fp32-grade gradients times bf16-rounded weights (the wgrad
-// operands are bf16-rounded anyway: measured worst gradient error 6.8e-3 of the tensor maximum vs 5.1e-3 with 3 passes, 2.2 -> 1.9 ms)
+// dgrad MFMA passes per product: 22 = (W_hi + W_lo) * dY_hi, i.e. exact weights times bf16-rounded gradients — the same rounding the
+// wgrad applies to dY anyway (measured worst gradient error 6.0e-3 of the tensor maximum; 3 passes: 5.1e-3 at +0.3 ms;
+// 2 = (dY_hi + dY_lo) * W_hi: 6.8e-3 at the same speed)
 #ifndef RNERF_DGRAD_PASSES
-#define RNERF_DGRAD_PASSES 2
+#define RNERF_DGRAD_PASSES 22
 #endif
 constexpr int DGRAD_PASSES = RNERF_DGRAD_PASSES;
 constexpr int kBwdBlocks = 8 * 8 + 8 * 16 * 8;   // (k-steps over n) x (8 input-feature tiles): L9 then L8..L1
@@ -783,6 +791,7 @@ __global__ void nerfmlp_pack_bwd_kernel(const float* __restrict__ params, char* 
 // into bf16 hi/lo, computed pair by pair in the shadow of the current k-step's MFMAs.
 template <int PREC, int S>
 struct GradConv {
+  static constexpr bool NEED_LO = DGRAD_PASSES != 22 && DGRAD_PASSES != 1;   // is the lo part of the gradient operand consumed?
   const f32x16& p0;   // m-tile 0 state (accumulator registers of the previous dgrad layer)
   float v1[8];        // m-tile 1 state (from LDS)
   float wv[8];        // w_sigma of these 8 features (0 unless this is the layer that receives d sigma)
@@ -807,11 +816,14 @@ struct GradConv {
     } else if constexpr (C == 2) {
       hi[mt][p] = pack2<false>(x0, x1);
     } else if constexpr (C == 3) {
-      float ha, hb;
-      unpack2<false>(hi[mt][p], ha, hb);
-      x0 -= ha; x1 -= hb;
+      if constexpr (NEED_LO) {
+        float ha, hb;
+        unpack2<false>(hi[mt][p], ha, hb);
+        x0 -= ha; x1 -= hb;
+      }
     } else {
-      lo[mt][p] = pack2<false>(x0, x1);
+      if constexpr (NEED_LO) lo[mt][p] = pack2<false>(x0, x1);
+      else lo[mt][p] = 0;
     }
   }
   __device__ __forceinline__ KOps result() const {
