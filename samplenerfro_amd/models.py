@@ -98,6 +98,8 @@ class NerfModel:
         self.use_random_choice = bool(use_random_choice)
         self.use_online_sparsity, self.use_fine_sparsity = bool(use_online_sparsity), bool(use_fine_sparsity)
         self.precision = PRECISIONS[precision]
+        self.coarse_step_size = (self.far - self.near) / self.num_coarse_samples         # rnerf/models.py:133-134
+        self.fine_step_size = (self.far - self.near) / (self.num_coarse_samples + self.num_fine_samples)
         self.num_samples = self.num_coarse_samples * self.num_path_samples               # rnerf/models.py:121
         self.step_size = (self.far - self.near) / (self.num_samples - 1)                 # :122
         self.spec = Grid.make(self.ndim, self.nmin, self.nmax)
@@ -350,6 +352,45 @@ class NerfModel:
                                                           self.rgb_padding)
             return out
         return ops.bkgd_forward(self._flat(variables, "bkgd_mlp", BKGD_MLP_SHAPES).detach(), viewdirs, self.rgb_padding)
+
+
+    # ---- auxiliary entry points (rnerf/models.py:142-218), forward only -------------------------------------------------------
+    def _point_query(self, variables, mlp: str, pts: torch.Tensor, viewdirs: torch.Tensor):
+        """PE + NerfMLP on free-standing points: pts [..., 3], viewdirs [..., 3] (broadcast against pts) -> raw [n, 4]."""
+        p = pts.reshape(-1, 3)
+        v = viewdirs.expand(*pts.shape[:-1], 3).reshape(-1, 3) if viewdirs.shape != pts.shape else viewdirs.reshape(-1, 3)
+        n = p.shape[0]
+        z = torch.zeros((n, 1), dtype=torch.float32, device=p.device)
+        pd = torch.cat([p.float(), z], -1).reshape(1, n, 4).contiguous()
+        dr = torch.cat([v.float(), z], -1).reshape(1, n, 4).contiguous()
+        return ops.nerfmlp_forward(self._packed_weights(variables, mlp), self.precision, pd, dr, None, 1, n).reshape(n, 4)
+
+    def sample_points(self, variables, pts: torch.Tensor, viewdirs: torch.Tensor):
+        """rnerf/models.py:193-218 (used by extract_mesh.py:243): colour and per-step alpha of the fine (or coarse) field at points."""
+        fine = self.num_fine_samples > 0
+        raw = self._point_query(variables, "fine_mlp" if fine else "coarse_mlp", pts, viewdirs)
+        step = self.fine_step_size if fine else self.coarse_step_size
+        rgb = torch.sigmoid(raw[:, :3]) * (1 + 2 * self.rgb_padding) - self.rgb_padding
+        sigma = torch.nn.functional.softplus(raw[:, 3:4] + self.sigma_bias)
+        alpha = 1 - torch.exp(-step * sigma)
+        return rgb.reshape(*pts.shape[:-1], 3), alpha.reshape(*pts.shape[:-1], 1)
+
+    def compute_sparsity_loss(self, variables, ray_pos: torch.Tensor, coarse_alpha_target, fine_alpha_target):
+        """rnerf/models.py:142-179 (train.py:116, the offline sparsity term): view direction zero, alpha vs a running target."""
+        zero_dir = torch.zeros_like(ray_pos)
+
+        def alpha_of(mlp, step):
+            raw = self._point_query(variables, mlp, ray_pos, zero_dir)
+            return 1 - torch.exp(-step * torch.nn.functional.softplus(raw[:, 3] + self.sigma_bias))
+
+        alpha = alpha_of("coarse_mlp", self.coarse_step_size)
+        loss_sp = (alpha - coarse_alpha_target).abs().mean()
+        next_c, next_f = alpha.mean(), 0.0
+        if self.num_fine_samples > 0 and self.use_fine_sparsity:
+            alpha = alpha_of("fine_mlp", self.fine_step_size)
+            loss_sp = loss_sp + (alpha - fine_alpha_target).abs().mean()
+            next_f = alpha.mean()
+        return loss_sp, next_c, next_f
 
 
 class PathHandle:
