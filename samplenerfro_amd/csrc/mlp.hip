@@ -1055,120 +1055,100 @@ struct WgradTable {
 
 // One job shape (KT k-tiles of X, KSd k-steps = ceil(KSd/2) n-tiles of dY) is a compile-time instance: with run-time shapes the
 // compiler guards every load with a branch and a vmcnt(0), which serialises the 32 loads of a chunk (measured: 21 us per chunk).
-#ifndef RNERF_WG_ABL
-#define RNERF_WG_ABL 0     // profiling ablations (results are garbage): 1 = no accumulate phase, 2 = operands fetched once, 3 = no transposition
-#endif
+// Workgroup = 8 waves = 2 per SIMD (<= 256 registers each): waves 0..3 fetch + transpose the X slots of row groups 0..3, waves
+// 4..7 the dY slots; in the accumulate phase wave w owns k-tile w (all n-tiles).  One wave's load waits / packing VALU overlap the
+// partner wave's MFMAs, and the prefetch registers per wave halve (the 4-wave form with 2 k-tiles per wave took 1.92 ms, this 1.42).
 template <bool X_F16, int KT, int KSd>
 __device__ __forceinline__ void wgrad_body(const uint4* __restrict__ saved, const uint4* __restrict__ dy, long long R, long long total_rows,
-                                           int n_chunks, float* __restrict__ pg, float* __restrict__ pbias, int qx, int qd, int g, int G,
-                                           char* smem) {
-  constexpr int NT = (KSd + 1) / 2, KI = (KT + 3) / 4, BI = (NT + 3) / 4;
+                                            int n_chunks, float* __restrict__ pg, float* __restrict__ pbias, int qx, int qd, int g, int G,
+                                            char* smem) {
+  constexpr int NT = (KSd + 1) / 2;
+  constexpr int NOP = 2 * (KT > NT ? KT : NT);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, rw = wave & 3;
   const int m = lane & 31, h = lane >> 5;
-  uint4* myT = (uint4*)(smem + wave * 32768) + lane;       // slot*64: X^T fragments 0..15, dY^T fragments 16..31
+  uint4* myT = (uint4*)(smem + rw * 32768) + lane + (grp ? 16 * 64 : 0);   // slot*64: X^T fragments 0..15, dY^T fragments 16..31
   const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  const uint4 ixl = shifted_identity<X_F16>(lane, 0), ixh = shifted_identity<X_F16>(lane, 1);
-  const uint4 idl = shifted_identity<false>(lane, 0), idh = shifted_identity<false>(lane, 1);
+  const uint4 il = grp ? shifted_identity<false>(lane, 0) : shifted_identity<X_F16>(lane, 0);
+  const uint4 ih = grp ? shifted_identity<false>(lane, 1) : shifted_identity<X_F16>(lane, 1);
   const uint32_t one2 = (m == 0) ? 0x3F803F80u : 0u;
-  const uint4 ones = make_uint4(one2, one2, one2, one2);      // A operand whose row 0 is all ones: D[0][n] = sum over rows
+  const uint4 ones = make_uint4(one2, one2, one2, one2);
   const uint4 z4 = make_uint4(0, 0, 0, 0);
-  f32x16 acc[KI][NT], accb[BI];
+  f32x16 acc[NT], accb = zero;
 #pragma unroll
-  for (int a = 0; a < KI; ++a)
-#pragma unroll
-    for (int b = 0; b < NT; ++b) acc[a][b] = zero;
-#pragma unroll
-  for (int b = 0; b < BI; ++b) accb[b] = zero;
-
-  // register double buffer: the next chunk's operands are in flight while the current one is accumulated
-  uint4 xr[2 * KT], dr[2 * NT];
+  for (int b = 0; b < NT; ++b) acc[b] = zero;
+  uint4 opr[NOP];
   auto load_chunk = [&](int chunk) {
-    const size_t row2 = ((size_t)chunk * 128 + wave * 32 + m) * 2 + h;
+    const size_t row2 = ((size_t)chunk * 128 + rw * 32 + m) * 2 + h;
+    if (grp == 0) {
 #pragma unroll
-    for (int t = 0; t < 2 * KT; ++t) xr[t] = stream_load(saved + (size_t)(qx + t) * R * 2 + row2);
+      for (int t = 0; t < 2 * KT; ++t) opr[t] = stream_load(saved + (size_t)(qx + t) * R * 2 + row2);
+    } else {
 #pragma unroll
-    for (int t = 0; t < 2 * NT; ++t) dr[t] = t < KSd ? stream_load(dy + (size_t)(qd + t) * R * 2 + row2) : z4;
+      for (int t = 0; t < 2 * NT; ++t) opr[t] = t < KSd ? stream_load(dy + (size_t)(qd + t) * R * 2 + row2) : z4;
+    }
   };
   if (g < n_chunks) load_chunk(g);
   for (int chunk = g; chunk < n_chunks; chunk += G) {
-    const bool ok = (long long)chunk * 128 + wave * 32 + m < total_rows;
-    // ---- transpose this wave's 32 rows
+    const bool ok = (long long)chunk * 128 + rw * 32 + m < total_rows;
+    if (grp == 0) {
 #pragma unroll
-    for (int t = 0; t < (RNERF_WG_ABL == 3 ? 0 : KT); ++t) {
-      f32x16 d = mfma16<X_F16>(xr[2 * t], ixl, zero);
-      d = mfma16<X_F16>(xr[2 * t + 1], ixh, d);
-      uint4 u0, u1;
-      pack_rows_bf16(d, u0, u1);
-      myT[(2 * t) * 64] = u0; myT[(2 * t + 1) * 64] = u1;
-    }
+      for (int t = 0; t < KT; ++t) {
+        f32x16 d = mfma16<X_F16>(opr[2 * t], il, zero);
+        d = mfma16<X_F16>(opr[2 * t + 1], ih, d);
+        uint4 u0, u1;
+        pack_rows_bf16(d, u0, u1);
+        myT[(2 * t) * 64] = u0; myT[(2 * t + 1) * 64] = u1;
+      }
+    } else {
 #pragma unroll
-    for (int t = 0; t < (RNERF_WG_ABL == 3 ? 0 : NT); ++t) {
-      const uint4 a0 = ok ? dr[2 * t] : z4, a1 = ok ? dr[2 * t + 1] : z4;   // padded rows carry replayed data: they must not contribute
-      f32x16 d = mfma16<false>(a0, idl, zero);
-      d = mfma16<false>(a1, idh, d);
-      uint4 u0, u1;
-      pack_rows_bf16(d, u0, u1);
-      myT[(16 + 2 * t) * 64] = u0; myT[(16 + 2 * t + 1) * 64] = u1;
+      for (int t = 0; t < NT; ++t) {
+        const uint4 a0 = ok ? opr[2 * t] : z4, a1 = ok ? opr[2 * t + 1] : z4;   // padded rows carry replayed data: they must not contribute
+        f32x16 d = mfma16<false>(a0, il, zero);
+        d = mfma16<false>(a1, ih, d);
+        uint4 u0, u1;
+        pack_rows_bf16(d, u0, u1);
+        myT[(2 * t) * 64] = u0; myT[(2 * t + 1) * 64] = u1;
+      }
     }
     __syncthreads();
-#if RNERF_WG_ABL != 2
     if (chunk + G < n_chunks) load_chunk(chunk + G);
-#endif
-    // ---- accumulate this wave's dW tiles (k-tiles wave, wave+4; all n-tiles) over the 4 x 32 rows
+    if (wave < KT || wave < NT) {
 #pragma unroll 1
-    for (int v = 0; v < (RNERF_WG_ABL == 1 ? 0 : 4); ++v) {
-      const uint4* T = (const uint4*)(smem + v * 32768) + lane;
+      for (int v = 0; v < 4; ++v) {
+        const uint4* T = (const uint4*)(smem + v * 32768) + lane;
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        uint4 b[NT];
+        for (int u = 0; u < 2; ++u) {
+          if (wave < KT) {
+            const uint4 a = T[(2 * wave + u) * 64];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) b[nt] = T[(16 + 2 * nt + u) * 64];
-#pragma unroll
-        for (int ki = 0; ki < KI; ++ki) {
-          const int kt = wave + 4 * ki;
-          if (kt < KT) {
-            const uint4 a = T[(2 * kt + u) * 64];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[ki][nt] = mfma16<false>(a, b[nt], acc[ki][nt]);
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma16<false>(a, T[(16 + 2 * nt + u) * 64], acc[nt]);
           }
-        }
-#pragma unroll
-        for (int bi = 0; bi < BI; ++bi) {                    // bias sums: n-tile wave + 4*bi
-#pragma unroll
-          for (int q = 0; q < NT; ++q) if (q == wave + 4 * bi) accb[bi] = mfma16<false>(ones, b[q], accb[bi]);
+          if (wave < NT) accb = mfma16<false>(ones, T[(16 + 2 * wave + u) * 64], accb);
         }
       }
     }
     __syncthreads();
   }
-  // ---- per-workgroup partials: partial[KT*32][NT*32], partial_bias[NT*32]
   constexpr size_t ldn = (size_t)NT * 32;
+  if (wave < KT) {
 #pragma unroll
-  for (int ki = 0; ki < KI; ++ki) {
-    const int kt = wave + 4 * ki;
-    if (kt < KT) {
+    for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
-          pg[(size_t)(kt * 32 + i) * ldn + nt * 32 + m] = acc[ki][nt][r];
-        }
+      for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+        pg[(size_t)(wave * 32 + i) * ldn + nt * 32 + m] = acc[nt][r];
       }
     }
   }
-#pragma unroll
-  for (int bi = 0; bi < BI; ++bi) {
-    const int nt = wave + 4 * bi;
-    if (nt < NT && h == 0) pbias[nt * 32 + m] = accb[bi][0];
-  }
+  if (wave < NT && h == 0) pbias[wave * 32 + m] = accb[0];
 }
 
 template <bool X_F16>
-__global__ void __launch_bounds__(256, 1)
+__global__ void __launch_bounds__(512)
 nerfmlp_wgrad_kernel(const uint4* __restrict__ saved, const uint4* __restrict__ dy, long long R, long long total_rows, int n_chunks,
-                     float* __restrict__ workspace, const WgradTable tab) {
+                      float* __restrict__ workspace, const WgradTable tab) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int j = 0;
   while ((int)blockIdx.x >= tab.wg0[j + 1]) ++j;
@@ -1179,12 +1159,7 @@ nerfmlp_wgrad_kernel(const uint4* __restrict__ saved, const uint4* __restrict__ 
   float* pb = workspace + tab.pboff[j] + (size_t)g * NT * 32;
 #define RNERF_WGRAD_CASE(KT_, KSD_)                                                                                                 \
   if (KSx == 2 * (KT_) && KSd == (KSD_)) { wgrad_body<X_F16, KT_, KSD_>(saved, dy, R, total_rows, n_chunks, pg, pb, qx, qd, g, G, smem); return; }
-  RNERF_WGRAD_CASE(8, 16)      // hidden layer -> hidden layer
-  RNERF_WGRAD_CASE(2, 16)      // position encoding -> Dense_0 / Dense_5
-  RNERF_WGRAD_CASE(8, 1)       // -> sigma head
-  RNERF_WGRAD_CASE(8, 8)       // bottleneck -> view layer
-  RNERF_WGRAD_CASE(1, 8)       // view encoding -> view layer
-  RNERF_WGRAD_CASE(4, 1)       // view layer -> rgb head
+  RNERF_WGRAD_CASE(8, 16) RNERF_WGRAD_CASE(2, 16) RNERF_WGRAD_CASE(8, 1) RNERF_WGRAD_CASE(8, 8) RNERF_WGRAD_CASE(1, 8) RNERF_WGRAD_CASE(4, 1)
 #undef RNERF_WGRAD_CASE
   __builtin_trap();
 }
@@ -1936,10 +1911,10 @@ extern "C" int rnerf_nerfmlp_wgrad(int fwd_precision, const void* save, const vo
   const int n_chunks = (int)((rows + 127) / 128);
   hipStream_t st = (hipStream_t)stream;
   if (fwd_precision == RNERF_PREC_F16X3)
-    hipLaunchKernelGGL(nerfmlp_wgrad_kernel<true>, dim3(tab.wg0[tab.n]), dim3(256), 131072, st, (const uint4*)save, (const uint4*)dy, R,
+    hipLaunchKernelGGL(nerfmlp_wgrad_kernel<true>, dim3(tab.wg0[tab.n]), dim3(512), 131072, st, (const uint4*)save, (const uint4*)dy, R,
                        (long long)rows, n_chunks, (float*)workspace, tab);
   else
-    hipLaunchKernelGGL(nerfmlp_wgrad_kernel<false>, dim3(tab.wg0[tab.n]), dim3(256), 131072, st, (const uint4*)save, (const uint4*)dy, R,
+    hipLaunchKernelGGL(nerfmlp_wgrad_kernel<false>, dim3(tab.wg0[tab.n]), dim3(512), 131072, st, (const uint4*)save, (const uint4*)dy, R,
                        (long long)rows, n_chunks, (float*)workspace, tab);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(256, tab.n), dim3(256), 0, st, (const float*)workspace, tab, grads);
   RNERF_CHECK_LAUNCH();
