@@ -218,6 +218,14 @@ __device__ __forceinline__ void issue_slab(const char* __restrict__ gsrc, unsign
 }
 
 // B operands of one k-step for the wave's two 32-row m-tiles
+// min(u16, 1) of both halves of a dword = the non-zero flags of two non-negative 16-bit floats.  Written as the instruction:
+// hipcc expands __builtin_elementwise_min(u16x2, {1,1}) into ~20 SDWA compares / scalar mask ops per dword.
+__device__ __forceinline__ uint32_t pk_min1(uint32_t w) {
+  uint32_t r;
+  asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(w), "v"(0x00010001u));
+  return r;
+}
+
 struct KOps { uint4 h0, l0, h1, l1; };
 
 // streaming accesses of the training tensors (written once, read once by a later kernel): keep them out of the L2 working set
@@ -296,11 +304,9 @@ struct PrevConv {
     } else {
       if constexpr (PP::NP == 2) lo[mt][p] = pack2<PP::F16>(x0, x1);
       else lo[mt][p] = 0;
-      if constexpr (MASK) {   // post-ReLU values are non-negative: min(u16, 1) is the non-zero flag of each half
-        typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-        const u16x2 one = {1, 1};
-        nz[mt] |= __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, hi[mt][p]), one)) << p;
-      }
+#ifndef RNERF_FWD_NOMASK
+      if constexpr (MASK) nz[mt] |= pk_min1(hi[mt][p]) << p;   // post-ReLU values are non-negative: min(u16, 1) = non-zero flag of each half
+#endif
     }
   }
   __device__ __forceinline__ KOps result() const {
@@ -417,10 +423,7 @@ constexpr int SAVE_PE = 0, SAVE_L1 = 4, SAVE_VIEW = 148, SAVE_RGBIN = 150, SAVE_
 
 // non-zero flags of the 8 post-ReLU (non-negative) 16-bit values of one operand: bits 0..3 = even elements, 16..19 = odd elements
 __device__ __forceinline__ uint32_t nz_nibbles(const uint4& o) {
-  typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-  const u16x2 one = {1, 1};
-  auto f = [&](uint32_t w) -> uint32_t { return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, w), one)); };
-  return f(o.x) | (f(o.y) << 1) | (f(o.z) << 2) | (f(o.w) << 3);
+  return pk_min1(o.x) | (pk_min1(o.y) << 1) | (pk_min1(o.z) << 2) | (pk_min1(o.w) << 3);
 }
 __device__ __forceinline__ uint32_t nz_byte(uint32_t nib) { return (nib & 0xFu) | (nib >> 12); }   // even flags | odd flags << 4
 
@@ -473,14 +476,19 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
     const long long srow0 = (long long)tile * 256 + wave * 64 + m;
     auto save_ops = [&](int q, const KOps& o) {
       if constexpr (TRAIN) {
+#ifndef RNERF_FWD_NOSAVE      /* profiling ablation */
         uint4* dst = save + ((size_t)q * save_rows + srow0) * 2 + h;
         stream_store(dst, o.h0);
         stream_store(dst + 64, o.h1);          // m-tile 1 = rows + 32
+#endif
       }
     };
 
     uint32_t mw0 = 0, mw1 = 0;                                                // mask bytes of up to 4 k-steps, then one dword store
     auto save_mask = [&](int set, int s, uint32_t nib0, uint32_t nib1) {      // nib: nz_nibbles() of the hi operands of k-step s
+#ifdef RNERF_FWD_NOMASK
+      return;
+#endif
       if constexpr (TRAIN) {
         if ((s & 3) == 0) { mw0 = nz_byte(nib0); mw1 = nz_byte(nib1); }
         else { mw0 |= nz_byte(nib0) << (8 * (s & 3)); mw1 |= nz_byte(nib1) << (8 * (s & 3)); }
