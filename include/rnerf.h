@@ -141,6 +141,17 @@ int rnerf_resample(const float* path_pd, const float* path_dr, int32_t num_nodes
  * key: HOST uint32[2]; u: device float[num_fine][B] (the layout rnerf_resample takes with u_per_ray = 1). */
 int rnerf_stratified_u(const uint32_t* key, int32_t B, int32_t num_fine, float* u, void* stream);
 
+/* ---- the voxeliser.  Replaces voxelize_mesh.py:54-106 (pysdf point-in-mesh in a Python loop over G^3 voxels):
+ * out[i][j][k] = mean over the K^3 sub-samples c + linspace(-1,1,K)^3 * pitch of (inside ? ior_inside : ior_outside), x slowest.
+ * verts: device double[V][3]; faces: device int32[F][3]; bin_start int32[num_bins^2 + 1] / bin_tris: CSR lists of the triangles
+ * overlapping each cell of a num_bins x num_bins grid over the xy plane (cell index bx * num_bins + by), built by the host;
+ * bin_origin_size: HOST double[4] = (x0, y0, cell size x, cell size y).  Inside = odd number of surface crossings along +z
+ * (top-left rule on shared edges, fp64).  count: device int32[G^3] scratch; overflow: device int32[1], non-zero if a column met
+ * more than 96 crossings (result then invalid). */
+int rnerf_voxelize(const double* verts, const int32_t* faces, const int32_t* bin_start, const int32_t* bin_tris, int32_t num_bins,
+                   const double* bin_origin_size, const rnerf_grid* g, int32_t num_samples, double ior_inside, double ior_outside,
+                   int32_t* count, float* out, int32_t* overflow, void* stream);
+
 /* ---- G4 + P2: VoxMLP.__call__ (rnerf/ior_utils.py:269-312, shipped gin: annealed, use_residual, use_direct_output):
  * (n, grad n) by trilinear lookup and pred_grad = grad n rotated (Rodrigues) by the axis-angle so3_mlp(annealed_pos_enc(x)).
  * so3_params: device float[RNERF_SO3MLP_PARAMS] (flax order); window10: HOST float[10] = cosine_easing_window(0, 9, 10,

@@ -551,3 +551,46 @@ def generate_rays(camtoworld, h, w, focal=None, cam_mat=None, pixel_center=True)
     origins = np.broadcast_to(c2w[None, None, :3, -1], directions.shape).astype(F32)
     viewdirs = directions / np.sqrt(_seqsum(directions * directions, axis=-1, keepdims=True))
     return origins, directions.astype(F32), viewdirs.astype(F32)
+
+
+# ----------------------------------------------------------------------------
+# voxeliser                       (voxelize_mesh.py:54-106)
+# ----------------------------------------------------------------------------
+def mesh_contains(verts, faces, pts):
+    """Point-in-mesh by crossing parity along +z (fp64, top-left rule on shared edges).  Stands in for pysdf's SDF.contains
+    (voxelize_mesh.py:55-66), which is not available offline; identical away from the surface itself."""
+    v = np.asarray(verts, np.float64)[np.asarray(faces)]               # [F,3,3]
+    A, B, C = v[:, 0], v[:, 1], v[:, 2]
+    area = (B[:, 0] - A[:, 0]) * (C[:, 1] - A[:, 1]) - (B[:, 1] - A[:, 1]) * (C[:, 0] - A[:, 0])
+    sgn = np.where(area > 0, 1.0, -1.0)
+    pts = np.asarray(pts, np.float64)
+    inside = np.zeros(len(pts), bool)
+    for n, (x, y, z) in enumerate(pts):
+        def edge(P, Q):
+            e = ((Q[:, 0] - P[:, 0]) * (y - P[:, 1]) - (Q[:, 1] - P[:, 1]) * (x - P[:, 0])) * sgn
+            dx, dy = (Q[:, 0] - P[:, 0]) * sgn, (Q[:, 1] - P[:, 1]) * sgn
+            return e, (e > 0) | ((e == 0) & ((dy > 0) | ((dy == 0) & (dx < 0))))
+        eab, ab = edge(A, B); ebc, bc = edge(B, C); eca, ca = edge(C, A)
+        hit = ab & bc & ca & (area != 0)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            zc = (ebc * A[:, 2] + eca * B[:, 2] + eab * C[:, 2]) / (eab + ebc + eca)
+        inside[n] = (np.count_nonzero(hit & (zc > z)) & 1) == 1
+    return inside
+
+
+def voxelize(verts, faces, num_voxels, nmin, nmax, num_samples=4, ior_inside=1.33, ior_outside=1.0):
+    """voxelize_mesh.py:70-106 with the containment test above. -> float64 [G,G,G], x slowest."""
+    G, K = num_voxels, num_samples
+    nmin = np.asarray(nmin, np.float64); nmax = np.asarray(nmax, np.float64)
+    lin = np.linspace(0, 1, G)
+    off1 = np.linspace(-1, 1, K)
+    offset = np.stack(np.meshgrid(off1, off1, off1, indexing="ij"), -1).reshape(-1, 3)
+    offset_scale = (2 * (nmax - nmin))[None] / (G - 1) * 0.5
+    out = np.zeros((G, G, G))
+    for i in range(G):
+        for j in range(G):
+            for k in range(G):
+                c = np.array([lin[i], lin[j], lin[k]]) * (nmax - nmin) + nmin
+                ior = np.where(mesh_contains(verts, faces, c[None] + offset * offset_scale), ior_inside, ior_outside)
+                out[i, j, k] = np.mean(ior)
+    return out
