@@ -292,9 +292,10 @@ struct PrevConv {
     } else if constexpr (C == 3) {
       if constexpr (PP::NP == 2) {
         if constexpr (PP::F16) {   // x - (float)hi as one v_fma_mix_f32 per value (exact: the residual is representable)
-          const half2v hv = __builtin_bit_cast(half2v, hi[mt][p]);
-          x0 = __builtin_fmaf((float)hv[0], -1.0f, x0);
-          x1 = __builtin_fmaf((float)hv[1], -1.0f, x1);
+          // written as the instruction: hipcc lowers fmaf((float)half, -1, x) to v_cvt_f32_f16 + v_add_f32 (2 ops per value)
+          const uint32_t hw = hi[mt][p];
+          asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(x0) : "v"(hw));
+          asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(x1) : "v"(hw));
         } else {
           float ha, hb;
           unpack2<false>(hi[mt][p], ha, hb);
