@@ -819,9 +819,13 @@ struct GradConv {
       x0 = fmaf(mt == 0 ? gw0 : gw1, wv[2 * p], r0);
       x1 = fmaf(mt == 0 ? gw0 : gw1, wv[2 * p + 1], r1);
     } else if constexpr (C == 1) {
-      const uint32_t w = mt == 0 ? w0 : w1;
-      x0 = (w & bit0) ? x0 : 0.f;
-      x1 = (w & bit1) ? x1 : 0.f;
+      const uint32_t w = mt == 0 ? w0 : w1;      // v_bfe_i32 spreads the flag into a 0 / ~0 word, v_and applies it: 2 ops per value
+      constexpr int pos0 = 8 * (S & 3) + p, pos1 = pos0 + 4;
+      uint32_t m0, m1;                           // (asm: hipcc rewrites the builtin form back into v_and + v_cmp + v_cndmask)
+      asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m0) : "v"(w), "n"(pos0));
+      asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m1) : "v"(w), "n"(pos1));
+      x0 = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, x0) & m0);
+      x1 = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, x1) & m1);
     } else if constexpr (C == 2) {
       hi[mt][p] = pack2<false>(x0, x1);
     } else if constexpr (C == 3) {
