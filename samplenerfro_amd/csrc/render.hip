@@ -314,13 +314,14 @@ __global__ void __launch_bounds__(64) composite_bwd_kernel(const float4* __restr
 }
 
 // Resampling = two kernels.
-//  (1) resample_depths_kernel, one lane per ray: sorted_piecewise_constant_pdf + jnp.sort(concat(coarse, fine)).
+//  (1) resample_depths_kernel, four lanes per ray: sorted_piecewise_constant_pdf + jnp.sort(concat(coarse, fine)).
 //        bins  = mids of the S coarse depths (S-1 values), weights = w[1..S-2] (S-2 values)         models.py:371-374
 //        cdf   = [0, min(1, cumsum(pdf[:-1])), 1]  (S-1 values)                                      model_utils.py:335-340
 //        i*(u) = #(cdf <= u) - 1 ; sample = bins[i*] + clip((u-cdf[i*])/(cdf[i*+1]-cdf[i*]),0,1)*(bins[i*+1]-bins[i*])
 //      u must be non-decreasing along the sample axis of each ray (true for both branches at :345-356), which makes the
 //      samples non-decreasing, so the sort (:405) is a two-way merge of two sorted sequences.  The ray's coarse depths
-//      and weights are first staged into LDS with independent (pipelined) loads; the serial walk then runs out of LDS.
+//      and weights are staged in LDS; the two prefix chains run in index order through quad broadcasts, the inverse-CDF
+//      lookups and the merge ranks are binary searches (independent per element).
 //  (2) resample_gather_kernel, one lane per (sample, ray): searchsorted(z_vals, z, 'left') into the N node depths
 //      (:415-421) from an arithmetic guess + gallop + bisection (node depths are near + ~k*step), then the gather
 //      pos = path_pos[idx] + dir[idx]*(z - z_vals[idx]) (:423-427).  Neighbouring lanes = neighbouring rays at the same
@@ -329,60 +330,85 @@ __global__ void __launch_bounds__(64) resample_depths_kernel(const float4* __res
                                                              const int* __restrict__ jitter, int S,
                                                              const float* __restrict__ weights, const float* __restrict__ u,
                                                              int u_per_ray, int F, float* __restrict__ zbuf) {
-  extern __shared__ float lds[];                 // [2][S][64]: coarse depths, coarse weights
-  const int lane = threadIdx.x;
-  const int r0 = blockIdx.x * 64 + lane;
+  // Four lanes (a quad) per ray, 16 rays per wave.  LDS arrays are [index][16 rays] (quad lanes hit consecutive banks):
+  //   tcA[S] coarse depths, wA[S] coarse weights -> pdf terms, cdfA[S-1], zfA[F] fine depths, mgA[S+F] merged depths.
+  // Only two chains are inherently sequential — the weight sum and the cdf prefix sum; both are replayed in index order through
+  // quad broadcasts (same individually rounded additions as a one-lane loop).  The inverse-CDF lookups and the merge of the two
+  // sorted lists are independent per element: binary searches instead of the serial (and lane-divergent) walk.
+  extern __shared__ float lds[];
+  float* tcA = lds; float* wA = tcA + (size_t)S * 16; float* cdfA = wA + (size_t)S * 16; float* zfA = cdfA + (size_t)S * 16;
+  float* mgA = zfA + (size_t)F * 16;
+  const int lane = threadIdx.x, q = lane & 3, rl = lane >> 2;          // rl = ray within the block
+  const int r0 = blockIdx.x * 16 + rl;
   const int r = r0 < B ? r0 : B - 1;
-  float* s_tc = lds + lane;                      // + i*64
-  float* s_w = lds + (size_t)S * 64 + lane;
-  for (int i = 0; i < S; ++i) {
-    s_tc[i * 64] = path_pd[(size_t)jitter[i] * B + r].w;
-    s_w[i * 64] = weights[(size_t)i * B + r];
-  }
-  if (r0 >= B) return;
   const int nb = S - 1;        // number of bin edges / cdf entries
   const int nw = S - 2;        // number of weights
-  // weight_sum, padding (model_utils.py:327-331)
+  for (int i = q; i < S; i += 4) {
+    tcA[i * 16 + rl] = path_pd[(size_t)jitter[i] * B + r].w;
+    wA[i * 16 + rl] = weights[(size_t)i * B + r];
+  }
+  __syncthreads();
+  auto acc4 = [&](float a, float p) -> float {      // (((a + p0) + p1) + p2) + p3
+    return fadd(fadd(fadd(fadd(a, quad_bcast<0>(p)), quad_bcast<1>(p)), quad_bcast<2>(p)), quad_bcast<3>(p));
+  };
+  // weight_sum, padding (model_utils.py:327-331): sequential sum of w[1..S-2]
   float wsum = 0.f;
-  for (int i = 0; i < nw; ++i) wsum = fadd(wsum, s_w[(i + 1) * 64]);
+  for (int j = 0; j < nw; j += 4) {
+    const int i = j + q;
+    wsum = acc4(wsum, i < nw ? wA[(i + 1) * 16 + rl] : 0.f);
+  }
   const float padding = fmaxf(0.f, fsub(1e-5f, wsum));
   const float padw = fdiv(padding, (float)nw);
   wsum = fadd(wsum, padding);
-  auto tc = [&](int i) -> float { return s_tc[i * 64]; };
-  auto cdf_at = [&](int k, float cumsum) -> float { return k == 0 ? 0.f : (k == nb - 1 ? 1.f : fminf(1.f, cumsum)); };
-  // walk state of the inverse CDF: interval i, c0 = cdf[i], c1 = cdf[i+1], cum_n = cumsum(pdf[0..i])
-  int i = 0;
-  float cum_n = fdiv(fadd(s_w[64], padw), wsum);
-  float c0 = 0.f, c1 = cdf_at(1, cum_n);
-  float tca = tc(0), tcb = tc(1), tcc = (nb > 1) ? tc(2) : tcb;
-  float b0 = fmul(0.5f, fadd(tcb, tca));              // mids (models.py:371): .5*(t[1:] + t[:-1])
-  float b1 = (nb > 1) ? fmul(0.5f, fadd(tcc, tcb)) : b0;
-  auto fine_at = [&](int j) -> float {
+  // cdf[0] = 0, cdf[k] = min(1, P_{k-1}) for 1 <= k <= nb-2 with P_m = P_{m-1} + (w[m+1] + padw) / wsum, cdf[nb-1] = 1  (:335-340)
+  float cum = 0.f;
+  for (int j = 0; j < nw; j += 4) {
+    const int m = j + q;
+    const float term = m < nw ? fdiv(fadd(wA[(m + 1) * 16 + rl], padw), wsum) : 0.f;
+    const float t0 = quad_bcast<0>(term), t1 = quad_bcast<1>(term), t2 = quad_bcast<2>(term), t3 = quad_bcast<3>(term);
+    // the serial code starts the running sum AT the first term (no 0 + term), so P_0 is the term itself
+    const float c0 = (j == 0) ? t0 : fadd(cum, t0);
+    const float c1 = fadd(c0, t1), c2 = fadd(c1, t2), c3 = fadd(c2, t3);
+    const float mine = q == 0 ? c0 : (q == 1 ? c1 : (q == 2 ? c2 : c3));
+    if (m + 1 <= nb - 2) cdfA[(m + 1) * 16 + rl] = fminf(1.f, mine);
+    cum = c3;
+  }
+  if (q == 0) { cdfA[rl] = 0.f; cdfA[(nb - 1) * 16 + rl] = 1.f; }
+  __syncthreads();
+  // fine depths: interval i = #{k in [1, nb-2] : cdf[k] <= u} (the walk of :360-370), then the affine map inside it (:372-373)
+  for (int j = q; j < F; j += 4) {
     const float uj = u_per_ray ? u[(size_t)j * B + r] : u[j];
-    while (c1 <= uj && i < nb - 2) {                  // advance to the last entry with cdf <= u
-      ++i;
-      c0 = c1;
-      if (i + 1 < nb - 1) cum_n = fadd(cum_n, fdiv(fadd(s_w[(i + 1) * 64], padw), wsum));
-      c1 = cdf_at(i + 1, cum_n);
-      tca = tcb; tcb = tcc; tcc = (i + 2 < S) ? tc(i + 2) : tcc;
-      b0 = b1; b1 = fmul(0.5f, fadd(tcc, tcb));
-    }
+    int lo = 1, hi = nb - 1;                                       // first k in [1, nb-1) with cdf[k] > uj
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (cdfA[mid * 16 + rl] > uj) hi = mid; else lo = mid + 1; }
+    const int i = lo - 1;
+    const float c0 = cdfA[i * 16 + rl], c1 = cdfA[(i + 1) * 16 + rl];
+    const float ta = tcA[i * 16 + rl], tb = tcA[(i + 1) * 16 + rl], tcx = tcA[(i + 2) * 16 + rl];
+    const float b0 = fmul(0.5f, fadd(tb, ta)), b1 = fmul(0.5f, fadd(tcx, tb));     // mids (models.py:371)
     float t = fdiv(fsub(uj, c0), fsub(c1, c0));
     if (t != t) t = 0.f;                              // nan_to_num(., 0): NaN -> 0, inf -> +-FLT_MAX then clip
     t = fminf(fmaxf(t, 0.f), 1.f);
-    return fadd(b0, fmul(t, fsub(b1, b0)));
-  };
-  int ic = 0, jf = 0;
-  float zc = tc(0);
-  float zf = (F > 0) ? fine_at(0) : 0.f;
-  const int total = S + F;
-  for (int q = 0; q < total; ++q) {
-    float z;
-    const bool take_c = (jf >= F) || (ic < S && zc <= zf);
-    if (take_c) { z = zc; ++ic; if (ic < S) zc = tc(ic); }
-    else { z = zf; ++jf; if (jf < F) zf = fine_at(jf); }
-    zbuf[(size_t)q * B + r] = z;
+    zfA[j * 16 + rl] = fadd(b0, fmul(t, fsub(b1, b0)));
   }
+  __syncthreads();
+  // merge of the two sorted lists (jnp.sort of the concatenation, :405; coarse first on ties): rank by binary search
+  for (int i = q; i < S; i += 4) {
+    const float z = tcA[i * 16 + rl];
+    int lo = 0, hi = F;                                            // #{j : zf[j] < z}
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (zfA[mid * 16 + rl] < z) lo = mid + 1; else hi = mid; }
+    mgA[(i + lo) * 16 + rl] = z;
+  }
+  for (int j = q; j < F; j += 4) {
+    const float z = zfA[j * 16 + rl];
+    int lo = 0, hi = S;                                            // #{i : tc[i] <= z}
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (tcA[mid * 16 + rl] <= z) lo = mid + 1; else hi = mid; }
+    mgA[(j + lo) * 16 + rl] = z;
+  }
+  __syncthreads();
+  // coalesced write-out: 16 consecutive rays per 64-byte segment
+  const int total = S + F;
+  const int rr = lane & 15;
+  if (blockIdx.x * 16 + rr < B)
+    for (int p = lane >> 4; p < total; p += 4) zbuf[(size_t)p * B + blockIdx.x * 16 + rr] = mgA[p * 16 + rr];
 }
 
 __global__ void __launch_bounds__(256) resample_gather_kernel(const float4* __restrict__ path_pd, const float4* __restrict__ path_dr,
@@ -459,17 +485,17 @@ extern "C" int rnerf_resample(const float* path_pd, const float* path_dr, int32_
   RNERF_CHECK_ARG(path_pd && path_dr && jitter && weights && rows_pd && rows_dr && scratch, "rnerf_resample: null pointer");
   RNERF_CHECK_ARG(u || num_fine == 0, "rnerf_resample: u must be given (use linspace(0,1-eps,F) for randomized=False)");
   RNERF_CHECK_ARG(S >= 3 && B >= 1 && num_nodes >= 2 && num_fine >= 0, "rnerf_resample: need S >= 3, B >= 1, num_nodes >= 2");
-  RNERF_CHECK_ARG(S <= 320, "rnerf_resample: S > 320 coarse samples do not fit the 160 KiB LDS staging");
+  RNERF_CHECK_ARG(4 * (long long)S + 2 * (long long)num_fine <= 2560, "rnerf_resample: 4*S + 2*num_fine > 2560 does not fit the 160 KiB LDS staging");
   RNERF_CHECK_ARG((((uintptr_t)path_pd | (uintptr_t)path_dr | (uintptr_t)rows_pd | (uintptr_t)rows_dr) & 15) == 0,
                   "rnerf_resample: float4 buffers must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
-  const size_t lds = (size_t)2 * S * 64 * sizeof(float);
+  const size_t lds = ((size_t)4 * S + 2 * (size_t)num_fine) * 16 * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     RNERF_CHECK_HIP(hipFuncSetAttribute((const void*)resample_depths_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
     attr_set = true;
   }
-  hipLaunchKernelGGL(resample_depths_kernel, dim3((B + 63) / 64), dim3(64), lds, st, (const float4*)path_pd, B, jitter, S, weights, u,
+  hipLaunchKernelGGL(resample_depths_kernel, dim3((B + 15) / 16), dim3(64), lds, st, (const float4*)path_pd, B, jitter, S, weights, u,
                      u_per_ray, num_fine, scratch);
   const long long total = (long long)(S + num_fine) * B;
   hipLaunchKernelGGL(resample_gather_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float4*)path_pd,
