@@ -167,7 +167,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pipeline", action="store_true",
                     help="issue the march of step k+1 on a side stream beside step k (default: every step runs its stages in sequence)")
-    ap.add_argument("--frame", action="store_true", help="also time one 800x800 full-frame render (ms/frame, BASELINE metric 2)")
+    ap.add_argument("--no-frame", dest="frame", action="store_false",
+                    help="skip the 800x800 full-frame render (ms/frame, the second part of BASELINE's metric; ~1 s)")
     ap.add_argument("--reserve-cus", type=int, default=32, help="CUs kept free of MLP workgroups for the overlapped march")
     ap.add_argument("--cpu-rays", type=int, default=None, help="rays in the CPU baseline sample (default 8192 forward / 1536 train)")
     ap.add_argument("--mode", choices=["train", "forward"], default="train",
@@ -345,7 +346,7 @@ def main():
     frame = None
     if args.frame:
         # ms/frame @ 800x800 (BASELINE.json metric 2): pinhole rays of the example camera looking at the volume, rendered in
-        # pipelined chunks; each rank renders its own full frame here (the sharded variant is distributed.render_image_sharded)
+        # chunks; each rank renders its own full frame here (the sharded variant is distributed.render_image_sharded)
         from samplenerfro_amd import utils as U
         H = W = 800
         focal = 0.5 * W / np.tan(0.5 * 0.6911112070083618)          # example_data/transforms_train.json camera_angle_x
@@ -354,10 +355,10 @@ def main():
         fr = Rays(o_w, None, v_w, None)
         fn = lambda k0, k1, r, path=None: model.apply(variables, k0, k1, r, False, path=path)
         chunk = 8192 * 4
-        U.render_image(fn, fr, key, False, chunk=chunk, model=model)
+        U.render_image(fn, fr, key, False, chunk=chunk)
         barrier()
         t1 = time.perf_counter()
-        rgb_img, _, _ = U.render_image(fn, fr, key, False, chunk=chunk, model=model)
+        rgb_img, _, _ = U.render_image(fn, fr, key, False, chunk=chunk)
         barrier()
         frame = {"ms_per_frame": 1e3 * D.max_over_ranks(time.perf_counter() - t1, device), "height": H, "width": W, "samples": cfg["S"] + fine,
                  "chunk": chunk, "finite": bool(torch.isfinite(rgb_img).all())}
@@ -365,13 +366,14 @@ def main():
         total_rays = B * args.steps * world
         rows_per_ray = S + (S + fine if fine > 0 else 0)
         line = {
-            "metric": "rays_per_sec", "value": total_rays / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
+            "metric": "rays/sec (train step)" if train else "rays/sec (forward render pass)", "value": total_rays / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32 (MLP on %s MFMA, fp32 accumulate)" % args.precision, "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {'train step (forward + backward + grad all-reduce + Adam)' if train else 'forward render pass'}, "
                                    f"{B} rays/GPU x {S} coarse + {fine} fine samples, "
                                    f"P={cfg['P']} (N={N} eikonal steps), grid {cfg['G']}^3", "rays_per_gpu": B,
-                       "mlp_rows_per_ray": rows_per_ray, "precision": args.precision, "pass": args.mode,
+                       "mlp_rows_per_ray": rows_per_ray, "pass": args.mode,
+                       "precision": args.precision + ": fp32 operands split into 16-bit parts for the MFMAs, fp32 accumulate",
                        "pipeline": ("none" if not args.pipeline else ("march(k+1) on a side stream beside backward(k)" if train
                                                                           else "march(k+1) on a side stream overlaps MLP(k)"))},
             "roofline": {"kernel": "nerfmlp_fwd_kernel", "bound": "mfma", "achieved": mlp_achieved / 1e12, "peak": PEAK_MFMA_16BIT / 1e12,
