@@ -487,7 +487,7 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
 
     uint32_t mw0 = 0, mw1 = 0;                                                // mask bytes of up to 4 k-steps, then one dword store
     auto save_mask = [&](int set, int s, uint32_t nib0, uint32_t nib1) {      // nib: nz_nibbles() of the hi operands of k-step s
-#ifdef RNERF_FWD_NOMASK
+#ifdef RNERF_FWD_NOMASK       /* profiling ablation */
       return;
 #endif
       if constexpr (TRAIN) {
@@ -881,12 +881,11 @@ nerfmlp_dgrad_kernel(const char* __restrict__ packed_bwd, const float* __restric
     f32x16 acc0[8], acc1[8], prev0[8];
 
     auto dy_store = [&](int q, const KOps& o) {
-#ifdef RNERF_DGRAD_NOSTORE
-      if (g[0].x != 12345.f) return;
-#endif
+#ifndef RNERF_DGRAD_NOSTORE   /* profiling ablation */
       uint4* dst = dy + ((size_t)q * save_rows + srow0) * 2 + h;
       stream_store(dst, o.h0);
       stream_store(dst + 64, o.h1);
+#endif
     };
     // ReLU masks: one uint4 of non-zero flags per (row, half) per layer (SAVE_MASK), fetched one layer ahead
     auto mask_at = [&](int set, uint4& a, uint4& b) {
