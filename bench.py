@@ -165,8 +165,10 @@ def main():
     ap.add_argument("--precision", default="f16x3")
     ap.add_argument("--rays", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--pipeline", action="store_true",
-                    help="issue the march of step k+1 on a side stream beside step k (default: every step runs its stages in sequence)")
+    ap.add_argument("--pipeline", dest="pipeline", action="store_true", default=None,
+                    help="issue the march of step k+1 on a side stream (train: beside the small tail kernels of step k, default ON; "
+                         "forward: beside the MLP on reserved CUs, default OFF)")
+    ap.add_argument("--no-pipeline", dest="pipeline", action="store_false", help="every step runs its stages strictly in sequence")
     ap.add_argument("--no-frame", dest="frame", action="store_false",
                     help="skip the 800x800 full-frame render (ms/frame, the second part of BASELINE's metric; ~1 s)")
     ap.add_argument("--reserve-cus", type=int, default=32, help="CUs kept free of MLP workgroups for the overlapped march")
@@ -174,6 +176,8 @@ def main():
     ap.add_argument("--mode", choices=["train", "forward"], default="train",
                     help="train: the whole optimisation step (BASELINE metric 'rays/sec (train step)'); forward: the render pass only")
     args = ap.parse_args()
+    if args.pipeline is None:
+        args.pipeline = args.mode == "train"
     if args.cpu_rays is None:
         args.cpu_rays = 8192 if args.mode == "forward" else 1536
 
@@ -374,7 +378,7 @@ def main():
                                    f"P={cfg['P']} (N={N} eikonal steps), grid {cfg['G']}^3", "rays_per_gpu": B,
                        "mlp_rows_per_ray": rows_per_ray, "pass": args.mode,
                        "precision": args.precision + ": fp32 operands split into 16-bit parts for the MFMAs, fp32 accumulate",
-                       "pipeline": ("none" if not args.pipeline else ("march(k+1) on a side stream beside backward(k)" if train
+                       "pipeline": ("none" if not args.pipeline else ("march(k+1) on a side stream beside the tail of step k (bkgd backward, Adam)" if train
                                                                           else "march(k+1) on a side stream overlaps MLP(k)"))},
             "roofline": {"kernel": "nerfmlp_fwd_kernel", "bound": "mfma", "achieved": mlp_achieved / 1e12, "peak": PEAK_MFMA_16BIT / 1e12,
                          "unit": "TFLOP/s", "frac": mlp_achieved / PEAK_MFMA_16BIT, "traffic": traffic_of("nerfmlp_fwd_kernel<1, 0, false>"),

@@ -121,8 +121,8 @@ def train_step(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], 
     """One optimisation step (train.py:58-183).  batch: {"rays": Rays of [B,3], "pixels": [B,>=3], "annealed_alpha": float,
     "env_rays": Rays with viewdirs [ps,ps,3] (when bg_smooth_weight > 0)}.  path: an optional NerfModel.prefetch_path handle for
     these rays (the march carries no gradient and does not read the trained parameters, so it may overlap the previous step);
-    next_rays: the rays of the NEXT step — their march is issued on the model's side stream right after this step's forward, so
-    that it runs beside the backward kernels; the handle is left in state.next_path.  Returns (state, stats, rng); the Stats fields are
+    next_rays: the rays of the NEXT step — their march is issued on the model's side stream after this step's wgrad, so that it
+    runs beside the small kernels of the step's tail; the handle is left in state.next_path.  Returns (state, stats, rng); the Stats fields are
     0-dim device tensors (no host synchronisation inside the step)."""
     flags = state.flags if flags is None else flags           # the reference reads the global FLAGS (train.py:52)
     if not (flags.stage.startswith("radiance")):
@@ -142,7 +142,6 @@ def train_step(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], 
         ctx["env_dirs"] = ev.reshape(-1, 3)
     ret, _loss_sp = model.apply(variables, key_0, key_1, rays, flags.randomized, annealed, jitter=jitter, u_fine=u_fine, ctx=ctx, path=path)
     B = ctx["B"]
-    next_path = model.prefetch_path(next_rays, sync_inputs=True, reserve_cus=0) if next_rays is not None else None
     rgb_f, _, _, trans_f, tb_f = ret[-1]
     rgb_c = ret[0][0] if len(ret) > 1 else None
     sums = ops.loss_reduce(rgb_c, rgb_f, trans_f, tb_f, pixels)
@@ -167,6 +166,10 @@ def train_step(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], 
                                                  sigma_bias=model.sigma_bias, white_bkgd=model.white_bkgd)
     ops.nerfmlp_backward(_bwd_packed(model, state, "coarse_mlp"), model._packed_weights(variables, "coarse_mlp"), prec, ctx["save_c"],
                          d_raw_c, Nc * B, grads=state.grad_view("coarse_mlp"))
+    # The march of the NEXT step (it reads neither the trained parameters nor anything of this step) goes to the side stream here:
+    # it starts when the wgrad above has finished and runs beside the small, latency-bound kernels of the step's tail (background-MLP
+    # backward, loss glue, Adam), which leave most of the chip idle; the big persistent MLP kernels are never shared with it.
+    next_path = model.prefetch_path(next_rays, sync_inputs=True, reserve_cus=0) if next_rays is not None else None
     bk_flat = variables["flat"]["bkgd_mlp"]
     g_bk = state.grad_view("bkgd_mlp")
     # ---- env-map smoothness (train.py:127-132): its rows went through the background MLP together with the rays' rows
