@@ -216,10 +216,11 @@ class NerfModel:
             raise NotImplementedError("prefetch_path: the all* march depends on the so3_mlp parameters; call apply() without a handle")
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.device)
+        if int(reserve_cus) != getattr(self, "_reserved_cus", 0):      # 0 = no limit: the MLP kernels use every CU again
             lib = _lib.load()
-            cus = lib.rnerf_device_cus()
-            if reserve_cus > 0:
-                _lib.check(lib.rnerf_set_mlp_workgroup_limit(max(cus - int(reserve_cus), 1)), "rnerf_set_mlp_workgroup_limit")
+            limit = max(lib.rnerf_device_cus() - int(reserve_cus), 1) if reserve_cus > 0 else 0
+            _lib.check(lib.rnerf_set_mlp_workgroup_limit(limit), "rnerf_set_mlp_workgroup_limit")
+            self._reserved_cus = int(reserve_cus)
         cur = torch.cuda.current_stream()
         if sync_inputs:
             self._side.wait_stream(cur)
