@@ -358,6 +358,7 @@ def main():
         o_w, _, v_w = ops.generate_rays(c2w, H, W, device, focal=focal)                           # rays are generated on the device
         fr = Rays(o_w, None, v_w, None)
         fn = lambda k0, k1, r, path=None: model.apply(variables, k0, k1, r, False, path=path)
+        model.release_reserved_cus()
         chunk = 8192 * 4
         U.render_image(fn, fr, key, False, chunk=chunk)
         barrier()

@@ -231,6 +231,12 @@ class NerfModel:
             ev.record(self._side)
         return PathHandle(pd, dr, ior, ev, rays.origins.shape[0])
 
+    def release_reserved_cus(self) -> None:
+        """Give the CUs reserved by prefetch_path(reserve_cus > 0) back to the MLP kernels."""
+        if getattr(self, "_reserved_cus", 0):
+            _lib.check(_lib.load().rnerf_set_mlp_workgroup_limit(0), "rnerf_set_mlp_workgroup_limit")
+            self._reserved_cus = 0
+
     # ---- forward ------------------------------------------------------------------------------------------------------------
     def apply(self, variables, *args, method=None, **kwargs):
         """flax-style entry: model.apply(variables, rng_0, rng_1, rays, randomized[, annealed_alpha]) or
