@@ -179,6 +179,15 @@ int rnerf_generate_rays(const float* camtoworld, int32_t opencv, double fx, doub
 int rnerf_loss_reduce(const float* rgb_c, const float* rgb_f, const float* trans_f, const float* trans_bkgd_f,
                       const float* pixels, int32_t B, float* sums, void* stream);
 
+/* ---- T1 (scalar tail of loss_fn).  rnerf_env_smooth_backward: the env-map smoothness term of train.py:127-130 on the patch
+ * rgb_env float[ps][ps][3]: d_out float[ps*ps][3] = grad_scale * d mean(0.5 dv^2 + 0.5 dh^2) / d rgb_env; *loss_sum (device) =
+ * the un-normalised sum.  rnerf_train_stats: utils.Stats scalars (train.py:147-162) into stats8 (device float[8], zeroed by the
+ * caller): [0] loss, [1] loss_c, [2] loss_bg, [3] loss_bg_smooth, [4] weight_l2 = (sum theta^2 + frozen_sq) / n_all, [6] psnr,
+ * [7] psnr_c; sums = rnerf_loss_reduce's output. */
+int rnerf_env_smooth_backward(const float* rgb_env, int32_t ps, double grad_scale, float* d_out, float* loss_sum, void* stream);
+int rnerf_train_stats(const float* sums, int32_t B, int32_t two_levels, double bg_on, const float* env_loss_sum, int32_t ps, double env_on,
+                      const float* theta, int64_t n_theta, double frozen_sq, int64_t n_all, float* stats8, void* stream);
+
 /* ---- T1 (backward of V1 + activations): d loss / d raw of one level, replacing jax.value_and_grad through
  * volumetric_rendering and the rgb/sigma activations (rnerf/model_utils.py:247-309, rnerf/models.py:334-338; train.py:164).
  * rgb: this level's comp_rgb float[B][3]; mse_scale = 2/(3B); bg_scale = bg_weight*1[annealed_alpha>0] for the level

@@ -602,6 +602,75 @@ extern "C" int rnerf_loss_reduce(const float* rgb_c, const float* rgb_f, const f
   return RNERF_OK;
 }
 
+// ---- the scalar tail of loss_fn in two small kernels (instead of ~35 framework elementwise launches per step) ----------------
+// env-map smoothness (train.py:127-130): loss = mean(0.5 dv^2 + 0.5 dh^2) over the [ps-1, ps, 3] / [ps, ps-1, 3] differences of the
+// patch; d_out = scale * d loss / d rgb_env; the un-normalised sum of squares is accumulated into *loss_sum.
+__global__ void __launch_bounds__(256) env_smooth_kernel(const float* __restrict__ x, int ps, float k, float* __restrict__ d_out,
+                                                         float* __restrict__ loss_sum) {
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = ps * ps * 3;
+  float part = 0.f;
+  if (id < n) {
+    const int c = id % 3, j = (id / 3) % ps, i = id / (3 * ps);
+    const float v = x[id];
+    float g = 0.f;
+    if (i > 0) g += v - x[id - 3 * ps];
+    if (i < ps - 1) { const float d = x[id + 3 * ps] - v; g -= d; part += 0.5f * d * d; }
+    if (j > 0) g += v - x[id - 3];
+    if (j < ps - 1) { const float d = x[id + 3] - v; g -= d; part += 0.5f * d * d; }
+    d_out[id] = g * k;
+    (void)c;
+  }
+  for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o);
+  if ((threadIdx.x & 63) == 0 && part != 0.f) atomicAdd(loss_sum, part);
+}
+
+__global__ void __launch_bounds__(256) sumsq_kernel(const float* __restrict__ x, long long n, float* __restrict__ out) {
+  float s = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) s += x[i] * x[i];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+  if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+}
+
+// st[0] loss, st[1] loss_c, st[2] loss_bg, st[3] loss_bg_smooth, st[4] weight_l2, st[6] psnr, st[7] psnr_c (utils.Stats, train.py:147-162)
+__global__ void train_stats_kernel(const float* __restrict__ sums, float inv3B, int two_levels, float bg_on, const float* __restrict__ env_sum,
+                                   float env_scale, float frozen_sq, float inv_n_all, float* __restrict__ st) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const float kp = -4.342944819032518f;                 // -10 / ln 10 (utils.compute_psnr)
+  const float loss = sums[0] * inv3B;
+  st[0] = loss;
+  st[6] = kp * logf(loss);
+  if (two_levels) { const float lc = sums[1] * inv3B; st[1] = lc; st[7] = kp * logf(lc); }
+  st[2] = bg_on * sums[2] / (sums[3] + 1.0f);
+  if (env_sum) st[3] = env_sum[0] * env_scale;
+  st[4] = (st[5] + frozen_sq) * inv_n_all;              // st[5]: sum of squares of the trained parameters (sumsq_kernel)
+  st[5] = 0.f;
+}
+
+extern "C" int rnerf_env_smooth_backward(const float* rgb_env, int32_t ps, double grad_scale, float* d_out, float* loss_sum, void* stream) {
+  RNERF_CHECK_ARG(rgb_env && d_out && loss_sum && ps >= 2, "rnerf_env_smooth_backward: null pointer or ps < 2");
+  hipStream_t st = (hipStream_t)stream;
+  RNERF_CHECK_HIP(hipMemsetAsync(loss_sum, 0, sizeof(float), st));
+  const int n = ps * ps * 3;
+  const double m = (double)(ps - 1) * ps * 3;
+  hipLaunchKernelGGL(env_smooth_kernel, dim3((n + 255) / 256), dim3(256), 0, st, rgb_env, ps, (float)(grad_scale / m), d_out, loss_sum);
+  RNERF_CHECK_LAUNCH();
+  return RNERF_OK;
+}
+
+extern "C" int rnerf_train_stats(const float* sums, int32_t B, int32_t two_levels, double bg_on, const float* env_loss_sum, int32_t ps,
+                                 double env_on, const float* theta, int64_t n_theta, double frozen_sq, int64_t n_all, float* stats8,
+                                 void* stream) {
+  RNERF_CHECK_ARG(sums && theta && stats8 && B >= 1 && n_theta >= 1 && n_all >= n_theta, "rnerf_train_stats: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(256), dim3(256), 0, st, theta, (long long)n_theta, stats8 + 5);
+  const double m = ps >= 2 ? (double)(ps - 1) * ps * 3 : 1.0;
+  hipLaunchKernelGGL(train_stats_kernel, dim3(1), dim3(64), 0, st, sums, (float)(1.0 / (3.0 * B)), two_levels, (float)bg_on, env_loss_sum,
+                     (float)(env_on / m), (float)frozen_sq, (float)(1.0 / (double)n_all), stats8);
+  RNERF_CHECK_LAUNCH();
+  return RNERF_OK;
+}
+
 extern "C" int rnerf_composite_backward(const float* raw, const float* rows_pd, const float* rows_dr, const int32_t* node_of_sample,
                                         int32_t S, int32_t B, const float* bkgd, double rgb_padding, double sigma_bias,
                                         const float* rgb, const float* pixels, const float* trans, const float* trans_bkgd,

@@ -177,12 +177,13 @@ def loss_reduce(rgb_c: Optional[torch.Tensor], rgb_f: torch.Tensor, trans_f: tor
 
 def composite_backward(raw, rows_pd, rows_dr, node_of_sample, S: int, B: int, bkgd, rgb, pixels, trans=None, trans_bkgd=None,
                        sums=None, mse_scale: float = 0.0, bg_scale: float = 0.0, d_bkgd: Optional[torch.Tensor] = None,
-                       rgb_padding: float = 0.001, sigma_bias: float = -1.0, bd_cut_bbox=None, white_bkgd: bool = False):
+                       rgb_padding: float = 0.001, sigma_bias: float = -1.0, bd_cut_bbox=None, white_bkgd: bool = False,
+                       accumulate_bkgd: Optional[bool] = None):
     """T1: backward of activations + volumetric_rendering for one level. -> d_raw [S,B,4], d_bkgd [B,3] (accumulated if given)."""
     lib = _lib.load()
     dev = raw.device
     d_raw = torch.empty((S, B, 4), dtype=torch.float32, device=dev)
-    acc = d_bkgd is not None
+    acc = (d_bkgd is not None) if accumulate_bkgd is None else bool(accumulate_bkgd)
     if d_bkgd is None:
         d_bkgd = torch.empty((B, 3), dtype=torch.float32, device=dev)
     check(lib.rnerf_composite_backward(ptr(_chk(raw, "raw")), ptr(rows_pd), ptr(rows_dr), ptr(node_of_sample), int(S), int(B),
@@ -324,3 +325,19 @@ def march_all(table: torch.Tensor, spec: Grid, so3_flat: torch.Tensor, origins: 
     check(lib.rnerf_march_all(ptr(table), C.byref(spec), ptr(_chk(so3_flat, "so3_flat")), w.ctypes.data_as(C.c_void_p), ptr(o), ptr(v), B,
                               float(near), float(far), int(num_nodes), ptr(pd), ptr(dr), ptr(ior), current_stream()), "rnerf_march_all")
     return pd, dr, ior
+
+
+def env_smooth_backward(rgb_env: torch.Tensor, ps: int, grad_scale: float, d_out: torch.Tensor, loss_sum: torch.Tensor) -> None:
+    """train.py:127-130: gradient of the env-map smoothness term into d_out [ps*ps,3], un-normalised loss sum into loss_sum[1]."""
+    lib = _lib.load()
+    check(lib.rnerf_env_smooth_backward(ptr(_chk(rgb_env, "rgb_env")), int(ps), float(grad_scale), ptr(_chk(d_out, "d_out")), ptr(loss_sum),
+                                        current_stream()), "rnerf_env_smooth_backward")
+
+
+def train_stats(sums, B: int, two_levels: bool, bg_on: float, env_loss_sum, ps: int, env_on: float, theta, frozen_sq: float, n_all: int,
+                stats8: torch.Tensor) -> None:
+    """utils.Stats scalars of one step (train.py:147-162) into stats8 (device float[8])."""
+    lib = _lib.load()
+    check(lib.rnerf_train_stats(ptr(sums), int(B), int(bool(two_levels)), float(bg_on), ptr(env_loss_sum), int(ps), float(env_on),
+                                ptr(_chk(theta, "theta")), int(theta.numel()), float(frozen_sq), int(n_all), ptr(_chk(stats8, "stats8")),
+                                current_stream()), "rnerf_train_stats")

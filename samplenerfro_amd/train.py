@@ -20,7 +20,6 @@ plain torch arithmetic on that flat buffer: weights and optimiser state stay on 
 """
 from __future__ import annotations
 
-import math
 from typing import Any, Dict, Optional
 
 import numpy as np
@@ -75,6 +74,8 @@ class TrainState:
         count = self.step
         lr = self.lr_fn(count)
         t = count + 1
+        # (seven elementwise launches, ~35 us for 1.25 M parameters; torch._fused_adam_ — a multi-tensor-apply kernel — takes 97 us
+        #  on one big tensor)
         self.mu.mul_(b1).add_(grads, alpha=1 - b1)
         self.nu.mul_(b2).addcmul_(grads, grads, value=1 - b2)
         denom = (self.nu / (1 - b2 ** t)).sqrt_().add_(eps)
@@ -100,20 +101,6 @@ def _bwd_packed(model: NerfModel, state: TrainState, name: str) -> torch.Tensor:
         buf = ops.nerfmlp_pack_bwd(flat, ent[2] if ent is not None else None)
         cache[name] = (flat.data_ptr(), flat._version, buf)
     return cache[name][2]
-
-
-def env_smooth_loss_and_grad(rgb_env: torch.Tensor, scale: float):
-    """train.py:130: mean(0.5*dv^2 + 0.5*dh^2) over the [ps-1, ps, 3] / [ps, ps-1, 3] differences; returns (loss, d loss/d rgb_env * scale)."""
-    ps = rgb_env.shape[0]
-    dv = rgb_env[1:, :] - rgb_env[:-1, :]
-    dh = rgb_env[:, 1:] - rgb_env[:, :-1]
-    m = float((ps - 1) * ps * rgb_env.shape[-1])
-    loss = (0.5 * (dv * dv).sum() + 0.5 * (dh * dh).sum()) / m
-    g = torch.zeros_like(rgb_env)
-    k = scale / m
-    g[1:, :] += dv * k; g[:-1, :] -= dv * k
-    g[:, 1:] += dh * k; g[:, :-1] -= dh * k
-    return loss, g
 
 
 def train_step(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], flags=None, *, jitter=None, u_fine=None,
@@ -151,10 +138,14 @@ def train_step(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], 
     G = state.grads
     G.zero_()
     # ---- backward: last level first ---------------------------------------------------------------------------------------
+    M_env = ctx["rgb_env"].shape[0] if flags.bg_smooth_weight > 0 else 0
+    d_all = torch.empty((B + M_env, 3), dtype=torch.float32, device=pixels.device)     # rows [0,B): rays' bkgd, [B,B+M): env-map patch
+    d_first = d_all[:B]
     if Nf > 0:
         d_raw_f, d_bkgd = ops.composite_backward(ctx["raw_f"], ctx["rows_pd"], ctx["rows_dr"], None, Nc + Nf, B, ctx["bkgd"], rgb_f, pixels,
                                                  trans_f, tb_f, sums, mse_scale, flags.bg_weight * bg_on, rgb_padding=model.rgb_padding,
-                                                 sigma_bias=model.sigma_bias, bd_cut_bbox=ctx.get("bd_cut_bbox"), white_bkgd=model.white_bkgd)
+                                                 sigma_bias=model.sigma_bias, bd_cut_bbox=ctx.get("bd_cut_bbox"), white_bkgd=model.white_bkgd,
+                                                 d_bkgd=d_first, accumulate_bkgd=False)
         ops.nerfmlp_backward(_bwd_packed(model, state, "fine_mlp"), model._packed_weights(variables, "fine_mlp"), prec, ctx["save_f"],
                              d_raw_f, (Nc + Nf) * B, grads=state.grad_view("fine_mlp"))
         d_raw_c, d_bkgd = ops.composite_backward(ctx["raw_c"], ctx["path_pd"], ctx["path_dr"], ctx["jit"], Nc, B, ctx["bkgd"], rgb_c, pixels,
@@ -163,7 +154,7 @@ def train_step(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], 
     else:
         d_raw_c, d_bkgd = ops.composite_backward(ctx["raw_c"], ctx["path_pd"], ctx["path_dr"], ctx["jit"], Nc, B, ctx["bkgd"], rgb_f, pixels,
                                                  trans_f, tb_f, sums, mse_scale, flags.bg_weight * bg_on, rgb_padding=model.rgb_padding,
-                                                 sigma_bias=model.sigma_bias, white_bkgd=model.white_bkgd)
+                                                 sigma_bias=model.sigma_bias, white_bkgd=model.white_bkgd, d_bkgd=d_first, accumulate_bkgd=False)
     ops.nerfmlp_backward(_bwd_packed(model, state, "coarse_mlp"), model._packed_weights(variables, "coarse_mlp"), prec, ctx["save_c"],
                          d_raw_c, Nc * B, grads=state.grad_view("coarse_mlp"))
     # The march of the NEXT step (it reads neither the trained parameters nor anything of this step) goes to the side stream here:
@@ -173,34 +164,24 @@ def train_step(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], 
     bk_flat = variables["flat"]["bkgd_mlp"]
     g_bk = state.grad_view("bkgd_mlp")
     # ---- env-map smoothness (train.py:127-132): its rows went through the background MLP together with the rays' rows
-    loss_bg_smooth = None
+    ps, on, env_sum = 0, 0.0, None
     if flags.bg_smooth_weight > 0:
         ps = batch["env_rays"].viewdirs.shape[0]
         on = 1.0 if annealed > 0 else 0.0
-        loss_bg_smooth, g_env = env_smooth_loss_and_grad(ctx["rgb_env"].reshape(ps, ps, -1), flags.bg_smooth_weight * on)
-        loss_bg_smooth = loss_bg_smooth * on
-        d_bkgd = torch.cat([d_bkgd, g_env.reshape(-1, 3)], 0)
-    ops.bkgd_backward(bk_flat, ctx["save_bkgd"], d_bkgd, g_bk, model.rgb_padding)
-    # ---- weight_l2 over ALL variables, the frozen path_sampler included (train.py:147-153) ----------------------------------
+        env_sum = torch.empty(1, dtype=torch.float32, device=pixels.device)
+        ops.env_smooth_backward(ctx["rgb_env"], ps, flags.bg_smooth_weight * on, d_all[B:], env_sum)
+    ops.bkgd_backward(bk_flat, ctx["save_bkgd"], d_all, g_bk, model.rgb_padding)
+    # ---- weight_l2 over ALL variables, the frozen path_sampler included (train.py:147-153), and the Stats scalars: they ride in the
+    #      tail of the gradient buffer, one all-reduce for both (train.py:166-167)
     n_theta = state.theta.numel()
     if state.frozen_sq is None:
         so3 = variables.get("flat", {}).get("so3_mlp")
-        state.frozen_sq = ((so3 * so3).sum() if so3 is not None else torch.zeros((), device=state.theta.device),
-                           so3.numel() if so3 is not None else 0)
+        state.frozen_sq = (float((so3.double() ** 2).sum()) if so3 is not None else 0.0, so3.numel() if so3 is not None else 0)   # once
     n_all = n_theta + state.frozen_sq[1]
-    weight_l2 = ((state.theta * state.theta).sum() + state.frozen_sq[0]) / n_all
     if flags.weight_decay_mult > 0:
         G[:n_theta].add_(state.theta, alpha=2.0 * flags.weight_decay_mult / n_all)
-    # ---- stats ride in the tail of the gradient buffer: one all-reduce for both (train.py:166-167) ---------------------------
-    # (only device tensors are assigned: `st[i] = python_float` is a synchronising host-to-device copy; G.zero_() cleared the rest)
     st = G[n_theta:]
-    st[0] = sums[0] / (3.0 * B)
-    if rgb_c is not None:
-        st[1] = sums[1] / (3.0 * B)
-    st[2] = bg_on * sums[2] / (sums[3] + 1.0)
-    if loss_bg_smooth is not None:
-        st[3] = loss_bg_smooth
-    st[4] = weight_l2
+    ops.train_stats(sums, B, rgb_c is not None, bg_on, env_sum, ps, on, state.theta, state.frozen_sq[0], n_all, st)
     distributed.allreduce_mean_([G])
     grads = G[:n_theta]
     if flags.grad_max_val > 0:                                                            # train.py:169-172
@@ -211,8 +192,7 @@ def train_step(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], 
     if taps is not None:
         taps.update(grads=grads.clone(), sums=sums, ctx=ctx)
     state.apply_gradients(grads)
-    k = -10.0 / math.log(10.0)
-    stats = Stats(loss=st[0], psnr=k * torch.log(st[0]), loss_c=st[1], psnr_c=(k * torch.log(st[1]) if rgb_c is not None else 0.0),
+    stats = Stats(loss=st[0], psnr=st[6], loss_c=st[1], psnr_c=(st[7] if rgb_c is not None else 0.0),
                   weight_l2=st[4], loss_sp=0.0, loss_nrm=0.0, annealing_rate=annealed, coarse_alpha_target=0.0, fine_alpha_target=0.0,
                   loss_bg=flags.bg_weight * st[2], loss_bg_c=0.0, loss_bg_smooth=st[3])
     state.next_path = next_path
