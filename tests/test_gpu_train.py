@@ -146,3 +146,57 @@ def test_stratified_u_matches_the_host_prng():
     model.num_fine_samples = 11                                    # odd B*F: the padded counter
     u = ops.stratified_u(key, 37, 11, "cuda:0").cpu().numpy()
     assert np.array_equal(u, model.make_u_host(key, 37))
+
+
+def test_loss_trajectory_matches_a_torch_training_loop():
+    """Six optimisation steps (flat N_f = 0, fixed jitter: the sampled rows do not depend on the parameters) against the same loop in
+    torch float64 (autograd + the optax Adam formula): the per-step losses must agree, which also covers the re-packing of the MFMA
+    weight streams after every update."""
+    from samplenerfro_amd.train import train_step
+    from samplenerfro_amd.utils import learning_rate_decay
+    model, state, batch, flags, ev = _setup(0)
+    flags.weight_decay_mult = 0.0
+    state.lr_fn = lambda c: 2e-3
+    rng = np.array([1, 2], np.uint32)
+    jitter = np.arange(0, 32, 4) + 2
+    taps = {}
+    losses = []
+    theta0 = state.theta.cpu().numpy().astype(np.float64)
+    for i in range(6):
+        state, stats, rng = train_step(model, rng, state, batch, flags, jitter=jitter, taps=taps if i == 0 else None)
+        losses.append((float(stats.loss), float(stats.loss_bg), float(stats.loss_bg_smooth)))
+    # ---- reference loop on the rows of step 0
+    ctx = taps["ctx"]
+    B = ctx["B"]
+    jit = ctx["jit"].cpu().long()
+    pd, dr = ctx["path_pd"].cpu()[jit], ctx["path_dr"].cpu()[jit]
+    S = pd.shape[0]
+    pos = pd[..., :3].permute(1, 0, 2).reshape(-1, 3).numpy(); dirs = dr[..., :3].permute(1, 0, 2).reshape(-1, 3).numpy()
+    enc = torch.tensor(R.pos_enc(pos, 0, 10), dtype=torch.float64); venc = torch.tensor(R.pos_enc(dirs, 0, 4), dtype=torch.float64)
+    t = pd[..., 3].permute(1, 0).double(); dirs_t = torch.tensor(dirs, dtype=torch.float64).reshape(B, S, 3)
+    last_dir = torch.tensor(R.pos_enc(ctx["path_dr"].cpu()[int(jit[-1])][:, :3].numpy(), 0, 4), dtype=torch.float64)
+    env_enc = torch.tensor(R.pos_enc(ev.reshape(-1, 3), 0, 4), dtype=torch.float64)
+    pix = batch["pixels"].cpu().double()
+    th = torch.tensor(theta0, dtype=torch.float64, requires_grad=True)
+    seg = state.segments
+    mu = torch.zeros_like(th); nu = torch.zeros_like(th)
+    for i in range(6):
+        bflat = th[seg["bkgd_mlp"][0]:seg["bkgd_mlp"][1]]
+        bk = TR.bkgd_mlp(bflat, last_dir, model.rgb_padding)
+        raw = TR.nerf_mlp(th[seg["coarse_mlp"][0]:seg["coarse_mlp"][1]], enc, venc).reshape(B, S, 4)
+        rgb, sigma = TR.activations(raw, model.rgb_padding, model.sigma_bias)
+        comp, acc, w, trans, tb = TR.volumetric_rendering(rgb, sigma, t, dirs_t, bk)
+        total, parts = TR.radiance_loss([(comp, trans, tb)], pix, flags.bg_weight, batch["annealed_alpha"])
+        envc = TR.bkgd_mlp(bflat, env_enc, model.rgb_padding).reshape(8, 8, 3)
+        smooth = (0.5 * ((envc[1:, :] - envc[:-1, :]) ** 2).reshape(-1) + 0.5 * ((envc[:, 1:] - envc[:, :-1]) ** 2).reshape(-1)).mean()
+        (total + flags.bg_smooth_weight * smooth).backward()
+        want = (float(parts["loss"].detach()), flags.bg_weight * float(parts["loss_bg"].detach()), float(smooth.detach()))
+        assert abs(losses[i][0] - want[0]) < 2e-5 * max(1.0, want[0] / 1e-2), (i, losses[i], want)
+        assert abs(losses[i][1] - want[1]) < 2e-5 and abs(losses[i][2] - want[2]) < 2e-6, (i, losses[i], want)
+        with torch.no_grad():
+            g = th.grad
+            mu = 0.9 * mu + 0.1 * g; nu = 0.999 * nu + 0.001 * g * g
+            k = i + 1
+            th -= 2e-3 * (mu / (1 - 0.9 ** k)) / (torch.sqrt(nu / (1 - 0.999 ** k)) + 1e-8)
+            th.grad = None
+    assert losses[-1][0] < losses[0][0]
