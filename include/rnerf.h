@@ -155,9 +155,11 @@ int rnerf_voxelize(const double* verts, const int32_t* faces, const int32_t* bin
 /* ---- G4 + P2: VoxMLP.__call__ (rnerf/ior_utils.py:269-312, shipped gin: annealed, use_residual, use_direct_output):
  * (n, grad n) by trilinear lookup and pred_grad = grad n rotated (Rodrigues) by the axis-angle so3_mlp(annealed_pos_enc(x)).
  * so3_params: device float[RNERF_SO3MLP_PARAMS] (flax order); window10: HOST float[10] = cosine_easing_window(0, 9, 10,
- * annealed_alpha * 10) (rnerf/model_utils.py:218-233); pts: device float[n][3]; out4: float4[n] = (n, grad n); pred_grad: float[n][3]. */
+ * annealed_alpha * 10) (rnerf/model_utils.py:218-233); pts: device float[n][3]; out4: float4[n] = (n, grad n); pred_grad: float[n][3].
+ * condition (nullable, device float[n][3]): rotate this vector instead of the looked-up gradient = VoxMLP.wrapper_grad_mlp
+ * (rnerf/ior_utils.py:225-267), the building block of E4 compute_normal_loss_and_smooth (rnerf/eikonal_utils.py:84-98). */
 int rnerf_so3_query(const float* table, const rnerf_grid* g, const float* so3_params, const float* window10, const float* pts,
-                    int64_t n, float* out4, float* pred_grad, void* stream);
+                    const float* condition, int64_t n, float* out4, float* pred_grad, void* stream);
 
 /* ---- E1/E2 with stage "all*": the march with grad = where(|grad n| > 1e-3, pred_grad, grad n) (rnerf/eikonal_utils.py:34-39).
  * Outputs as rnerf_march (path_ior nullable). */

@@ -131,11 +131,24 @@ def safe_l2_normalize(x, eps=1e-6):
 # ----------------------------------------------------------------------------
 # E1/E2: eikonal march                       (rnerf/eikonal_utils.py:29-49,100-124)
 # ----------------------------------------------------------------------------
-def vox_mlp_call(table, so3_params, pts, ndim, nmin, nmax, annealed_alpha=1.0, dtype=F32, max_deg_point=10):
+def normal_loss_and_smooth(table, so3_params, ray_pos, idx_grad, ndim, nmin, nmax, annealed_alpha, noise, dtype=F32):
+    """E4: PathSampler.compute_normal_loss_and_smooth (rnerf/eikonal_utils.py:84-98) with the random draw `noise` given explicitly."""
+    x = np.asarray(ray_pos, dtype).reshape(-1, 3); g = np.asarray(idx_grad, dtype).reshape(-1, 3)
+    ndelta = np.array(compute_ndelta(ndim, nmin, nmax), dtype)
+    pred = vox_mlp_call(table, so3_params, x, ndim, nmin, nmax, annealed_alpha, dtype, condition=g)[2]
+    pred_r = vox_mlp_call(table, so3_params, x + np.asarray(noise, dtype).reshape(-1, 3) * ndelta, ndim, nmin, nmax, annealed_alpha, dtype,
+                          condition=g)[2]
+    factor = safe_l2_norm(g)
+    return 0.0, float((np.abs((pred - pred_r) / factor)).sum(-1).mean())
+
+
+def vox_mlp_call(table, so3_params, pts, ndim, nmin, nmax, annealed_alpha=1.0, dtype=F32, max_deg_point=10, condition=None):
     """VoxMLP.__call__ (rnerf/ior_utils.py:269-312) with the shipped gin settings (annealed, use_residual, use_direct_output):
     -> (n [B,1], grad n [B,3], pred_grad [B,3]); pred_grad = grad n rotated by the axis-angle so3_mlp(annealed_pos_enc(x))."""
     ret = linear3(table, pts, ndim, nmin, nmax, dtype)
     n, g = ret[:, :1], ret[:, 1:]
+    if condition is not None:                                               # wrapper_grad_mlp (:225-267) rotates the given vector
+        g = np.asarray(condition, dtype)
     enc = annealed_pos_enc(np.asarray(pts, dtype)[:, None], 0, max_deg_point, dtype(annealed_alpha) * dtype(max_deg_point), dtype)   # :283
     raw = simple_mlp(so3_params, enc)[:, 0]
     theta = safe_l2_norm(raw)                                               # :305-312

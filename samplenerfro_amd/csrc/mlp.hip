@@ -1455,8 +1455,8 @@ __device__ __forceinline__ void so3_rotate(const float (&raw)[3], const float (&
 
 // G4: VoxMLP.__call__ for arbitrary points -> (n, grad n) and pred_grad
 __global__ void __launch_bounds__(64) so3_query_kernel(const float4* __restrict__ table, GridParams gp, const float* __restrict__ params,
-                                                       So3Window win, const float* __restrict__ pts, long long n, float4* __restrict__ out4,
-                                                       float* __restrict__ pred_out) {
+                                                       So3Window win, const float* __restrict__ pts, const float* __restrict__ cond, long long n,
+                                                       float4* __restrict__ out4, float* __restrict__ pred_out) {
   const int lane = threadIdx.x & 63, m = lane & 31, h = lane >> 5;
   long long row = (long long)blockIdx.x * 32 + m;
   const bool ok = row < n;
@@ -1465,7 +1465,8 @@ __global__ void __launch_bounds__(64) so3_query_kernel(const float4* __restrict_
   const float4 c = trilinear(table, gp, px, py, pz, nullptr);
   float raw[3], pred[3];
   so3_eval(params, px, py, pz, win, m, h, raw);
-  const float g[3] = {c.y, c.z, c.w};
+  // wrapper_grad_mlp (ior_utils.py:225-267) rotates a caller-supplied vector; VoxMLP.__call__ (:269-312) the looked-up gradient
+  const float g[3] = {cond ? cond[3 * row] : c.y, cond ? cond[3 * row + 1] : c.z, cond ? cond[3 * row + 2] : c.w};
   so3_rotate(raw, g, pred);
   if (ok && h == 0) { out4[row] = c; pred_out[3 * row] = pred[0]; pred_out[3 * row + 1] = pred[1]; pred_out[3 * row + 2] = pred[2]; }
 }
@@ -1976,7 +1977,7 @@ extern "C" int rnerf_bkgd_backward(const float* params, const void* save, const 
 }
 
 extern "C" int rnerf_so3_query(const float* table, const rnerf_grid* g, const float* so3_params, const float* window10, const float* pts,
-                               int64_t n, float* out4, float* pred_grad, void* stream) {
+                               const float* condition, int64_t n, float* out4, float* pred_grad, void* stream) {
   RNERF_CHECK_ARG(table && g && so3_params && window10 && pts && out4 && pred_grad, "rnerf_so3_query: null pointer");
   RNERF_CHECK_ARG(n >= 1, "rnerf_so3_query: n must be >= 1");
   GridParams gp;
@@ -1984,7 +1985,7 @@ extern "C" int rnerf_so3_query(const float* table, const rnerf_grid* g, const fl
   So3Window w;
   for (int i = 0; i < 10; ++i) w.w[i] = window10[i];
   hipLaunchKernelGGL(so3_query_kernel, dim3((unsigned)((n + 31) / 32)), dim3(64), 0, (hipStream_t)stream, (const float4*)table, gp, so3_params, w,
-                     pts, (long long)n, (float4*)out4, pred_grad);
+                     pts, condition, (long long)n, (float4*)out4, pred_grad);
   RNERF_CHECK_LAUNCH();
   return RNERF_OK;
 }

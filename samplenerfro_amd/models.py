@@ -382,6 +382,21 @@ class NerfModel:
         alpha = 1 - torch.exp(-step * sigma)
         return rgb.reshape(*pts.shape[:-1], 3), alpha.reshape(*pts.shape[:-1], 1)
 
+    def wrapper_compute_normal_loss_and_smooth(self, variables, ray_pos: torch.Tensor, idx_grad: torch.Tensor, annealed_alpha: float = 1.0,
+                                               noise: Optional[torch.Tensor] = None):
+        """E4: PathSampler.compute_normal_loss_and_smooth (rnerf/eikonal_utils.py:84-98; rnerf/models.py:139-140), forward only:
+        (0.0, mean sum_c |so3-rotated(idx_grad) at x - at x + noise * ndelta| / |idx_grad|).  noise [..., 3]: the standard-normal draw
+        scaled by normal_radius_scale = 0.1 (the reference takes it from numpy's global RNG; default: torch.randn * 0.1)."""
+        so3 = self._flat(variables, "so3_mlp", SO3_MLP_SHAPES).detach()
+        x = ray_pos.reshape(-1, 3).float().contiguous(); g = idx_grad.reshape(-1, 3).float().contiguous()
+        if noise is None:
+            noise = 0.1 * torch.randn_like(x)
+        ndelta = torch.tensor([(self.nmax[i] - self.nmin[i]) / (self.ndim[i] - 1.0) for i in range(3)], dtype=torch.float32, device=x.device)
+        _, pred = ops.so3_query(self.table, self.spec, so3, x, annealed_alpha, condition=g)
+        _, pred_r = ops.so3_query(self.table, self.spec, so3, (x + noise.reshape(-1, 3).float() * ndelta).contiguous(), annealed_alpha, condition=g)
+        factor = torch.sqrt(torch.clamp((g * g).sum(-1, keepdim=True), min=1e-6))
+        return 0.0, ((pred - pred_r).abs() / factor).sum(-1, keepdim=True).mean()
+
     def compute_sparsity_loss(self, variables, ray_pos: torch.Tensor, coarse_alpha_target, fine_alpha_target):
         """rnerf/models.py:142-179 (train.py:116, the offline sparsity term): view direction zero, alpha vs a running target."""
         zero_dir = torch.zeros_like(ray_pos)

@@ -299,16 +299,19 @@ def so3_window(annealed_alpha: float, max_deg_point: int = 10):
     return np.ascontiguousarray((f(0.5) * (f(1) + np.cos(f(np.pi) * x + f(np.pi)))).astype(f))
 
 
-def so3_query(table: torch.Tensor, spec: Grid, so3_flat: torch.Tensor, pts: torch.Tensor, annealed_alpha: float = 1.0):
-    """G4 + P2: VoxMLP.__call__ (rnerf/ior_utils.py:269-312). pts [n,3] -> (out [n,4] = (n, grad n), pred_grad [n,3])."""
+def so3_query(table: torch.Tensor, spec: Grid, so3_flat: torch.Tensor, pts: torch.Tensor, annealed_alpha: float = 1.0,
+              condition: Optional[torch.Tensor] = None):
+    """G4 + P2: VoxMLP.__call__ (rnerf/ior_utils.py:269-312). pts [n,3] -> (out [n,4] = (n, grad n), pred_grad [n,3]).
+    condition [n,3]: rotate this vector instead of the looked-up gradient (wrapper_grad_mlp, :225-267)."""
     lib = _lib.load()
     p = _chk(pts, "pts")
     n = p.shape[0]
     out = torch.empty((n, 4), dtype=torch.float32, device=p.device)
     pred = torch.empty((n, 3), dtype=torch.float32, device=p.device)
     w = so3_window(annealed_alpha)
-    check(lib.rnerf_so3_query(ptr(table), C.byref(spec), ptr(_chk(so3_flat, "so3_flat")), w.ctypes.data_as(C.c_void_p), ptr(p), n, ptr(out),
-                              ptr(pred), current_stream()), "rnerf_so3_query")
+    check(lib.rnerf_so3_query(ptr(table), C.byref(spec), ptr(_chk(so3_flat, "so3_flat")), w.ctypes.data_as(C.c_void_p), ptr(p),
+                              ptr(_chk(condition, "condition")) if condition is not None else None, n, ptr(out), ptr(pred), current_stream()),
+          "rnerf_so3_query")
     return out, pred
 
 

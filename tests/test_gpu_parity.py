@@ -507,3 +507,19 @@ def test_sample_points_and_sparsity_loss(scene):
     a_f = 1 - np.exp(-F32(4.0 / 40) * R.sigma_activation(R.nerf_mlp(tree["fine_mlp"], R.pos_enc(pts, 0, 10), R.pos_enc(np.zeros_like(pts), 0, 4))[1], -1.0))
     want = np.abs(a_c - 0.1).mean() + np.abs(a_f - 0.2).mean()
     assert abs(float(loss) - want) < 2e-6 and abs(float(nc) - a_c.mean()) < 2e-6 and abs(float(nf) - a_f.mean()) < 2e-6
+
+
+def test_normal_loss_and_smooth(scene):
+    """E4 (forward): compute_normal_loss_and_smooth with the random draw injected, vs the numpy restatement."""
+    from samplenerfro_amd import models
+    flat, tree = _so3()
+    pf = syn.init_params_flat(2, fine=False)
+    model = models.NerfModel(ndim=scene.ndim, nmin=scene.nmin, nmax=scene.nmax, grid=T(scene.grid), num_coarse_samples=8, num_fine_samples=0,
+                             num_path_samples=4, stage="all")
+    variables = models.make_variables({**{k: T(v) for k, v in pf.items()}, "so3_mlp": T(flat)})
+    rng = np.random.default_rng(12)
+    x = rng.uniform(-1, 1, (40, 1, 3)).astype(F32); g = rng.standard_normal((40, 1, 3)).astype(F32) * 0.3
+    noise = (0.1 * rng.standard_normal((40, 1, 3))).astype(F32)
+    zero, smooth = model.apply(variables, T(x), T(g), 0.7, noise=T(noise), method=model.wrapper_compute_normal_loss_and_smooth)
+    _, want = R.normal_loss_and_smooth(scene.table, tree, x, g, scene.ndim, scene.nmin, scene.nmax, 0.7, noise)
+    assert zero == 0.0 and abs(float(smooth) - want) < 2e-5 * max(1.0, want)
