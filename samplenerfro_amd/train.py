@@ -157,6 +157,10 @@ def train_step(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], 
                                                  sigma_bias=model.sigma_bias, white_bkgd=model.white_bkgd, d_bkgd=d_first, accumulate_bkgd=False)
     ops.nerfmlp_backward(_bwd_packed(model, state, "coarse_mlp"), model._packed_weights(variables, "coarse_mlp"), prec, ctx["save_c"],
                          d_raw_c, Nc * B, grads=state.grad_view("coarse_mlp"))
+    # jax.lax.pmean of the gradients (train.py:166), first part: the NerfMLP segments are final here, their all-reduce (95 % of the
+    # bytes) starts now and runs beside the rest of the step; the background-MLP gradients and the stats follow in a small second one
+    n_big = state.segments["bkgd_mlp"][0]
+    pending = distributed.allreduce_begin(G[:n_big])
     # The march of the NEXT step (it reads neither the trained parameters nor anything of this step) goes to the side stream here:
     # it starts when the wgrad above has finished and runs beside the small, latency-bound kernels of the step's tail (background-MLP
     # backward, loss glue, Adam), which leave most of the chip idle; the big persistent MLP kernels are never shared with it.
@@ -178,12 +182,13 @@ def train_step(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], 
         so3 = variables.get("flat", {}).get("so3_mlp")
         state.frozen_sq = (float((so3.double() ** 2).sum()) if so3 is not None else 0.0, so3.numel() if so3 is not None else 0)   # once
     n_all = n_theta + state.frozen_sq[1]
-    if flags.weight_decay_mult > 0:
-        G[:n_theta].add_(state.theta, alpha=2.0 * flags.weight_decay_mult / n_all)
     st = G[n_theta:]
     ops.train_stats(sums, B, rgb_c is not None, bg_on, env_sum, ps, on, state.theta, state.frozen_sq[0], n_all, st)
-    distributed.allreduce_mean_([G])
+    distributed.allreduce_mean_([G[n_big:]])
+    distributed.allreduce_end_mean_(pending, G[:n_big])
     grads = G[:n_theta]
+    if flags.weight_decay_mult > 0:      # d (weight_decay_mult * weight_l2) / d theta: identical on every rank, so it is added after the mean
+        grads.add_(state.theta, alpha=2.0 * flags.weight_decay_mult / n_all)
     if flags.grad_max_val > 0:                                                            # train.py:169-172
         grads.clamp_(-flags.grad_max_val, flags.grad_max_val)
     if flags.grad_max_norm > 0:                                                           # train.py:174-180

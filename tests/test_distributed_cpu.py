@@ -46,6 +46,12 @@ def _worker(rank, world, port, H, W, tmp):
     assert torch.allclose(a, torch.full((1000,), m)) and torch.allclose(b, torch.arange(7, dtype=torch.float32) * m)
     assert torch.allclose(st, torch.full((13,), (world - 1) / 2.0))
     assert D.max_over_ranks(1.0 + rank) == float(world)
+    # the split form the train step uses: a big part started asynchronously, a small part in between, then the wait
+    big = torch.full((4096,), float(rank + 1)); small = torch.full((9,), float(10 * (rank + 1)))
+    h = D.allreduce_begin(big)
+    D.allreduce_mean_([small])
+    D.allreduce_end_mean_(h, big)
+    assert torch.allclose(big, torch.full((4096,), m)) and torch.allclose(small, torch.full((9,), 10 * m))
     if rank == 0:
         torch.save([t.clone() for t in full], tmp)
     dist.barrier()
