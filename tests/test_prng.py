@@ -1,4 +1,6 @@
-"""Host PRNG (samplenerfro_amd/prng.py): the Threefry-2x32-20 block cipher is pinned by the public Random123 vectors."""
+"""Host PRNG (samplenerfro_amd/prng.py): the Threefry-2x32-20 block cipher is pinned by the public Random123 vectors, the
+key-derivation / bit-stream layout around it by the values JAX itself documents (jax.random module docstring, the "JAX 101:
+pseudo random numbers" tutorial).  `randint`'s range reduction has no published vector and stays pinned only by its statistics."""
 import numpy as np
 
 from samplenerfro_amd import prng
@@ -36,3 +38,16 @@ def test_uniform_range():
     k = prng.PRNGKey(3)
     u = prng.uniform(k, (64, 128), maxval=1 / 128 - np.finfo(np.float32).eps)
     assert u.dtype == np.float32 and u.min() >= 0 and u.max() < 1 / 128
+
+
+def test_published_jax_values():
+    """Outputs printed in JAX's own documentation (jax.random module docstring: `random.uniform(random.PRNGKey(0))` ->
+    0.41845703, `random.split(PRNGKey(0))`; JAX 101 PRNG tutorial: PRNGKey(42) -> new key / subkey).  They pin PRNGKey, the counter
+    layout of split / _random_bits (first half of the counters -> word 0) and the 23-bit mantissa construction of uniform."""
+    k0 = prng.PRNGKey(0)
+    assert k0.tolist() == [0, 0]
+    assert prng.split(k0).tolist() == [[4146024105, 967050713], [2718843009, 1272950319]]
+    assert float(prng.uniform(k0, ())) == float(np.float32(0.41845703))
+    k42 = prng.PRNGKey(42)
+    assert k42.tolist() == [0, 42]
+    assert prng.split(k42).tolist() == [[2465931498, 3679230171], [255383827, 267815257]]
