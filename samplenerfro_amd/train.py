@@ -104,7 +104,7 @@ def _bwd_packed(model: NerfModel, state: TrainState, name: str) -> torch.Tensor:
 
 
 def train_step(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], flags=None, *, jitter=None, u_fine=None,
-               taps: Optional[dict] = None, path=None, next_rays: Optional[Rays] = None):
+               taps: Optional[dict] = None, path=None, next_rays: Optional[Rays] = None, forward_taps: Optional[dict] = None):
     """One optimisation step (train.py:58-183).  batch: {"rays": Rays of [B,3], "pixels": [B,>=3], "annealed_alpha": float,
     "env_rays": Rays with viewdirs [ps,ps,3] (when bg_smooth_weight > 0)}.  path: an optional NerfModel.prefetch_path handle for
     these rays (the march carries no gradient and does not read the trained parameters, so it may overlap the previous step);
@@ -127,7 +127,8 @@ def train_step(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], 
     if flags.bg_smooth_weight > 0:
         ev = batch["env_rays"].viewdirs
         ctx["env_dirs"] = ev.reshape(-1, 3)
-    ret, _loss_sp = model.apply(variables, key_0, key_1, rays, flags.randomized, annealed, jitter=jitter, u_fine=u_fine, ctx=ctx, path=path)
+    ret, _loss_sp = model.apply(variables, key_0, key_1, rays, flags.randomized, annealed, jitter=jitter, u_fine=u_fine, ctx=ctx, path=path,
+                             taps=forward_taps)
     B = ctx["B"]
     rgb_f, _, _, trans_f, tb_f = ret[-1]
     rgb_c = ret[0][0] if len(ret) > 1 else None

@@ -1,0 +1,239 @@
+"""The BASELINE.json configurations restated as seeded test cases, with the oracle evaluation of each (TEST INFRASTRUCTURE).
+
+    example_full   config 1 at its full size: 512 rays of the example_data camera, 64 + 128 samples, P = 12 (N = 768), the 128^3 grid
+                   voxelised from the reference's own example_data/voxelize/mesh_4_128_1.5_1.165.obj, prefilter (3, 1.0)
+    dolphin_train  config 4's shape: one optimisation step, OpenCV pinhole rays, near 0.2 / far 1.2, the dolphin bbox of
+                   voxelize_opencv.sh:16 (off-centre, side 0.4), ri 0.33, prefilter (5, 1.0), 64 + 128, P = 12, randomized resampling,
+                   bg_weight 0.025, bg_smooth_weight 1.0 on a 128 x 128 env-map patch (configs/dolphin.yaml); 512 rays (= 4096 / 8 GPUs)
+    glass_flat     config 5's shape, flat: S = 256, P = 24 (N = 6144 eikonal steps), near 0.2 / far 14, the anisotropic glass bbox of
+                   voxelize_opencv.sh:13, ri 0.33, prefilter (5, 3.0) (configs/glass.{yaml,gin})
+    glass_hier     the shipped glass setting: 64 + 128, P = 24 (N = 1536), bd_cut_dist (configs/glass.gin:13)
+
+`inputs_*()` rebuild the inputs deterministically (numpy PCG64 streams + the committed example_obj.npz); `oracle_*()` evaluate them with
+oracle/ref_np.py (+ oracle/torch_ref.py in float64 for the gradient).  tests/golden/make_golden.py stores the oracle outputs;
+tests/test_golden_configs.py compares the oracle (CPU) and the HIP path (GPU) with the stored numbers.
+
+The dolphin / glass grids are reduced to G = 128 / 96 voxels per axis for these oracle-sized cases (the oracle's 256^3 / 384^3 tables
+take minutes to build on the host); tests/test_gpu_fullsize.py runs the same configurations at G = 256 / 384 through property checks.
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from oracle import ref_np as R                       # noqa: E402
+from samplenerfro_amd import prng, synthetic as syn  # noqa: E402
+
+F32 = np.float32
+SEED = 20200823                                       # train.py:187
+
+# example_data/transforms_train.json (frame r_0): camera_angle_x and the 3x4 camera-to-world matrix
+EXAMPLE_CAMERA_ANGLE_X = 0.6911112070083618
+EXAMPLE_C2W = np.array([[-0.8074861764907837, -0.10379794985055923, -0.5806824564933777, -2.340805768966675],
+                        [-0.5898865461349487, 0.14208734035491943, 0.7948868274688721, 3.2042911052703857],
+                        [0.0, 0.9843968152999878, -0.17596258223056793, -0.7093278169631958]], F32)
+DOLPHIN_BBOX = ([0.205134, 0.211988, 0.170866], [0.605134, 0.611988, 0.570866])            # voxelize_opencv.sh:16
+GLASS_BBOX = ([-1.79102, 0.711703, -1.75], [1.70898, 4.2117, 1.75])                          # voxelize_opencv.sh:13
+
+
+def sha(a) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def load_example_obj():
+    """tests/golden/example_obj.npz: the reference's OBJ (vertices / faces as data) and the per-voxel inside counts the oracle's
+    voxeliser gives for it (G = 128, extent 1.5, 4^3 sub-samples: the numbers in the file name, voxelize_mesh.py:135)."""
+    z = np.load(os.path.join(HERE, "example_obj.npz"))
+    return z["verts"], z["faces"], z["counts"]
+
+
+def example_obj_world(verts, N=128, extent=1.5):
+    """voxelize_mesh.py:134: the OBJ holds marching-cubes vertices (voxel index units) / N - 0.5 -> back to world coordinates."""
+    return ((np.asarray(verts, np.float64) + 0.5) * N / (N - 1)) * 2 * extent - extent
+
+
+def example_grid(counts):
+    """train.py:220-225 with configs/example.gin:9-10: mean IoR from the counts, ri = 0.5 scaling, Gaussian prefilter (3, 1.0)."""
+    data = R.counts_to_ior(counts.astype(np.int32), 4)
+    return R.conv3d_normal(R.scale_ior(data, 0.5).reshape(-1, 1), [128] * 3, 3, 1.0).reshape(128, 128, 128)
+
+
+def _look_at(eye, target, up=(0.0, 0.0, 1.0)):
+    """OpenCV camera-to-world (x right, y down, z forward), float32 [3,4]."""
+    eye = np.asarray(eye, np.float64); fwd = np.asarray(target, np.float64) - eye
+    fwd /= np.linalg.norm(fwd)
+    right = np.cross(fwd, np.asarray(up, np.float64)); right /= np.linalg.norm(right)
+    down = np.cross(fwd, right)
+    return np.concatenate([np.stack([right, down, fwd], 1), eye[:, None]], 1).astype(F32)
+
+
+def _ball_grid(G, nmin, nmax, centre, radius, ri, ksize, ksigma):
+    """A solid ball (supersampling-like one-voxel boundary, raw values in [1, 1.33] like voxelize_mesh.py) -> scaled, prefiltered f32."""
+    ax = [np.linspace(nmin[i], nmax[i], G) for i in range(3)]
+    h = (nmax[0] - nmin[0]) / (G - 1)
+    r = np.sqrt((ax[0][:, None, None] - centre[0]) ** 2 + (ax[1][None, :, None] - centre[1]) ** 2 + (ax[2][None, None, :] - centre[2]) ** 2)
+    raw = 1.0 + 0.33 * np.clip((radius - r) / h + 0.5, 0.0, 1.0)
+    return R.conv3d_normal(R.scale_ior(raw, ri).reshape(-1, 1), [G] * 3, ksize, ksigma).reshape(G, G, G)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+def inputs_example():
+    verts, faces, counts = load_example_obj()
+    grid = example_grid(counts)
+    H = W = 400                                                           # 800 / factor 2 (configs/example.yaml:4)
+    focal = 0.5 * W / np.tan(0.5 * EXAMPLE_CAMERA_ANGLE_X)                # datasets.py:361
+    o, _, v = R.generate_rays(EXAMPLE_C2W, H, W, focal=focal)
+    idx = np.random.default_rng(SEED).choice(H * W, 512, replace=False)   # datasets.py:169-170
+    key = prng.PRNGKey(SEED)
+    k0, _ = prng.split(key)                                               # models.py:232: key, rng_0 = split(rng_0)
+    S, P = 64, 12
+    jitter = (np.arange(0, S * P, P) + prng.randint(k0, (S,), 0, P)).astype(np.int32)        # models.py:240-242
+    return dict(grid=grid.astype(F32), ndim=[128] * 3, nmin=[-1.5] * 3, nmax=[1.5] * 3, origins=o.reshape(-1, 3)[idx].copy(),
+                viewdirs=v.reshape(-1, 3)[idx].copy(), ray_idx=idx, key=key, jitter=jitter, S=S, F=128, P=P, near=2.0, far=6.0,
+                params=syn.init_params_flat(SEED % 1000, fine=True, bias_scale=0.05))
+
+
+def oracle_example(c):
+    table = R.build_table(c["grid"], c["ndim"], c["nmin"], c["nmax"])
+    cfg = R.ModelConfig(c["ndim"], c["nmin"], c["nmax"], near=c["near"], far=c["far"], num_coarse_samples=c["S"], num_fine_samples=c["F"],
+                        num_path_samples=c["P"])
+    taps = {}
+    ret, _ = R.nerf_forward(cfg, syn.params_tree(c["params"]), table, c["origins"], c["viewdirs"], c["jitter"], taps=taps)
+    out = _levels(ret)
+    out.update(jitter=c["jitter"], ray_idx_probe=c["ray_idx"][:16].astype(np.int64), idx_f=taps["idx_f"].astype(np.int16),
+               ray_pos_sha=sha(taps["ray_pos"]), ray_dist_sha=sha(taps["ray_dist"]), ray_dir_sha=sha(taps["ray_dir"]),
+               ray_pos_sub=taps["ray_pos"][:, ::64].copy(), ray_dist_sub=taps["ray_dist"][:, ::64].copy(), z_f=taps["z_f"])
+    return out
+
+
+def _levels(ret):
+    out = {}
+    for lvl, name in enumerate(("coarse", "fine")[:len(ret)]):
+        rgb, dist, acc, trans, tb = ret[lvl]
+        out.update({f"{name}_rgb": rgb, f"{name}_dist": dist, f"{name}_acc": acc, f"{name}_trans": trans.reshape(-1), f"{name}_trans_bkgd": tb})
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+def inputs_dolphin(B=512, G=128):
+    nmin, nmax = DOLPHIN_BBOX
+    centre = [0.5 * (nmin[i] + nmax[i]) for i in range(3)]
+    grid = _ball_grid(G, nmin, nmax, centre, 0.1, 0.33, 5, 1.0)                            # configs/dolphin.gin:9-10, ri 0.33 (train.py:220)
+    H = W = 96
+    c2w = _look_at([centre[0] + 0.45, centre[1] - 0.5, centre[2] + 0.2], centre)          # pinhole at distance ~0.7 from the object
+    cam = [[140.0, 0.0, 47.3], [0.0, 141.0, 48.9], [0.0, 0.0, 1.0]]
+    o, _, v = R.generate_rays(c2w, H, W, cam_mat=cam)                                      # datasets.py:486-518
+    rng = np.random.default_rng(SEED + 4)
+    idx = rng.choice(H * W, B, replace=False)
+    pixels = rng.uniform(0, 1, (B, 3)).astype(F32)
+    ev = rng.standard_normal((128, 128, 3)).astype(F32)
+    ev = (ev / np.sqrt((ev * ev).sum(-1, keepdims=True))).astype(F32)
+    S, F, P = 64, 128, 12
+    rng_key = prng.PRNGKey(SEED + 4)
+    # train_step: rng, key_0, key_1 = split(rng, 3) (train.py:72); NerfModel.__call__: key, rng_0 = split(rng_0); key, rng_1 = split(rng_1)
+    _, key_0, key_1 = prng.split(rng_key, 3)
+    kj, _ = prng.split(key_0)
+    ku, _ = prng.split(key_1)
+    jitter = (np.arange(0, S * P, P) + prng.randint(kj, (S,), 0, P)).astype(np.int32)
+    eps = float(np.finfo(np.float32).eps)
+    u = (np.arange(F, dtype=F32) * F32(1.0 / F))[None, :] + prng.uniform(ku, (B, F), maxval=1.0 / F - eps)   # model_utils.py:345-354
+    u = np.minimum(u, F32(1.0 - eps)).astype(F32)
+    return dict(grid=grid.astype(F32), ndim=[G] * 3, nmin=list(nmin), nmax=list(nmax), origins=o.reshape(-1, 3)[idx].copy(),
+                viewdirs=v.reshape(-1, 3)[idx].copy(), pixels=pixels, env_dirs=ev, rng=rng_key, jitter=jitter, u=u, S=S, F=F, P=P,
+                near=0.2, far=1.2, bg_weight=0.025, bg_smooth_weight=1.0, annealed_alpha=0.5,
+                params=syn.init_params_flat(41, fine=True, bias_scale=0.05))
+
+
+def oracle_dolphin(c, probes=4096):
+    """One loss_fn evaluation + gradient (train.py:75-164): fp32 oracle for the march / resampling (no gradient there), torch float64
+    autograd for the differentiable part on the sampled rows."""
+    import torch
+    from oracle import torch_ref as TR
+    B, S, F = c["origins"].shape[0], c["S"], c["F"]
+    table = R.build_table(c["grid"], c["ndim"], c["nmin"], c["nmax"])
+    cfg = R.ModelConfig(c["ndim"], c["nmin"], c["nmax"], near=c["near"], far=c["far"], num_coarse_samples=S, num_fine_samples=F,
+                        num_path_samples=c["P"])
+    taps = {}
+    ret, _ = R.nerf_forward(cfg, syn.params_tree(c["params"]), table, c["origins"], c["viewdirs"], c["jitter"], u_fine=c["u"], taps=taps)
+    names = ["coarse_mlp", "fine_mlp", "bkgd_mlp"]
+    th = {k: torch.tensor(c["params"][k], dtype=torch.float64, requires_grad=True) for k in names}
+    f64 = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64)
+    jit = np.asarray(c["jitter"], np.int64)
+
+    def level(name, pos, dirs, t, bk):
+        n = pos.shape[1]
+        raw = TR.nerf_mlp(th[name], f64(R.pos_enc(pos.reshape(-1, 3), 0, 10)), f64(R.pos_enc(dirs.reshape(-1, 3), 0, 4))).reshape(B, n, 4)
+        rgb, sigma = TR.activations(raw)
+        comp, acc, w, trans, tb = TR.volumetric_rendering(rgb, sigma, f64(t), f64(dirs), bk)
+        return comp, trans, tb
+
+    pos_c, dir_c, t_c = taps["ray_pos"][:, jit], taps["ray_dir"][:, jit], taps["ray_dist"][:, jit]
+    bk = TR.bkgd_mlp(th["bkgd_mlp"], f64(R.pos_enc(dir_c[:, -1], 0, 4)))
+    levels = [level("coarse_mlp", pos_c, dir_c, t_c, bk), level("fine_mlp", taps["pos_f"], taps["dir_f"], taps["z_f"], bk)]
+    total, parts = TR.radiance_loss(levels, f64(c["pixels"]), c["bg_weight"], c["annealed_alpha"])
+    env = TR.bkgd_mlp(th["bkgd_mlp"], f64(R.pos_enc(c["env_dirs"].reshape(-1, 3), 0, 4))).reshape(128, 128, 3)
+    smooth = (0.5 * ((env[1:, :] - env[:-1, :]) ** 2).reshape(-1) + 0.5 * ((env[:, 1:] - env[:, :-1]) ** 2).reshape(-1)).mean()   # train.py:127-130
+    (total + c["bg_smooth_weight"] * float(c["annealed_alpha"] > 0) * smooth).backward()
+    out = _levels(ret)
+    out.update(loss=float(parts["loss"]), loss_c=float(parts["loss_c"]), loss_bg=float(parts["loss_bg"]), loss_bg_smooth=float(smooth),
+               jitter=c["jitter"], u_probe=c["u"][:4, :8].copy(), idx_f=taps["idx_f"].astype(np.int16))
+    rng = np.random.default_rng(7)
+    for k in names:
+        g = th[k].grad.numpy()
+        sel = np.sort(rng.choice(g.size, probes, replace=False))
+        out.update({f"grad_{k}_idx": sel.astype(np.int32), f"grad_{k}_val": g[sel], f"grad_{k}_max": np.abs(g).max(), f"grad_{k}_norm": np.linalg.norm(g),
+                    f"grad_{k}_dense_norms": _dense_norms(g, syn.BKGD_MLP_SHAPES if k == "bkgd_mlp" else syn.NERF_MLP_SHAPES)})
+    return out
+
+
+def _dense_norms(g, shapes):
+    """L2 norm of every kernel / bias gradient, flax order: [kernel_0, bias_0, kernel_1, ...]."""
+    res, off = [], 0
+    for i, o in shapes:
+        res += [np.linalg.norm(g[off:off + i * o]), np.linalg.norm(g[off + i * o:off + i * o + o])]
+        off += i * o + o
+    return np.asarray(res)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+def inputs_glass(variant, B=128, G=96):
+    nmin, nmax = GLASS_BBOX
+    centre = [0.5 * (nmin[i] + nmax[i]) for i in range(3)]
+    grid = _ball_grid(G, nmin, nmax, centre, 0.8, 0.33, 5, 3.0)                            # configs/glass.gin:9-10
+    H = W = 64
+    c2w = _look_at([centre[0] + 3.2, centre[1] - 3.4, centre[2] + 1.4], centre)
+    cam = [[70.0, 0.0, 31.6], [0.0, 70.5, 32.2], [0.0, 0.0, 1.0]]
+    o, _, v = R.generate_rays(c2w, H, W, cam_mat=cam)
+    idx = np.random.default_rng(SEED + 5).choice(H * W, B, replace=False)
+    S, F, P = (256, 0, 24) if variant == "flat" else (64, 128, 24)
+    key = prng.PRNGKey(SEED + 5)
+    k0, _ = prng.split(key)
+    jitter = (np.arange(0, S * P, P) + prng.randint(k0, (S,), 0, P)).astype(np.int32)
+    bbox = None
+    if variant == "hier":                                                                  # models.py:496-497: nmax[1] -= 0.7 for glass
+        bbox = list(nmin) + [nmax[0], nmax[1] - 0.7, nmax[2]]
+    return dict(grid=grid.astype(F32), ndim=[G] * 3, nmin=list(nmin), nmax=list(nmax), origins=o.reshape(-1, 3)[idx].copy(),
+                viewdirs=v.reshape(-1, 3)[idx].copy(), key=key, jitter=jitter, S=S, F=F, P=P, near=0.2, far=14.0, bd_cut_bbox=bbox,
+                params=syn.init_params_flat(52, fine=F > 0, bias_scale=0.05))
+
+
+def oracle_glass(c):
+    table = R.build_table(c["grid"], c["ndim"], c["nmin"], c["nmax"])
+    cfg = R.ModelConfig(c["ndim"], c["nmin"], c["nmax"], near=c["near"], far=c["far"], num_coarse_samples=c["S"], num_fine_samples=c["F"],
+                        num_path_samples=c["P"])
+    cfg.bd_cut_bbox = c["bd_cut_bbox"]
+    taps = {}
+    ret, _ = R.nerf_forward(cfg, syn.params_tree(c["params"]), table, c["origins"], c["viewdirs"], c["jitter"], taps=taps)
+    out = _levels(ret)
+    out.update(jitter=c["jitter"], ray_pos_sha=sha(taps["ray_pos"]), ray_dist_sha=sha(taps["ray_dist"]), ray_dir_sha=sha(taps["ray_dir"]),
+               ray_pos_sub=taps["ray_pos"][:, ::256].copy(), n_max=float(taps["idx_data"].max()))
+    if c["F"] > 0:
+        out["idx_f"] = taps["idx_f"].astype(np.int16)
+    return out
+
+
+CASES = {"example_full": (inputs_example, oracle_example), "dolphin_train": (inputs_dolphin, oracle_dolphin),
+         "glass_flat": (lambda: inputs_glass("flat"), oracle_glass), "glass_hier": (lambda: inputs_glass("hier"), oracle_glass)}

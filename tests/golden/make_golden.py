@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Regenerates tests/golden/*.npz.
+"""Regenerates tests/golden/*.npz:  python tests/golden/make_golden.py [small] [obj] [cases | example_full dolphin_train glass_flat glass_hier]
 
 These vectors come from THIS repository's oracle (oracle/ref_np.py), not from the reference implementation: the reference needs
 jax/flax, which cannot be imported offline, and ships no fixtures for the path — parity therefore stays
@@ -54,8 +54,36 @@ def run_oracle(c):
     return out
 
 
+def make_example_obj(ref_obj="/root/reference/example_data/voxelize/mesh_4_128_1.5_1.165.obj"):
+    """example_obj.npz: the one real artefact of the missing example grid that the reference ships (the marching-cubes OBJ written by
+    voxelize_mesh.py:134-135), stored as DATA (vertex / face arrays), plus the oracle voxeliser's per-voxel inside counts for it.
+    Needs the reference checkout (this container only); the GPU box uses the committed file."""
+    from samplenerfro_amd.voxelize import load_obj
+    import cases
+    verts, faces = load_obj(ref_obj)
+    counts = R.voxelize_counts(cases.example_obj_world(verts), faces, 128, [-1.5] * 3, [1.5] * 3, 4)
+    np.savez_compressed(os.path.join(HERE, "example_obj.npz"), verts=verts, faces=faces.astype(np.int32), counts=counts.astype(np.uint8))
+    print("wrote example_obj.npz", verts.shape, faces.shape, "occupied fraction", float((counts > 0).mean()))
+
+
+def make_config_cases(names=None):
+    import cases
+    for name, (make_inputs, run) in cases.CASES.items():
+        if names and name not in names:
+            continue
+        out = run(make_inputs())
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+        print("wrote", name + ".npz", {k: getattr(v, "shape", v) for k, v in list(out.items())[:4]})
+
+
 if __name__ == "__main__":
-    c = small_case()
-    o = run_oracle(c)
-    np.savez_compressed(os.path.join(HERE, "example_small.npz"), **c, **{f"out_{k}": v for k, v in o.items() if k != "table"})
-    print("wrote", os.path.join(HERE, "example_small.npz"))
+    what = sys.argv[1:] or ["small", "obj", "cases"]
+    if "small" in what:
+        c = small_case()
+        o = run_oracle(c)
+        np.savez_compressed(os.path.join(HERE, "example_small.npz"), **c, **{f"out_{k}": v for k, v in o.items() if k != "table"})
+        print("wrote", os.path.join(HERE, "example_small.npz"))
+    if "obj" in what:
+        make_example_obj()
+    if "cases" in what or any(w in ("example_full", "dolphin_train", "glass_flat", "glass_hier") for w in what):
+        make_config_cases([w for w in what if w not in ("small", "obj", "cases")])

@@ -128,3 +128,169 @@ def test_gradient_is_the_mean_of_the_half_batch_gradients():
     err = float((full - halves).abs().max() / full.abs().max())
     print(f"full vs mean-of-halves gradient: cosine {cos:.7f}, max err / max |g| {err:.2e}")
     assert cos > 0.99999 and err < 2e-3
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# BASELINE configs 4 (dolphin) and 5 (glass) at their full sizes.  The oracle cannot march 8192 x 6144 nodes in test time, but rays are
+# independent (test_rays_are_independent): a SAMPLE of the rays of the full-size batch is marched / rendered by the oracle on the very
+# table the device built (384^3 / 256^3), and the full batch must reproduce those rays bit for bit (path) / within 1e-4 (RGB, depth).
+# ---------------------------------------------------------------------------------------------------------------------------------
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+
+
+def _ball_grid_dev(G, nmin, nmax, radius, ri, ksize, ksigma, dev):
+    from samplenerfro_amd import ops
+    ax = [torch.linspace(nmin[i], nmax[i], G, dtype=torch.float64, device=dev) for i in range(3)]
+    c = [0.5 * (nmin[i] + nmax[i]) for i in range(3)]
+    r = torch.sqrt((ax[0][:, None, None] - c[0]) ** 2 + (ax[1][None, :, None] - c[1]) ** 2 + (ax[2][None, None, :] - c[2]) ** 2)
+    h = (nmax[0] - nmin[0]) / (G - 1)
+    raw = 1.0 + 0.33 * torch.clamp((radius - r) / h + 0.5, 0.0, 1.0)
+    del r
+    return ops.grid_prefilter(((raw - 1.0) * ri / 0.33 + 1.0).float(), ksize, ksigma), c
+
+
+def _opencv_frame(c2w, H, W, cam, dev):
+    from samplenerfro_amd import ops
+    o, _, v = ops.generate_rays(c2w, H, W, dev, cam_mat=cam)
+    return o.reshape(-1, 3), v.reshape(-1, 3)
+
+
+def _oracle_sample(model, pf, o, v, jitter, sel, cfg_kw, u=None):
+    """The oracle on rays `sel` of the batch, with the device-built table as its grid input."""
+    from oracle import ref_np as R
+    table = model.table.cpu().numpy().reshape(-1, 4)
+    mc = R.ModelConfig(model.ndim, model.nmin, model.nmax, near=model.near, far=model.far, num_coarse_samples=model.num_coarse_samples,
+                       num_fine_samples=model.num_fine_samples, num_path_samples=model.num_path_samples)
+    for k, val in cfg_kw.items():
+        setattr(mc, k, val)
+    taps = {}
+    ret, _ = R.nerf_forward(mc, syn.params_tree(pf), table, o[sel].cpu().numpy(), v[sel].cpu().numpy(), jitter, u_fine=u, taps=taps)
+    return ret, taps
+
+
+def test_config5_glass_full_size_chunk():
+    """One render_image chunk of config 5: 8192 OpenCV rays, flat S = 256, P = 24 (N = 6144 eikonal steps), G = 384 anisotropic glass bbox,
+    prefilter (5, 3.0).  24 rays of the chunk against the oracle (bit-exact path and voxel walk, RGB / depth 1e-4), the chunk's invariants."""
+    import cases as CS
+    from samplenerfro_amd import models
+    from samplenerfro_amd.utils import Rays
+    dev = torch.device("cuda:0")
+    G, Sg, Pg, Bg = 384, 256, 24, 8192
+    nmin, nmax = CS.GLASS_BBOX
+    grid, c = _ball_grid_dev(G, nmin, nmax, 0.8, 0.33, 5, 3.0, dev)
+    model = models.NerfModel(ndim=[G] * 3, nmin=nmin, nmax=nmax, grid=grid, near=0.2, far=14.0, num_coarse_samples=Sg, num_fine_samples=0,
+                             num_path_samples=Pg, device=dev)
+    del grid
+    pf = syn.init_params_flat(52, fine=False, bias_scale=0.05)
+    variables = models.make_variables({k: torch.from_numpy(val).to(dev) for k, val in pf.items()})
+    o, v = _opencv_frame(CS._look_at([c[0] + 3.2, c[1] - 3.4, c[2] + 1.4], c), 800, 800, [[875.0, 0.0, 399.6], [0.0, 880.0, 400.2], [0.0, 0.0, 1.0]], dev)
+    lo = 400 * 800 - Bg // 2                                             # a chunk around the image centre: its rays cross the object
+    o, v = o[lo:lo + Bg].contiguous(), v[lo:lo + Bg].contiguous()
+    key = np.array([0, 5], np.uint32)
+    taps = {}
+    ret, _ = model.apply(variables, key, key, Rays(o, None, v, None), False, taps=taps)
+    rgb, dist, acc, trans, tb = ret[0]
+    w = taps["weights_c"]
+    assert torch.isfinite(rgb).all() and torch.isfinite(dist).all()
+    assert float((w.sum(0) + trans.reshape(-1) - 1).abs().max()) < 5e-5
+    zn = taps["path_pd"][..., 3]
+    assert zn.shape == (Sg * Pg, Bg) and bool((zn[1:] > zn[:-1]).all())                       # arc length strictly increases
+    assert float(taps["path_ior"][..., 0].max()) > 1.3                                         # the chunk really crosses the glass ball
+    sel = torch.arange(0, Bg, Bg // 24, device=dev)[:24]
+    oret, otaps = _oracle_sample(model, pf, o, v, taps["jitter"], sel, {})
+    sel_c = sel.cpu().numpy()
+    pd = taps["path_pd"][:, sel].cpu().numpy()
+    assert np.array_equal(pd[..., :3].transpose(1, 0, 2), otaps["ray_pos"]) and np.array_equal(pd[..., 3].T, otaps["ray_dist"])
+    assert np.array_equal(taps["path_dr"][:, sel].cpu().numpy()[..., :3].transpose(1, 0, 2), otaps["ray_dir"])
+    for got, want in zip((rgb, dist, acc), oret[0][:3]):
+        assert float(np.abs(got[sel].cpu().numpy() - want).max()) < 1e-4
+    # the same 24 rays rendered alone: bit-identical to their values inside the 8192-ray chunk
+    ret_s, _ = model.apply(variables, key, key, Rays(o[sel].contiguous(), None, v[sel].contiguous(), None), False)
+    for a, b in zip(ret_s[0], ret[0]):
+        assert torch.equal(a, b[sel])
+    assert sel_c.size == 24
+
+
+def _dolphin_world(B, dev):
+    import cases as CS
+    from samplenerfro_amd import models, utils as U
+    from samplenerfro_amd.train import TrainState
+    from samplenerfro_amd.utils import Rays
+    G = 256
+    nmin, nmax = CS.DOLPHIN_BBOX
+    grid, c = _ball_grid_dev(G, nmin, nmax, 0.1, 0.33, 5, 1.0, dev)
+    flags = U.default_flags(num_coarse_samples=64, num_fine_samples=128, num_path_samples=12, white_bkgd=False, bg_weight=0.025, bg_smooth_weight=1.0,
+                            bg_patch_size=128, use_online_sparsity=False, randomized=True, near=0.2, far=1.2, batch_size=B, config="dolphin")
+    model, variables = models.construct_nerf(np.array([0, 4], np.uint32), None, flags, [G] * 3, nmin, nmax, grid)
+    del grid
+    pf = syn.init_params_flat(41, fine=True, bias_scale=0.05)
+    for k in ("coarse_mlp", "fine_mlp", "bkgd_mlp"):
+        variables["flat"][k].copy_(torch.from_numpy(pf[k]).to(dev))
+    o, v = _opencv_frame(CS._look_at([c[0] + 0.45, c[1] - 0.5, c[2] + 0.2], c), 128, 128, [[187.0, 0.0, 63.3], [0.0, 188.0, 64.9], [0.0, 0.0, 1.0]], dev)
+    gen = np.random.default_rng(9)
+    idx = torch.from_numpy(gen.choice(128 * 128, B, replace=False)).to(dev)
+    ev = gen.standard_normal((128, 128, 3)).astype(np.float32)
+    ev /= np.linalg.norm(ev, axis=-1, keepdims=True)
+    batch = {"rays": Rays(o[idx].contiguous(), None, v[idx].contiguous(), None),
+             "pixels": torch.from_numpy(gen.uniform(0, 1, (B, 3)).astype(np.float32)).to(dev), "annealed_alpha": 0.5,
+             "env_rays": Rays(None, None, torch.from_numpy(ev).to(dev), None)}
+    return model, variables, flags, batch, pf
+
+
+@pytest.mark.parametrize("Bd", [4096, 512])
+def test_config4_dolphin_train_step_full_size(Bd):
+    """Config 4 as written: hierarchical 64 + 128 train step, OpenCV rays, near 0.2 / far 1.2, G = 256, the shipped loss terms, at 4096 rays
+    (global batch) and 512 rays (one of 8 GPUs).  Forward of 16 rays and the loss against the oracle; the gradient against a central
+    finite difference of the device loss along the gradient direction (a checksum of the whole backward at full size)."""
+    from samplenerfro_amd.train import TrainState, train_step
+    from samplenerfro_amd.utils import Rays
+    dev = torch.device("cuda:0")
+    model, variables, flags, batch, pf = _dolphin_world(Bd, dev)
+    state = TrainState.create(model, variables, flags)
+    theta0 = state.theta.clone()
+    rng = np.array([4, 4], np.uint32)
+    taps, ftaps = {}, {}
+    state.lr_fn = lambda count: 0.0                                      # keep theta: the step is evaluated three times below
+    _, stats, _ = train_step(model, rng, state, batch, flags, taps=taps, forward_taps=ftaps)
+    g = taps["grads"].double()
+    assert torch.isfinite(g).all() and float(g.abs().max()) > 0
+    # --- forward parity of a ray sample (randomized resampling: u from the device threefry)
+    sel = torch.arange(0, Bd, Bd // 16, device=dev)[:16]
+    u = ftaps["u"][:, sel].T.cpu().numpy()
+    oret, otaps = _oracle_sample(model, pf, batch["rays"].origins, batch["rays"].viewdirs, ftaps["jitter"], sel, {}, u=u)
+    assert np.array_equal(ftaps["idx_f"][:, sel].cpu().numpy().T, otaps["idx_f"])
+    # (the forward outputs of the step are not returned by train_step: evaluate the model again with the same keys)
+    from samplenerfro_amd import prng
+    _, key_0, key_1 = prng.split(rng, 3)
+    ret, _ = model.apply(state.variables, key_0, key_1, batch["rays"], True, 0.5)
+    for lvl in range(2):
+        for got, want in zip(ret[lvl][:3], oret[lvl][:3]):
+            assert float(np.abs(got[sel].cpu().numpy() - want).max()) < 1e-4
+    mse_f = float(((ret[1][0] - batch["pixels"]) ** 2).mean()); mse_c = float(((ret[0][0] - batch["pixels"]) ** 2).mean())
+    assert abs(float(stats.loss) - mse_f) < 1e-6 and abs(float(stats.loss_c) - mse_c) < 1e-6
+    # --- directional finite differences of the device loss.  The resampled fine rows depend on the COARSE parameters only, and that
+    #     dependence carries no gradient (stop_gradient, model_utils.py:406-411), so: (1) along the fine + bkgd part of the gradient the
+    #     total loss is differentiated (rows fixed: jitter and u are functions of the key); (2) along the coarse part only loss_c, the
+    #     one term through which the coarse parameters receive gradient.
+    n_theta = state.theta.numel()
+    lo_c, hi_c = state.segments["coarse_mlp"]
+    gt = g[:n_theta].clone()
+    d1 = gt.clone(); d1[lo_c:hi_c] = 0
+    d2 = torch.zeros_like(gt); d2[lo_c:hi_c] = gt[lo_c:hi_c]
+    eps = 2e-3
+
+    def loss_at(dirn, sign, which):
+        state.theta.copy_(theta0 + (sign * eps * dirn).float())
+        _, st, _ = train_step(model, rng, state, batch, flags)
+        if which == "coarse":
+            return float(st.loss_c.double())
+        return float(st.loss.double() + st.loss_c.double() + st.loss_bg.double() + flags.bg_smooth_weight * st.loss_bg_smooth.double())
+    for dirn, which in ((d1 / d1.norm(), "total"), (d2 / d2.norm(), "coarse")):
+        fd = (loss_at(dirn, +1, which) - loss_at(dirn, -1, which)) / (2 * eps)
+        analytic = float((gt * dirn).sum())
+        print(f"[B={Bd}] d {which} loss along its gradient: analytic {analytic:.6e}, finite difference {fd:.6e}")
+        assert abs(fd - analytic) < 0.03 * abs(analytic) + 1e-5
+    state.theta.copy_(theta0)
