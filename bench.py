@@ -173,6 +173,9 @@ def main():
                     help="skip the 800x800 full-frame render (ms/frame, the second part of BASELINE's metric; ~1 s)")
     ap.add_argument("--reserve-cus", type=int, default=32, help="CUs kept free of MLP workgroups for the overlapped march")
     ap.add_argument("--cpu-rays", type=int, default=None, help="rays in the CPU baseline sample (default 8192 forward / 1536 train)")
+    ap.add_argument("--backward", choices=["f32", "tf32", "bf16"], default="f32",
+                    help="arithmetic of the NerfMLP backward: f32 = hi + lo f16 parts (fp32-grade, the reference differentiates in fp32; "
+                         "default), tf32 = f16 parts (11-bit significand), bf16 = 8-bit significand (round 1's arithmetic)")
     ap.add_argument("--mode", choices=["train", "forward"], default="train",
                     help="train: the whole optimisation step (BASELINE metric 'rays/sec (train step)'); forward: the render pass only")
     args = ap.parse_args()
@@ -218,7 +221,7 @@ def main():
         from samplenerfro_amd.train import TrainState, train_step
         flags = U.default_flags(num_coarse_samples=cfg["S"], num_fine_samples=fine, num_path_samples=cfg["P"], white_bkgd=False,
                                 bg_weight=0.025, bg_smooth_weight=1.0, bg_patch_size=128, use_online_sparsity=False, randomized=True,
-                                near=cfg["near"], far=cfg["far"], batch_size=B * world)
+                                near=cfg["near"], far=cfg["far"], batch_size=B * world, backward_precision=args.backward)
         tstate = TrainState.create(model, variables, flags)
         gen = np.random.default_rng(syn.SEED + 1000 + rank)
         ev_d = gen.standard_normal((flags.bg_patch_size, flags.bg_patch_size, 3)).astype(np.float32)
@@ -291,10 +294,11 @@ def main():
     if train:
         lib = _lib.load()
         rows = S * B
-        pbwd = ops.nerfmlp_pack_bwd(variables["flat"]["coarse_mlp"])
-        raw_t, save_t = ops.nerfmlp_forward_train(packed, model.precision, path_pd, path_dr, jit, S, B)
+        BW = _lib.BACKWARDS[args.backward]
+        pbwd = ops.nerfmlp_pack_bwd(variables["flat"]["coarse_mlp"], None, BW)
+        raw_t, save_t = ops.nerfmlp_forward_train(packed, model.precision, path_pd, path_dr, jit, S, B, BW)
         d_raw = torch.randn((S, B, 4), device=device) * 1e-3
-        dy_t = torch.empty(lib.rnerf_nerfmlp_dy_bytes(rows), dtype=torch.uint8, device=device)
+        dy_t = torch.empty(lib.rnerf_nerfmlp_dy_bytes(rows, BW), dtype=torch.uint8, device=device)
         ws_t = torch.empty(lib.rnerf_nerfmlp_wgrad_workspace_bytes(), dtype=torch.uint8, device=device)
         g_t = torch.empty(_lib.NERFMLP_PARAMS, device=device)
 
@@ -309,11 +313,11 @@ def main():
 
         jp = jit.data_ptr()
         t_f = timed(lambda: lib.rnerf_nerfmlp_forward_train(packed.data_ptr(), model.precision, path_pd.data_ptr(), path_dr.data_ptr(), jp, S, B,
-                                                            raw_t.data_ptr(), save_t.data_ptr(), _lib.current_stream()))
-        t_d = timed(lambda: ops.nerfmlp_backward(pbwd, packed, model.precision, save_t, d_raw, rows, dy=dy_t, stages="d"))
-        t_w = timed(lambda: ops.nerfmlp_backward(pbwd, packed, model.precision, save_t, d_raw, rows, grads=g_t, workspace=ws_t, dy=dy_t, stages="w"))
+                                                            raw_t.data_ptr(), save_t.data_ptr(), BW, _lib.current_stream()))
+        t_d = timed(lambda: ops.nerfmlp_backward(pbwd, packed, model.precision, save_t, d_raw, rows, dy=dy_t, stages="d", backward=BW))
+        t_w = timed(lambda: ops.nerfmlp_backward(pbwd, packed, model.precision, save_t, d_raw, rows, grads=g_t, workspace=ws_t, dy=dy_t, stages="w", backward=BW))
         R_pad = (rows + 255) // 256 * 256
-        wgrad_bytes = (8 * 32 + 2 * 20 + 17 + 24 + 10 + 9) * R_pad * 32        # sum over the 14 jobs of (X slots + dY slots) x R x 32 B
+        wgrad_bytes = (8 * 32 + 2 * 20 + 17 + 24 + 10 + 9) * R_pad * 32 * (2 if args.backward == "f32" else 1)   # sum over the 14 jobs of (X slots + dY slots) x R x 32 B (x 2: hi + lo)
         for name, ms, flop, bound, byt in (("nerfmlp_fwd_kernel<train>", t_f, MLP_FLOP_PER_ROW * rows, "mfma", None),
                                            ("nerfmlp_dgrad_kernel", t_d, 2 * 557696 * rows, "mfma", None),
                                            ("nerfmlp_wgrad_kernel", t_w, MLP_FLOP_PER_ROW * rows, "hbm", wgrad_bytes)):

@@ -47,6 +47,19 @@ enum rnerf_precision {
   RNERF_PREC_BF16 = 4
 };
 
+/* Arithmetic of the NerfMLP backward (dgrad + wgrad).  The reference differentiates in fp32 (train.py:164).
+ *   BF16  : gradients rounded to bf16 (8-bit significand), saved activations rounded to bf16 in the wgrad: 1 MFMA per product.
+ *   F16   : every row's gradient chain is normalised by a power of two m_row ~ max |d raw[row]| (the chain is linear in d raw[row], so
+ *           the normalised values fit f16's range whatever the loss scale); f16 operands (11-bit significand, the class of the TF32
+ *           tensor-core arithmetic XLA uses for fp32 matmuls on the authors' Ampere GPU): 1 MFMA per product, same HBM traffic as BF16.
+ *   F16X2 : as F16 with hi + lo parts of the saved activations and of every gradient (22 bits), 3 MFMAs per product: fp32-grade
+ *           (<= 1e-5 of the largest gradient entry against float64); twice the saved bytes. */
+enum rnerf_backward {
+  RNERF_BWD_BF16 = 0,
+  RNERF_BWD_F16 = 1,
+  RNERF_BWD_F16X2 = 2
+};
+
 /* Voxel grid geometry: reference VoxMLP.ndim/nmin/nmax (rnerf/ior_utils.py:124-144).  Doubles, because the
  * reference derives ndelta = (nmax-nmin)/(ndim-1) in Python doubles before it meets float32 data. */
 typedef struct rnerf_grid {
@@ -206,23 +219,24 @@ int rnerf_composite_backward(const float* raw, const float* rows_pd, const float
                              const double* bd_cut_bbox, void* stream);
 
 /* ---- T1 (backward of P1+N1): gradient of the NerfMLP parameters, replacing jax.value_and_grad through
- * NerfMLP.__call__ (train.py:164; rnerf/model_utils.py:30-90).  Three steps:
- *   rnerf_nerfmlp_forward_train : as rnerf_nerfmlp_forward (precision f16x3 / bf16x3) and additionally keeps the hi-part
- *       operands of every layer in `save` (rnerf_nerfmlp_save_bytes(S*B) bytes);
- *   rnerf_nerfmlp_dgrad : d_raw float4[rows] (d loss / d raw rgb, sigma) -> dy (rnerf_nerfmlp_dy_bytes(rows) bytes), the
- *       gradients w.r.t. every layer's pre-activation output; packed_bwd from rnerf_nerfmlp_pack_bwd (transposed weights);
+ * NerfMLP.__call__ (train.py:164; rnerf/model_utils.py:30-90).  `backward` is an enum rnerf_backward, the same in all calls of a step.
+ *   rnerf_nerfmlp_forward_train : as rnerf_nerfmlp_forward (precision f16x3 only: bf16x3 / f16 / bf16 are inference precisions) and keeps
+ *       the 16-bit operands of every layer in `save` (rnerf_nerfmlp_save_bytes(S*B, backward) bytes; F16X2: hi and lo parts);
+ *   rnerf_nerfmlp_pack_bwd : transposed weight stream of the dgrad chain (rnerf_nerfmlp_bwd_packed_bytes() bytes);
+ *   rnerf_nerfmlp_dgrad : d_raw float4[rows] (d loss / d raw rgb, sigma) -> dy (rnerf_nerfmlp_dy_bytes(rows, backward) bytes), the
+ *       gradients w.r.t. every layer's pre-activation output (F16 modes: normalised per row, + the row scales);
  *   rnerf_nerfmlp_wgrad : (save, dy) -> grads float[RNERF_NERFMLP_PARAMS] in the flat parameter order (every entry is
  *       overwritten); workspace: rnerf_nerfmlp_wgrad_workspace_bytes() bytes. */
-size_t rnerf_nerfmlp_save_bytes(int64_t rows);
-size_t rnerf_nerfmlp_dy_bytes(int64_t rows);
+size_t rnerf_nerfmlp_save_bytes(int64_t rows, int backward);
+size_t rnerf_nerfmlp_dy_bytes(int64_t rows, int backward);
 size_t rnerf_nerfmlp_bwd_packed_bytes(void);
 size_t rnerf_nerfmlp_wgrad_workspace_bytes(void);
 int rnerf_nerfmlp_forward_train(const void* packed, int precision, const float* rows_pd, const float* rows_dr,
-                                const int32_t* node_of_sample, int32_t S, int32_t B, float* out_raw, void* save, void* stream);
-int rnerf_nerfmlp_pack_bwd(const float* params, void* packed_bwd, void* stream);
-int rnerf_nerfmlp_dgrad(const void* packed_bwd, const void* packed_fwd, int fwd_precision, const void* save, const float* d_raw,
+                                const int32_t* node_of_sample, int32_t S, int32_t B, float* out_raw, void* save, int backward, void* stream);
+int rnerf_nerfmlp_pack_bwd(const float* params, int backward, void* packed_bwd, void* stream);
+int rnerf_nerfmlp_dgrad(const void* packed_bwd, const void* packed_fwd, int fwd_precision, int backward, const void* save, const float* d_raw,
                         int64_t rows, void* dy, void* stream);
-int rnerf_nerfmlp_wgrad(int fwd_precision, const void* save, const void* dy, int64_t rows, float* grads, void* workspace,
+int rnerf_nerfmlp_wgrad(int fwd_precision, int backward, const void* save, const void* dy, int64_t rows, float* grads, void* workspace,
                         void* stream);
 
 /* ---- T1 (backward of P1+N2): the background MLP, exact fp32 on the matrix cores like its forward.

@@ -13,6 +13,10 @@ LIB_PATH = os.path.join(HERE, "lib", "librnerf.so")
 
 PREC_F32, PREC_F16X3, PREC_BF16X3, PREC_F16, PREC_BF16 = 0, 1, 2, 3, 4
 PRECISIONS = {"f16x3": PREC_F16X3, "bf16x3": PREC_BF16X3, "f16": PREC_F16, "bf16": PREC_BF16}
+# enum rnerf_backward (include/rnerf.h): arithmetic of the NerfMLP dgrad + wgrad.  "f32" = hi + lo f16 parts (fp32-grade, the reference
+# differentiates in fp32, train.py:164); "tf32" = single f16 parts (11-bit significand); "bf16" = 8-bit significand.
+BWD_BF16, BWD_F16, BWD_F16X2 = 0, 1, 2
+BACKWARDS = {"f32": BWD_F16X2, "tf32": BWD_F16, "bf16": BWD_BF16}
 NERFMLP_PARAMS = 595844
 BKGDMLP_PARAMS = 56963
 SO3MLP_PARAMS = 65411
@@ -58,14 +62,14 @@ SIGNATURES = {
     "rnerf_train_stats": (C.c_int, [_vp, _i32, _i32, _dbl, _vp, _i32, _dbl, _vp, _i64, _dbl, _i64, _vp, _vp]),
     "rnerf_composite_backward": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _dbl, _dbl, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl,
                                            _vp, _vp, C.c_int, C.c_int, C.POINTER(C.c_double * 6), _vp]),
-    "rnerf_nerfmlp_save_bytes": (C.c_size_t, [_i64]),
-    "rnerf_nerfmlp_dy_bytes": (C.c_size_t, [_i64]),
+    "rnerf_nerfmlp_save_bytes": (C.c_size_t, [_i64, C.c_int]),
+    "rnerf_nerfmlp_dy_bytes": (C.c_size_t, [_i64, C.c_int]),
     "rnerf_nerfmlp_bwd_packed_bytes": (C.c_size_t, []),
     "rnerf_nerfmlp_wgrad_workspace_bytes": (C.c_size_t, []),
-    "rnerf_nerfmlp_forward_train": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
-    "rnerf_nerfmlp_pack_bwd": (C.c_int, [_vp, _vp, _vp]),
-    "rnerf_nerfmlp_dgrad": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _i64, _vp, _vp]),
-    "rnerf_nerfmlp_wgrad": (C.c_int, [C.c_int, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "rnerf_nerfmlp_forward_train": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _i32, _i32, _vp, _vp, C.c_int, _vp]),
+    "rnerf_nerfmlp_pack_bwd": (C.c_int, [_vp, C.c_int, _vp, _vp]),
+    "rnerf_nerfmlp_dgrad": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _i64, _vp, _vp]),
+    "rnerf_nerfmlp_wgrad": (C.c_int, [C.c_int, C.c_int, _vp, _vp, _i64, _vp, _vp, _vp]),
     "rnerf_voxelize": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _GP, _i32, _dbl, _dbl, _vp, _vp, _vp, _vp]),
     "rnerf_so3_query": (C.c_int, [_vp, _GP, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "rnerf_march_all": (C.c_int, [_vp, _GP, _vp, _vp, _vp, _vp, _i32, _dbl, _dbl, _i32, _vp, _vp, _vp, _vp]),

@@ -162,7 +162,15 @@ extern "C" int rnerf_grid_query(const float* table, const rnerf_grid* g, const f
 // ------------------------------------------------------------------------------------------------------------------
 namespace rnerf {
 
-struct VoxGrid { int G, K, nb; double mn[3], pitch[3], off[8]; double bin0x, bin0y, inv_bx, inv_by; };
+// Sample coordinates are formed with the reference's own expressions (voxelize_mesh.py:70-97, numpy float64):
+//   grid = linspace(0, 1, G)[i] * (max - min) + min,  sample = grid + linspace(-1, 1, K)[a] * ((2 * (max - min)) / (G - 1) * 0.5)
+// (np.linspace: i * step, the last element set to the end point) so that columns through mesh vertices / edges — the rule for a
+// marching-cubes mesh, whose vertices sit on voxel edges — are classified identically.
+struct VoxGrid { int G, K, nb; double mn[3], span[3], scale[3], step, off[8]; double bin0x, bin0y, inv_bx, inv_by; };
+__device__ __forceinline__ double vox_coord(const VoxGrid& vg, int axis, int i, int a) {
+  const double lin = (i == vg.G - 1) ? 1.0 : i * vg.step;
+  return (lin * vg.span[axis] + vg.mn[axis]) + vg.off[a] * vg.scale[axis];
+}
 
 constexpr int VOX_MAXC = 96;      // crossings kept per column (a column with more is flagged)
 
@@ -174,8 +182,8 @@ __global__ void __launch_bounds__(128) voxel_columns_kernel(const double* __rest
   if (id >= (long long)GK * GK) return;
   const int xi = (int)(id / GK), yi = (int)(id % GK);
   const int i = xi / vg.K, a = xi % vg.K, j = yi / vg.K, b = yi % vg.K;
-  const double x = (vg.mn[0] + i * vg.pitch[0]) + vg.off[a] * vg.pitch[0];
-  const double y = (vg.mn[1] + j * vg.pitch[1]) + vg.off[b] * vg.pitch[1];
+  const double x = vox_coord(vg, 0, i, a);
+  const double y = vox_coord(vg, 1, j, b);
   int bx = (int)floor((x - vg.bin0x) * vg.inv_bx), by = (int)floor((y - vg.bin0y) * vg.inv_by);
   double zc[VOX_MAXC];
   int n = 0;
@@ -208,7 +216,7 @@ __global__ void __launch_bounds__(128) voxel_columns_kernel(const double* __rest
   for (int k = 0; k < vg.G; ++k) {
     int inside = 0;
     for (int c = 0; c < vg.K; ++c) {
-      const double z = (vg.mn[2] + k * vg.pitch[2]) + vg.off[c] * vg.pitch[2];
+      const double z = vox_coord(vg, 2, k, c);
       int lo = 0, hi = n;                                         // first crossing with zc > z
       while (lo < hi) { const int mid = (lo + hi) >> 1; if (zc[mid] > z) hi = mid; else lo = mid + 1; }
       inside += (n - lo) & 1;                                     // odd number of crossings above -> inside
@@ -234,8 +242,13 @@ extern "C" int rnerf_voxelize(const double* verts, const int32_t* faces, const i
   RNERF_CHECK_ARG(num_samples >= 1 && num_samples <= 8 && num_bins >= 1, "rnerf_voxelize: need 1 <= num_samples <= 8, num_bins >= 1");
   VoxGrid vg;
   vg.G = g->dims[0]; vg.K = num_samples; vg.nb = num_bins;
-  for (int i = 0; i < 3; ++i) { vg.mn[i] = g->nmin[i]; vg.pitch[i] = (g->nmax[i] - g->nmin[i]) / (vg.G - 1.0); }
-  for (int a = 0; a < 8; ++a) vg.off[a] = num_samples > 1 ? -1.0 + 2.0 * a / (num_samples - 1.0) : -1.0;    // np.linspace(-1, 1, K)
+  for (int i = 0; i < 3; ++i) {
+    vg.mn[i] = g->nmin[i]; vg.span[i] = g->nmax[i] - g->nmin[i];
+    vg.scale[i] = (2 * (g->nmax[i] - g->nmin[i])) / (vg.G - 1) * 0.5;                                       // voxelize_mesh.py:92
+  }
+  vg.step = 1.0 / (vg.G - 1);                                                                                // np.linspace(0, 1, G)
+  const double ostep = num_samples > 1 ? 2.0 / (num_samples - 1) : 0.0;
+  for (int a = 0; a < 8; ++a) vg.off[a] = a * ostep + -1.0;                                                  // np.linspace(-1, 1, K)
   if (num_samples > 1) vg.off[num_samples - 1] = 1.0;
   vg.bin0x = bin_origin_size[0]; vg.bin0y = bin_origin_size[1]; vg.inv_bx = 1.0 / bin_origin_size[2]; vg.inv_by = 1.0 / bin_origin_size[3];
   hipStream_t st = (hipStream_t)stream;

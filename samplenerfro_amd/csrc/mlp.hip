@@ -428,7 +428,8 @@ __device__ __forceinline__ uint32_t nz_nibbles(const uint4& o) {
 }
 __device__ __forceinline__ uint32_t nz_byte(uint32_t nib) { return (nib & 0xFu) | (nib >> 12); }   // even flags | odd flags << 4
 
-template <int PREC, int dbg, bool TRAIN>
+// TRAIN: 0 = evaluation, 1 = training forward keeping the hi 16-bit operand parts, 2 = hi and lo parts (fp32-grade backward)
+template <int PREC, int dbg, int TRAIN>
 __global__ void __launch_bounds__(256, 1)
 nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ rows_pd, const float4* __restrict__ rows_dr,
                    const int* __restrict__ node_of_sample, int B, long long total_rows, int n_tiles, float4* __restrict__ out_raw,
@@ -476,11 +477,16 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
     // training forward: keep the hi parts of the operands of slot q (see SAVE_* above); padded rows are written too
     const long long srow0 = (long long)tile * 256 + wave * 64 + m;
     auto save_ops = [&](int q, const KOps& o) {
-      if constexpr (TRAIN) {
+      if constexpr (TRAIN != 0) {
 #ifndef RNERF_FWD_NOSAVE      /* profiling ablation */
         uint4* dst = save + ((size_t)q * save_rows + srow0) * 2 + h;
         stream_store(dst, o.h0);
         stream_store(dst + 64, o.h1);          // m-tile 1 = rows + 32
+        if constexpr (TRAIN == 2) {            // lo plane: slots SAVE_TOTAL + q
+          uint4* dl = save + ((size_t)(SAVE_TOTAL + q) * save_rows + srow0) * 2 + h;
+          stream_store(dl, o.l0);
+          stream_store(dl + 64, o.l1);
+        }
 #endif
       }
     };
@@ -490,7 +496,7 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
 #ifdef RNERF_FWD_NOMASK       /* profiling ablation */
       return;
 #endif
-      if constexpr (TRAIN) {
+      if constexpr (TRAIN != 0) {
         if ((s & 3) == 0) { mw0 = nz_byte(nib0); mw1 = nz_byte(nib1); }
         else { mw0 |= nz_byte(nib0) << (8 * (s & 3)); mw1 |= nz_byte(nib1) << (8 * (s & 3)); }
         if ((s & 3) == 3) {      // word-major: a wave's 64 dwords are contiguous (full-line writes)
@@ -611,17 +617,17 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
 #define RNERF_KSTEP(S)                                                                                              \
       {                                                                                                              \
         save_ops(SAVE_L1 + 16 * (l - 1) + S, cur);                                                                   \
-        if constexpr (TRAIN && S == 0) save_mask(l - 1, 0, nz_nibbles(cur.h0), nz_nibbles(cur.h1));                  \
+        if constexpr (TRAIN != 0 && S == 0) save_mask(l - 1, 0, nz_nibbles(cur.h0), nz_nibbles(cur.h1));                  \
         float bnn[8];                                                                                                \
         if constexpr (S + 2 < 16) load_bias8(S + 2, bias, bnn);   /* consumed in the NEXT slab */                     \
         auto dma = [&]() { SLAB_PREFETCH(true); };                                                                   \
         if constexpr (S + 1 < 16) {                                                                                  \
-          PrevConv<PREC, S + 1, TRAIN> cv(prev0[(S + 1) >> 1]);                                                      \
+          PrevConv<PREC, S + 1, TRAIN != 0> cv(prev0[(S + 1) >> 1]);                                                      \
           cv.floor_v = 0.f;                                                                                          \
           _Pragma("unroll") for (int j = 0; j < 8; ++j) cv.b[j] = bnext[j];                                          \
           load_state8(S + 1, cv.v1);                                                                                 \
           if (dbg & 8) { kstep_mfma<PREC, 8, 0, S == 0, NoWork, (dbg & 16) != 0>(acc0, acc1, cur, smem + buf * SLAB, lane, nowork, dma); } \
-          else { if (!(dbg & 2)) kstep_mfma<PREC, 8, 0, S == 0, PrevConv<PREC, S + 1, TRAIN>, (dbg & 16) != 0, decltype(dma)>(acc0, acc1, cur, smem + buf * SLAB, lane, cv, dma);              \
+          else { if (!(dbg & 2)) kstep_mfma<PREC, 8, 0, S == 0, PrevConv<PREC, S + 1, TRAIN != 0>, (dbg & 16) != 0, decltype(dma)>(acc0, acc1, cur, smem + buf * SLAB, lane, cv, dma);              \
           cur = cv.result();                                                                                         \
           save_mask(l - 1, S + 1, cv.nz[0], cv.nz[1]); }                                                             \
         } else {                                                                                                     \
@@ -714,14 +720,18 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
             rv0[4 * g + i] = v0; rv1[4 * g + i] = v1;
           }
         }
-        if constexpr (TRAIN) {   // rgb-head input (ReLU'd view-layer output) in operand-slot order: k-step 2t + half, slot j = reg & 7
+        if constexpr (TRAIN != 0) {   // rgb-head input (ReLU'd view-layer output) in operand-slot order: k-step 2t + half, slot j = reg & 7
 #pragma unroll
           for (int half = 0; half < 2; ++half) {
             KOps o;
-            o.h0 = make_uint4(pack2<PP::F16>(rv0[8 * half], rv0[8 * half + 1]), pack2<PP::F16>(rv0[8 * half + 2], rv0[8 * half + 3]),
-                              pack2<PP::F16>(rv0[8 * half + 4], rv0[8 * half + 5]), pack2<PP::F16>(rv0[8 * half + 6], rv0[8 * half + 7]));
-            o.h1 = make_uint4(pack2<PP::F16>(rv1[8 * half], rv1[8 * half + 1]), pack2<PP::F16>(rv1[8 * half + 2], rv1[8 * half + 3]),
-                              pack2<PP::F16>(rv1[8 * half + 4], rv1[8 * half + 5]), pack2<PP::F16>(rv1[8 * half + 6], rv1[8 * half + 7]));
+            float a0[8], a1[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { a0[j] = rv0[8 * half + j]; a1[j] = rv1[8 * half + j]; }
+            if constexpr (TRAIN == 2) { split8<PREC>(a0, o.h0, o.l0); split8<PREC>(a1, o.h1, o.l1); }
+            else {
+              o.h0 = make_uint4(pack2<PP::F16>(a0[0], a0[1]), pack2<PP::F16>(a0[2], a0[3]), pack2<PP::F16>(a0[4], a0[5]), pack2<PP::F16>(a0[6], a0[7]));
+              o.h1 = make_uint4(pack2<PP::F16>(a1[0], a1[1]), pack2<PP::F16>(a1[2], a1[3]), pack2<PP::F16>(a1[4], a1[5]), pack2<PP::F16>(a1[6], a1[7]));
+            }
             save_ops(SAVE_RGBIN + 2 * t + half, o);
             save_mask(8, 2 * t + half, nz_nibbles(o.h0), nz_nibbles(o.h1));
           }
@@ -796,15 +806,14 @@ __global__ void nerfmlp_pack_bwd_kernel(const float* __restrict__ params, char* 
   if (PP::NP == 2) dst[64 + lane] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
 }
 
-// dgrad twin of PrevConv: the B operands of k-step S of the NEXT dgrad GEMM = (state [+ d sigma * w_sigma]) * ReLU mask, split
-// into bf16 hi/lo, computed pair by pair in the shadow of the current k-step's MFMAs.
-template <int PREC, int S>
+// dgrad twin of PrevConv: the B operands of k-step S of the NEXT dgrad GEMM = (state / WSCALE [+ d sigma * w_sigma]) * ReLU mask, split
+// into 16-bit hi/lo parts, computed pair by pair in the shadow of the current k-step's MFMAs.
+template <int PREC, int S, bool NEED_LO>
 struct GradConv {
-  static constexpr bool NEED_LO = DGRAD_PASSES != 22 && DGRAD_PASSES != 1;   // is the lo part of the gradient operand consumed?
+  using PP = Prec<PREC>;
   const f32x16& p0;   // m-tile 0 state (accumulator registers of the previous dgrad layer)
   float v1[8];        // m-tile 1 state (from LDS)
-  float wv[8];        // w_sigma of these 8 features (0 unless this is the layer that receives d sigma)
-  float gw0, gw1;     // d raw_sigma of the lane's two rows
+  float t0[8], t1[8]; // d raw_sigma * w_sigma of these 8 features for the two m-tiles (0 unless this layer receives d sigma)
   uint32_t w0, w1;    // mask word S>>2 of both m-tiles (all ones: no ReLU)
   uint32_t hi[2][4], lo[2][4];
   float x0, x1;
@@ -812,12 +821,12 @@ struct GradConv {
   template <int C, int PI>
   __device__ __forceinline__ void chunk() {
     constexpr int mt = PI >> 2, p = PI & 3;
-    constexpr uint32_t bit0 = 1u << (8 * (S & 3) + p), bit1 = 1u << (8 * (S & 3) + p + 4);     // elements 2p, 2p+1
+    constexpr float INV_SCALE = 1.0f / PP::WSCALE;
     if constexpr (C == 0) {
       const float r0 = mt == 0 ? p0[8 * (S & 1) + 2 * p] : v1[2 * p];
       const float r1 = mt == 0 ? p0[8 * (S & 1) + 2 * p + 1] : v1[2 * p + 1];
-      x0 = fmaf(mt == 0 ? gw0 : gw1, wv[2 * p], r0);
-      x1 = fmaf(mt == 0 ? gw0 : gw1, wv[2 * p + 1], r1);
+      x0 = fmaf(r0, INV_SCALE, mt == 0 ? t0[2 * p] : t1[2 * p]);
+      x1 = fmaf(r1, INV_SCALE, mt == 0 ? t0[2 * p + 1] : t1[2 * p + 1]);
     } else if constexpr (C == 1) {
       const uint32_t w = mt == 0 ? w0 : w1;      // v_bfe_i32 spreads the flag into a 0 / ~0 word, v_and applies it: 2 ops per value
       constexpr int pos0 = 8 * (S & 3) + p, pos1 = pos0 + 4;
@@ -827,15 +836,15 @@ struct GradConv {
       x0 = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, x0) & m0);
       x1 = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, x1) & m1);
     } else if constexpr (C == 2) {
-      hi[mt][p] = pack2<false>(x0, x1);
+      hi[mt][p] = pack2<PP::F16>(x0, x1);
     } else if constexpr (C == 3) {
       if constexpr (NEED_LO) {
         float ha, hb;
-        unpack2<false>(hi[mt][p], ha, hb);
+        unpack2<PP::F16>(hi[mt][p], ha, hb);
         x0 -= ha; x1 -= hb;
       }
     } else {
-      if constexpr (NEED_LO) lo[mt][p] = pack2<false>(x0, x1);
+      if constexpr (NEED_LO) lo[mt][p] = pack2<PP::F16>(x0, x1);
       else lo[mt][p] = 0;
     }
   }
@@ -847,14 +856,32 @@ struct GradConv {
   }
 };
 
-template <int PREC>
+// Backward arithmetic (enum rnerf_backward): BF16 = gradients rounded to bf16 (8-bit significand), one 16-bit part per operand;
+// F16 / F16X2 = every row's gradient chain is normalised by a power of two m_row >= max |d raw[row]| (the chain is linear in d raw, so
+// the normalised values sit in f16's range whatever the loss scale), operands are f16 (11-bit significand) or f16 hi + lo (22 bits);
+// the wgrad multiplies the saved activations by m_row / m_ref again (m_ref = max m_row, collected with an atomic).
+template <int BWD> struct Bwd {
+  static constexpr bool F16 = BWD != RNERF_BWD_BF16;
+  static constexpr int NP = BWD == RNERF_BWD_F16X2 ? 2 : 1;                               // 16-bit parts stored per gradient / consumed per activation
+  static constexpr int PREC = F16 ? RNERF_PREC_F16X3 : RNERF_PREC_BF16X3;                 // operand type + weight split of the dgrad MFMAs
+  static constexpr int PASSES = BWD == RNERF_BWD_F16X2 ? 3 : (BWD == RNERF_BWD_F16 ? 22 : DGRAD_PASSES);
+  static constexpr bool NEED_LO = PASSES != 22 && PASSES != 1;
+};
+// dy buffer: uint4[DY_SLOTS * NP][R][2] operand planes (hi, then lo), then float row_scale[R] and uint32 m_ref bits (F16 modes)
+__host__ __device__ constexpr size_t dy_plane_uint4(long long R, int np) { return (size_t)DY_SLOTS * np * (size_t)R * 2; }
+
+template <int BWD>
 __global__ void __launch_bounds__(256, 1)
 nerfmlp_dgrad_kernel(const char* __restrict__ packed_bwd, const float* __restrict__ fwd_aux, const uint4* __restrict__ saved,
                      long long save_rows, const float4* __restrict__ d_raw, long long total_rows, int n_tiles,
                      uint4* __restrict__ dy) {
+  using BW = Bwd<BWD>;
+  constexpr int PREC = BW::PREC;
+  constexpr int DGP = BW::PASSES;
+  constexpr bool NEED_LO = BW::NEED_LO;
   using PP = Prec<PREC>;
-  static_assert(!PP::F16, "gradients need the bf16 exponent range");
   constexpr int SLAB = PP::SLAB;
+  constexpr float INV_SCALE = 1.0f / PP::WSCALE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -869,6 +896,7 @@ nerfmlp_dgrad_kernel(const char* __restrict__ packed_bwd, const float* __restric
   slab_wait_dma();
   __syncthreads();
 
+  float mref = 0.f;
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const bool has_next_tile = tile + (int)gridDim.x < n_tiles;
     const long long srow0 = (long long)tile * 256 + wave * 64 + m;
@@ -877,6 +905,20 @@ nerfmlp_dgrad_kernel(const char* __restrict__ packed_bwd, const float* __restric
     for (int mt = 0; mt < 2; ++mt) {
       const long long row = srow0 + 32 * mt;
       g[mt] = row < total_rows ? d_raw[row] : make_float4(0.f, 0.f, 0.f, 0.f);
+      if constexpr (BW::F16) {          // row normalisation
+        const float mx = fmaxf(fmaxf(fabsf(g[mt].x), fabsf(g[mt].y)), fmaxf(fabsf(g[mt].z), fabsf(g[mt].w)));
+        const uint32_t ex = __builtin_bit_cast(uint32_t, mx) >> 23;
+        // m_row = 2^(exponent(max |g|) - 5): 32 <= max |g / m_row| < 64 — 2^10 of headroom below f16's 65504 for growth along the chain,
+        // and every value above 0.2 % of the row's maximum keeps a NORMAL f16 lo part.  Rows with no (or a subnormal) gradient
+        // contribute nothing: m_row = 0 (a non-finite d raw still yields NaN gradients: NaN * 0).
+        const bool okx = ex >= 8 && ex <= 250;
+        const float m_row = okx ? __builtin_bit_cast(float, (ex - 5) << 23) : 0.0f;
+        const float inv = okx ? __builtin_bit_cast(float, (259 - ex) << 23) : 0.0f;
+        g[mt].x *= inv; g[mt].y *= inv; g[mt].z *= inv; g[mt].w *= inv;
+        float* rs = (float*)(dy + dy_plane_uint4(save_rows, BW::NP));
+        if (h == 0) rs[row] = m_row;
+        mref = fmaxf(mref, m_row);
+      }
     }
     f32x16 acc0[8], acc1[8], prev0[8];
 
@@ -885,6 +927,11 @@ nerfmlp_dgrad_kernel(const char* __restrict__ packed_bwd, const float* __restric
       uint4* dst = dy + ((size_t)q * save_rows + srow0) * 2 + h;
       stream_store(dst, o.h0);
       stream_store(dst + 64, o.h1);
+      if constexpr (BW::NP == 2) {
+        uint4* dl = dy + ((size_t)(DY_SLOTS + q) * save_rows + srow0) * 2 + h;
+        stream_store(dl, o.l0);
+        stream_store(dl + 64, o.l1);
+      }
 #endif
     };
     // ReLU masks: one uint4 of non-zero flags per (row, half) per layer (SAVE_MASK), fetched one layer ahead
@@ -905,7 +952,7 @@ nerfmlp_dgrad_kernel(const char* __restrict__ packed_bwd, const float* __restric
       float x0[8], x1[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        float a = prev0[s >> 1][8 * (s & 1) + j], b = r1[j];
+        float a = prev0[s >> 1][8 * (s & 1) + j] * INV_SCALE, b = r1[j] * INV_SCALE;
         if (wadd) { const float w = wadd[16 * s + 8 * (j >> 2) + 4 * h + (j & 3)]; a = fmaf(g[0].w, w, a); b = fmaf(g[1].w, w, b); }
         if (use_mask) {
           const uint32_t bit = 1u << (8 * (s & 3) + (j >> 1) + 4 * (j & 1));
@@ -915,8 +962,12 @@ nerfmlp_dgrad_kernel(const char* __restrict__ packed_bwd, const float* __restric
         x0[j] = a; x1[j] = b;
       }
       KOps o;
-      split8<PREC>(x0, o.h0, o.l0);
-      split8<PREC>(x1, o.h1, o.l1);
+      if constexpr (NEED_LO || BW::NP == 2) { split8<PREC>(x0, o.h0, o.l0); split8<PREC>(x1, o.h1, o.l1); }
+      else {
+        o.h0 = make_uint4(pack2<PP::F16>(x0[0], x0[1]), pack2<PP::F16>(x0[2], x0[3]), pack2<PP::F16>(x0[4], x0[5]), pack2<PP::F16>(x0[6], x0[7]));
+        o.h1 = make_uint4(pack2<PP::F16>(x1[0], x1[1]), pack2<PP::F16>(x1[2], x1[3]), pack2<PP::F16>(x1[4], x1[5]), pack2<PP::F16>(x1[6], x1[7]));
+        o.l0 = make_uint4(0, 0, 0, 0); o.l1 = o.l0;
+      }
       return o;
     };
     auto layer_end = [&]() {
@@ -948,8 +999,8 @@ nerfmlp_dgrad_kernel(const char* __restrict__ packed_bwd, const float* __restric
           if (t < 4) {
             const int n = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
             const float wr = fwd_aux[AUX_WRGB + n], wg = fwd_aux[AUX_WRGB + 128 + n], wb = fwd_aux[AUX_WRGB + 256 + n];
-            a = g[0].x * wr + g[0].y * wg + g[0].z * wb;
-            b = g[1].x * wr + g[1].y * wg + g[1].z * wb;
+            a = (g[0].x * wr + g[0].y * wg + g[0].z * wb) * PP::WSCALE;       // the state is kept in the accumulators' units (x WSCALE)
+            b = (g[1].x * wr + g[1].y * wg + g[1].z * wb) * PP::WSCALE;
           }
           acc0[t][r] = a; acc1[t][r] = b;
         }
@@ -966,19 +1017,21 @@ nerfmlp_dgrad_kernel(const char* __restrict__ packed_bwd, const float* __restric
         dy_store((SLOT0) + S, cur);                                                                                             \
         PREFETCH_STMT;                                                                                                          \
         if constexpr (S + 1 < NSTEPS) {                                                                                         \
-          GradConv<PREC, S + 1> cv(prev0[(S + 1) >> 1]);                                                                        \
+          GradConv<PREC, S + 1, NEED_LO> cv(prev0[(S + 1) >> 1]);                                                                        \
           {                                                                                                                     \
             const float4 u0 = st1[(((S + 1) >> 1) * 4 + 2 * ((S + 1) & 1)) * 64], u1 = st1[(((S + 1) >> 1) * 4 + 2 * ((S + 1) & 1) + 1) * 64]; \
             cv.v1[0] = u0.x; cv.v1[1] = u0.y; cv.v1[2] = u0.z; cv.v1[3] = u0.w; cv.v1[4] = u1.x; cv.v1[5] = u1.y; cv.v1[6] = u1.z; cv.v1[7] = u1.w; \
           }                                                                                                                     \
-          _Pragma("unroll") for (int j = 0; j < 8; ++j) cv.wv[j] = wadd ? wadd[16 * (S + 1) + 8 * (j >> 2) + 4 * h + (j & 3)] : 0.f; \
-          cv.gw0 = g[0].w; cv.gw1 = g[1].w;                                                                                     \
+          _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                                       \
+            const float wv = wadd ? wadd[16 * (S + 1) + 8 * (j >> 2) + 4 * h + (j & 3)] : 0.f;                                  \
+            cv.t0[j] = g[0].w * wv; cv.t1[j] = g[1].w * wv;                                                                     \
+          }                                                                                                                     \
           cv.w0 = ((S + 1) >> 2) == 0 ? ma.x : (((S + 1) >> 2) == 1 ? ma.y : (((S + 1) >> 2) == 2 ? ma.z : ma.w));             \
           cv.w1 = ((S + 1) >> 2) == 0 ? mb.x : (((S + 1) >> 2) == 1 ? mb.y : (((S + 1) >> 2) == 2 ? mb.z : mb.w));             \
-          kstep_mfma<PREC, 8, 0, S == 0, GradConv<PREC, S + 1>, false, NoDma, DGRAD_PASSES>(acc0, acc1, cur, smem + buf * SLAB, lane, cv); \
+          kstep_mfma<PREC, 8, 0, S == 0, GradConv<PREC, S + 1, NEED_LO>, false, NoDma, DGP>(acc0, acc1, cur, smem + buf * SLAB, lane, cv); \
           cur = cv.result();                                                                                                    \
         } else {                                                                                                                \
-          kstep_mfma<PREC, 8, 0, false, NoWork, false, NoDma, DGRAD_PASSES>(acc0, acc1, cur, smem + buf * SLAB, lane, nowork);  \
+          kstep_mfma<PREC, 8, 0, false, NoWork, false, NoDma, DGP>(acc0, acc1, cur, smem + buf * SLAB, lane, nowork);  \
         }                                                                                                                       \
         SLAB_DONE();                                                                                                            \
       }
@@ -1023,6 +1076,12 @@ nerfmlp_dgrad_kernel(const char* __restrict__ packed_bwd, const float* __restric
     }
 #undef SLAB_PREFETCH
 #undef SLAB_DONE
+  }
+  if constexpr (BW::F16) {      // m_ref = max m_row over all rows (positive floats order like their bit patterns)
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mref = fmaxf(mref, __shfl_xor(mref, o));
+    if (lane == 0 && mref > 0.f)
+      atomicMax((unsigned int*)((float*)(dy + dy_plane_uint4(save_rows, BW::NP)) + save_rows), __builtin_bit_cast(unsigned int, mref));
   }
 }
 
@@ -1157,6 +1216,195 @@ __device__ __forceinline__ void wgrad_body(const uint4* __restrict__ saved, cons
   if (wave < NT && h == 0) pbias[wave * 32 + m] = accb[0];
 }
 
+// ---- wgrad of the row-normalised f16 modes (RNERF_BWD_F16: NP = 1, RNERF_BWD_F16X2: NP = 2) -----------------------------------------
+// Same scheme as wgrad_body (transposition on the matrix cores, fragments through LDS, wave w accumulates k-tile w), with
+//   * f16 operands: X^T as saved by the forward (exact), scaled per row by m_row / m_ref (a power of two <= 1: exact; rows whose
+//     gradient is many orders below the largest underflow harmlessly), dY^T = the normalised gradients of the dgrad chain;
+//   * NP = 2: hi and lo parts of both operands, 3 MFMAs per product (hi*hi + hi*lo + lo*hi: ~2^-22 relative), 64-row chunks
+//     (2 row groups x 66 KiB of fragments); NP = 1: 128-row chunks (4 x 34 KiB);
+//   * the bias row sum_rows m_row dY^[row][n] through an A operand holding the row scales (the "ones" row of the bf16 body).
+// LDS slots (1 KiB) of a row group: X^T hi [0,16), X^T lo [16,32) if NP = 2, dY^T hi [16 NP, 16 NP + 16), dY^T lo, then 2 scale slots.
+template <int NP> struct WgF16 {
+  static constexpr int ROWG = NP == 2 ? 2 : 4, CH = 32 * ROWG, RG_SLOTS = 32 * NP + 2, RG_BYTES = RG_SLOTS * 1024, LDS = ROWG * RG_BYTES;
+};
+
+__device__ __forceinline__ void pack_rows_f16(const f32x16& d, uint4& u0, uint4& u1) {
+  u0 = make_uint4(pack2<true>(d[0], d[1]), pack2<true>(d[2], d[3]), pack2<true>(d[4], d[5]), pack2<true>(d[6], d[7]));
+  u1 = make_uint4(pack2<true>(d[8], d[9]), pack2<true>(d[10], d[11]), pack2<true>(d[12], d[13]), pack2<true>(d[14], d[15]));
+}
+
+template <int NP, int KT, int KSd>
+__device__ __forceinline__ void wgrad_body_f16(const uint4* __restrict__ saved, const uint4* __restrict__ dy, long long R, long long total_rows,
+                                                int n_chunks, float* __restrict__ pg, float* __restrict__ pbias, int qx, int qd, int g, int G,
+                                                char* smem) {
+  using W = WgF16<NP>;
+  constexpr int NT = (KSd + 1) / 2;
+  constexpr int TSTRIDE = NP;                                  // NP = 2: two waves share the slots of one (side, row group)
+  constexpr int NIT = ((KT > NT ? KT : NT) + TSTRIDE - 1) / TSTRIDE;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int side = wave >> 2;                                  // 0: X slots, 1: dY slots
+  const int rg = NP == 2 ? ((wave >> 1) & 1) : (wave & 3);
+  const int tpart = NP == 2 ? (wave & 1) : 0;
+  const int m = lane & 31, h = lane >> 5;
+  const float* __restrict__ rs = (const float*)(dy + dy_plane_uint4(R, NP));
+  const float mref = rs[R];                                     // bits written by the dgrad's atomicMax
+  const float inv_mref = mref > 0.f ? 1.0f / mref : 0.f;        // m_ref is a power of two: exact
+  uint4* myT = (uint4*)(smem + rg * W::RG_BYTES) + lane;
+  const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const uint4 il = shifted_identity<true>(lane, 0), ih = shifted_identity<true>(lane, 1);
+  const uint4 z4 = make_uint4(0, 0, 0, 0);
+  f32x16 acc[NT], accb = zero;
+#pragma unroll
+  for (int b = 0; b < NT; ++b) acc[b] = zero;
+  uint4 opr[NIT][2 * NP];
+  float4 scq[4];
+  auto load_chunk = [&](int chunk) {
+    const size_t row0 = (size_t)chunk * W::CH + rg * 32;
+    const size_t row2 = (row0 + m) * 2 + h;
+    if (side == 0) {
+#pragma unroll
+      for (int i = 0; i < NIT; ++i) {
+        const int t = tpart + i * TSTRIDE;
+        if (t < KT) {
+#pragma unroll
+          for (int p = 0; p < NP; ++p) {
+            const uint4* base = saved + (size_t)(p * SAVE_TOTAL + qx + 2 * t) * R * 2 + row2;
+            opr[i][2 * p] = stream_load(base);
+            opr[i][2 * p + 1] = stream_load(base + (size_t)R * 2);
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) scq[q] = *(const float4*)(rs + row0 + 8 * q + 4 * h);
+    } else {
+#pragma unroll
+      for (int i = 0; i < NIT; ++i) {
+        const int t = tpart + i * TSTRIDE;
+        if (t < NT) {
+#pragma unroll
+          for (int p = 0; p < NP; ++p) {
+            const uint4* base = dy + (size_t)(p * DY_SLOTS + qd + 2 * t) * R * 2 + row2;
+            opr[i][2 * p] = stream_load(base);
+            opr[i][2 * p + 1] = (2 * t + 1 < KSd) ? stream_load(base + (size_t)R * 2) : z4;
+          }
+        }
+      }
+    }
+  };
+  if (g < n_chunks) load_chunk(g);
+  for (int chunk = g; chunk < n_chunks; chunk += G) {
+    const bool ok = (long long)chunk * W::CH + rg * 32 + m < total_rows;
+    if (side == 0) {
+      float sc[16];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { sc[4 * q] = scq[q].x * inv_mref; sc[4 * q + 1] = scq[q].y * inv_mref; sc[4 * q + 2] = scq[q].z * inv_mref; sc[4 * q + 3] = scq[q].w * inv_mref; }
+#pragma unroll
+      for (int i = 0; i < NIT; ++i) {
+        const int t = tpart + i * TSTRIDE;
+        if (t < KT) {
+#pragma unroll
+          for (int p = 0; p < NP; ++p) {
+            f32x16 d = mfma16<true>(opr[i][2 * p], il, zero);
+            d = mfma16<true>(opr[i][2 * p + 1], ih, d);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d[r] *= sc[r];
+            uint4 u0, u1;
+            pack_rows_f16(d, u0, u1);
+            myT[(16 * p + 2 * t) * 64] = u0; myT[(16 * p + 2 * t + 1) * 64] = u1;
+          }
+        }
+      }
+      if (tpart == 0) {                                          // the row scales as an A operand: row m = 0 holds them, the others 0
+        f32x16 d;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d[r] = m == 0 ? sc[r] : 0.f;
+        uint4 u0, u1;
+        pack_rows_f16(d, u0, u1);
+        myT[(32 * NP) * 64] = u0; myT[(32 * NP + 1) * 64] = u1;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NIT; ++i) {
+        const int t = tpart + i * TSTRIDE;
+        if (t < NT) {
+#pragma unroll
+          for (int p = 0; p < NP; ++p) {
+            const uint4 a0 = ok ? opr[i][2 * p] : z4, a1 = ok ? opr[i][2 * p + 1] : z4;
+            f32x16 d = mfma16<true>(a0, il, zero);
+            d = mfma16<true>(a1, ih, d);
+            uint4 u0, u1;
+            pack_rows_f16(d, u0, u1);
+            myT[(16 * NP + 16 * p + 2 * t) * 64] = u0; myT[(16 * NP + 16 * p + 2 * t + 1) * 64] = u1;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (chunk + G < n_chunks) load_chunk(chunk + G);
+    if (wave < KT || wave < NT) {
+#pragma unroll 1
+      for (int v = 0; v < W::ROWG; ++v) {
+        const uint4* T = (const uint4*)(smem + v * W::RG_BYTES) + lane;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          if (wave < KT) {
+            const uint4 ah = T[(2 * wave + u) * 64];
+            uint4 al = z4;
+            if constexpr (NP == 2) al = T[(16 + 2 * wave + u) * 64];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              const uint4 bh = T[(16 * NP + 2 * nt + u) * 64];
+              acc[nt] = mfma16<true>(ah, bh, acc[nt]);
+              if constexpr (NP == 2) {
+                acc[nt] = mfma16<true>(ah, T[(48 + 2 * nt + u) * 64], acc[nt]);
+                acc[nt] = mfma16<true>(al, bh, acc[nt]);
+              }
+            }
+          }
+          if (wave < NT) {
+            const uint4 sv = T[(32 * NP + u) * 64];
+            accb = mfma16<true>(sv, T[(16 * NP + 2 * wave + u) * 64], accb);
+            if constexpr (NP == 2) accb = mfma16<true>(sv, T[(48 + 2 * wave + u) * 64], accb);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  constexpr size_t ldn = (size_t)NT * 32;
+  if (wave < KT) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+        pg[(size_t)(wave * 32 + i) * ldn + nt * 32 + m] = acc[nt][r];
+      }
+    }
+  }
+  if (wave < NT && h == 0) pbias[wave * 32 + m] = accb[0];
+}
+
+template <int NP>
+__global__ void __launch_bounds__(512)
+nerfmlp_wgrad_f16_kernel(const uint4* __restrict__ saved, const uint4* __restrict__ dy, long long R, long long total_rows, int n_chunks,
+                          float* __restrict__ workspace, const WgradTable tab) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int j = 0;
+  while ((int)blockIdx.x >= tab.wg0[j + 1]) ++j;
+  const int qx = tab.qx[j], KSx = tab.KSx[j], qd = tab.qd[j], KSd = tab.KSd[j];
+  const int g = blockIdx.x - tab.wg0[j], G = tab.wg0[j + 1] - tab.wg0[j];
+  const int KT = KSx >> 1, NT = (KSd + 1) >> 1;
+  float* pg = workspace + tab.poff[j] + (size_t)g * (size_t)KT * 32 * NT * 32;
+  float* pb = workspace + tab.pboff[j] + (size_t)g * NT * 32;
+#define RNERF_WGRAD_CASE(KT_, KSD_)                                                                                                 \
+  if (KSx == 2 * (KT_) && KSd == (KSD_)) { wgrad_body_f16<NP, KT_, KSD_>(saved, dy, R, total_rows, n_chunks, pg, pb, qx, qd, g, G, smem); return; }
+  RNERF_WGRAD_CASE(8, 16) RNERF_WGRAD_CASE(2, 16) RNERF_WGRAD_CASE(8, 1) RNERF_WGRAD_CASE(8, 8) RNERF_WGRAD_CASE(1, 8) RNERF_WGRAD_CASE(4, 1)
+#undef RNERF_WGRAD_CASE
+  __builtin_trap();
+}
+
 template <bool X_F16>
 __global__ void __launch_bounds__(512)
 nerfmlp_wgrad_kernel(const uint4* __restrict__ saved, const uint4* __restrict__ dy, long long R, long long total_rows, int n_chunks,
@@ -1176,7 +1424,9 @@ nerfmlp_wgrad_kernel(const uint4* __restrict__ saved, const uint4* __restrict__ 
   __builtin_trap();
 }
 
-__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ workspace, const WgradTable tab, float* __restrict__ grads) {
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ workspace, const WgradTable tab, float* __restrict__ grads,
+                                                           const float* __restrict__ out_scale) {
+  const float osc = out_scale ? *out_scale : 1.0f;      // m_ref of the row-normalised modes
   const int jb = blockIdx.y;
   const WgradJob job = tab.job[jb];
   const int n_wg = tab.wg0[jb + 1] - tab.wg0[jb];
@@ -1206,12 +1456,12 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
     const int fout = out_feature(J);
     if (fin >= 0 && fout >= 0) {
       fin += job.row_off;
-      if (fin < in_dim) grads[nerf_koff(job.dense) + fin * out_dim + fout] = sum_over(partial + e, (size_t)rows * ldn);
+      if (fin < in_dim) grads[nerf_koff(job.dense) + fin * out_dim + fout] = sum_over(partial + e, (size_t)rows * ldn) * osc;
     }
   }
   if (job.write_bias && e < ldn) {
     const int fout = out_feature(e);
-    if (fout >= 0) grads[nerf_boff(job.dense) + fout] = sum_over(partial_bias + e, (size_t)ldn);
+    if (fout >= 0) grads[nerf_boff(job.dense) + fout] = sum_over(partial_bias + e, (size_t)ldn) * osc;
   }
 }
 
@@ -1730,7 +1980,7 @@ static int mlp_debug_flags() {
   return v;
 }
 
-template <int PREC, int DBG, bool TRAIN = false>
+template <int PREC, int DBG, int TRAIN = 0>
 static int launch_fwd_dbg(const void* packed, const float* rows_pd, const float* rows_dr, const int32_t* node_of_sample, int32_t B,
                           long long total_rows, float* out_raw, hipStream_t st, void* save = nullptr);
 
@@ -1758,7 +2008,7 @@ static int launch_fwd(const void* packed, const float* rows_pd, const float* row
   return launch_fwd_dbg<PREC, 0>(packed, rows_pd, rows_dr, node_of_sample, B, total_rows, out_raw, st);
 }
 
-template <int PREC, int DBG, bool TRAIN>
+template <int PREC, int DBG, int TRAIN>
 static int launch_fwd_dbg(const void* packed, const float* rows_pd, const float* rows_dr, const int32_t* node_of_sample, int32_t B,
                       long long total_rows, float* out_raw, hipStream_t st, void* save) {
   using PP = Prec<PREC>;
@@ -1798,48 +2048,51 @@ extern "C" int rnerf_nerfmlp_forward(const void* packed, int precision, const fl
   }
 }
 
-extern "C" size_t rnerf_nerfmlp_save_bytes(int64_t rows) {
+static bool bwd_ok(int b) { return b == RNERF_BWD_BF16 || b == RNERF_BWD_F16 || b == RNERF_BWD_F16X2; }
+
+extern "C" size_t rnerf_nerfmlp_save_bytes(int64_t rows, int backward) {
   const int64_t padded = (rows + 255) / 256 * 256;
-  return (size_t)SAVE_TOTAL * (size_t)padded * 2 * sizeof(uint4);
+  return (size_t)(SAVE_TOTAL + (backward == RNERF_BWD_F16X2 ? SAVE_SLOTS : 0)) * (size_t)padded * 2 * sizeof(uint4);
 }
 
 extern "C" int rnerf_nerfmlp_forward_train(const void* packed, int precision, const float* rows_pd, const float* rows_dr,
                                            const int32_t* node_of_sample, int32_t S, int32_t B, float* out_raw, void* save,
-                                           void* stream) {
+                                           int backward, void* stream) {
   RNERF_CHECK_ARG(packed && rows_pd && rows_dr && out_raw && save, "rnerf_nerfmlp_forward_train: null pointer");
-  RNERF_CHECK_ARG(precision == RNERF_PREC_F16X3 || precision == RNERF_PREC_BF16X3, "rnerf_nerfmlp_forward_train: precision must be f16x3 or bf16x3");
+  RNERF_CHECK_ARG(bwd_ok(backward), "rnerf_nerfmlp_forward_train: unknown backward mode %d", backward);
+  // (the bf16x3 forward is an inference-only precision: its 8-bit saved operands would cap every backward mode at bf16 accuracy)
+  RNERF_CHECK_ARG(precision == RNERF_PREC_F16X3, "rnerf_nerfmlp_forward_train: the training forward is built for precision f16x3");
   RNERF_CHECK_ARG(S >= 1 && B >= 1, "rnerf_nerfmlp_forward_train: need S >= 1 and B >= 1");
   RNERF_CHECK_ARG((((uintptr_t)packed | (uintptr_t)rows_pd | (uintptr_t)rows_dr | (uintptr_t)out_raw | (uintptr_t)save) & 15) == 0,
                   "rnerf_nerfmlp_forward_train: buffers must be 16-byte aligned");
   const long long total = (long long)S * B;
   hipStream_t st = (hipStream_t)stream;
-  if (precision == RNERF_PREC_F16X3) return launch_fwd_dbg<RNERF_PREC_F16X3, 0, true>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, save);
-  return launch_fwd_dbg<RNERF_PREC_BF16X3, 0, true>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, save);
+  if (backward == RNERF_BWD_F16X2) return launch_fwd_dbg<RNERF_PREC_F16X3, 0, 2>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, save);
+  return launch_fwd_dbg<RNERF_PREC_F16X3, 0, 1>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, save);
 }
 
 extern "C" size_t rnerf_nerfmlp_bwd_packed_bytes(void) { return (size_t)kBwdBlocks * 2 * 1024; }
-extern "C" size_t rnerf_nerfmlp_dy_bytes(int64_t rows) {
+extern "C" size_t rnerf_nerfmlp_dy_bytes(int64_t rows, int backward) {
   const int64_t padded = (rows + 255) / 256 * 256;
-  return (size_t)DY_SLOTS * (size_t)padded * 2 * sizeof(uint4);
+  const int np = backward == RNERF_BWD_F16X2 ? 2 : 1;
+  return dy_plane_uint4(padded, np) * sizeof(uint4) + (backward == RNERF_BWD_BF16 ? 0 : ((size_t)padded + 4) * sizeof(float));
 }
 
-extern "C" int rnerf_nerfmlp_pack_bwd(const float* params, void* packed_bwd, void* stream) {
+extern "C" int rnerf_nerfmlp_pack_bwd(const float* params, int backward, void* packed_bwd, void* stream) {
   RNERF_CHECK_ARG(params && packed_bwd, "rnerf_nerfmlp_pack_bwd: null pointer");
+  RNERF_CHECK_ARG(bwd_ok(backward), "rnerf_nerfmlp_pack_bwd: unknown backward mode %d", backward);
   const int threads = kBwdBlocks * 64;
-  hipLaunchKernelGGL(nerfmlp_pack_bwd_kernel<RNERF_PREC_BF16X3>, dim3((threads + 255) / 256), dim3(256), 0, (hipStream_t)stream, params,
-                     (char*)packed_bwd);
+  if (backward == RNERF_BWD_BF16)
+    hipLaunchKernelGGL(nerfmlp_pack_bwd_kernel<RNERF_PREC_BF16X3>, dim3((threads + 255) / 256), dim3(256), 0, (hipStream_t)stream, params, (char*)packed_bwd);
+  else
+    hipLaunchKernelGGL(nerfmlp_pack_bwd_kernel<RNERF_PREC_F16X3>, dim3((threads + 255) / 256), dim3(256), 0, (hipStream_t)stream, params, (char*)packed_bwd);
   RNERF_CHECK_LAUNCH();
   return RNERF_OK;
 }
 
-extern "C" int rnerf_nerfmlp_dgrad(const void* packed_bwd, const void* packed_fwd, int fwd_precision, const void* save,
-                                   const float* d_raw, int64_t rows, void* dy, void* stream) {
-  RNERF_CHECK_ARG(packed_bwd && packed_fwd && save && d_raw && dy, "rnerf_nerfmlp_dgrad: null pointer");
-  RNERF_CHECK_ARG(fwd_precision == RNERF_PREC_F16X3 || fwd_precision == RNERF_PREC_BF16X3, "rnerf_nerfmlp_dgrad: forward precision must be f16x3 or bf16x3");
-  RNERF_CHECK_ARG(rows >= 1, "rnerf_nerfmlp_dgrad: rows must be >= 1");
-  using PB = Prec<RNERF_PREC_BF16X3>;
-  const size_t fwd_stream = fwd_precision == RNERF_PREC_F16X3 ? Prec<RNERF_PREC_F16X3>::STREAM_BYTES : Prec<RNERF_PREC_BF16X3>::STREAM_BYTES;
-  const float* fwd_aux = (const float*)((const char*)packed_fwd + fwd_stream);
+template <int BWD>
+static int launch_dgrad(const void* packed_bwd, const float* fwd_aux, const void* save, const float* d_raw, int64_t rows, void* dy, hipStream_t st) {
+  using PB = Prec<Bwd<BWD>::PREC>;
   const int n_tiles = (int)((rows + 255) / 256);
   int dev = 0, cus = 0;
   RNERF_CHECK_HIP(hipGetDevice(&dev));
@@ -1848,13 +2101,29 @@ extern "C" int rnerf_nerfmlp_dgrad(const void* packed_bwd, const void* packed_fw
   const size_t lds = 2 * (size_t)PB::SLAB + 4 * 32768;
   static bool attr_set = false;
   if (!attr_set) {
-    RNERF_CHECK_HIP(hipFuncSetAttribute((const void*)nerfmlp_dgrad_kernel<RNERF_PREC_BF16X3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    RNERF_CHECK_HIP(hipFuncSetAttribute((const void*)nerfmlp_dgrad_kernel<BWD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL(nerfmlp_dgrad_kernel<RNERF_PREC_BF16X3>, dim3(grid), dim3(256), lds, (hipStream_t)stream, (const char*)packed_bwd, fwd_aux,
-                     (const uint4*)save, (long long)n_tiles * 256, (const float4*)d_raw, (long long)rows, n_tiles, (uint4*)dy);
+  const long long R = (long long)n_tiles * 256;
+  if (Bwd<BWD>::F16)       // m_ref accumulator (atomicMax) behind the row scales
+    RNERF_CHECK_HIP(hipMemsetAsync((char*)dy + dy_plane_uint4(R, Bwd<BWD>::NP) * sizeof(uint4) + (size_t)R * sizeof(float), 0, 4 * sizeof(float), st));
+  hipLaunchKernelGGL(nerfmlp_dgrad_kernel<BWD>, dim3(grid), dim3(256), lds, st, (const char*)packed_bwd, fwd_aux, (const uint4*)save, R,
+                     (const float4*)d_raw, (long long)rows, n_tiles, (uint4*)dy);
   RNERF_CHECK_LAUNCH();
   return RNERF_OK;
+}
+
+extern "C" int rnerf_nerfmlp_dgrad(const void* packed_bwd, const void* packed_fwd, int fwd_precision, int backward, const void* save,
+                                   const float* d_raw, int64_t rows, void* dy, void* stream) {
+  RNERF_CHECK_ARG(packed_bwd && packed_fwd && save && d_raw && dy, "rnerf_nerfmlp_dgrad: null pointer");
+  RNERF_CHECK_ARG(fwd_precision == RNERF_PREC_F16X3, "rnerf_nerfmlp_dgrad: forward precision must be f16x3");
+  RNERF_CHECK_ARG(bwd_ok(backward), "rnerf_nerfmlp_dgrad: unknown backward mode %d", backward);
+  RNERF_CHECK_ARG(rows >= 1, "rnerf_nerfmlp_dgrad: rows must be >= 1");
+  const float* fwd_aux = (const float*)((const char*)packed_fwd + Prec<RNERF_PREC_F16X3>::STREAM_BYTES);
+  hipStream_t st = (hipStream_t)stream;
+  if (backward == RNERF_BWD_F16X2) return launch_dgrad<RNERF_BWD_F16X2>(packed_bwd, fwd_aux, save, d_raw, rows, dy, st);
+  if (backward == RNERF_BWD_F16) return launch_dgrad<RNERF_BWD_F16>(packed_bwd, fwd_aux, save, d_raw, rows, dy, st);
+  return launch_dgrad<RNERF_BWD_BF16>(packed_bwd, fwd_aux, save, d_raw, rows, dy, st);
 }
 
 // the 15 wgrad jobs of one NerfMLP: {x slot base, x k-steps, dy slot base, dy k-steps, job}
@@ -1907,29 +2176,40 @@ extern "C" size_t rnerf_nerfmlp_wgrad_workspace_bytes(void) {
   return build_wgrad_table(device_cus(), t) * sizeof(float);
 }
 
-extern "C" int rnerf_nerfmlp_wgrad(int fwd_precision, const void* save, const void* dy, int64_t rows, float* grads, void* workspace,
+extern "C" int rnerf_nerfmlp_wgrad(int fwd_precision, int backward, const void* save, const void* dy, int64_t rows, float* grads, void* workspace,
                                    void* stream) {
   RNERF_CHECK_ARG(save && dy && grads && workspace, "rnerf_nerfmlp_wgrad: null pointer");
-  RNERF_CHECK_ARG(fwd_precision == RNERF_PREC_F16X3 || fwd_precision == RNERF_PREC_BF16X3, "rnerf_nerfmlp_wgrad: forward precision must be f16x3 or bf16x3");
+  RNERF_CHECK_ARG(fwd_precision == RNERF_PREC_F16X3, "rnerf_nerfmlp_wgrad: forward precision must be f16x3");
+  RNERF_CHECK_ARG(bwd_ok(backward), "rnerf_nerfmlp_wgrad: unknown backward mode %d", backward);
   RNERF_CHECK_ARG(rows >= 1, "rnerf_nerfmlp_wgrad: rows must be >= 1");
   static WgradTable tab;
   static bool ready = false;
   if (!ready) {
     build_wgrad_table(device_cus(), tab);
     RNERF_CHECK_HIP(hipFuncSetAttribute((const void*)nerfmlp_wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
-    RNERF_CHECK_HIP(hipFuncSetAttribute((const void*)nerfmlp_wgrad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+    RNERF_CHECK_HIP(hipFuncSetAttribute((const void*)nerfmlp_wgrad_f16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, WgF16<1>::LDS));
+    RNERF_CHECK_HIP(hipFuncSetAttribute((const void*)nerfmlp_wgrad_f16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, WgF16<2>::LDS));
     ready = true;
   }
   const long long R = (rows + 255) / 256 * 256;
-  const int n_chunks = (int)((rows + 127) / 128);
   hipStream_t st = (hipStream_t)stream;
-  if (fwd_precision == RNERF_PREC_F16X3)
+  const float* out_scale = nullptr;
+  if (backward == RNERF_BWD_BF16) {
+    const int n_chunks = (int)((rows + 127) / 128);
     hipLaunchKernelGGL(nerfmlp_wgrad_kernel<true>, dim3(tab.wg0[tab.n]), dim3(512), 131072, st, (const uint4*)save, (const uint4*)dy, R,
                        (long long)rows, n_chunks, (float*)workspace, tab);
-  else
-    hipLaunchKernelGGL(nerfmlp_wgrad_kernel<false>, dim3(tab.wg0[tab.n]), dim3(512), 131072, st, (const uint4*)save, (const uint4*)dy, R,
+  } else if (backward == RNERF_BWD_F16) {
+    const int n_chunks = (int)((rows + WgF16<1>::CH - 1) / WgF16<1>::CH);
+    hipLaunchKernelGGL(nerfmlp_wgrad_f16_kernel<1>, dim3(tab.wg0[tab.n]), dim3(512), WgF16<1>::LDS, st, (const uint4*)save, (const uint4*)dy, R,
                        (long long)rows, n_chunks, (float*)workspace, tab);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(256, tab.n), dim3(256), 0, st, (const float*)workspace, tab, grads);
+    out_scale = (const float*)((const uint4*)dy + dy_plane_uint4(R, 1)) + R;
+  } else {
+    const int n_chunks = (int)((rows + WgF16<2>::CH - 1) / WgF16<2>::CH);
+    hipLaunchKernelGGL(nerfmlp_wgrad_f16_kernel<2>, dim3(tab.wg0[tab.n]), dim3(512), WgF16<2>::LDS, st, (const uint4*)save, (const uint4*)dy, R,
+                       (long long)rows, n_chunks, (float*)workspace, tab);
+    out_scale = (const float*)((const uint4*)dy + dy_plane_uint4(R, 2)) + R;
+  }
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(256, tab.n), dim3(256), 0, st, (const float*)workspace, tab, grads, out_scale);
   RNERF_CHECK_LAUNCH();
   return RNERF_OK;
 }

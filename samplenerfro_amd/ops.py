@@ -195,44 +195,45 @@ def composite_backward(raw, rows_pd, rows_dr, node_of_sample, S: int, B: int, bk
     return d_raw, d_bkgd
 
 
-def nerfmlp_forward_train(packed, precision: int, rows_pd, rows_dr, node_of_sample, S: int, B: int):
-    """Training forward: raw [S,B,4] + the saved operands (uint8 buffer) for the backward kernels."""
+def nerfmlp_forward_train(packed, precision: int, rows_pd, rows_dr, node_of_sample, S: int, B: int, backward: int = _lib.BWD_F16X2):
+    """Training forward: raw [S,B,4] + the saved operands (uint8 buffer) for the backward kernels (`backward`: _lib.BWD_*)."""
     lib = _lib.load()
     dev = rows_pd.device
     out = torch.empty((S, B, 4), dtype=torch.float32, device=dev)
-    save = torch.empty(lib.rnerf_nerfmlp_save_bytes(S * B), dtype=torch.uint8, device=dev)
+    save = torch.empty(lib.rnerf_nerfmlp_save_bytes(S * B, int(backward)), dtype=torch.uint8, device=dev)
     check(lib.rnerf_nerfmlp_forward_train(ptr(packed), int(precision), ptr(_chk(rows_pd, "rows_pd")), ptr(_chk(rows_dr, "rows_dr")),
-                                          ptr(node_of_sample), int(S), int(B), ptr(out), ptr(save), current_stream()),
+                                          ptr(node_of_sample), int(S), int(B), ptr(out), ptr(save), int(backward), current_stream()),
           "rnerf_nerfmlp_forward_train")
     return out, save
 
 
-def nerfmlp_pack_bwd(params_flat: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def nerfmlp_pack_bwd(params_flat: torch.Tensor, out: Optional[torch.Tensor] = None, backward: int = _lib.BWD_F16X2) -> torch.Tensor:
     lib = _lib.load()
     p = _chk(params_flat, "params_flat")
     if out is None:
         out = torch.empty(lib.rnerf_nerfmlp_bwd_packed_bytes(), dtype=torch.uint8, device=p.device)
-    check(lib.rnerf_nerfmlp_pack_bwd(ptr(p), ptr(out), current_stream()), "rnerf_nerfmlp_pack_bwd")
+    check(lib.rnerf_nerfmlp_pack_bwd(ptr(p), int(backward), ptr(out), current_stream()), "rnerf_nerfmlp_pack_bwd")
     return out
 
 
 def nerfmlp_backward(packed_bwd, packed_fwd, precision: int, save, d_raw: torch.Tensor, rows: int,
                      grads: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None, dy: Optional[torch.Tensor] = None,
-                     stages: str = "dw") -> torch.Tensor:
-    """d_raw [S,B,4] (d loss / d raw) -> flat fp32 gradient of the NerfMLP parameters (595844 floats)."""
+                     stages: str = "dw", backward: int = _lib.BWD_F16X2) -> torch.Tensor:
+    """d_raw [S,B,4] (d loss / d raw) -> flat fp32 gradient of the NerfMLP parameters (595844 floats).  `backward` (_lib.BWD_*) must be
+    the mode the forward saved for and packed_bwd was packed for."""
     lib = _lib.load()
     dev = d_raw.device
-    dy = torch.empty(lib.rnerf_nerfmlp_dy_bytes(rows), dtype=torch.uint8, device=dev) if dy is None else dy
+    dy = torch.empty(lib.rnerf_nerfmlp_dy_bytes(rows, int(backward)), dtype=torch.uint8, device=dev) if dy is None else dy
     if "d" in stages:
-        check(lib.rnerf_nerfmlp_dgrad(ptr(packed_bwd), ptr(packed_fwd), int(precision), ptr(save), ptr(_chk(d_raw, "d_raw")), int(rows), ptr(dy),
-                                      current_stream()), "rnerf_nerfmlp_dgrad")
+        check(lib.rnerf_nerfmlp_dgrad(ptr(packed_bwd), ptr(packed_fwd), int(precision), int(backward), ptr(save), ptr(_chk(d_raw, "d_raw")), int(rows),
+                                      ptr(dy), current_stream()), "rnerf_nerfmlp_dgrad")
     if "w" not in stages:
         return dy
     if grads is None:
         grads = torch.empty(_lib.NERFMLP_PARAMS, dtype=torch.float32, device=dev)
     if workspace is None:
         workspace = torch.empty(lib.rnerf_nerfmlp_wgrad_workspace_bytes(), dtype=torch.uint8, device=dev)
-    check(lib.rnerf_nerfmlp_wgrad(int(precision), ptr(save), ptr(dy), int(rows), ptr(grads), ptr(workspace), current_stream()),
+    check(lib.rnerf_nerfmlp_wgrad(int(precision), int(backward), ptr(save), ptr(dy), int(rows), ptr(grads), ptr(workspace), current_stream()),
           "rnerf_nerfmlp_wgrad")
     return grads
 

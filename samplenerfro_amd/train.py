@@ -92,15 +92,27 @@ class TrainState:
             getattr(self, k).copy_(d[k])
 
 
-def _bwd_packed(model: NerfModel, state: TrainState, name: str) -> torch.Tensor:
-    """The transposed (dgrad) weight stream of one NerfMLP, re-packed when the parameters changed."""
+def _bwd_packed(model: NerfModel, state: TrainState, name: str, backward: int) -> torch.Tensor:
+    """The transposed (dgrad) weight stream of one NerfMLP, re-packed when the parameters (or the backward mode) changed."""
     cache = model.__dict__.setdefault("_packed_bwd", {})
     flat = state.variables["flat"][name]
     ent = cache.get(name)
-    if ent is None or ent[0] != flat.data_ptr() or ent[1] != flat._version:
-        buf = ops.nerfmlp_pack_bwd(flat, ent[2] if ent is not None else None)
-        cache[name] = (flat.data_ptr(), flat._version, buf)
+    if ent is None or ent[0] != flat.data_ptr() or ent[1] != flat._version or ent[3] != backward:
+        buf = ops.nerfmlp_pack_bwd(flat, ent[2] if ent is not None else None, backward)
+        cache[name] = (flat.data_ptr(), flat._version, buf, backward)
     return cache[name][2]
+
+
+def backward_mode(flags, model: NerfModel) -> int:
+    """flags.backward_precision: "f32" (default; hi + lo f16 parts, fp32-grade like the reference's jax.value_and_grad, train.py:164),
+    "tf32" (single f16 parts: the 11-bit class of Ampere's TF32 matmuls) or "bf16" (8-bit significand, the round-1 arithmetic)."""
+    name = getattr(flags, "backward_precision", "f32")
+    if name not in _lib.BACKWARDS:
+        raise ValueError(f"backward_precision must be one of {sorted(_lib.BACKWARDS)}")
+    mode = _lib.BACKWARDS[name]
+    if model.precision != _lib.PREC_F16X3:
+        raise ValueError('training is built on the f16x3 forward (NerfModel(precision="f16x3")); the other precisions are inference modes')
+    return mode
 
 
 def train_step(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], flags=None, *, jitter=None, u_fine=None,
@@ -123,7 +135,8 @@ def train_step(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], 
     variables = state.variables
     prec = model.precision
     Nc, Nf = model.num_coarse_samples, model.num_fine_samples
-    ctx: Dict[str, Any] = {}
+    bwd = backward_mode(flags, model)
+    ctx: Dict[str, Any] = {"backward": bwd}
     if flags.bg_smooth_weight > 0:
         ev = batch["env_rays"].viewdirs
         ctx["env_dirs"] = ev.reshape(-1, 3)
@@ -147,8 +160,8 @@ def train_step(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], 
                                                  trans_f, tb_f, sums, mse_scale, flags.bg_weight * bg_on, rgb_padding=model.rgb_padding,
                                                  sigma_bias=model.sigma_bias, bd_cut_bbox=ctx.get("bd_cut_bbox"), white_bkgd=model.white_bkgd,
                                                  d_bkgd=d_first, accumulate_bkgd=False)
-        ops.nerfmlp_backward(_bwd_packed(model, state, "fine_mlp"), model._packed_weights(variables, "fine_mlp"), prec, ctx["save_f"],
-                             d_raw_f, (Nc + Nf) * B, grads=state.grad_view("fine_mlp"))
+        ops.nerfmlp_backward(_bwd_packed(model, state, "fine_mlp", bwd), model._packed_weights(variables, "fine_mlp"), prec, ctx["save_f"],
+                             d_raw_f, (Nc + Nf) * B, grads=state.grad_view("fine_mlp"), backward=bwd)
         d_raw_c, d_bkgd = ops.composite_backward(ctx["raw_c"], ctx["path_pd"], ctx["path_dr"], ctx["jit"], Nc, B, ctx["bkgd"], rgb_c, pixels,
                                                  None, None, None, mse_scale, 0.0, d_bkgd=d_bkgd, rgb_padding=model.rgb_padding,
                                                  sigma_bias=model.sigma_bias, white_bkgd=model.white_bkgd)
@@ -156,8 +169,8 @@ def train_step(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], 
         d_raw_c, d_bkgd = ops.composite_backward(ctx["raw_c"], ctx["path_pd"], ctx["path_dr"], ctx["jit"], Nc, B, ctx["bkgd"], rgb_f, pixels,
                                                  trans_f, tb_f, sums, mse_scale, flags.bg_weight * bg_on, rgb_padding=model.rgb_padding,
                                                  sigma_bias=model.sigma_bias, white_bkgd=model.white_bkgd, d_bkgd=d_first, accumulate_bkgd=False)
-    ops.nerfmlp_backward(_bwd_packed(model, state, "coarse_mlp"), model._packed_weights(variables, "coarse_mlp"), prec, ctx["save_c"],
-                         d_raw_c, Nc * B, grads=state.grad_view("coarse_mlp"))
+    ops.nerfmlp_backward(_bwd_packed(model, state, "coarse_mlp", bwd), model._packed_weights(variables, "coarse_mlp"), prec, ctx["save_c"],
+                         d_raw_c, Nc * B, grads=state.grad_view("coarse_mlp"), backward=bwd)
     # jax.lax.pmean of the gradients (train.py:166), first part: the NerfMLP segments are final here, their all-reduce (95 % of the
     # bytes) starts now and runs beside the rest of the step; the background-MLP gradients and the stats follow in a small second one
     n_big = state.segments["bkgd_mlp"][0]

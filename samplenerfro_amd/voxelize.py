@@ -43,8 +43,10 @@ def build_xy_bins(verts: np.ndarray, faces: np.ndarray, lo: Sequence[float], hi:
     v = verts[faces]                                                  # [F,3,3]
     size = (np.asarray(hi[:2], np.float64) - np.asarray(lo[:2], np.float64)) / num_bins
     size = np.maximum(size, 1e-300)
-    b0 = np.clip(np.floor((v[:, :, :2].min(1) - lo[:2]) / size).astype(np.int64), 0, num_bins - 1)
-    b1 = np.clip(np.floor((v[:, :, :2].max(1) - lo[:2]) / size).astype(np.int64), 0, num_bins - 1)
+    # one cell of slack on both sides: the device finds a column's cell with floor((x - x0) * (1 / size)), which may differ by one from
+    # this floor((x - x0) / size) for a column exactly on a cell border (marching-cubes vertices sit on such sample coordinates)
+    b0 = np.clip(np.floor((v[:, :, :2].min(1) - lo[:2]) / size).astype(np.int64) - 1, 0, num_bins - 1)
+    b1 = np.clip(np.floor((v[:, :, :2].max(1) - lo[:2]) / size).astype(np.int64) + 1, 0, num_bins - 1)
     outside = (v[:, :, 0].max(1) < lo[0]) | (v[:, :, 0].min(1) > hi[0]) | (v[:, :, 1].max(1) < lo[1]) | (v[:, :, 1].min(1) > hi[1])
     cells, tris = [], []
     for f in np.nonzero(~outside)[0]:

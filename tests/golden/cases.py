@@ -105,7 +105,8 @@ def oracle_example(c):
     out = _levels(ret)
     out.update(jitter=c["jitter"], ray_idx_probe=c["ray_idx"][:16].astype(np.int64), idx_f=taps["idx_f"].astype(np.int16),
                ray_pos_sha=sha(taps["ray_pos"]), ray_dist_sha=sha(taps["ray_dist"]), ray_dir_sha=sha(taps["ray_dir"]),
-               ray_pos_sub=taps["ray_pos"][:, ::64].copy(), ray_dist_sub=taps["ray_dist"][:, ::64].copy(), z_f=taps["z_f"])
+               ray_pos_sub=taps["ray_pos"][:, ::64].copy(), ray_dist_sub=taps["ray_dist"][:, ::64].copy(), z_f=taps["z_f"],
+               weights_c=taps["weights_c"])
     return out
 
 

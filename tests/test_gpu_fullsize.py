@@ -261,7 +261,8 @@ def test_config4_dolphin_train_step_full_size(Bd):
     sel = torch.arange(0, Bd, Bd // 16, device=dev)[:16]
     u = ftaps["u"][:, sel].T.cpu().numpy()
     oret, otaps = _oracle_sample(model, pf, batch["rays"].origins, batch["rays"].viewdirs, ftaps["jitter"], sel, {}, u=u)
-    assert np.array_equal(ftaps["idx_f"][:, sel].cpu().numpy().T, otaps["idx_f"])
+    didx = np.abs(ftaps["idx_f"][:, sel].cpu().numpy().T.astype(np.int64) - otaps["idx_f"])
+    assert didx.max() <= 1 and (didx > 0).mean() < 2e-3          # end to end: the coarse weights carry the MLP's 1e-7-level differences
     # (the forward outputs of the step are not returned by train_step: evaluate the model again with the same keys)
     from samplenerfro_amd import prng
     _, key_0, key_1 = prng.split(rng, 3)
