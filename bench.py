@@ -76,15 +76,21 @@ def cpu_baseline(cfg, pf, fine, sample_rays, seed, train=False):
                        num_fine_samples=fine, num_path_samples=cfg["P"])
     jitter = np.arange(0, mc.num_samples, cfg["P"]) + (cfg["P"] // 2)
     params = syn.params_tree(pf)
-    if train:
-        return cpu_train_step(R, mc, pf, params, table, o, d, jitter, cfg, fine, seed)
-    t0 = time.perf_counter()
-    R.nerf_forward(mc, params, table, o, d, jitter)
-    dt = time.perf_counter() - t0
+    times = []
+    for it in range(1 + 3):                  # one warm-up (thread pools, page faults, BLAS autotuning) + 3 timed: the median is reported
+        if train:
+            _, dt = cpu_train_step(R, mc, pf, params, table, o, d, jitter, cfg, fine, seed)
+        else:
+            t0 = time.perf_counter()
+            R.nerf_forward(mc, params, table, o, d, jitter)
+            dt = time.perf_counter() - t0
+        if it > 0:
+            times.append(dt)
+    dt = float(np.median(times))
     return sample_rays / dt, dt
 
 
-def parity_vs_oracle(model, pf, cfg, fine, device, n_rays=256):
+def parity_vs_oracle(model, pf, cfg, fine, device, n_rays=4096):
     """BASELINE metric 'PSNR vs ref' / max-abs error: the GPU path against the fp32 oracle on a small sample of the SAME workload
     (same table, initial weights, rays, jitter).  The oracle is the checker here, never the thing measured."""
     import torch
@@ -169,6 +175,8 @@ def main():
                     help="issue the march of step k+1 on a side stream (train: beside the small tail kernels of step k, default ON; "
                          "forward: beside the MLP on reserved CUs, default OFF)")
     ap.add_argument("--no-pipeline", dest="pipeline", action="store_false", help="every step runs its stages strictly in sequence")
+    ap.add_argument("--no-extra", dest="extra", action="store_false",
+                    help="skip the short timing of the other backward modes (train mode)")
     ap.add_argument("--no-frame", dest="frame", action="store_false",
                     help="skip the 800x800 full-frame render (ms/frame, the second part of BASELINE's metric; ~1 s)")
     ap.add_argument("--reserve-cus", type=int, default=32, help="CUs kept free of MLP workgroups for the overlapped march")
@@ -176,13 +184,16 @@ def main():
     ap.add_argument("--backward", choices=["f32", "tf32", "bf16"], default="f32",
                     help="arithmetic of the NerfMLP backward: f32 = hi + lo f16 parts (fp32-grade, the reference differentiates in fp32; "
                          "default), tf32 = f16 parts (11-bit significand), bf16 = 8-bit significand (round 1's arithmetic)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: every rank owns --rays rays (default); strong: --rays is the GLOBAL batch, split over the ranks "
+                         "(BASELINE config 4 as written: 4096 rays = 512 per GPU on 8 GPUs)")
     ap.add_argument("--mode", choices=["train", "forward"], default="train",
                     help="train: the whole optimisation step (BASELINE metric 'rays/sec (train step)'); forward: the render pass only")
     args = ap.parse_args()
     if args.pipeline is None:
         args.pipeline = args.mode == "train"
     if args.cpu_rays is None:
-        args.cpu_rays = 8192 if args.mode == "forward" else 1536
+        args.cpu_rays = 4096 if args.mode == "forward" else 768
 
     import torch
     import torch.distributed as dist
@@ -195,19 +206,27 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the hot path has no CPU implementation)")
+    # one process per GPU (RCCL).  RNERF_DIST_BACKEND=gloo lets the tests drive this very branch with two ranks on one device
+    backend = os.environ.get("RNERF_DIST_BACKEND", "nccl")
+    local_rank = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     from samplenerfro_amd import distributed as D
-    D.init("nccl")   # one process per GPU, RCCL; only used for the timing barrier and the max over ranks
+    os.environ["LOCAL_RANK"] = str(local_rank)
+    D.init(backend)   # the train step's gradient all-reduce, the timing barrier and the max over ranks
 
     cfg = dict(syn.CONFIGS[args.workload])
     fine = cfg["F"] if args.fine is None else args.fine
     B = args.rays or min(cfg["B"], 4096 if args.workload != "glass_frame" else 8192)
+    if args.scaling == "strong":
+        if B % world:
+            raise SystemExit("--scaling strong: the global batch must be divisible by the number of ranks (train.py:196)")
+        B //= world
     model, variables, pf = build_scene(cfg, device, args.precision, fine)
     # weak scaling: every rank marches its own B rays (different seed per rank), grid + weights replicated
     o, d = syn.sphere_rays(B, seed=syn.SEED + rank)
     rays = Rays(torch.from_numpy(o).to(device), None, torch.from_numpy(d).to(device), None)
-    key = prng.PRNGKey(syn.SEED)
+    key = prng.split(prng.PRNGKey(syn.SEED), world)[rank]      # one key per device (train.py:338-339)
 
     # Software pipeline across steps: the march of batch k+1 (latency-bound, no matrix cores) runs on a side stream
     # while the MLP/compositing phase of batch k (MFMA-bound) runs on the main stream.  Every step still does its whole
@@ -260,6 +279,7 @@ def main():
 
     # ---- per-kernel roofline of the dominant kernel (PE + NerfMLP), HIP events on the launch stream --------------------
     from samplenerfro_amd import ops, _lib
+    rnerf_cus = _lib.load().rnerf_device_cus()
     S = cfg["S"]
     N = S * cfg["P"]
     path_pd, path_dr, _, _ = ops.march(model.table, model.spec, rays.origins, rays.viewdirs, cfg["near"], cfg["far"], N)
@@ -331,26 +351,64 @@ def main():
                                       "algorithmic_flop_per_launch": flop})
         del raw_t, save_t, dy_t, ws_t
 
-    # HBM bytes per launch from the committed rocprofv3 --pmc passes of this very command (profiles/);
-    # PMC counters cannot be collected from inside the process, so `traffic` is null when no matching profile exists.
-    traffic = {}
+    # HBM bytes and SQ / GRBM counters per launch come from rocprofv3 --pmc passes of THIS command (tools/r02/pmc_all.sh; PMC counters
+    # cannot be read from inside the process).  The committed JSON is stamped with the sha of bench.py and csrc/mlp.hip it was taken
+    # with; `traffic` / `counters` are null / absent when no profile of this workload exists or its stamp is stale.
+    traffic, sq, pmc_meta = {}, {}, None
     try:
+        import hashlib
         if args.workload == "ship_straight" and fine == 0 and B == 4096:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01", "c_pmc_%s.json" % args.mode)))["counters"]
-            for k, v in pm.items():
-                # KiB -> bytes; wide (16 B/lane) streaming reads are reported at half their size on gfx950 (MI355X_MICROARCH.md, HBM):
-                # doubled for the MLP kernels (weight DMA / saved-operand streams); the march's 4-byte gathers stay as reported
-                ff = 2.0 if "nerfmlp" in k else 1.0
+            tag = args.mode if args.mode == "forward" else "train_" + args.backward
+            pj = json.load(open(os.path.join(ROOT, "profiles", "r02", "pmc_%s.json" % tag)))
+            sha = lambda q: hashlib.sha256(open(q, "rb").read()).hexdigest()[:16]
+            fresh = pj.get("mlp_hip_sha16") == sha(os.path.join(ROOT, "samplenerfro_amd", "csrc", "mlp.hip"))
+            pmc_meta = {"file": "profiles/r02/pmc_%s.json" % tag, "head": pj.get("head"), "bench_py_sha16": pj.get("bench_py_sha16"),
+                        "kernels_unchanged_since": bool(fresh)}
+            for k, v in pj["counters"].items():
                 name = k.split("::")[-1]
-                traffic[name] = 1024.0 * (ff * v["FETCH_SIZE"]["mean"] + v["WRITE_SIZE"]["mean"])
+                if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+                    # KiB -> bytes; wide (16 B/lane) streaming reads are reported at half their size on gfx950 (MI355X_MICROARCH.md, HBM):
+                    # doubled for the MLP kernels (weight DMA / saved-operand streams); the march's 4-byte gathers stay as reported
+                    ff = 2.0 if "nerfmlp" in k else 1.0
+                    traffic[name] = 1024.0 * (ff * v["FETCH_SIZE"]["mean"] + v["WRITE_SIZE"]["mean"])
+                if "SQ_VALU_MFMA_BUSY_CYCLES" in v and "GRBM_GUI_ACTIVE" in v:
+                    gui = v["GRBM_GUI_ACTIVE"]["mean"]
+                    sq[name] = {"mfma_busy_frac": v["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"] / (4.0 * rnerf_cus * gui),
+                                "effective_clock_ghz": gui / v["avg_ns"]["mean"] if "avg_ns" in v else None,
+                                "wave_wait_frac": (v["SQ_WAIT_ANY"]["mean"] / v["SQ_WAVE_CYCLES"]["mean"]) if "SQ_WAIT_ANY" in v and "SQ_WAVE_CYCLES" in v else None}
     except Exception:
-        traffic = {}
+        traffic, sq = {}, {}
 
     def traffic_of(prefix):
         for k, v in traffic.items():
             if k.startswith(prefix):
                 return v
         return None
+
+    def counters_of(prefix):
+        for k, v in sq.items():
+            if k.startswith(prefix):
+                return v
+        return None
+    other_modes = None
+    if train and args.extra:
+        # the same step with the other backward arithmetics (5 steps each, after 2 warm-up steps), for the record in the same line
+        other_modes = {}
+        for name in ("f32", "tf32", "bf16"):
+            if name == args.backward:
+                continue
+            flags.backward_precision = name
+            state["h"] = None
+            for i in range(2):
+                step(last=(i == 1))
+            barrier()
+            t1 = time.perf_counter()
+            for i in range(5):
+                step(last=(i == 4))
+            barrier()
+            dt_m = D.max_over_ranks(time.perf_counter() - t1, device)
+            other_modes[name] = {"ms_per_step": 1e3 * dt_m / 5, "rays_per_s": B * world * 5 / dt_m}
+        flags.backward_precision = args.backward
     frame = None
     if args.frame:
         # ms/frame @ 800x800 (BASELINE.json metric 2): pinhole rays of the example camera looking at the volume, rendered in
@@ -376,30 +434,43 @@ def main():
         rows_per_ray = S + (S + fine if fine > 0 else 0)
         line = {
             "metric": "rays/sec (train step)" if train else "rays/sec (forward render pass)", "value": total_rays / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": args.scaling,
+            "vs_baseline": None, "dtype": ("f32" if (not train or args.backward == "f32") else ("f16" if args.backward == "tf32" else "bf16")), "data": "synthetic",
             "config": {"workload": f"{args.workload}: {'train step (forward + backward + grad all-reduce + Adam)' if train else 'forward render pass'}, "
                                    f"{B} rays/GPU x {S} coarse + {fine} fine samples, "
                                    f"P={cfg['P']} (N={N} eikonal steps), grid {cfg['G']}^3", "rays_per_gpu": B,
                        "mlp_rows_per_ray": rows_per_ray, "pass": args.mode,
-                       "precision": args.precision + ": fp32 operands split into 16-bit parts for the MFMAs, fp32 accumulate",
+                       "precision": args.precision + ": forward — fp32 operands split into hi + lo 16-bit parts, 3 MFMAs per product, fp32 accumulate",
+                       "backward_precision": (None if not train else args.backward),
+                       "backward_precision_note": (None if not train else {
+                           "f32": "row-normalised f16 hi + lo parts of every saved activation and gradient (22 bits), 3 MFMAs per product: within 1e-5 of max|g| vs float64",
+                           "tf32": "row-normalised f16 parts (11-bit significand), 1-2 MFMAs per product: ~1e-3 of max|g| on small batches, ~1e-5 at this size",
+                           "bf16": "bf16 parts (8-bit significand), round 1's arithmetic: ~6e-3 of max|g| on small batches"}[args.backward]),
                        "pipeline": ("none" if not args.pipeline else ("march(k+1) on a side stream beside the tail of step k (bkgd backward, Adam)" if train
                                                                           else "march(k+1) on a side stream overlaps MLP(k)"))},
             "roofline": {"kernel": "nerfmlp_fwd_kernel", "bound": "mfma", "achieved": mlp_achieved / 1e12, "peak": PEAK_MFMA_16BIT / 1e12,
-                         "unit": "TFLOP/s", "frac": mlp_achieved / PEAK_MFMA_16BIT, "traffic": traffic_of("nerfmlp_fwd_kernel<1, 0, false>"),
+                         "unit": "TFLOP/s", "frac": mlp_achieved / PEAK_MFMA_16BIT, "traffic": traffic_of("nerfmlp_fwd_kernel<1, 0, 0>"),
                          "avg_launch_ms": mlp_ms, "algorithmic_flop_per_launch": mlp_flops,
-                         "mfma_issue_frac": (3 if "x3" in args.precision else 1) * mlp_achieved / PEAK_MFMA_16BIT},
+                         # computed, not a counter: MFMA flops issued (3 passes in the x3 modes) / (launch time x 2.5 PF)
+                         "mfma_issue_frac_computed": (3 if "x3" in args.precision else 1) * mlp_achieved / PEAK_MFMA_16BIT,
+                         "counters": counters_of("nerfmlp_fwd_kernel<1, 0, 0>")},
             "roofline_march": {"kernel": "march_kernel", "bound": "hbm", "achieved": march_achieved / 1e9, "peak": PEAK_HBM / 1e9,
                                "unit": "GB/s", "frac": march_achieved / PEAK_HBM, "traffic": traffic_of("march_kernel"), "avg_launch_ms": march_ms,
                                "algorithmic_bytes_per_launch": march_bytes},
         }
         if train:
             # the dominant kernel of a train step is the training forward (the forward + the operand/mask stores for the backward)
-            for tk, pref in zip(train_kernels, ("nerfmlp_fwd_kernel<1, 0, true>", "nerfmlp_dgrad_kernel", "nerfmlp_wgrad_kernel")):
+            fk = "nerfmlp_fwd_kernel<1, 0, 2>" if args.backward == "f32" else "nerfmlp_fwd_kernel<1, 0, 1>"
+            for tk, pref in zip(train_kernels, (fk, "nerfmlp_dgrad_kernel", "nerfmlp_wgrad")):
                 tk["traffic"] = traffic_of(pref)
+                tk["counters"] = counters_of(pref)
             line["roofline_forward_kernel"] = line["roofline"]
             line["roofline"] = max(train_kernels, key=lambda t: t["avg_launch_ms"])
             line["roofline_train_kernels"] = train_kernels
+        if pmc_meta is not None:
+            line["pmc_profile"] = pmc_meta
+        if other_modes:
+            line["other_backward_modes"] = other_modes
         if frame is not None:
             line["frame"] = frame
         if not args.no_cpu_baseline:
@@ -414,7 +485,7 @@ def main():
             used = torch.get_num_threads() if train else blas
             line["parity"] = parity_vs_oracle(model, pf, cfg, fine, device)
             line["cpu_baseline"] = {"value": cpu_rps, "unit": "rays/s", "cores": used, "host_cpus": os.cpu_count(), "kind": "port",
-                                    "sample": f"{args.cpu_rays} rays of the same workload, {what} (threaded BLAS), {cpu_dt:.1f} s"}
+                                    "sample": f"{args.cpu_rays} rays of the same workload, {what} (threaded BLAS); 1 warm-up + median of 3 passes, {cpu_dt:.1f} s each"}
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

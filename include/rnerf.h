@@ -103,11 +103,6 @@ int rnerf_march(const float* table, const rnerf_grid* g, const float* origins, c
                 double near, double far, int32_t num_nodes, float* path_pd, float* path_dr, float* path_ior,
                 int32_t* vox, void* stream);
 
-/* Cap the persistent grid of rnerf_nerfmlp_forward at n workgroups (0 = one per CU).  The MLP kernel owns a whole CU
- * (512 VGPRs, 160 KiB LDS); leaving a few CUs free lets the latency-bound march of the NEXT ray batch run concurrently
- * on another stream.  Process-wide setting. */
-int rnerf_set_mlp_workgroup_limit(int n);
-
 /* ---- N1 weights: pack a flat fp32 NerfMLP parameter buffer into the MFMA operand stream of `precision`. */
 size_t rnerf_nerfmlp_packed_bytes(int precision);
 int rnerf_nerfmlp_pack(const float* params, int precision, void* packed, void* stream);
@@ -117,9 +112,11 @@ int rnerf_nerfmlp_pack(const float* params, int precision, void* packed, void* s
  * Rows are sample-major: row = s*B + b.  If node_of_sample != NULL (int32[S], device) the record of row (s,b) is
  * read at node_of_sample[s]*B + b (coarse pass reading the path record through the jitter); otherwise at s*B + b.
  * packed: the buffer written by rnerf_nerfmlp_pack (weight stream + fp32 biases and sigma/rgb heads).
- * out_raw: float4[S*B] = (raw_r, raw_g, raw_b, raw_sigma) before activation. */
+ * out_raw: float4[S*B] = (raw_r, raw_g, raw_b, raw_sigma) before activation.
+ * max_workgroups: cap of the persistent grid (0 = one workgroup per CU).  The kernel owns a whole CU (512 VGPRs, 160 KiB LDS); a
+ * caller that marches the NEXT ray batch on another stream leaves a few CUs free for it with this argument (no library state). */
 int rnerf_nerfmlp_forward(const void* packed, int precision, const float* rows_pd, const float* rows_dr,
-                          const int32_t* node_of_sample, int32_t S, int32_t B, float* out_raw, void* stream);
+                          const int32_t* node_of_sample, int32_t S, int32_t B, float* out_raw, int32_t max_workgroups, void* stream);
 
 /* ---- P1 + N2: background MLP on one direction per ray.  Replaces bkgd_mlp(viewdirs_enc[:, -1:]) +
  * rgb activation (rnerf/models.py:303,336-337) and NerfModel.forward_envmap (:181-191).

@@ -50,10 +50,9 @@ SIGNATURES = {
     "rnerf_grid_build_table": (C.c_int, [_vp, _vp, _GP, _vp]),
     "rnerf_grid_query": (C.c_int, [_vp, _GP, _vp, _i64, _vp, _vp, _vp]),
     "rnerf_march": (C.c_int, [_vp, _GP, _vp, _vp, _i32, _dbl, _dbl, _i32, _vp, _vp, _vp, _vp, _vp]),
-    "rnerf_set_mlp_workgroup_limit": (C.c_int, [C.c_int]),
     "rnerf_nerfmlp_packed_bytes": (C.c_size_t, [C.c_int]),
     "rnerf_nerfmlp_pack": (C.c_int, [_vp, C.c_int, _vp, _vp]),
-    "rnerf_nerfmlp_forward": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _i32, _i32, _vp, _vp]),
+    "rnerf_nerfmlp_forward": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _vp]),
     "rnerf_bkgd_forward": (C.c_int, [_vp, _vp, _i32, _i64, _dbl, _vp, _vp]),
     "rnerf_composite": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, C.c_int, _dbl, _dbl,
                                   _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.POINTER(C.c_double * 6), _vp]),

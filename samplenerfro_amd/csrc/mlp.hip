@@ -1940,14 +1940,6 @@ using namespace rnerf;
 
 static bool prec_ok(int p) { return p == RNERF_PREC_F16X3 || p == RNERF_PREC_BF16X3 || p == RNERF_PREC_F16 || p == RNERF_PREC_BF16; }
 
-static int g_mlp_wg_limit = 0;   // 0 = one workgroup per CU
-
-extern "C" int rnerf_set_mlp_workgroup_limit(int n) {
-  RNERF_CHECK_ARG(n >= 0, "rnerf_set_mlp_workgroup_limit: n must be >= 0");
-  g_mlp_wg_limit = n;
-  return RNERF_OK;
-}
-
 extern "C" size_t rnerf_nerfmlp_packed_bytes(int precision) {
   switch (precision) {
     case RNERF_PREC_F16X3: return Prec<RNERF_PREC_F16X3>::PACKED_BYTES;
@@ -1982,41 +1974,41 @@ static int mlp_debug_flags() {
 
 template <int PREC, int DBG, int TRAIN = 0>
 static int launch_fwd_dbg(const void* packed, const float* rows_pd, const float* rows_dr, const int32_t* node_of_sample, int32_t B,
-                          long long total_rows, float* out_raw, hipStream_t st, void* save = nullptr);
+                          long long total_rows, float* out_raw, hipStream_t st, void* save = nullptr, int max_wg = 0);
 
 template <int PREC>
 static int launch_fwd(const void* packed, const float* rows_pd, const float* rows_dr, const int32_t* node_of_sample, int32_t B,
-                      long long total_rows, float* out_raw, hipStream_t st) {
+                      long long total_rows, float* out_raw, hipStream_t st, int max_wg) {
 #ifdef RNERF_MLP_ABLATE
   switch (mlp_debug_flags()) {
-    case 1: return launch_fwd_dbg<PREC, 1>(packed, rows_pd, rows_dr, node_of_sample, B, total_rows, out_raw, st);
-    case 2: return launch_fwd_dbg<PREC, 2>(packed, rows_pd, rows_dr, node_of_sample, B, total_rows, out_raw, st);
-    case 3: return launch_fwd_dbg<PREC, 3>(packed, rows_pd, rows_dr, node_of_sample, B, total_rows, out_raw, st);
-    case 4: return launch_fwd_dbg<PREC, 4>(packed, rows_pd, rows_dr, node_of_sample, B, total_rows, out_raw, st);
-    case 5: return launch_fwd_dbg<PREC, 5>(packed, rows_pd, rows_dr, node_of_sample, B, total_rows, out_raw, st);
-    case 8: return launch_fwd_dbg<PREC, 8>(packed, rows_pd, rows_dr, node_of_sample, B, total_rows, out_raw, st);
-    case 13: return launch_fwd_dbg<PREC, 13>(packed, rows_pd, rows_dr, node_of_sample, B, total_rows, out_raw, st);
-    case 16: return launch_fwd_dbg<PREC, 16>(packed, rows_pd, rows_dr, node_of_sample, B, total_rows, out_raw, st);
-    case 48: return launch_fwd_dbg<PREC, 48>(packed, rows_pd, rows_dr, node_of_sample, B, total_rows, out_raw, st);
-    case 128: return launch_fwd_dbg<PREC, 128>(packed, rows_pd, rows_dr, node_of_sample, B, total_rows, out_raw, st);
-    case 64: return launch_fwd_dbg<PREC, 64>(packed, rows_pd, rows_dr, node_of_sample, B, total_rows, out_raw, st);
-    case 32: return launch_fwd_dbg<PREC, 32>(packed, rows_pd, rows_dr, node_of_sample, B, total_rows, out_raw, st);
-    case 29: return launch_fwd_dbg<PREC, 29>(packed, rows_pd, rows_dr, node_of_sample, B, total_rows, out_raw, st);
+    case 1: return launch_fwd_dbg<PREC, 1>(packed, rows_pd, rows_dr, node_of_sample, B, total_rows, out_raw, st, nullptr, max_wg);
+    case 2: return launch_fwd_dbg<PREC, 2>(packed, rows_pd, rows_dr, node_of_sample, B, total_rows, out_raw, st, nullptr, max_wg);
+    case 3: return launch_fwd_dbg<PREC, 3>(packed, rows_pd, rows_dr, node_of_sample, B, total_rows, out_raw, st, nullptr, max_wg);
+    case 4: return launch_fwd_dbg<PREC, 4>(packed, rows_pd, rows_dr, node_of_sample, B, total_rows, out_raw, st, nullptr, max_wg);
+    case 5: return launch_fwd_dbg<PREC, 5>(packed, rows_pd, rows_dr, node_of_sample, B, total_rows, out_raw, st, nullptr, max_wg);
+    case 8: return launch_fwd_dbg<PREC, 8>(packed, rows_pd, rows_dr, node_of_sample, B, total_rows, out_raw, st, nullptr, max_wg);
+    case 13: return launch_fwd_dbg<PREC, 13>(packed, rows_pd, rows_dr, node_of_sample, B, total_rows, out_raw, st, nullptr, max_wg);
+    case 16: return launch_fwd_dbg<PREC, 16>(packed, rows_pd, rows_dr, node_of_sample, B, total_rows, out_raw, st, nullptr, max_wg);
+    case 48: return launch_fwd_dbg<PREC, 48>(packed, rows_pd, rows_dr, node_of_sample, B, total_rows, out_raw, st, nullptr, max_wg);
+    case 128: return launch_fwd_dbg<PREC, 128>(packed, rows_pd, rows_dr, node_of_sample, B, total_rows, out_raw, st, nullptr, max_wg);
+    case 64: return launch_fwd_dbg<PREC, 64>(packed, rows_pd, rows_dr, node_of_sample, B, total_rows, out_raw, st, nullptr, max_wg);
+    case 32: return launch_fwd_dbg<PREC, 32>(packed, rows_pd, rows_dr, node_of_sample, B, total_rows, out_raw, st, nullptr, max_wg);
+    case 29: return launch_fwd_dbg<PREC, 29>(packed, rows_pd, rows_dr, node_of_sample, B, total_rows, out_raw, st, nullptr, max_wg);
     default: break;
   }
 #endif
-  return launch_fwd_dbg<PREC, 0>(packed, rows_pd, rows_dr, node_of_sample, B, total_rows, out_raw, st);
+  return launch_fwd_dbg<PREC, 0>(packed, rows_pd, rows_dr, node_of_sample, B, total_rows, out_raw, st, nullptr, max_wg);
 }
 
 template <int PREC, int DBG, int TRAIN>
 static int launch_fwd_dbg(const void* packed, const float* rows_pd, const float* rows_dr, const int32_t* node_of_sample, int32_t B,
-                      long long total_rows, float* out_raw, hipStream_t st, void* save) {
+                      long long total_rows, float* out_raw, hipStream_t st, void* save, int max_wg) {
   using PP = Prec<PREC>;
   const int n_tiles = (int)((total_rows + 255) / 256);
   int dev = 0, cus = 0;
   RNERF_CHECK_HIP(hipGetDevice(&dev));
   RNERF_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-  const int lim = (g_mlp_wg_limit > 0 && g_mlp_wg_limit < cus) ? g_mlp_wg_limit : cus;
+  const int lim = (max_wg > 0 && max_wg < cus) ? max_wg : cus;
   const int grid = n_tiles < lim ? n_tiles : lim;
   const size_t lds = 2 * (size_t)PP::SLAB + 4 * 32768;
   static bool attr_set = false;
@@ -2032,8 +2024,10 @@ static int launch_fwd_dbg(const void* packed, const float* rows_pd, const float*
 }
 
 extern "C" int rnerf_nerfmlp_forward(const void* packed, int precision, const float* rows_pd, const float* rows_dr,
-                                     const int32_t* node_of_sample, int32_t S, int32_t B, float* out_raw, void* stream) {
+                                     const int32_t* node_of_sample, int32_t S, int32_t B, float* out_raw, int32_t max_workgroups,
+                                     void* stream) {
   RNERF_CHECK_ARG(packed && rows_pd && rows_dr && out_raw, "rnerf_nerfmlp_forward: null pointer");
+  RNERF_CHECK_ARG(max_workgroups >= 0, "rnerf_nerfmlp_forward: max_workgroups must be >= 0");
   RNERF_CHECK_ARG(prec_ok(precision), "rnerf_nerfmlp_forward: unsupported precision %d", precision);
   RNERF_CHECK_ARG(S >= 1 && B >= 1, "rnerf_nerfmlp_forward: need S >= 1 and B >= 1");
   RNERF_CHECK_ARG((((uintptr_t)packed | (uintptr_t)rows_pd | (uintptr_t)rows_dr | (uintptr_t)out_raw) & 15) == 0,
@@ -2041,10 +2035,10 @@ extern "C" int rnerf_nerfmlp_forward(const void* packed, int precision, const fl
   const long long total = (long long)S * B;
   hipStream_t st = (hipStream_t)stream;
   switch (precision) {
-    case RNERF_PREC_F16X3: return launch_fwd<RNERF_PREC_F16X3>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st);
-    case RNERF_PREC_BF16X3: return launch_fwd<RNERF_PREC_BF16X3>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st);
-    case RNERF_PREC_F16: return launch_fwd<RNERF_PREC_F16>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st);
-    default: return launch_fwd<RNERF_PREC_BF16>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st);
+    case RNERF_PREC_F16X3: return launch_fwd<RNERF_PREC_F16X3>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, max_workgroups);
+    case RNERF_PREC_BF16X3: return launch_fwd<RNERF_PREC_BF16X3>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, max_workgroups);
+    case RNERF_PREC_F16: return launch_fwd<RNERF_PREC_F16>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, max_workgroups);
+    default: return launch_fwd<RNERF_PREC_BF16>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, max_workgroups);
   }
 }
 

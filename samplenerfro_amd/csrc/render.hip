@@ -326,6 +326,7 @@ __global__ void __launch_bounds__(64) composite_bwd_kernel(const float4* __restr
 //      (:415-421) from an arithmetic guess + gallop + bisection (node depths are near + ~k*step), then the gather
 //      pos = path_pos[idx] + dir[idx]*(z - z_vals[idx]) (:423-427).  Neighbouring lanes = neighbouring rays at the same
 //      sample index, whose node indices nearly coincide, so the probes and gathers of a wave are near-contiguous.
+template <int RPB>      // rays per 64-lane block: 16 (a quad per ray); 4 or 1 when S and F do not fit the LDS staging at 16 (quads then duplicate rays)
 __global__ void __launch_bounds__(64) resample_depths_kernel(const float4* __restrict__ path_pd, int B,
                                                              const int* __restrict__ jitter, int S,
                                                              const float* __restrict__ weights, const float* __restrict__ u,
@@ -336,16 +337,16 @@ __global__ void __launch_bounds__(64) resample_depths_kernel(const float4* __res
   // quad broadcasts (same individually rounded additions as a one-lane loop).  The inverse-CDF lookups and the merge of the two
   // sorted lists are independent per element: binary searches instead of the serial (and lane-divergent) walk.
   extern __shared__ float lds[];
-  float* tcA = lds; float* wA = tcA + (size_t)S * 16; float* cdfA = wA + (size_t)S * 16; float* zfA = cdfA + (size_t)S * 16;
-  float* mgA = zfA + (size_t)F * 16;
-  const int lane = threadIdx.x, q = lane & 3, rl = lane >> 2;          // rl = ray within the block
-  const int r0 = blockIdx.x * 16 + rl;
+  float* tcA = lds; float* wA = tcA + (size_t)S * RPB; float* cdfA = wA + (size_t)S * RPB; float* zfA = cdfA + (size_t)S * RPB;
+  float* mgA = zfA + (size_t)F * RPB;
+  const int lane = threadIdx.x, q = lane & 3, rl = (lane >> 2) % RPB;  // rl = ray within the block
+  const int r0 = blockIdx.x * RPB + rl;
   const int r = r0 < B ? r0 : B - 1;
   const int nb = S - 1;        // number of bin edges / cdf entries
   const int nw = S - 2;        // number of weights
   for (int i = q; i < S; i += 4) {
-    tcA[i * 16 + rl] = path_pd[(size_t)jitter[i] * B + r].w;
-    wA[i * 16 + rl] = weights[(size_t)i * B + r];
+    tcA[i * RPB + rl] = path_pd[(size_t)jitter[i] * B + r].w;
+    wA[i * RPB + rl] = weights[(size_t)i * B + r];
   }
   __syncthreads();
   auto acc4 = [&](float a, float p) -> float {      // (((a + p0) + p1) + p2) + p3
@@ -355,7 +356,7 @@ __global__ void __launch_bounds__(64) resample_depths_kernel(const float4* __res
   float wsum = 0.f;
   for (int j = 0; j < nw; j += 4) {
     const int i = j + q;
-    wsum = acc4(wsum, i < nw ? wA[(i + 1) * 16 + rl] : 0.f);
+    wsum = acc4(wsum, i < nw ? wA[(i + 1) * RPB + rl] : 0.f);
   }
   const float padding = fmaxf(0.f, fsub(1e-5f, wsum));
   const float padw = fdiv(padding, (float)nw);
@@ -364,51 +365,51 @@ __global__ void __launch_bounds__(64) resample_depths_kernel(const float4* __res
   float cum = 0.f;
   for (int j = 0; j < nw; j += 4) {
     const int m = j + q;
-    const float term = m < nw ? fdiv(fadd(wA[(m + 1) * 16 + rl], padw), wsum) : 0.f;
+    const float term = m < nw ? fdiv(fadd(wA[(m + 1) * RPB + rl], padw), wsum) : 0.f;
     const float t0 = quad_bcast<0>(term), t1 = quad_bcast<1>(term), t2 = quad_bcast<2>(term), t3 = quad_bcast<3>(term);
     // the serial code starts the running sum AT the first term (no 0 + term), so P_0 is the term itself
     const float c0 = (j == 0) ? t0 : fadd(cum, t0);
     const float c1 = fadd(c0, t1), c2 = fadd(c1, t2), c3 = fadd(c2, t3);
     const float mine = q == 0 ? c0 : (q == 1 ? c1 : (q == 2 ? c2 : c3));
-    if (m + 1 <= nb - 2) cdfA[(m + 1) * 16 + rl] = fminf(1.f, mine);
+    if (m + 1 <= nb - 2) cdfA[(m + 1) * RPB + rl] = fminf(1.f, mine);
     cum = c3;
   }
-  if (q == 0) { cdfA[rl] = 0.f; cdfA[(nb - 1) * 16 + rl] = 1.f; }
+  if (q == 0) { cdfA[rl] = 0.f; cdfA[(nb - 1) * RPB + rl] = 1.f; }
   __syncthreads();
   // fine depths: interval i = #{k in [1, nb-2] : cdf[k] <= u} (the walk of :360-370), then the affine map inside it (:372-373)
   for (int j = q; j < F; j += 4) {
     const float uj = u_per_ray ? u[(size_t)j * B + r] : u[j];
     int lo = 1, hi = nb - 1;                                       // first k in [1, nb-1) with cdf[k] > uj
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (cdfA[mid * 16 + rl] > uj) hi = mid; else lo = mid + 1; }
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (cdfA[mid * RPB + rl] > uj) hi = mid; else lo = mid + 1; }
     const int i = lo - 1;
-    const float c0 = cdfA[i * 16 + rl], c1 = cdfA[(i + 1) * 16 + rl];
-    const float ta = tcA[i * 16 + rl], tb = tcA[(i + 1) * 16 + rl], tcx = tcA[(i + 2) * 16 + rl];
+    const float c0 = cdfA[i * RPB + rl], c1 = cdfA[(i + 1) * RPB + rl];
+    const float ta = tcA[i * RPB + rl], tb = tcA[(i + 1) * RPB + rl], tcx = tcA[(i + 2) * RPB + rl];
     const float b0 = fmul(0.5f, fadd(tb, ta)), b1 = fmul(0.5f, fadd(tcx, tb));     // mids (models.py:371)
     float t = fdiv(fsub(uj, c0), fsub(c1, c0));
     if (t != t) t = 0.f;                              // nan_to_num(., 0): NaN -> 0, inf -> +-FLT_MAX then clip
     t = fminf(fmaxf(t, 0.f), 1.f);
-    zfA[j * 16 + rl] = fadd(b0, fmul(t, fsub(b1, b0)));
+    zfA[j * RPB + rl] = fadd(b0, fmul(t, fsub(b1, b0)));
   }
   __syncthreads();
   // merge of the two sorted lists (jnp.sort of the concatenation, :405; coarse first on ties): rank by binary search
   for (int i = q; i < S; i += 4) {
-    const float z = tcA[i * 16 + rl];
+    const float z = tcA[i * RPB + rl];
     int lo = 0, hi = F;                                            // #{j : zf[j] < z}
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (zfA[mid * 16 + rl] < z) lo = mid + 1; else hi = mid; }
-    mgA[(i + lo) * 16 + rl] = z;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (zfA[mid * RPB + rl] < z) lo = mid + 1; else hi = mid; }
+    mgA[(i + lo) * RPB + rl] = z;
   }
   for (int j = q; j < F; j += 4) {
-    const float z = zfA[j * 16 + rl];
+    const float z = zfA[j * RPB + rl];
     int lo = 0, hi = S;                                            // #{i : tc[i] <= z}
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (tcA[mid * 16 + rl] <= z) lo = mid + 1; else hi = mid; }
-    mgA[(j + lo) * 16 + rl] = z;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (tcA[mid * RPB + rl] <= z) lo = mid + 1; else hi = mid; }
+    mgA[(j + lo) * RPB + rl] = z;
   }
   __syncthreads();
-  // coalesced write-out: 16 consecutive rays per 64-byte segment
+  // coalesced write-out: RPB consecutive rays per segment
   const int total = S + F;
-  const int rr = lane & 15;
-  if (blockIdx.x * 16 + rr < B)
-    for (int p = lane >> 4; p < total; p += 4) zbuf[(size_t)p * B + blockIdx.x * 16 + rr] = mgA[p * 16 + rr];
+  const int rr = lane % RPB;
+  if (blockIdx.x * RPB + rr < B)
+    for (int p = lane / RPB; p < total; p += 64 / RPB) zbuf[(size_t)p * B + blockIdx.x * RPB + rr] = mgA[p * RPB + rr];
 }
 
 __global__ void __launch_bounds__(256) resample_gather_kernel(const float4* __restrict__ path_pd, const float4* __restrict__ path_dr,
@@ -485,18 +486,27 @@ extern "C" int rnerf_resample(const float* path_pd, const float* path_dr, int32_
   RNERF_CHECK_ARG(path_pd && path_dr && jitter && weights && rows_pd && rows_dr && scratch, "rnerf_resample: null pointer");
   RNERF_CHECK_ARG(u || num_fine == 0, "rnerf_resample: u must be given (use linspace(0,1-eps,F) for randomized=False)");
   RNERF_CHECK_ARG(S >= 3 && B >= 1 && num_nodes >= 2 && num_fine >= 0, "rnerf_resample: need S >= 3, B >= 1, num_nodes >= 2");
-  RNERF_CHECK_ARG(4 * (long long)S + 2 * (long long)num_fine <= 2560, "rnerf_resample: 4*S + 2*num_fine > 2560 does not fit the 160 KiB LDS staging");
+  const long long need = 4 * (long long)S + 2 * (long long)num_fine;      // floats of LDS staging per ray
+  RNERF_CHECK_ARG(need <= 40960, "rnerf_resample: 4*S + 2*num_fine > 40960 does not fit the 160 KiB LDS staging even at one ray per block");
   RNERF_CHECK_ARG((((uintptr_t)path_pd | (uintptr_t)path_dr | (uintptr_t)rows_pd | (uintptr_t)rows_dr) & 15) == 0,
                   "rnerf_resample: float4 buffers must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
-  const size_t lds = ((size_t)4 * S + 2 * (size_t)num_fine) * 16 * sizeof(float);
+  const int rpb = need <= 2560 ? 16 : (need <= 10240 ? 4 : 1);             // rays per block: as many as the 160 KiB of LDS hold
+  const size_t lds = (size_t)need * rpb * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    RNERF_CHECK_HIP(hipFuncSetAttribute((const void*)resample_depths_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+    RNERF_CHECK_HIP(hipFuncSetAttribute((const void*)resample_depths_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+    RNERF_CHECK_HIP(hipFuncSetAttribute((const void*)resample_depths_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+    RNERF_CHECK_HIP(hipFuncSetAttribute((const void*)resample_depths_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
     attr_set = true;
   }
-  hipLaunchKernelGGL(resample_depths_kernel, dim3((B + 15) / 16), dim3(64), lds, st, (const float4*)path_pd, B, jitter, S, weights, u,
-                     u_per_ray, num_fine, scratch);
+  const dim3 rgrid((unsigned)((B + rpb - 1) / rpb));
+  if (rpb == 16)
+    hipLaunchKernelGGL(resample_depths_kernel<16>, rgrid, dim3(64), lds, st, (const float4*)path_pd, B, jitter, S, weights, u, u_per_ray, num_fine, scratch);
+  else if (rpb == 4)
+    hipLaunchKernelGGL(resample_depths_kernel<4>, rgrid, dim3(64), lds, st, (const float4*)path_pd, B, jitter, S, weights, u, u_per_ray, num_fine, scratch);
+  else
+    hipLaunchKernelGGL(resample_depths_kernel<1>, rgrid, dim3(64), lds, st, (const float4*)path_pd, B, jitter, S, weights, u, u_per_ray, num_fine, scratch);
   const long long total = (long long)(S + num_fine) * B;
   hipLaunchKernelGGL(resample_gather_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float4*)path_pd,
                      (const float4*)path_dr, num_nodes, B, scratch, total, (float4*)rows_pd, (float4*)rows_dr, node_idx);

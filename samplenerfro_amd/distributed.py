@@ -23,6 +23,9 @@ def init(backend: Optional[str] = None) -> Tuple[int, int]:
     """Initialise torch.distributed from the torchrun environment; returns (rank, world). No-op for world == 1."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if torch.cuda.is_available():
+        # one process per GPU: bind before anything allocates (NerfModel defaults to the current device; RCCL needs distinct devices)
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -134,7 +137,10 @@ def render_image_sharded(render_fn: Callable, rays: Rays, rng, normalize_disp: b
             res.append(torch.cat([bufs[k][:shard_bounds(H, w, k)[1] - shard_bounds(H, w, k)[0]] for k in range(w)], dim=0))
         rgb, distance, acc = res
     if normalize_disp:
-        mn, mx = distance.min(), distance.max()
+        if distance.numel() > 0:
+            mn, mx = distance.min(), distance.max()
+        else:                               # a rank without rows (H < world) still takes part in the MIN / MAX reduction below
+            mn = torch.tensor(float("inf"), device=distance.device); mx = torch.tensor(float("-inf"), device=distance.device)
         if gather is False and w > 1:
             dist.all_reduce(mn, op=dist.ReduceOp.MIN); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         distance = (distance - mn) / (mx - mn)

@@ -44,8 +44,8 @@ def tree_to_flat(tree, shapes, device=None) -> torch.Tensor:
     parts = []
     for k, (i, o) in enumerate(shapes):
         d = tree[f"Dense_{k}"]
-        kern = torch.as_tensor(np.asarray(d["kernel"]) if not isinstance(d["kernel"], torch.Tensor) else d["kernel"])
-        bias = torch.as_tensor(np.asarray(d["bias"]) if not isinstance(d["bias"], torch.Tensor) else d["bias"])
+        kern = d["kernel"] if isinstance(d["kernel"], torch.Tensor) else torch.from_numpy(np.array(d["kernel"]))     # (copy: msgpack buffers are read-only)
+        bias = d["bias"] if isinstance(d["bias"], torch.Tensor) else torch.from_numpy(np.array(d["bias"]))
         if tuple(kern.shape) != (i, o) or tuple(bias.shape) != (o,):
             raise ValueError(f"Dense_{k}: expected kernel {(i, o)} / bias {(o,)}, got {tuple(kern.shape)} / {tuple(bias.shape)}")
         parts += [kern.reshape(-1).float(), bias.reshape(-1).float()]
@@ -114,6 +114,7 @@ class NerfModel:
         self._jit_cache: Dict[bytes, torch.Tensor] = {}
         self._u_lin: Optional[torch.Tensor] = None
         self._side: Optional[torch.cuda.Stream] = None
+        self._mlp_wg_limit = 0
 
     # ---- parameters -------------------------------------------------------------------------------------------------------
     def init(self, key, **unused) -> Dict[str, Any]:
@@ -216,15 +217,14 @@ class NerfModel:
             raise NotImplementedError("prefetch_path: the all* march depends on the so3_mlp parameters; call apply() without a handle")
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.device)
-        if int(reserve_cus) != getattr(self, "_reserved_cus", 0):      # 0 = no limit: the MLP kernels use every CU again
-            lib = _lib.load()
-            limit = max(lib.rnerf_device_cus() - int(reserve_cus), 1) if reserve_cus > 0 else 0
-            _lib.check(lib.rnerf_set_mlp_workgroup_limit(limit), "rnerf_set_mlp_workgroup_limit")
-            self._reserved_cus = int(reserve_cus)
+        # per-model cap of the MLP kernels' persistent grid, passed with every rnerf_nerfmlp_forward call (0 = every CU)
+        self._mlp_wg_limit = max(_lib.load().rnerf_device_cus() - int(reserve_cus), 1) if reserve_cus > 0 else 0
         cur = torch.cuda.current_stream()
         if sync_inputs:
             self._side.wait_stream(cur)
         with torch.cuda.stream(self._side):
+            # the caller may drop its ray tensors before the side stream has marched them: keep the allocator from reusing that memory
+            rays.origins.record_stream(self._side); rays.viewdirs.record_stream(self._side)
             pd, dr, ior, _ = ops.march(self.table, self.spec, rays.origins, rays.viewdirs, self.near, self.far,
                                        self.num_samples, want_ior=self.use_online_sparsity)
             ev = torch.cuda.Event()
@@ -233,9 +233,7 @@ class NerfModel:
 
     def release_reserved_cus(self) -> None:
         """Give the CUs reserved by prefetch_path(reserve_cus > 0) back to the MLP kernels."""
-        if getattr(self, "_reserved_cus", 0):
-            _lib.check(_lib.load().rnerf_set_mlp_workgroup_limit(0), "rnerf_set_mlp_workgroup_limit")
-            self._reserved_cus = 0
+        self._mlp_wg_limit = 0
 
     # ---- forward ------------------------------------------------------------------------------------------------------------
     def apply(self, variables, *args, method=None, **kwargs):
@@ -284,7 +282,8 @@ class NerfModel:
         bkgd_flat = self._flat(variables, "bkgd_mlp", BKGD_MLP_SHAPES).detach()
         if ctx is None:
             bkgd = ops.bkgd_forward(bkgd_flat, path_dr[last], self.rgb_padding)
-            raw_c = ops.nerfmlp_forward(self._packed_weights(variables, "coarse_mlp"), self.precision, path_pd, path_dr, jit, Nc, B)
+            raw_c = ops.nerfmlp_forward(self._packed_weights(variables, "coarse_mlp"), self.precision, path_pd, path_dr, jit, Nc, B,
+                                        max_workgroups=self._mlp_wg_limit)
         else:
             if not self.stage.startswith("radiance"):
                 raise NotImplementedError("training is built for the radiance* stages (all*: back-propagation through the march, SURVEY §8f N3)")
@@ -322,7 +321,8 @@ class NerfModel:
             rows_pd, rows_dr, idx = ops.resample(path_pd, path_dr, jit, weights, u, Nf, want_idx=(taps is not None) or fine_sp)
             S = Nc + Nf
             if ctx is None:
-                raw_f = ops.nerfmlp_forward(self._packed_weights(variables, "fine_mlp"), self.precision, rows_pd, rows_dr, None, S, B)
+                raw_f = ops.nerfmlp_forward(self._packed_weights(variables, "fine_mlp"), self.precision, rows_pd, rows_dr, None, S, B,
+                                            max_workgroups=self._mlp_wg_limit)
             else:
                 raw_f, ctx["save_f"] = ops.nerfmlp_forward_train(self._packed_weights(variables, "fine_mlp"), self.precision, rows_pd,
                                                                 rows_dr, None, S, B, ctx.get("backward", _lib.BWD_F16X2))

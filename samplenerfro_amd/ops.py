@@ -90,8 +90,10 @@ def nerfmlp_pack(params_flat: torch.Tensor, precision: int, out: Optional[torch.
 
 
 def nerfmlp_forward(packed: torch.Tensor, precision: int, rows_pd: torch.Tensor, rows_dr: torch.Tensor,
-                    node_of_sample: Optional[torch.Tensor], S: int, B: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """P1+N1: pos_enc + NerfMLP (rnerf/model_utils.py:187-214, :30-90). -> raw [S,B,4] = (rgb raw, sigma raw)."""
+                    node_of_sample: Optional[torch.Tensor], S: int, B: int, out: Optional[torch.Tensor] = None,
+                    max_workgroups: int = 0) -> torch.Tensor:
+    """P1+N1: pos_enc + NerfMLP (rnerf/model_utils.py:187-214, :30-90). -> raw [S,B,4] = (rgb raw, sigma raw).
+    max_workgroups: cap of the persistent grid (0 = every CU), see include/rnerf.h."""
     lib = _lib.load()
     rows_pd = _chk(rows_pd, "rows_pd"); rows_dr = _chk(rows_dr, "rows_dr")
     if node_of_sample is not None:
@@ -99,7 +101,7 @@ def nerfmlp_forward(packed: torch.Tensor, precision: int, rows_pd: torch.Tensor,
     if out is None:
         out = torch.empty((S, B, 4), dtype=torch.float32, device=rows_pd.device)
     check(lib.rnerf_nerfmlp_forward(ptr(packed), int(precision), ptr(rows_pd), ptr(rows_dr), ptr(node_of_sample), int(S), int(B),
-                                    ptr(out), current_stream()), "rnerf_nerfmlp_forward")
+                                    ptr(out), int(max_workgroups), current_stream()), "rnerf_nerfmlp_forward")
     return out
 
 

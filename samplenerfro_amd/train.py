@@ -86,6 +86,24 @@ class TrainState:
     def state_dict(self) -> Dict[str, Any]:
         return {"step": self.step, "theta": self.theta, "mu": self.mu, "nu": self.nu}
 
+    def restore_flax(self, state: Dict[str, Any]) -> "TrainState":
+        """Resume from a reference-format TrainState dict (checkpoint.restore_checkpoint; train.py:322): parameters, step and — when
+        present — the Adam moments of the optax "adam_lr_scheduler" group."""
+        from .checkpoint import find_params, flat_from_params
+        flat = flat_from_params(find_params(state), self.theta.device, tuple(self.segments))
+        for name, (lo, hi) in self.segments.items():
+            self.theta[lo:hi].copy_(flat[name])
+        self.step = int(state.get("step", 0))
+        try:
+            adam = state["opt_state"]["inner_states"]["adam_lr_scheduler"]["inner_state"]["0"]
+            for which, buf in (("mu", self.mu), ("nu", self.nu)):
+                m = flat_from_params(adam[which]["params"], self.theta.device, tuple(self.segments))
+                for name, (lo, hi) in self.segments.items():
+                    buf[lo:hi].copy_(m[name])
+        except (KeyError, TypeError, ValueError):
+            pass                                            # weights-only checkpoint: the moments restart from zero
+        return self
+
     def load_state_dict(self, d: Dict[str, Any]) -> None:
         self.step = int(d["step"])
         for k in ("theta", "mu", "nu"):
@@ -206,7 +224,15 @@ def train_step(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], 
     if flags.grad_max_val > 0:                                                            # train.py:169-172
         grads.clamp_(-flags.grad_max_val, flags.grad_max_val)
     if flags.grad_max_norm > 0:                                                           # train.py:174-180
-        norm = torch.sqrt((grads * grads).sum())
+        # the reference's norm runs over the WHOLE gradient tree: the frozen path_sampler's entries are 2 wd theta / n_all (from
+        # weight_l2; its optimiser label is "zero" but jax.grad still returns them), value-clipped like the rest
+        sq = (grads * grads).sum()
+        if flags.weight_decay_mult > 0 and state.frozen_sq[1] > 0:
+            fg = variables["flat"]["so3_mlp"] * (2.0 * flags.weight_decay_mult / n_all)
+            if flags.grad_max_val > 0:
+                fg = fg.clamp(-flags.grad_max_val, flags.grad_max_val)
+            sq = sq + (fg * fg).sum()
+        norm = torch.sqrt(sq)
         grads.mul_(torch.clamp(flags.grad_max_norm / (1e-7 + norm), max=1.0))
     if taps is not None:
         taps.update(grads=grads.clone(), sums=sums, ctx=ctx)

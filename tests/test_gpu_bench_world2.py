@@ -1,0 +1,33 @@
+"""bench.py's multi-rank branch end to end: two ranks launched exactly like the driver does (torch.distributed.run, --gpus 2), both on
+cuda:0 with the gloo backend (RNERF_DIST_BACKEND; RCCL refuses two ranks on one device).  Covers process-group init, per-rank keys and
+rays, the in-step gradient all-reduce, the barrier + max-over-ranks timing and the single JSON line of rank 0."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_two_ranks(scaling):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, RNERF_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "example", "--rays", "512", "--no-frame",
+           "--no-cpu-baseline", "--scaling", scaling]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=560)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]                       # rank 0 prints the one line
+    d = json.loads(lines[0])
+    per = 512 if scaling == "weak" else 256
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == scaling and d["config"]["rays_per_gpu"] == per
+    assert d["metric"] == "rays/sec (train step)" and d["unit"] == "rays/s" and d["value"] > 0
+    assert abs(d["value"] - 2 * per * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]      # whole-job rays / max-over-ranks time
+    assert d["roofline"]["frac"] > 0 and d["config"]["backward_precision"] == "f32"

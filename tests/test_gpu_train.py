@@ -200,3 +200,32 @@ def test_loss_trajectory_matches_a_torch_training_loop():
             th -= 2e-3 * (mu / (1 - 0.9 ** k)) / (torch.sqrt(nu / (1 - 0.999 ** k)) + 1e-8)
             th.grad = None
     assert losses[-1][0] < losses[0][0]
+
+
+@pytest.mark.parametrize("max_val,max_norm", [(2e-3, 0.0), (0.0, 5e-3), (2e-3, 4e-3)])
+def test_gradient_clipping_matches_the_reference_formulas(max_val, max_norm):
+    """train.py:169-180: clip by value, then by the norm of the WHOLE gradient tree — including the frozen path_sampler, whose entries
+    are 2 * weight_decay_mult * theta / n_all (jax.grad returns them although the optimiser label is "zero")."""
+    from samplenerfro_amd.train import train_step
+    model, state, batch, flags, ev = _setup(12)
+    flags.weight_decay_mult = 50.0                       # large enough for the frozen so3_mlp term to move the norm
+    flags.grad_max_val, flags.grad_max_norm = max_val, max_norm
+    # so3_mlp of _setup's construct_nerf: N(0, 1e-5) output layer, glorot elsewhere -> non-trivial frozen gradient
+    theta0 = state.theta.cpu().numpy().astype(np.float64)
+    taps = {}
+    state, stats, _ = train_step(model, np.array([1, 2], np.uint32), state, batch, flags, taps=taps)
+    got = taps["grads"].cpu().numpy().astype(np.float64)
+    ref, _ = _reference_grads(model, state, batch, flags, taps, ev, theta0)           # includes d (wd * weight_l2) / d theta
+    so3 = state.variables["flat"]["so3_mlp"].cpu().numpy().astype(np.float64)
+    n_all = theta0.size + so3.size
+    frozen = 2.0 * flags.weight_decay_mult * so3 / n_all
+    if max_val > 0:
+        ref = np.clip(ref, -max_val, max_val); frozen = np.clip(frozen, -max_val, max_val)
+        assert (np.abs(ref) == max_val).mean() > 0.001                              # the value clip really bites
+    if max_norm > 0:
+        norm = np.sqrt((ref ** 2).sum() + (frozen ** 2).sum())
+        assert norm > max_norm and (frozen ** 2).sum() > 0.02 * (ref ** 2).sum()       # the norm clip bites and the frozen term matters
+        ref = ref * min(1.0, max_norm / (1e-7 + norm))
+    err = np.abs(got - ref).max() / np.abs(ref).max()
+    print(f"clip ({max_val}, {max_norm}): max err / max |g| {err:.2e}")
+    assert err < 2e-5

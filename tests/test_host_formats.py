@@ -11,22 +11,80 @@ from samplenerfro_amd import checkpoint, models, utils
 from samplenerfro_amd import synthetic as syn
 
 
-def test_checkpoint_round_trip(tmp_path):
+def _fixture_checkpoint(tmp_path, sub="radiance"):
+    """tests/golden/flax_checkpoint_7.msgpack.gz (assembled by make_flax_ckpt.py, independent of samplenerfro_amd.checkpoint)."""
+    import gzip, os
+    d = tmp_path / sub
+    d.mkdir(exist_ok=True)
+    raw = gzip.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "flax_checkpoint_7.msgpack.gz"), "rb").read()
+    (d / "checkpoint_7").write_bytes(raw)
+    (d / "checkpoint_3").write_bytes(raw)              # an older one: restore_checkpoint(dir) must pick the largest step
+    return str(d)
+
+
+def _pattern(shape, salt):
+    n = int(np.prod(shape))
+    return (((np.arange(n, dtype=np.int64) * 7 + salt) % 13 - 6).astype(np.float32) / np.float32(64)).reshape(shape)
+
+
+def test_reads_a_flax_train_state_checkpoint(tmp_path):
+    """The byte fixture in flax 0.3.6's msgpack format, indexed exactly like eval.py:125-131."""
+    d = _fixture_checkpoint(tmp_path)
+    assert checkpoint.latest_checkpoint(d).endswith("checkpoint_7")
+    pretrain = checkpoint.restore_checkpoint(d)
+    assert int(pretrain["step"]) == 7
+    k = pretrain["params"]["params"]["coarse_mlp"]["Dense_5"]["kernel"]
+    assert k.shape == (319, 256) and k.dtype == np.float32 and np.array_equal(k, _pattern((319, 256), 100 + 10))
+    so3 = pretrain["params"]["params"]["path_sampler"]["scan"]["idx_model"]["so3_mlp"]["Dense_3"]["bias"]
+    assert np.array_equal(so3, _pattern((128,), 400 + 7))
+    assert pretrain["np_scalar_probe"] == np.float32(1.5) and isinstance(pretrain["np_scalar_probe"], np.floating)   # ext 3 = numpy scalar
+    adam = pretrain["opt_state"]["inner_states"]["adam_lr_scheduler"]["inner_state"]
+    assert int(adam["0"]["count"]) == 7 and adam["0"]["mu"]["params"]["path_sampler"]["scan"]["idx_model"]["so3_mlp"]["Dense_0"]["kernel"] == {}
+    v = checkpoint.variables_from_checkpoint(d, "cpu")
+    assert v["flat"]["coarse_mlp"].numel() == 595844 and v["flat"]["so3_mlp"].numel() == 65411
+    assert torch.equal(v["params"]["bkgd_mlp"]["Dense_4"]["bias"], torch.from_numpy(_pattern((3,), 300 + 9)))
+
+
+def test_graft_pretrained_by_weight_name(tmp_path):
+    """eval.py:124-152: which sub-trees each stage takes from which Config.*_weight_name directory."""
     pf = syn.init_params_flat(5, fine=True, bias_scale=0.1)
-    variables = models.make_variables({k: torch.from_numpy(v) for k, v in pf.items()})
-    p = str(tmp_path / "checkpoint_1000")
-    checkpoint.save_state_dict(p, checkpoint.params_to_state_dict(variables, step=1000))
+    fresh = models.make_variables({**{k: torch.from_numpy(v) for k, v in pf.items()}, "so3_mlp": torch.zeros(65411)})
+    _fixture_checkpoint(tmp_path, "radiance"); _fixture_checkpoint(tmp_path, "all")
+    v, step = checkpoint.graft_pretrained(fresh, str(tmp_path), "radiance", 128)
+    assert step == 7 and torch.equal(v["params"]["coarse_mlp"]["Dense_0"]["bias"], torch.from_numpy(_pattern((256,), 101)))
+    assert torch.equal(v["flat"]["so3_mlp"], fresh["flat"]["so3_mlp"])             # the radiance stage keeps the fresh path_sampler
+    v, _ = checkpoint.graft_pretrained(fresh, str(tmp_path), "radiance", 0)
+    assert torch.equal(v["flat"]["fine_mlp"], fresh["flat"]["fine_mlp"])           # num_fine_samples == 0: fine_mlp untouched (eval.py:130)
+    v, _ = checkpoint.graft_pretrained(fresh, str(tmp_path), "all", 128)
+    assert torch.equal(v["params"]["path_sampler"]["scan"]["idx_model"]["so3_mlp"]["Dense_4"]["kernel"], torch.from_numpy(_pattern((128, 3), 408)))
+    with pytest.raises(FileNotFoundError):
+        checkpoint.graft_pretrained(fresh, str(tmp_path), "ior", 128)                # needs <train_dir>/ior as well
+
+
+def test_checkpoint_export_is_a_train_state(tmp_path):
+    """What save_checkpoint writes is the TrainState layout of train.py:317 (step / params.params / opt_state), not flax.optim's."""
+    pf = syn.init_params_flat(5, fine=True, bias_scale=0.1)
+    variables = models.make_variables({**{k: torch.from_numpy(v) for k, v in pf.items()}, "so3_mlp": torch.ones(65411)})
+    p = checkpoint.save_checkpoint(str(tmp_path / "radiance"), variables, 1000)
+    assert p.endswith("checkpoint_1000")
     state = checkpoint.load_state_dict(p)
-    assert int(state["optimizer"]["state"]["step"]) == 1000
-    k = state["optimizer"]["target"]["params"]["coarse_mlp"]["Dense_5"]["kernel"]
+    assert int(state["step"]) == 1000 and sorted(state) == ["opt_state", "params", "step"]
+    k = state["params"]["params"]["coarse_mlp"]["Dense_5"]["kernel"]
     assert k.shape == (319, 256) and k.dtype == np.float32
-    back = checkpoint.variables_from_checkpoint(p, "cpu")
-    for name in ("coarse_mlp", "fine_mlp", "bkgd_mlp"):
+    inner = state["opt_state"]["inner_states"]
+    assert sorted(inner) == ["adam", "adam_lr_scheduler", "adam_lr_scheduler1", "zero"]
+    mu = inner["adam_lr_scheduler"]["inner_state"]["0"]["mu"]["params"]
+    assert mu["coarse_mlp"]["Dense_0"]["kernel"].shape == (63, 256) and mu["path_sampler"]["scan"]["idx_model"]["so3_mlp"]["Dense_0"]["bias"] == {}
+    back = checkpoint.variables_from_checkpoint(str(tmp_path / "radiance"), "cpu")
+    for name in ("coarse_mlp", "fine_mlp", "bkgd_mlp", "so3_mlp"):
         assert torch.equal(back["flat"][name], variables["flat"][name])
     assert back["params"]["bkgd_mlp"]["Dense_3"]["kernel"].shape == (155, 128)
     # views alias the flat buffers (what the kernels read and an optimiser updates)
     back["flat"]["coarse_mlp"][0] = 42.0
     assert back["params"]["coarse_mlp"]["Dense_0"]["kernel"][0, 0] == 42.0
+    # the legacy flax.optim layout is still found
+    legacy = {"optimizer": {"target": {"params": state["params"]["params"]}, "state": {"step": np.int32(5)}}}
+    assert "coarse_mlp" in checkpoint.find_params(legacy)
 
 
 def test_flat_layout_matches_flax_order():
@@ -74,3 +132,29 @@ def test_model_rejects_unbuilt_options():
         models.NerfModel(ndim=[4] * 3, nmin=[-1] * 3, nmax=[1] * 3, grid=np.ones((4, 4, 4), np.float32), stage="ior", device="cpu")
     with pytest.raises(NotImplementedError):
         models.NerfModel(ndim=[4] * 3, nmin=[-1] * 3, nmax=[1] * 3, grid=np.ones((4, 4, 4), np.float32), sh_deg=2, device="cpu")
+
+
+def test_train_state_resumes_from_a_reference_checkpoint(tmp_path):
+    """train.py:322 `state = checkpoints.restore_checkpoint(stage_dir, state)`: step, parameters and the Adam moments of the trained group."""
+    from samplenerfro_amd.train import TrainState
+
+    class _M:                      # the two NerfModel members TrainState.create reads (no device needed)
+        num_fine_samples = 128
+        def _flat(self, variables, name, shapes):
+            return variables["flat"][name]
+    pf = syn.init_params_flat(5, fine=True, bias_scale=0.1)
+    variables = models.make_variables({k: torch.from_numpy(v) for k, v in pf.items()})
+    st = TrainState.create(_M(), variables, utils.default_flags())
+    st.restore_flax(checkpoint.restore_checkpoint(_fixture_checkpoint(tmp_path)))
+    assert st.step == 7
+    lo, hi = st.segments["bkgd_mlp"]
+    want = models.tree_to_flat({f"Dense_{k}": {"kernel": _pattern((i, o), 300 + 2 * k), "bias": _pattern((o,), 300 + 2 * k + 1)}
+                                for k, (i, o) in enumerate(models.BKGD_MLP_SHAPES)}, models.BKGD_MLP_SHAPES)
+    assert torch.equal(st.theta[lo:hi], want)
+    mu_want = models.tree_to_flat({f"Dense_{k}": {"kernel": _pattern((i, o), 1300 + 2 * k) * np.float32(1e-3), "bias": _pattern((o,), 1300 + 2 * k + 1) * np.float32(1e-3)}
+                                   for k, (i, o) in enumerate(models.BKGD_MLP_SHAPES)}, models.BKGD_MLP_SHAPES)
+    assert torch.equal(st.mu[lo:hi], mu_want) and float(st.nu.abs().max()) > 0
+    # and the exported state carries the moments back out
+    out = checkpoint.params_to_state_dict(st.variables, st.step, st)
+    mu = out["opt_state"]["inner_states"]["adam_lr_scheduler"]["inner_state"]["0"]["mu"]["params"]["bkgd_mlp"]["Dense_0"]["kernel"]
+    assert np.array_equal(mu, _pattern((27, 128), 1300) * np.float32(1e-3))
