@@ -372,7 +372,8 @@ def main():
                     ff = 2.0 if "nerfmlp" in k else 1.0
                     traffic[name] = 1024.0 * (ff * v["FETCH_SIZE"]["mean"] + v["WRITE_SIZE"]["mean"])
                 if "SQ_VALU_MFMA_BUSY_CYCLES" in v and "GRBM_GUI_ACTIVE" in v:
-                    gui = v["GRBM_GUI_ACTIVE"]["mean"]
+                    gui = v["GRBM_GUI_ACTIVE"]["mean"] / float(pj.get("xcd_instances", 8))     # reported summed over the XCDs' GRBM instances
+                    # measured matrix-pipe occupancy: MFMA-busy cycles (summed over SIMDs) / (SIMDs x GPU-active cycles of the launch)
                     sq[name] = {"mfma_busy_frac": v["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"] / (4.0 * rnerf_cus * gui),
                                 "effective_clock_ghz": gui / v["avg_ns"]["mean"] if "avg_ns" in v else None,
                                 "wave_wait_frac": (v["SQ_WAIT_ANY"]["mean"] / v["SQ_WAVE_CYCLES"]["mean"]) if "SQ_WAIT_ANY" in v and "SQ_WAVE_CYCLES" in v else None}

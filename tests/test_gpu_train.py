@@ -202,13 +202,13 @@ def test_loss_trajectory_matches_a_torch_training_loop():
     assert losses[-1][0] < losses[0][0]
 
 
-@pytest.mark.parametrize("max_val,max_norm", [(2e-3, 0.0), (0.0, 5e-3), (2e-3, 4e-3)])
+@pytest.mark.parametrize("max_val,max_norm", [(2e-3, 0.0), (0.0, 1.0), (2e-3, 0.5)])
 def test_gradient_clipping_matches_the_reference_formulas(max_val, max_norm):
     """train.py:169-180: clip by value, then by the norm of the WHOLE gradient tree — including the frozen path_sampler, whose entries
     are 2 * weight_decay_mult * theta / n_all (jax.grad returns them although the optimiser label is "zero")."""
     from samplenerfro_amd.train import train_step
     model, state, batch, flags, ev = _setup(12)
-    flags.weight_decay_mult = 50.0                       # large enough for the frozen so3_mlp term to move the norm
+    flags.weight_decay_mult = 2e4                        # large enough for the frozen so3_mlp term (5 % of the entries) to move the norm
     flags.grad_max_val, flags.grad_max_norm = max_val, max_norm
     # so3_mlp of _setup's construct_nerf: N(0, 1e-5) output layer, glorot elsewhere -> non-trivial frozen gradient
     theta0 = state.theta.cpu().numpy().astype(np.float64)

@@ -24,7 +24,8 @@ except Exception:
     head = ""
 res = {"note": note, "bench_py_sha16": sha(os.path.join(ROOT, "bench.py")), "mlp_hip_sha16": sha(os.path.join(ROOT, "samplenerfro_amd", "csrc", "mlp.hip")),
        "head": head or os.environ.get("GRAFT_HEAD", "(snapshot without .git)"),
-       "units": "FETCH_SIZE / WRITE_SIZE in KiB as reported by rocprofv3 (gfx950: wide 16 B/lane reads are counted at half their size); SQ_* as reported "
+       "xcd_instances": 8,
+       "units": "GRBM_GUI_ACTIVE / GRBM_COUNT are summed over the 8 XCDs' GRBM instances (divide by 8 for cycles); FETCH_SIZE / WRITE_SIZE in KiB as reported by rocprofv3 (gfx950: wide 16 B/lane reads are counted at half their size); SQ_* as reported "
                 "(SQ_WAVE_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_* in quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES in cycles summed over SIMDs); avg_ns from --kernel-trace of the same passes",
        "counters": {}}
 for k in sorted(set(acc) | set(dur)):
@@ -39,6 +40,6 @@ for k, cs in res["counters"].items():
     if "avg_ns" in cs and cs["avg_ns"]["mean"] > 50000:
         busy = cs.get("SQ_VALU_MFMA_BUSY_CYCLES", {}).get("mean"); gui = cs.get("GRBM_GUI_ACTIVE", {}).get("mean")
         extra = ""
-        if busy and gui:
-            extra = f" mfma_busy/(1024 SIMD x GRBM_GUI_ACTIVE) = {busy / (1024 * gui):.3f}, eff. clock {gui / cs['avg_ns']['mean']:.2f} GHz"
+        if busy and gui:        # GRBM_GUI_ACTIVE is reported summed over the 8 XCDs' GRBM instances
+            extra = f" mfma_busy/(1024 SIMD x GRBM_GUI_ACTIVE/8) = {busy / (1024 * gui / 8):.3f}, eff. clock {gui / 8 / cs['avg_ns']['mean']:.2f} GHz"
         print(k[-60:], round(cs["avg_ns"]["mean"] / 1e3, 1), "us", extra)
