@@ -240,13 +240,48 @@ int rnerf_nerfmlp_wgrad(int fwd_precision, int backward, const void* save, const
  * rnerf_bkgd_forward_train = rnerf_bkgd_forward + `save` (rnerf_bkgd_save_bytes(n) bytes).
  * rnerf_bkgd_backward: d_out float[n][3] (d loss / d activated bkgd colour) -> ACCUMULATES into grads
  * float[RNERF_BKGDMLP_PARAMS] (the caller zeroes it once per step: the per-ray bkgd and the env-map patch, train.py:127-130,
- * both add to it); dy: scratch of rnerf_bkgd_dy_bytes(n) bytes. */
+ * both add to it); dy: scratch of rnerf_bkgd_dy_bytes(n) bytes.  d_dirs (nullable): float4[n], d loss / d direction through pos_enc(dir)
+ * (stage "all*": the direction of the last coarse sample is a function of the so3 parameters). */
 size_t rnerf_bkgd_save_bytes(int64_t n);
 size_t rnerf_bkgd_dy_bytes(int64_t n);
 int rnerf_bkgd_forward_train(const float* params, const float* dirs, int32_t dir_stride, int64_t n, double rgb_padding,
                              float* out_rgb, void* save, void* stream);
 int rnerf_bkgd_backward(const float* params, const void* save, const float* d_out, int64_t n, double rgb_padding, void* dy,
-                        float* grads, void* stream);
+                        float* grads, float* d_dirs, void* stream);
+
+/* ---- training of stage "all*" — jax.value_and_grad (train.py:164) through the N-step eikonal recurrence
+ * (rnerf/eikonal_utils.py:29-49,100-124) and through so3_mlp + the Rodrigues rotation (rnerf/ior_utils.py:269-312), with path_sampler
+ * trainable (train.py:302-310).  The state of the recurrence is 6 numbers per ray, so its adjoint is a reverse scan with 3x3 Jacobians;
+ * everything that involves the so3 MLP runs as parallel batches over the (ray, node) PAIRS at which pred_grad was selected:
+ *   rnerf_march_all_train  : rnerf_march_all + the record the backward needs: path_rdn float4[N][B] = (raw direction, n) per node, and
+ *                            the compacted pairs (pair_count device int32, zeroed by the call; pair_id int32[cap][2] = (ray, node);
+ *                            pair_x / pair_g float4[cap] = position / looked-up gradient; pair_of_node int32[N][B], -1 = none);
+ *   rnerf_so3_forward_train: so3_mlp on pts4 float4[n] -> save (rnerf_so3_save_bytes(n); its tail float4[n] holds the raw outputs);
+ *   rnerf_so3_backward     : cotangents d_raw4 float4[nb] -> dx4 float4[nb] (nullable, d / d point) and, if grads != NULL (nb == n_save),
+ *                            grads float[RNERF_SO3MLP_PARAMS] += ...; row i uses the saved activations of row i % n_save, so the three
+ *                            unit cotangents of every point run as one batch of 3 n_save rows (the rows of J = d raw / d x);
+ *   rnerf_so3_pair_jacobian: per pair A = d grad / d position (P J + (d pred / d g) G, G = d g / d x of the trilinear interpolant) and
+ *                            P = d pred / d raw, float[np][12] each (9 used, row-major);
+ *   rnerf_march_adjoint    : the reverse scan; a_pos / a_dir float4[S][B] = d loss / d (position, normalised direction) of the coarse
+ *                            samples, sample_of_node int32[N] (-1 = the node is no sample) -> v4 float4[np], the cotangent of raw per pair;
+ *   rnerf_nerfmlp_input_grad: d loss / d (position, direction) of every row of a NerfMLP level from the dgrad's dy buffer (F16 modes):
+ *                            through pos_enc into Dense_0, the skip concat of Dense_5 and the view layer Dense_10. */
+int rnerf_march_all_train(const float* table, const rnerf_grid* g, const float* so3_params, const float* window10, const float* origins,
+                          const float* viewdirs, int32_t B, double near, double far, int32_t num_nodes, float* path_pd, float* path_dr,
+                          float* path_rdn, int32_t* pair_count, int32_t pair_cap, int32_t* pair_id, float* pair_x, float* pair_g,
+                          int32_t* pair_of_node, void* stream);
+size_t rnerf_so3_save_bytes(int64_t n);
+size_t rnerf_so3_dy_bytes(int64_t nb);
+int rnerf_so3_forward_train(const float* so3_params, const float* window10, const float* pts4, int64_t n, void* save, void* stream);
+int rnerf_so3_backward(const float* so3_params, const float* window10, const float* pts4, const void* save, int64_t n_save, const float* d_raw4,
+                       int64_t nb, void* dy, float* dx4, float* grads, void* stream);
+int rnerf_so3_pair_jacobian(const float* table, const rnerf_grid* g, const float* pair_x, const float* pair_g, const float* raw4, const float* J4,
+                            int64_t np, float* A12, float* P12, void* stream);
+int rnerf_march_adjoint(const float* table, const rnerf_grid* g, const float* path_pd, const float* path_rdn, const int32_t* pair_of_node,
+                        const float* A12, const float* P12, const float* a_pos, const float* a_dir, const int32_t* sample_of_node, int32_t B,
+                        double near, double far, int32_t num_nodes, float* v4, void* stream);
+int rnerf_nerfmlp_input_grad(const float* params, int backward, const void* dy, const float* rows_pd, const float* rows_dr,
+                             const int32_t* node_of_sample, int32_t S, int32_t B, float* d_pos4, float* d_dir4, void* stream);
 
 #ifdef __cplusplus
 }

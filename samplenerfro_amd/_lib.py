@@ -77,7 +77,15 @@ SIGNATURES = {
     "rnerf_bkgd_save_bytes": (C.c_size_t, [_i64]),
     "rnerf_bkgd_dy_bytes": (C.c_size_t, [_i64]),
     "rnerf_bkgd_forward_train": (C.c_int, [_vp, _vp, _i32, _i64, _dbl, _vp, _vp, _vp]),
-    "rnerf_bkgd_backward": (C.c_int, [_vp, _vp, _vp, _i64, _dbl, _vp, _vp, _vp]),
+    "rnerf_bkgd_backward": (C.c_int, [_vp, _vp, _vp, _i64, _dbl, _vp, _vp, _vp, _vp]),
+    "rnerf_march_all_train": (C.c_int, [_vp, _GP, _vp, _vp, _vp, _vp, _i32, _dbl, _dbl, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "rnerf_so3_save_bytes": (C.c_size_t, [_i64]),
+    "rnerf_so3_dy_bytes": (C.c_size_t, [_i64]),
+    "rnerf_so3_forward_train": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
+    "rnerf_so3_backward": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "rnerf_so3_pair_jacobian": (C.c_int, [_vp, _GP, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "rnerf_march_adjoint": (C.c_int, [_vp, _GP, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _dbl, _dbl, _i32, _vp, _vp]),
+    "rnerf_nerfmlp_input_grad": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
     "rnerf_resample": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
 }
 

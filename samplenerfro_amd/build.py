@@ -41,7 +41,8 @@ def _stale(out: str, deps) -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "rnerf.h")]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "rnerf.h"),
+               os.path.join(CSRC, "ior_train_kernels.inc"), os.path.join(CSRC, "ior_train_api.inc")]
     objs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)

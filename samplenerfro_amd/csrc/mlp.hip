@@ -1239,105 +1239,77 @@ __device__ __forceinline__ void wgrad_body_f16(const uint4* __restrict__ saved, 
                                                 char* smem) {
   using W = WgF16<NP>;
   constexpr int NT = (KSd + 1) / 2;
-  constexpr int TSTRIDE = NP;                                  // NP = 2: two waves share the slots of one (side, row group)
-  constexpr int NIT = ((KT > NT ? KT : NT) + TSTRIDE - 1) / TSTRIDE;
+  constexpr int NOP = 2 * (KT > NT ? KT : NT);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int side = wave >> 2;                                  // 0: X slots, 1: dY slots
+  // 8 waves = (side: X slots / dY slots) x (row group) x (NP = 2: hi plane / lo plane).  Every wave runs the SAME compile-time slot loop;
+  // what differs between waves is only a base pointer and an LDS offset (run-time predicates around the loads would make hipcc guard
+  // each of them with a branch and a vmcnt(0)).
+  const int side = wave >> 2;
   const int rg = NP == 2 ? ((wave >> 1) & 1) : (wave & 3);
-  const int tpart = NP == 2 ? (wave & 1) : 0;
+  const int part = NP == 2 ? (wave & 1) : 0;
   const int m = lane & 31, h = lane >> 5;
   const float* __restrict__ rs = (const float*)(dy + dy_plane_uint4(R, NP));
-  const float mref = rs[R];                                     // bits written by the dgrad's atomicMax
+  const float mref = rs[R];                                     // written by the dgrad's atomicMax
   const float inv_mref = mref > 0.f ? 1.0f / mref : 0.f;        // m_ref is a power of two: exact
-  uint4* myT = (uint4*)(smem + rg * W::RG_BYTES) + lane;
+  uint4* myT = (uint4*)(smem + rg * W::RG_BYTES) + lane + (size_t)(side * 16 * NP + part * 16) * 64;
+  uint4* mySc = (uint4*)(smem + rg * W::RG_BYTES) + lane + (size_t)(32 * NP) * 64;
   const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   const uint4 il = shifted_identity<true>(lane, 0), ih = shifted_identity<true>(lane, 1);
   const uint4 z4 = make_uint4(0, 0, 0, 0);
   f32x16 acc[NT], accb = zero;
 #pragma unroll
   for (int b = 0; b < NT; ++b) acc[b] = zero;
-  uint4 opr[NIT][2 * NP];
+  uint4 opr[NOP];
   float4 scq[4];
+  const uint4* __restrict__ src = side == 0 ? saved + (size_t)(part * SAVE_TOTAL + qx) * R * 2 : dy + (size_t)(part * DY_SLOTS + qd) * R * 2;
+  constexpr int NLOAD_X = 2 * KT, NLOAD_D = KSd < 2 * NT ? KSd : 2 * NT;
   auto load_chunk = [&](int chunk) {
     const size_t row0 = (size_t)chunk * W::CH + rg * 32;
-    const size_t row2 = (row0 + m) * 2 + h;
-    if (side == 0) {
+    const uint4* base = src + (row0 + m) * 2 + h;
 #pragma unroll
-      for (int i = 0; i < NIT; ++i) {
-        const int t = tpart + i * TSTRIDE;
-        if (t < KT) {
-#pragma unroll
-          for (int p = 0; p < NP; ++p) {
-            const uint4* base = saved + (size_t)(p * SAVE_TOTAL + qx + 2 * t) * R * 2 + row2;
-            opr[i][2 * p] = stream_load(base);
-            opr[i][2 * p + 1] = stream_load(base + (size_t)R * 2);
-          }
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) scq[q] = *(const float4*)(rs + row0 + 8 * q + 4 * h);
-    } else {
-#pragma unroll
-      for (int i = 0; i < NIT; ++i) {
-        const int t = tpart + i * TSTRIDE;
-        if (t < NT) {
-#pragma unroll
-          for (int p = 0; p < NP; ++p) {
-            const uint4* base = dy + (size_t)(p * DY_SLOTS + qd + 2 * t) * R * 2 + row2;
-            opr[i][2 * p] = stream_load(base);
-            opr[i][2 * p + 1] = (2 * t + 1 < KSd) ? stream_load(base + (size_t)R * 2) : z4;
-          }
-        }
-      }
+    for (int t = 0; t < NOP; ++t) {
+      // slots beyond this side's count are clamped to its last slot (loaded, never used): no predicate on the load
+      const int tx = t < NLOAD_X ? t : NLOAD_X - 1, td = t < NLOAD_D ? t : NLOAD_D - 1;
+      opr[t] = stream_load(base + (size_t)(side == 0 ? tx : td) * R * 2);
     }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) scq[q] = *(const float4*)(rs + row0 + 8 * q + 4 * h);
   };
   if (g < n_chunks) load_chunk(g);
   for (int chunk = g; chunk < n_chunks; chunk += G) {
     const bool ok = (long long)chunk * W::CH + rg * 32 + m < total_rows;
+    float sc[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { sc[4 * q] = scq[q].x * inv_mref; sc[4 * q + 1] = scq[q].y * inv_mref; sc[4 * q + 2] = scq[q].z * inv_mref; sc[4 * q + 3] = scq[q].w * inv_mref; }
     if (side == 0) {
-      float sc[16];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { sc[4 * q] = scq[q].x * inv_mref; sc[4 * q + 1] = scq[q].y * inv_mref; sc[4 * q + 2] = scq[q].z * inv_mref; sc[4 * q + 3] = scq[q].w * inv_mref; }
+      for (int t = 0; t < KT; ++t) {
+        f32x16 d = mfma16<true>(opr[2 * t], il, zero);
+        d = mfma16<true>(opr[2 * t + 1], ih, d);
 #pragma unroll
-      for (int i = 0; i < NIT; ++i) {
-        const int t = tpart + i * TSTRIDE;
-        if (t < KT) {
-#pragma unroll
-          for (int p = 0; p < NP; ++p) {
-            f32x16 d = mfma16<true>(opr[i][2 * p], il, zero);
-            d = mfma16<true>(opr[i][2 * p + 1], ih, d);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) d[r] *= sc[r];
-            uint4 u0, u1;
-            pack_rows_f16(d, u0, u1);
-            myT[(16 * p + 2 * t) * 64] = u0; myT[(16 * p + 2 * t + 1) * 64] = u1;
-          }
-        }
+        for (int r = 0; r < 16; ++r) d[r] *= sc[r];
+        uint4 u0, u1;
+        pack_rows_f16(d, u0, u1);
+        myT[(2 * t) * 64] = u0; myT[(2 * t + 1) * 64] = u1;
       }
-      if (tpart == 0) {                                          // the row scales as an A operand: row m = 0 holds them, the others 0
+      if (part == 0) {                                          // the row scales as an A operand: row m = 0 holds them, the others 0
         f32x16 d;
 #pragma unroll
         for (int r = 0; r < 16; ++r) d[r] = m == 0 ? sc[r] : 0.f;
         uint4 u0, u1;
         pack_rows_f16(d, u0, u1);
-        myT[(32 * NP) * 64] = u0; myT[(32 * NP + 1) * 64] = u1;
+        mySc[0] = u0; mySc[64] = u1;
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < NIT; ++i) {
-        const int t = tpart + i * TSTRIDE;
-        if (t < NT) {
-#pragma unroll
-          for (int p = 0; p < NP; ++p) {
-            const uint4 a0 = ok ? opr[i][2 * p] : z4, a1 = ok ? opr[i][2 * p + 1] : z4;
-            f32x16 d = mfma16<true>(a0, il, zero);
-            d = mfma16<true>(a1, ih, d);
-            uint4 u0, u1;
-            pack_rows_f16(d, u0, u1);
-            myT[(16 * NP + 16 * p + 2 * t) * 64] = u0; myT[(16 * NP + 16 * p + 2 * t + 1) * 64] = u1;
-          }
-        }
+      for (int t = 0; t < NT; ++t) {
+        const uint4 a0 = ok ? opr[2 * t] : z4, a1 = (ok && 2 * t + 1 < KSd) ? opr[2 * t + 1] : z4;   // padded rows / slots must not contribute
+        f32x16 d = mfma16<true>(a0, il, zero);
+        d = mfma16<true>(a1, ih, d);
+        uint4 u0, u1;
+        pack_rows_f16(d, u0, u1);
+        myT[(2 * t) * 64] = u0; myT[(2 * t + 1) * 64] = u1;
       }
     }
     __syncthreads();
@@ -1726,7 +1698,12 @@ __global__ void __launch_bounds__(64) so3_query_kernel(const float4* __restrict_
 __global__ void __launch_bounds__(64) march_all_kernel(const float4* __restrict__ table, GridParams gp, const float* __restrict__ params,
                                                        So3Window win, const float* __restrict__ origins, const float* __restrict__ viewdirs,
                                                        int B, float near, float step, int num_nodes, float4* __restrict__ path_pd,
-                                                       float4* __restrict__ path_dr, float4* __restrict__ path_ior) {
+                                                       float4* __restrict__ path_dr, float4* __restrict__ path_ior,
+                                                       // training record (nullable): raw direction + n per node, and the compacted list of
+                                                       // (ray, node) pairs at which pred_grad was selected (the object's boundary shell)
+                                                       float4* __restrict__ path_rdn, int* __restrict__ pair_count, int pair_cap,
+                                                       int2* __restrict__ pair_id, float4* __restrict__ pair_x, float4* __restrict__ pair_g,
+                                                       int* __restrict__ pair_of_node) {
   const int lane = threadIdx.x & 63, m = lane & 31, h = lane >> 5;
   int r = blockIdx.x * 32 + m;
   const bool ok = r < B;
@@ -1747,6 +1724,17 @@ __global__ void __launch_bounds__(64) march_all_kernel(const float4* __restrict_
     }
     const float g[3] = {c.y, c.z, c.w};
     const bool use = fsqrt(fadd(fadd(fmul(g[0], g[0]), fmul(g[1], g[1])), fmul(g[2], g[2]))) > 1e-3f;   // eikonal_utils.py:35
+    if (path_rdn && ok && h == 0) {
+      const size_t o = (size_t)k * B + r;
+      path_rdn[o] = make_float4(d[0], d[1], d[2], c.x);
+      int idx = -1;
+      if (use) {
+        idx = atomicAdd(pair_count, 1);
+        if (idx < pair_cap) { pair_id[idx] = make_int2(r, k); pair_x[idx] = make_float4(p[0], p[1], p[2], 0.f); pair_g[idx] = make_float4(g[0], g[1], g[2], 0.f); }
+        else idx = -1;
+      }
+      pair_of_node[o] = idx;
+    }
     float pred[3] = {0.f, 0.f, 0.f};
     if (__builtin_amdgcn_ballot_w64(use) != 0) {     // pred_grad is only selected where |grad n| > 1e-3: outside the object's boundary
       float raw[3];                                   // shell no ray of the wave needs the MLP (wave-uniform branch, same results)
@@ -1780,9 +1768,25 @@ __device__ __forceinline__ void small_prev_layer_T(f32x16 (&acc)[4], const f32x1
     }
 }
 
+// acc2[t2] += W[f = 32 t2 + m][n(h)] * x (contraction over the 128 outputs n held in x): the input-gradient GEMM of a small MLP, f < fin
+__device__ __forceinline__ void small_input_T(f32x16 (&acc2)[2], const f32x16 (&x)[4], const float* __restrict__ kern, int fin, int m, int h) {
+#pragma unroll
+  for (int ts = 0; ts < 4; ++ts)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int nf = 32 * ts + (r & 3) + 8 * (r >> 2) + 4 * h;
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2) {
+        const int f = 32 * t2 + m;
+        const float w = kern[(f < fin ? f : fin - 1) * 128 + nf];
+        acc2[t2] = __builtin_amdgcn_mfma_f32_32x32x2f32(f < fin ? w : 0.f, x[ts][r], acc2[t2], 0, 0, 0);
+      }
+    }
+}
+
 __global__ void __launch_bounds__(64) bkgd_dgrad_kernel(const float* __restrict__ params, const float* __restrict__ save,
                                                         const float* __restrict__ d_out, long long n, float pad_scale, float pad,
-                                                        float* __restrict__ dy) {
+                                                        float* __restrict__ dy, float4* __restrict__ d_dirs) {
   const int lane = threadIdx.x & 63, m = lane & 31, h = lane >> 5;
   long long row = (long long)blockIdx.x * 32 + m;
   const bool ok = row < n;
@@ -1831,6 +1835,8 @@ __global__ void __launch_bounds__(64) bkgd_dgrad_kernel(const float* __restrict_
     }
   mask_by(4, acc, x);
   store_dy(3, x);                                   // dY_3
+  f32x16 denc[2] = {zero, zero};                    // d loss / d pos_enc(dir) (stage "all": the direction is a function of the so3 parameters)
+  if (d_dirs) small_input_T(denc, x, params + bkgd_koff(3) + 128 * 128, 27, m, h);     // the skip-concat inputs of Dense_3
 #pragma unroll 1
   for (int k = 3; k >= 1; --k) {                    // through Dense_k (only the first 128 input rows of Dense_3 carry gradient)
 #pragma unroll
@@ -1838,6 +1844,25 @@ __global__ void __launch_bounds__(64) bkgd_dgrad_kernel(const float* __restrict_
     small_prev_layer_T(acc, x, params + (k == 3 ? bkgd_koff(3) : (k == 2 ? bkgd_koff(2) : bkgd_koff(1))), m, h);
     mask_by(k, acc, x);
     store_dy(k - 1, x);                             // dY_{k-1}
+  }
+  if (d_dirs) {
+    small_input_T(denc, x, params + bkgd_koff(0), 27, m, h);
+    const float* v = save + (size_t)row * 28;       // features 0..2 of the saved encoding = the direction itself
+    const float dcv[3] = {v[0], v[1], v[2]};
+    float gd3[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int f = (r & 3) + 8 * (r >> 2) + 4 * h;                  // [d(3) | sin(2^k d)(12) | sin(2^k d + pi/2)(12)]
+      if (f < 3) gd3[f] += denc[0][r];
+      else if (f < 27) {
+        const int q = (f - 3) % 12, is_cos = (f - 3) / 12, d = q / 3, c = q % 3;
+        const float xb = fmul(dcv[c], (float)(1 << d));
+        gd3[c] = fmaf(denc[0][r], (float)(1 << d) * cosf(is_cos ? fadd(xb, 1.5707963705062866f) : xb), gd3[c]);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) gd3[c] += __shfl_xor(gd3[c], 32);
+    if (ok && h == 0) d_dirs[row] = make_float4(gd3[0], gd3[1], gd3[2], 0.f);
   }
 }
 
@@ -1857,12 +1882,29 @@ __constant__ BkgdUnit kBkgdUnits[18] = {
     {4, 128, 128, 0, 4, 4, 3, bkgd_koff(4), 3, bkgd_boff(4)},       {4, 128, 128, 1, 4, 4, 3, bkgd_koff(4), 3, -1},
     {4, 128, 128, 2, 4, 4, 3, bkgd_koff(4), 3, -1},                  {4, 128, 128, 3, 4, 4, 3, bkgd_koff(4), 3, -1}};
 
+// the so3 MLP (60 -> 128 x 4 with the 60 inputs concatenated before Dense_3 -> 3, rnerf/ior_utils.py:148-152) has the same unit structure
+__constant__ BkgdUnit kSo3Units[20] = {
+    {0, 60, 60, 0, 0, 128, 128, so3_koff(0), 128, so3_boff(0)},      {0, 60, 60, 1, 0, 128, 128, so3_koff(0), 128, -1},
+    {1, 128, 128, 0, 1, 128, 128, so3_koff(1), 128, so3_boff(1)},    {1, 128, 128, 1, 1, 128, 128, so3_koff(1), 128, -1},
+    {1, 128, 128, 2, 1, 128, 128, so3_koff(1), 128, -1},             {1, 128, 128, 3, 1, 128, 128, so3_koff(1), 128, -1},
+    {2, 128, 128, 0, 2, 128, 128, so3_koff(2), 128, so3_boff(2)},    {2, 128, 128, 1, 2, 128, 128, so3_koff(2), 128, -1},
+    {2, 128, 128, 2, 2, 128, 128, so3_koff(2), 128, -1},             {2, 128, 128, 3, 2, 128, 128, so3_koff(2), 128, -1},
+    {3, 128, 128, 0, 3, 128, 128, so3_koff(3), 128, so3_boff(3)},    {3, 128, 128, 1, 3, 128, 128, so3_koff(3), 128, -1},
+    {3, 128, 128, 2, 3, 128, 128, so3_koff(3), 128, -1},             {3, 128, 128, 3, 3, 128, 128, so3_koff(3), 128, -1},
+    {0, 60, 60, 0, 3, 128, 128, so3_koff(3) + 128 * 128, 128, -1},   {0, 60, 60, 1, 3, 128, 128, so3_koff(3) + 128 * 128, 128, -1},
+    {4, 128, 128, 0, 4, 4, 3, so3_koff(4), 3, so3_boff(4)},          {4, 128, 128, 1, 4, 4, 3, so3_koff(4), 3, -1},
+    {4, 128, 128, 2, 4, 4, 3, so3_koff(4), 3, -1},                   {4, 128, 128, 3, 4, 4, 3, so3_koff(4), 3, -1}};
+template <int KIND> struct SmallNet {
+  static constexpr int ENC_LD = KIND == 0 ? 28 : 60, NPARAMS = KIND == 0 ? RNERF_BKGDMLP_PARAMS : RNERF_SO3MLP_PARAMS, UNITS = KIND == 0 ? 18 : 20;
+};
+
+template <int KIND>
 __global__ void __launch_bounds__(256) bkgd_wgrad_kernel(const float* __restrict__ save, const float* __restrict__ dy, long long n,
                                                          float* __restrict__ partial) {
   __shared__ float red[4][4][1024 + 32];            // [wave][n-tile][acc reg * 64 + lane] (+ the bias row)
-  const BkgdUnit u = kBkgdUnits[blockIdx.y];
+  const BkgdUnit u = KIND == 0 ? kBkgdUnits[blockIdx.y] : kSo3Units[blockIdx.y];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 31, h = lane >> 5;
-  const float* __restrict__ X = u.xk == 0 ? save : save + (size_t)n * 28 + (size_t)(u.xk - 1) * n * 128;
+  const float* __restrict__ X = u.xk == 0 ? save : save + (size_t)n * SmallNet<KIND>::ENC_LD + (size_t)(u.xk - 1) * n * 128;
   const float* __restrict__ dY = dy + (size_t)u.dk * n * 128;
   const int k = 32 * u.kt + m;
   const bool bias = u.boff >= 0;
@@ -1907,7 +1949,7 @@ __global__ void __launch_bounds__(256) bkgd_wgrad_kernel(const float* __restrict
   __syncthreads();
   const int nt = wave;                                // wave w sums n-tile w over the 4 waves
   if (nt < NT) {
-    float* pg = partial + (size_t)blockIdx.x * RNERF_BKGDMLP_PARAMS;
+    float* pg = partial + (size_t)blockIdx.x * SmallNet<KIND>::NPARAMS;
     const int nn = 32 * nt + m;
     if (nn < u.nout) {
 #pragma unroll
@@ -1921,18 +1963,21 @@ __global__ void __launch_bounds__(256) bkgd_wgrad_kernel(const float* __restrict
   }
 }
 
+template <int NPARAMS>
 __global__ void __launch_bounds__(256) bkgd_wgrad_reduce_kernel(const float* __restrict__ partial, int chunks, float* __restrict__ grads) {
   const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= RNERF_BKGDMLP_PARAMS) return;
+  if (e >= NPARAMS) return;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   int c = 0;
   for (; c + 4 <= chunks; c += 4) {
-    s0 += partial[(size_t)c * RNERF_BKGDMLP_PARAMS + e]; s1 += partial[(size_t)(c + 1) * RNERF_BKGDMLP_PARAMS + e];
-    s2 += partial[(size_t)(c + 2) * RNERF_BKGDMLP_PARAMS + e]; s3 += partial[(size_t)(c + 3) * RNERF_BKGDMLP_PARAMS + e];
+    s0 += partial[(size_t)c * NPARAMS + e]; s1 += partial[(size_t)(c + 1) * NPARAMS + e];
+    s2 += partial[(size_t)(c + 2) * NPARAMS + e]; s3 += partial[(size_t)(c + 3) * NPARAMS + e];
   }
-  for (; c < chunks; ++c) s0 += partial[(size_t)c * RNERF_BKGDMLP_PARAMS + e];
+  for (; c < chunks; ++c) s0 += partial[(size_t)c * NPARAMS + e];
   grads[e] += (s0 + s1) + (s2 + s3);
 }
+
+#include "ior_train_kernels.inc"
 
 }  // namespace rnerf
 
@@ -2233,18 +2278,18 @@ extern "C" int rnerf_bkgd_forward_train(const float* params, const float* dirs, 
 }
 
 extern "C" int rnerf_bkgd_backward(const float* params, const void* save, const float* d_out, int64_t n, double rgb_padding, void* dy,
-                                   float* grads, void* stream) {
+                                   float* grads, float* d_dirs, void* stream) {
   RNERF_CHECK_ARG(params && save && d_out && dy && grads, "rnerf_bkgd_backward: null pointer");
   RNERF_CHECK_ARG(n >= 1, "rnerf_bkgd_backward: n must be >= 1");
   hipStream_t st = (hipStream_t)stream;
   const float* sv = (const float*)save;
   float* dyf = (float*)dy;
   hipLaunchKernelGGL(bkgd_dgrad_kernel, dim3((unsigned)((n + 31) / 32)), dim3(64), 0, st, params, sv, d_out, (long long)n,
-                     (float)(1 + 2 * rgb_padding), (float)rgb_padding, dyf);
+                     (float)(1 + 2 * rgb_padding), (float)rgb_padding, dyf, (float4*)d_dirs);
   const unsigned chunks = (unsigned)((n + 255) / 256);
   float* partial = dyf + (size_t)n * 5 * 128;
-  hipLaunchKernelGGL(bkgd_wgrad_kernel, dim3(chunks, 18), dim3(256), 0, st, sv, (const float*)dyf, (long long)n, partial);
-  hipLaunchKernelGGL(bkgd_wgrad_reduce_kernel, dim3((RNERF_BKGDMLP_PARAMS + 255) / 256), dim3(256), 0, st, (const float*)partial, (int)chunks,
+  hipLaunchKernelGGL(bkgd_wgrad_kernel<0>, dim3(chunks, 18), dim3(256), 0, st, sv, (const float*)dyf, (long long)n, partial);
+  hipLaunchKernelGGL(bkgd_wgrad_reduce_kernel<RNERF_BKGDMLP_PARAMS>, dim3((RNERF_BKGDMLP_PARAMS + 255) / 256), dim3(256), 0, st, (const float*)partial, (int)chunks,
                      grads);
   RNERF_CHECK_LAUNCH();
   return RNERF_OK;
@@ -2275,7 +2320,10 @@ extern "C" int rnerf_march_all(const float* table, const rnerf_grid* g, const fl
   for (int i = 0; i < 10; ++i) w.w[i] = window10[i];
   const float stepf = (float)((far - near) / (num_nodes - 1));  // models.py:122
   hipLaunchKernelGGL(march_all_kernel, dim3((unsigned)((B + 31) / 32)), dim3(64), 0, (hipStream_t)stream, (const float4*)table, gp, so3_params, w,
-                     origins, viewdirs, B, (float)near, stepf, num_nodes, (float4*)path_pd, (float4*)path_dr, (float4*)path_ior);
+                     origins, viewdirs, B, (float)near, stepf, num_nodes, (float4*)path_pd, (float4*)path_dr, (float4*)path_ior,
+                     (float4*)nullptr, (int*)nullptr, 0, (int2*)nullptr, (float4*)nullptr, (float4*)nullptr, (int*)nullptr);
   RNERF_CHECK_LAUNCH();
   return RNERF_OK;
 }
+
+#include "ior_train_api.inc"

@@ -256,7 +256,7 @@ class NerfModel:
         B = origins.shape[0]
         Nc, Nf, N = self.num_coarse_samples, self.num_fine_samples, self.num_samples
         key, rng_0 = prng.split(np.asarray(rng_0, np.uint32))
-        want_ior = self.use_online_sparsity or (taps is not None)
+        want_ior = self.use_online_sparsity or (taps is not None and not (ctx is not None and self.stage.startswith("all")))
         if path is not None:
             if path.batch != B:
                 raise ValueError("path handle was marched for a different batch size")
@@ -268,6 +268,13 @@ class NerfModel:
                     t.record_stream(cur)
             if want_ior and path_ior is None:
                 raise ValueError("path handle lacks the IoR record (prefetch it from a model with the same options)")
+        elif self.stage.startswith("all") and ctx is not None:                            # training: the march also records what its adjoint needs
+            rec = ops.march_all_train(self.table, self.spec, self._flat(variables, "so3_mlp", SO3_MLP_SHAPES).detach(), origins, viewdirs,
+                                      self.near, self.far, N, annealed_alpha)
+            ctx["march_rec"] = rec
+            path_pd, path_dr, path_ior = rec["path_pd"], rec["path_dr"], None
+            if want_ior:
+                raise NotImplementedError("taps / online sparsity are not recorded by the training march of stage all*")
         elif self.stage.startswith("all"):                                                # so3_mlp bends the gradient (eikonal_utils.py:34-39)
             path_pd, path_dr, path_ior = ops.march_all(self.table, self.spec, self._flat(variables, "so3_mlp", SO3_MLP_SHAPES).detach(),
                                                        origins, viewdirs, self.near, self.far, N, annealed_alpha, want_ior=want_ior)
@@ -285,8 +292,6 @@ class NerfModel:
             raw_c = ops.nerfmlp_forward(self._packed_weights(variables, "coarse_mlp"), self.precision, path_pd, path_dr, jit, Nc, B,
                                         max_workgroups=self._mlp_wg_limit)
         else:
-            if not self.stage.startswith("radiance"):
-                raise NotImplementedError("training is built for the radiance* stages (all*: back-propagation through the march, SURVEY §8f N3)")
             if self.use_online_sparsity:
                 raise NotImplementedError("training with use_online_sparsity: the term carries annealing_rate = 0.0 (train.py:156), i.e. "
                                           "no gradient; run the model with use_online_sparsity=False (every shipped yaml does)")

@@ -220,7 +220,7 @@ def nerfmlp_pack_bwd(params_flat: torch.Tensor, out: Optional[torch.Tensor] = No
 
 def nerfmlp_backward(packed_bwd, packed_fwd, precision: int, save, d_raw: torch.Tensor, rows: int,
                      grads: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None, dy: Optional[torch.Tensor] = None,
-                     stages: str = "dw", backward: int = _lib.BWD_F16X2) -> torch.Tensor:
+                     stages: str = "dw", backward: int = _lib.BWD_F16X2, return_dy: bool = False) -> torch.Tensor:
     """d_raw [S,B,4] (d loss / d raw) -> flat fp32 gradient of the NerfMLP parameters (595844 floats).  `backward` (_lib.BWD_*) must be
     the mode the forward saved for and packed_bwd was packed for."""
     lib = _lib.load()
@@ -237,7 +237,7 @@ def nerfmlp_backward(packed_bwd, packed_fwd, precision: int, save, d_raw: torch.
         workspace = torch.empty(lib.rnerf_nerfmlp_wgrad_workspace_bytes(), dtype=torch.uint8, device=dev)
     check(lib.rnerf_nerfmlp_wgrad(int(precision), int(backward), ptr(save), ptr(dy), int(rows), ptr(grads), ptr(workspace), current_stream()),
           "rnerf_nerfmlp_wgrad")
-    return grads
+    return (grads, dy) if return_dy else grads
 
 
 def bkgd_forward_train(params_flat: torch.Tensor, dirs: torch.Tensor, rgb_padding: float = 0.001):
@@ -251,14 +251,17 @@ def bkgd_forward_train(params_flat: torch.Tensor, dirs: torch.Tensor, rgb_paddin
     return out, save
 
 
-def bkgd_backward(params_flat: torch.Tensor, save: torch.Tensor, d_out: torch.Tensor, grads: torch.Tensor, rgb_padding: float = 0.001):
-    """Accumulates d loss / d params of the background MLP into `grads` (56963 floats)."""
+def bkgd_backward(params_flat: torch.Tensor, save: torch.Tensor, d_out: torch.Tensor, grads: torch.Tensor, rgb_padding: float = 0.001,
+                  want_d_dirs: bool = False):
+    """Accumulates d loss / d params of the background MLP into `grads` (56963 floats); want_d_dirs: also returns d loss / d direction
+    [n, 4] (stage "all*")."""
     lib = _lib.load()
     n = d_out.shape[0]
     dy = torch.empty(lib.rnerf_bkgd_dy_bytes(n), dtype=torch.uint8, device=d_out.device)
+    d_dirs = torch.empty((n, 4), dtype=torch.float32, device=d_out.device) if want_d_dirs else None
     check(lib.rnerf_bkgd_backward(ptr(_chk(params_flat, "params_flat")), ptr(save), ptr(_chk(d_out, "d_out")), n, float(rgb_padding), ptr(dy),
-                                  ptr(_chk(grads, "grads")), current_stream()), "rnerf_bkgd_backward")
-    return grads
+                                  ptr(_chk(grads, "grads")), ptr(d_dirs), current_stream()), "rnerf_bkgd_backward")
+    return (grads, d_dirs) if want_d_dirs else grads
 
 
 def stratified_u(key, B: int, num_fine: int, device) -> torch.Tensor:
@@ -331,6 +334,85 @@ def march_all(table: torch.Tensor, spec: Grid, so3_flat: torch.Tensor, origins: 
     check(lib.rnerf_march_all(ptr(table), C.byref(spec), ptr(_chk(so3_flat, "so3_flat")), w.ctypes.data_as(C.c_void_p), ptr(o), ptr(v), B,
                               float(near), float(far), int(num_nodes), ptr(pd), ptr(dr), ptr(ior), current_stream()), "rnerf_march_all")
     return pd, dr, ior
+
+
+def march_all_train(table: torch.Tensor, spec: Grid, so3_flat: torch.Tensor, origins: torch.Tensor, viewdirs: torch.Tensor, near: float, far: float,
+                    num_nodes: int, annealed_alpha: float = 1.0, pair_cap: Optional[int] = None):
+    """rnerf_march_all_train: the stage "all*" march + the record its backward needs.  Returns a dict (pairs trimmed to their count:
+    this reads the device counter, i.e. synchronises once per step)."""
+    lib = _lib.load()
+    o = _chk(origins, "origins"); v = _chk(viewdirs, "viewdirs")
+    B, N, dev = o.shape[0], int(num_nodes), o.device
+    cap = int(pair_cap) if pair_cap else N * B
+    pd = torch.empty((N, B, 4), dtype=torch.float32, device=dev); dr = torch.empty_like(pd); rdn = torch.empty_like(pd)
+    count = torch.zeros(1, dtype=torch.int32, device=dev)
+    pair_id = torch.empty((cap, 2), dtype=torch.int32, device=dev)
+    pair_x = torch.empty((cap, 4), dtype=torch.float32, device=dev); pair_g = torch.empty_like(pair_x)
+    pair_of_node = torch.empty((N, B), dtype=torch.int32, device=dev)
+    w = so3_window(annealed_alpha)
+    check(lib.rnerf_march_all_train(ptr(table), C.byref(spec), ptr(_chk(so3_flat, "so3_flat")), w.ctypes.data_as(C.c_void_p), ptr(o), ptr(v), B,
+                                    float(near), float(far), N, ptr(pd), ptr(dr), ptr(rdn), ptr(count), cap, ptr(pair_id), ptr(pair_x), ptr(pair_g),
+                                    ptr(pair_of_node), current_stream()), "rnerf_march_all_train")
+    n = int(count.item())
+    if n > cap:
+        raise _lib.RnerfError(f"march_all_train: {n} boundary-shell pairs exceed pair_cap = {cap}")
+    return dict(path_pd=pd, path_dr=dr, path_rdn=rdn, n_pairs=n, pair_id=pair_id[:n], pair_x=pair_x[:n].contiguous(), pair_g=pair_g[:n].contiguous(),
+                pair_of_node=pair_of_node, window=w)
+
+
+def so3_forward_train(so3_flat: torch.Tensor, window, pts4: torch.Tensor):
+    """so3_mlp(annealed_pos_enc(x)) on pts4 [n,4] with saved activations -> (raw [n,4] view into save, save)."""
+    lib = _lib.load()
+    n = pts4.shape[0]
+    save = torch.empty(lib.rnerf_so3_save_bytes(n) // 4, dtype=torch.float32, device=pts4.device)
+    check(lib.rnerf_so3_forward_train(ptr(_chk(so3_flat, "so3_flat")), window.ctypes.data_as(C.c_void_p), ptr(_chk(pts4, "pts4")), n, ptr(save),
+                                      current_stream()), "rnerf_so3_forward_train")
+    raw = save[n * (60 + 4 * 128):].view(n, 4)
+    return raw, save
+
+
+def so3_backward(so3_flat: torch.Tensor, window, pts4: torch.Tensor, save: torch.Tensor, d_raw4: torch.Tensor, grads: Optional[torch.Tensor] = None,
+                 want_dx: bool = True):
+    """Cotangents d_raw4 [nb,4] (nb a multiple of the saved rows) -> dx4 [nb,4]; grads (65411 floats) accumulate when given (nb == n)."""
+    lib = _lib.load()
+    n, nb = pts4.shape[0], d_raw4.shape[0]
+    dy = torch.empty(lib.rnerf_so3_dy_bytes(nb) // 4, dtype=torch.float32, device=pts4.device)
+    dx = torch.empty((nb, 4), dtype=torch.float32, device=pts4.device) if want_dx else None
+    check(lib.rnerf_so3_backward(ptr(_chk(so3_flat, "so3_flat")), window.ctypes.data_as(C.c_void_p), ptr(pts4), ptr(save), n, ptr(_chk(d_raw4, "d_raw4")),
+                                 nb, ptr(dy), ptr(dx), ptr(grads), current_stream()), "rnerf_so3_backward")
+    return dx
+
+
+def so3_pair_jacobian(table: torch.Tensor, spec: Grid, pair_x: torch.Tensor, pair_g: torch.Tensor, raw4: torch.Tensor, J4: torch.Tensor):
+    lib = _lib.load()
+    n = pair_x.shape[0]
+    A = torch.empty((n, 12), dtype=torch.float32, device=pair_x.device); P = torch.empty_like(A)
+    check(lib.rnerf_so3_pair_jacobian(ptr(table), C.byref(spec), ptr(pair_x), ptr(pair_g), ptr(_chk(raw4, "raw4")), ptr(_chk(J4, "J4")), n, ptr(A), ptr(P),
+                                      current_stream()), "rnerf_so3_pair_jacobian")
+    return A, P
+
+
+def march_adjoint(table: torch.Tensor, spec: Grid, rec: dict, A, P, a_pos: torch.Tensor, a_dir: torch.Tensor, sample_of_node: torch.Tensor,
+                  near: float, far: float):
+    """The reverse scan of the march -> v4 [n_pairs, 4], the cotangent of the so3 output at every pair."""
+    lib = _lib.load()
+    N, B = rec["path_pd"].shape[0], rec["path_pd"].shape[1]
+    v = torch.zeros((max(rec["n_pairs"], 1), 4), dtype=torch.float32, device=a_pos.device)
+    check(lib.rnerf_march_adjoint(ptr(table), C.byref(spec), ptr(rec["path_pd"]), ptr(rec["path_rdn"]), ptr(rec["pair_of_node"]), ptr(A), ptr(P),
+                                  ptr(_chk(a_pos, "a_pos")), ptr(_chk(a_dir, "a_dir")), ptr(_chk(sample_of_node, "sample_of_node", torch.int32)), B,
+                                  float(near), float(far), N, ptr(v), current_stream()), "rnerf_march_adjoint")
+    return v
+
+
+def nerfmlp_input_grad(params_flat: torch.Tensor, backward: int, dy: torch.Tensor, rows_pd: torch.Tensor, rows_dr: torch.Tensor,
+                       node_of_sample: Optional[torch.Tensor], S: int, B: int):
+    """d loss / d (position, direction) of the S x B rows of a NerfMLP level -> (d_pos [S,B,4], d_dir [S,B,4])."""
+    lib = _lib.load()
+    dev = rows_pd.device
+    d_pos = torch.empty((S, B, 4), dtype=torch.float32, device=dev); d_dir = torch.empty_like(d_pos)
+    check(lib.rnerf_nerfmlp_input_grad(ptr(_chk(params_flat, "params_flat")), int(backward), ptr(dy), ptr(rows_pd), ptr(rows_dr), ptr(node_of_sample),
+                                       int(S), int(B), ptr(d_pos), ptr(d_dir), current_stream()), "rnerf_nerfmlp_input_grad")
+    return d_pos, d_dir
 
 
 def env_smooth_backward(rgb_env: torch.Tensor, ps: int, grad_scale: float, d_out: torch.Tensor, loss_sum: torch.Tensor) -> None:

@@ -26,7 +26,7 @@ import numpy as np
 import torch
 
 from . import _lib, distributed, ops, prng
-from .models import BKGD_MLP_SHAPES, NERF_MLP_SHAPES, NerfModel, make_variables
+from .models import BKGD_MLP_SHAPES, NERF_MLP_SHAPES, SO3_MLP_SHAPES, NerfModel, make_variables
 from .utils import Rays, Stats, learning_rate_decay
 
 _N_STATS = 8        # loss, loss_c, loss_bg, loss_bg_smooth, weight_l2, (3 spare)
@@ -51,7 +51,9 @@ class TrainState:
     @classmethod
     def create(cls, model: NerfModel, variables: Dict[str, Any], flags) -> "TrainState":
         names = ["coarse_mlp"] + (["fine_mlp"] if model.num_fine_samples > 0 else []) + ["bkgd_mlp"]
-        shapes = {"coarse_mlp": NERF_MLP_SHAPES, "fine_mlp": NERF_MLP_SHAPES, "bkgd_mlp": BKGD_MLP_SHAPES}
+        if getattr(flags, "stage", "radiance").startswith("all"):      # train.py:302-310: path_sampler joins the "adam_lr_scheduler" group
+            names.append("so3_mlp")
+        shapes = {"coarse_mlp": NERF_MLP_SHAPES, "fine_mlp": NERF_MLP_SHAPES, "bkgd_mlp": BKGD_MLP_SHAPES, "so3_mlp": SO3_MLP_SHAPES}
         parts = [model._flat(variables, n, shapes[n]).detach().reshape(-1).float() for n in names]
         theta = torch.cat(parts).contiguous()
         segments, off = {}, 0
@@ -133,6 +135,35 @@ def backward_mode(flags, model: NerfModel) -> int:
     return mode
 
 
+def _all_stage_backward(model: NerfModel, state: TrainState, variables, ctx, dy_c, d_bk_dirs, bwd: int, annealed: float, taps) -> None:
+    """Stage all*: d loss / d so3_mlp through the marched path (csrc/ior_train_kernels.inc).  Only the coarse level and the background
+    colour reach the path: sample_pdf stops the gradient of everything it returns (rnerf/model_utils.py:406-411), ray_dist is
+    stop_gradient'ed (eikonal_utils.py:121), and |ray_dir| = 1 makes the compositing's delta independent of the direction."""
+    B, Nc, N = ctx["B"], model.num_coarse_samples, model.num_samples
+    rec = ctx["march_rec"]
+    coarse_flat = variables["flat"]["coarse_mlp"]
+    so3_flat = variables["flat"]["so3_mlp"]
+    a_pos, a_dir = ops.nerfmlp_input_grad(coarse_flat, bwd, dy_c, ctx["path_pd"], ctx["path_dr"], ctx["jit"], Nc, B)
+    a_dir[Nc - 1] += d_bk_dirs[:B]                     # bkgd_mlp reads the direction of the LAST coarse sample (rnerf/models.py:303)
+    sample_of_node = torch.full((N,), -1, dtype=torch.int32, device=a_pos.device)
+    sample_of_node[ctx["jit"].long()] = torch.arange(Nc, dtype=torch.int32, device=a_pos.device)
+    n = rec["n_pairs"]
+    if n > 0:
+        raw, save = ops.so3_forward_train(so3_flat, rec["window"], rec["pair_x"])
+        eye = torch.zeros((3 * n, 4), dtype=torch.float32, device=a_pos.device)
+        for j in range(3):
+            eye[j * n:(j + 1) * n, j] = 1.0
+        J = ops.so3_backward(so3_flat, rec["window"], rec["pair_x"], save, eye)                   # rows of d raw / d x
+        A, P = ops.so3_pair_jacobian(model.table, model.spec, rec["pair_x"], rec["pair_g"], raw.contiguous(), J)
+    else:
+        A = P = torch.zeros((1, 12), dtype=torch.float32, device=a_pos.device)
+    v = ops.march_adjoint(model.table, model.spec, rec, A, P, a_pos, a_dir, sample_of_node, model.near, model.far)
+    if n > 0:
+        ops.so3_backward(so3_flat, rec["window"], rec["pair_x"], save, v, grads=state.grad_view("so3_mlp"), want_dx=False)
+    if taps is not None:
+        taps.update(a_pos=a_pos, a_dir=a_dir, n_pairs=n, v_pairs=v)
+
+
 def train_step(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], flags=None, *, jitter=None, u_fine=None,
                taps: Optional[dict] = None, path=None, next_rays: Optional[Rays] = None, forward_taps: Optional[dict] = None):
     """One optimisation step (train.py:58-183).  batch: {"rays": Rays of [B,3], "pixels": [B,>=3], "annealed_alpha": float,
@@ -142,8 +173,12 @@ def train_step(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], 
     runs beside the small kernels of the step's tail; the handle is left in state.next_path.  Returns (state, stats, rng); the Stats fields are
     0-dim device tensors (no host synchronisation inside the step)."""
     flags = state.flags if flags is None else flags           # the reference reads the global FLAGS (train.py:52)
-    if not (flags.stage.startswith("radiance")):
-        raise NotImplementedError("train_step: only the radiance stages are built (SURVEY.md §8f)")
+    all_stage = flags.stage.startswith("all")
+    if not (flags.stage.startswith("radiance") or all_stage):
+        raise NotImplementedError("train_step: the radiance* and all* stages are built (the ior* stage's only loss term carries "
+                                  "annealing_rate = 0.0, train.py:156: it trains nothing)")
+    if all_stage and model.stage != flags.stage:
+        raise ValueError("stage all*: build the model with the same stage (the march must evaluate so3_mlp)")
     if flags.beta_weight > 0 or flags.sparsity_weight > 0:
         pass        # both are multiplied by annealing_rate = 0.0 (train.py:156): no contribution to loss or gradient
     rng, key_0, key_1 = prng.split(np.asarray(rng, np.uint32), 3)
@@ -154,6 +189,8 @@ def train_step(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], 
     prec = model.precision
     Nc, Nf = model.num_coarse_samples, model.num_fine_samples
     bwd = backward_mode(flags, model)
+    if all_stage and bwd == _lib.BWD_BF16:
+        raise ValueError('stage all*: the input gradients are built on the row-normalised backward modes (backward_precision "f32" or "tf32")')
     ctx: Dict[str, Any] = {"backward": bwd}
     if flags.bg_smooth_weight > 0:
         ev = batch["env_rays"].viewdirs
@@ -187,8 +224,8 @@ def train_step(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], 
         d_raw_c, d_bkgd = ops.composite_backward(ctx["raw_c"], ctx["path_pd"], ctx["path_dr"], ctx["jit"], Nc, B, ctx["bkgd"], rgb_f, pixels,
                                                  trans_f, tb_f, sums, mse_scale, flags.bg_weight * bg_on, rgb_padding=model.rgb_padding,
                                                  sigma_bias=model.sigma_bias, white_bkgd=model.white_bkgd, d_bkgd=d_first, accumulate_bkgd=False)
-    ops.nerfmlp_backward(_bwd_packed(model, state, "coarse_mlp", bwd), model._packed_weights(variables, "coarse_mlp"), prec, ctx["save_c"],
-                         d_raw_c, Nc * B, grads=state.grad_view("coarse_mlp"), backward=bwd)
+    _, dy_c = ops.nerfmlp_backward(_bwd_packed(model, state, "coarse_mlp", bwd), model._packed_weights(variables, "coarse_mlp"), prec, ctx["save_c"],
+                                   d_raw_c, Nc * B, grads=state.grad_view("coarse_mlp"), backward=bwd, return_dy=True)
     # jax.lax.pmean of the gradients (train.py:166), first part: the NerfMLP segments are final here, their all-reduce (95 % of the
     # bytes) starts now and runs beside the rest of the step; the background-MLP gradients and the stats follow in a small second one
     n_big = state.segments["bkgd_mlp"][0]
@@ -206,12 +243,16 @@ def train_step(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], 
         on = 1.0 if annealed > 0 else 0.0
         env_sum = torch.empty(1, dtype=torch.float32, device=pixels.device)
         ops.env_smooth_backward(ctx["rgb_env"], ps, flags.bg_smooth_weight * on, d_all[B:], env_sum)
-    ops.bkgd_backward(bk_flat, ctx["save_bkgd"], d_all, g_bk, model.rgb_padding)
+    if all_stage:
+        _, d_bk_dirs = ops.bkgd_backward(bk_flat, ctx["save_bkgd"], d_all, g_bk, model.rgb_padding, want_d_dirs=True)
+        _all_stage_backward(model, state, variables, ctx, dy_c, d_bk_dirs, bwd, annealed, taps)
+    else:
+        ops.bkgd_backward(bk_flat, ctx["save_bkgd"], d_all, g_bk, model.rgb_padding)
     # ---- weight_l2 over ALL variables, the frozen path_sampler included (train.py:147-153), and the Stats scalars: they ride in the
     #      tail of the gradient buffer, one all-reduce for both (train.py:166-167)
     n_theta = state.theta.numel()
     if state.frozen_sq is None:
-        so3 = variables.get("flat", {}).get("so3_mlp")
+        so3 = variables.get("flat", {}).get("so3_mlp") if "so3_mlp" not in state.segments else None      # trained in stage all*: part of theta
         state.frozen_sq = (float((so3.double() ** 2).sum()) if so3 is not None else 0.0, so3.numel() if so3 is not None else 0)   # once
     n_all = n_theta + state.frozen_sq[1]
     st = G[n_theta:]

@@ -1,0 +1,122 @@
+"""Training of stage "all*" (SURVEY 8f N3): the gradient of every trained parameter — so3_mlp through the adjoint of the N-step march
+included — against torch float64 autograd of a restatement of the whole differentiable path (oracle/torch_ref.py:path_sampler_all)."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from oracle import ref_np as R, torch_ref as TR
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+
+
+def _setup(Nf, B=48, seed=5, so3_out_std=0.05):
+    from samplenerfro_amd import models, synthetic as syn, utils
+    from samplenerfro_amd.train import TrainState
+    G = 24
+    raw = syn.scale_ior(syn.sphere_grid(G, 1.5, 0.6), 0.5)
+    grid = R.conv3d_normal(raw.reshape(-1, 1), [G] * 3, 3, 1.0).reshape(G, G, G)
+    flags = utils.default_flags(stage="all", num_coarse_samples=8, num_fine_samples=Nf, num_path_samples=4, white_bkgd=False, bg_weight=0.025,
+                                bg_smooth_weight=1.0, bg_patch_size=8, use_online_sparsity=False, lr_delay_steps=0, max_steps=1000,
+                                weight_decay_mult=1e-3, near=2.0, far=6.0, randomized=False)
+    model, variables = models.construct_nerf(np.array([0, 7], np.uint32), None, flags, [G] * 3, [-1.5] * 3, [1.5] * 3, T(grid.astype(F32)))
+    pf = syn.init_params_flat(seed, fine=Nf > 0, bias_scale=0.1)
+    for k in ("coarse_mlp", "fine_mlp", "bkgd_mlp"):
+        if k in pf:
+            variables["flat"][k].copy_(T(pf[k]))
+    rng = np.random.default_rng(seed)
+    so3 = syn.init_mlp_flat(rng, TR.SO3_MLP_SHAPES, 0.05)
+    so3[-(128 * 3 + 3):-3] = (so3_out_std * rng.standard_normal(128 * 3)).astype(F32)      # a visible rotation (the reference starts at N(0, 1e-5))
+    variables["flat"]["so3_mlp"].copy_(T(so3))
+    o, d = syn.sphere_rays(B, seed=seed)
+    ev = R.safe_l2_normalize(rng.standard_normal((8, 8, 3)).astype(F32))
+    batch = {"rays": utils.Rays(T(o), T(d), T(d), None), "pixels": T(rng.uniform(0, 1, (B, 3)).astype(F32)), "annealed_alpha": 0.5,
+             "env_rays": utils.Rays(None, None, T(ev), None)}
+    state = TrainState.create(model, variables, flags)
+    return model, state, batch, flags, ev, grid.astype(F32), o, d
+
+
+def _reference(model, state, batch, flags, taps, ev, grid, o, d, theta0):
+    ctx = taps["ctx"]
+    B, Nc, Nf, N = ctx["B"], model.num_coarse_samples, model.num_fine_samples, model.num_samples
+    G = model.ndim[0]
+    table = torch.tensor(R.build_table(grid, model.ndim, model.nmin, model.nmax), dtype=torch.float64)
+    th = torch.tensor(theta0, dtype=torch.float64, requires_grad=True)
+    seg = state.segments
+    f64 = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64)
+    ray_pos, ray_dir, ray_dist = TR.path_sampler_all(f64(o), f64(d), table, th[seg["so3_mlp"][0]:seg["so3_mlp"][1]], model.ndim, model.nmin, model.nmax,
+                                                    model.near, model.far, N, batch["annealed_alpha"])
+    jit = ctx["jit"].cpu().long()
+    pix = batch["pixels"].cpu().double()
+    # evaluate everything downstream AT the device's fp32 path (straight-through: values from the device, derivatives from the float64
+    # march): position differences of 1e-5 would otherwise show up as 1e-3-level differences of the 2^9-frequency encodings' gradients
+    dev_pos = ctx["path_pd"].cpu().double()[..., :3].permute(1, 0, 2)
+    dev_dir = ctx["path_dr"].cpu().double()[..., :3].permute(1, 0, 2)
+    path_err = float((dev_pos - ray_pos.detach()).abs().max())
+    ray_pos = ray_pos + (dev_pos - ray_pos).detach()
+    ray_dir = ray_dir + (dev_dir - ray_dir).detach()
+    ray_dist = ctx["path_pd"].cpu().double()[..., 3].permute(1, 0)
+
+    def level(name, pos, dirs, t, bk):
+        S = pos.shape[1]
+        raw = TR.nerf_mlp(th[seg[name][0]:seg[name][1]], TR.pos_enc_t(pos.reshape(-1, 3), 10), TR.pos_enc_t(dirs.reshape(-1, 3), 4)).reshape(B, S, 4)
+        rgb, sigma = TR.activations(raw, model.rgb_padding, model.sigma_bias)
+        comp, acc, w, trans, tb = TR.volumetric_rendering(rgb, sigma, t, dirs, bk)
+        return comp, trans, tb
+
+    pos_c, dir_c, t_c = ray_pos[:, jit], ray_dir[:, jit], ray_dist[:, jit]
+    bflat = th[seg["bkgd_mlp"][0]:seg["bkgd_mlp"][1]]
+    bk = TR.bkgd_mlp(bflat, TR.pos_enc_t(dir_c[:, -1], 4), model.rgb_padding)
+    levels = [level("coarse_mlp", pos_c, dir_c, t_c, bk)]
+    if Nf > 0:      # sample_pdf stops the gradient of everything it returns (model_utils.py:406-411): the device's rows as constants
+        pdf, drf = ctx["rows_pd"].cpu().double(), ctx["rows_dr"].cpu().double()
+        levels.append(level("fine_mlp", pdf[..., :3].permute(1, 0, 2), drf[..., :3].permute(1, 0, 2), pdf[..., 3].permute(1, 0), bk))
+    total, parts = TR.radiance_loss(levels, pix, flags.bg_weight, batch["annealed_alpha"])
+    env = TR.bkgd_mlp(bflat, TR.pos_enc_t(f64(ev.reshape(-1, 3)), 4), model.rgb_padding).reshape(8, 8, 3)
+    smooth = (0.5 * ((env[1:, :] - env[:-1, :]) ** 2).reshape(-1) + 0.5 * ((env[:, 1:] - env[:, :-1]) ** 2).reshape(-1)).mean()
+    wl2 = (th * th).sum() / th.numel()
+    (total + flags.bg_smooth_weight * smooth + flags.weight_decay_mult * wl2).backward()
+    return th.grad.numpy(), path_err, {k: float(v.detach()) for k, v in parts.items()}
+
+
+@pytest.mark.parametrize("Nf,bwd", [(0, "f32"), (12, "f32"), (0, "tf32")])
+def test_all_stage_gradients(Nf, bwd):
+    from samplenerfro_amd.train import train_step
+    model, state, batch, flags, ev, grid, o, d = _setup(Nf)
+    flags.backward_precision = bwd
+    theta0 = state.theta.cpu().numpy().astype(np.float64)
+    assert "so3_mlp" in state.segments and state.theta.numel() == (595844 * (2 if Nf else 1) + 56963 + 65411)
+    taps = {}
+    state, stats, _ = train_step(model, np.array([1, 2], np.uint32), state, batch, flags, taps=taps)
+    g = taps["grads"].cpu().numpy().astype(np.float64)
+    ref, path_err, parts = _reference(model, state, batch, flags, taps, ev, grid, o, d, theta0)
+    assert taps["n_pairs"] > 100 and path_err < 2e-5
+    assert abs(float(stats.loss) - parts["loss"]) < 2e-5
+    tol = {"f32": 1e-5, "tf32": 5e-3}[bwd]
+    for name, (lo, hi) in state.segments.items():
+        a, b = g[lo:hi], ref[lo:hi]
+        cos = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b)))
+        err = np.abs(a - b).max() / np.abs(b).max()
+        print(f"[N_f={Nf}, {bwd}] {name}: cosine {cos:.7f}, max err / max |g| {err:.2e}, max |g| {np.abs(b).max():.2e}")
+        # so3_mlp's gradient passes through the coarse MLP's input gradient, the 32-node reverse scan and the so3 backward
+        assert cos > 0.9999 and err < ({"f32": 5e-5, "tf32": 5e-3}[bwd] if name == "so3_mlp" else tol), name
+    assert np.abs(ref[state.segments["so3_mlp"][0]:]).max() > 1e-6          # the path really carries gradient
+
+
+def test_all_stage_training_reduces_the_loss():
+    from samplenerfro_amd.train import train_step
+    model, state, batch, flags, ev, grid, o, d = _setup(12)
+    state.lr_fn = lambda c: 2e-3 if c > 0 else 0.0
+    so3_0 = state.variables["flat"]["so3_mlp"].clone()
+    rng = np.array([3, 4], np.uint32)
+    losses = []
+    for _ in range(30):
+        state, stats, rng = train_step(model, rng, state, batch)
+        losses.append(float(stats.loss))
+    assert losses[-1] < 0.7 * losses[0], losses[::6]
+    assert float((state.variables["flat"]["so3_mlp"] - so3_0).abs().max()) > 1e-4        # path_sampler is being trained (train.py:302-310)
