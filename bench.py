@@ -30,7 +30,7 @@ PEAK_MFMA_16BIT = 2.5e15               # dense bf16/f16 MFMA peak (MI355X_MICROA
 PEAK_HBM = 8.0e12
 
 
-def build_scene(cfg, device, precision, fine):
+def build_scene(cfg, device, precision, fine, stage="radiance"):
     import torch
     from samplenerfro_amd import models, ops, synthetic as syn
     G, ext = cfg["G"], cfg["extent"]
@@ -48,10 +48,13 @@ def build_scene(cfg, device, precision, fine):
         grid = torch.ones((G, G, G), dtype=torch.float32, device=device)
     model = models.NerfModel(ndim=ndim, nmin=nmin, nmax=nmax, grid=grid, near=cfg["near"], far=cfg["far"],
                              num_coarse_samples=cfg["S"], num_fine_samples=fine, num_path_samples=cfg["P"],
-                             precision=precision, device=device)
+                             precision=precision, device=device, stage=stage)
     del grid
     pf = syn.init_params_flat(0, fine=fine > 0)
-    variables = models.make_variables({k: torch.from_numpy(v).to(device) for k, v in pf.items()})
+    flat = {k: torch.from_numpy(v).to(device) for k, v in pf.items()}
+    if stage.startswith("all"):        # so3_mlp: glorot + N(0, 1e-5) output layer (rnerf/ior_utils.py:148-152)
+        flat["so3_mlp"] = models.init_mlp_flat(torch.Generator().manual_seed(1), models.SO3_MLP_SHAPES, out_std=1e-5).to(device)
+    variables = models.make_variables(flat)
     return model, variables, pf
 
 
@@ -184,6 +187,9 @@ def main():
     ap.add_argument("--backward", choices=["f32", "tf32", "bf16"], default="f32",
                     help="arithmetic of the NerfMLP backward: f32 = hi + lo f16 parts (fp32-grade, the reference differentiates in fp32; "
                          "default), tf32 = f16 parts (11-bit significand), bf16 = 8-bit significand (round 1's arithmetic)")
+    ap.add_argument("--stage", choices=["radiance", "all"], default="radiance",
+                    help="all: so3_mlp bends the gradient inside the march and is trained through its adjoint (train.py:302-310); needs a "
+                         "refractive workload (e.g. ship_refractive)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: every rank owns --rays rays (default); strong: --rays is the GLOBAL batch, split over the ranks "
                          "(BASELINE config 4 as written: 4096 rays = 512 per GPU on 8 GPUs)")
@@ -222,7 +228,9 @@ def main():
         if B % world:
             raise SystemExit("--scaling strong: the global batch must be divisible by the number of ranks (train.py:196)")
         B //= world
-    model, variables, pf = build_scene(cfg, device, args.precision, fine)
+    model, variables, pf = build_scene(cfg, device, args.precision, fine, args.stage)
+    if args.stage == "all":
+        args.pipeline = False           # the all* march reads the so3 parameters of the current step: no cross-step prefetch
     # weak scaling: every rank marches its own B rays (different seed per rank), grid + weights replicated
     o, d = syn.sphere_rays(B, seed=syn.SEED + rank)
     rays = Rays(torch.from_numpy(o).to(device), None, torch.from_numpy(d).to(device), None)
@@ -240,7 +248,7 @@ def main():
         from samplenerfro_amd.train import TrainState, train_step
         flags = U.default_flags(num_coarse_samples=cfg["S"], num_fine_samples=fine, num_path_samples=cfg["P"], white_bkgd=False,
                                 bg_weight=0.025, bg_smooth_weight=1.0, bg_patch_size=128, use_online_sparsity=False, randomized=True,
-                                near=cfg["near"], far=cfg["far"], batch_size=B * world, backward_precision=args.backward)
+                                near=cfg["near"], far=cfg["far"], batch_size=B * world, backward_precision=args.backward, stage=args.stage)
         tstate = TrainState.create(model, variables, flags)
         gen = np.random.default_rng(syn.SEED + 1000 + rank)
         ev_d = gen.standard_normal((flags.bg_patch_size, flags.bg_patch_size, 3)).astype(np.float32)
@@ -396,7 +404,7 @@ def main():
         # the same step with the other backward arithmetics (5 steps each, after 2 warm-up steps), for the record in the same line
         other_modes = {}
         for name in ("f32", "tf32", "bf16"):
-            if name == args.backward:
+            if name == args.backward or (args.stage == "all" and name == "bf16"):
                 continue
             flags.backward_precision = name
             state["h"] = None
@@ -440,7 +448,7 @@ def main():
             "config": {"workload": f"{args.workload}: {'train step (forward + backward + grad all-reduce + Adam)' if train else 'forward render pass'}, "
                                    f"{B} rays/GPU x {S} coarse + {fine} fine samples, "
                                    f"P={cfg['P']} (N={N} eikonal steps), grid {cfg['G']}^3", "rays_per_gpu": B,
-                       "mlp_rows_per_ray": rows_per_ray, "pass": args.mode,
+                       "mlp_rows_per_ray": rows_per_ray, "pass": args.mode, "stage": args.stage,
                        "precision": args.precision + ": forward — fp32 operands split into hi + lo 16-bit parts, 3 MFMAs per product, fp32 accumulate",
                        "backward_precision": (None if not train else args.backward),
                        "backward_precision_note": (None if not train else {
@@ -474,7 +482,7 @@ def main():
             line["other_backward_modes"] = other_modes
         if frame is not None:
             line["frame"] = frame
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and args.stage == "radiance":      # (the oracle legs below restate the radiance stage)
             cpu_rps, cpu_dt = cpu_baseline(cfg, pf, fine, args.cpu_rays, syn.SEED, train)
             what = ("one train step: numpy fp32 oracle for march/sampling + torch CPU fp32 autograd of train.py's loss_fn + Adam"
                     if train else "one pass of the numpy fp32 oracle")

@@ -76,8 +76,8 @@ class NerfModel:
                  use_fine_sparsity=False, net_depth=8, net_width=256, net_depth_condition=1, net_width_condition=128,
                  skip_layer=4, num_rgb_channels=3, num_sigma_channels=1, legacy_posenc_order=False, lindisp=False,
                  precision="f16x3", device=None, **unused):
-        if not (stage.startswith("radiance") or stage.startswith("all")):
-            raise NotImplementedError(f"stage={stage!r}: the radiance* and all* stages are built (forward; training only for radiance*)")
+        if not (stage.startswith("radiance") or stage.startswith("all") or stage.startswith("ior")):
+            raise NotImplementedError(f"stage={stage!r}: expected radiance*, ior* or all* (rnerf/eikonal_utils.py:34-39, train.py:286-310)")
         if (net_depth, net_width, net_depth_condition, net_width_condition, skip_layer) != (8, 256, 1, 128, 4):
             raise NotImplementedError("the HIP NerfMLP kernel is specialised for the reference's 8x256 / skip 4 / 1x128 network")
         if (min_deg_point, max_deg_point, deg_view) != (0, 10, 4) or legacy_posenc_order or not use_viewdirs:

@@ -51,8 +51,11 @@ class TrainState:
     @classmethod
     def create(cls, model: NerfModel, variables: Dict[str, Any], flags) -> "TrainState":
         names = ["coarse_mlp"] + (["fine_mlp"] if model.num_fine_samples > 0 else []) + ["bkgd_mlp"]
-        if getattr(flags, "stage", "radiance").startswith("all"):      # train.py:302-310: path_sampler joins the "adam_lr_scheduler" group
+        stage = getattr(flags, "stage", "radiance")
+        if stage.startswith("all"):        # train.py:302-310: path_sampler joins the "adam_lr_scheduler" group
             names.append("so3_mlp")
+        elif stage.startswith("ior"):      # train.py:294-301: only path_sampler is trained, the rest is labelled "zero"
+            names = ["so3_mlp"]
         shapes = {"coarse_mlp": NERF_MLP_SHAPES, "fine_mlp": NERF_MLP_SHAPES, "bkgd_mlp": BKGD_MLP_SHAPES, "so3_mlp": SO3_MLP_SHAPES}
         parts = [model._flat(variables, n, shapes[n]).detach().reshape(-1).float() for n in names]
         theta = torch.cat(parts).contiguous()
@@ -135,6 +138,37 @@ def backward_mode(flags, model: NerfModel) -> int:
     return mode
 
 
+def _ior_stage_step(model: NerfModel, rng, state: TrainState, batch, flags):
+    """Stage ior* exactly as the reference ships it (train.py:133-146,156-162): the only data term, loss_nrm =
+    compute_normal_loss_and_smooth(...)[0] (eikonal_utils.py:84-98, which returns the constant 0.0 for it), enters the objective as
+    annealing_rate * loss_nrm with annealing_rate hard-wired to 0.0 (train.py:156), so what jax.value_and_grad returns for the trained
+    group (path_sampler, train.py:294-301) is the weight-decay term alone: 2 * weight_decay_mult * theta / n_all.  Plain tensor
+    arithmetic on the flat buffer — there is no kernel to run."""
+    rng, _key_0, _key_1 = prng.split(np.asarray(rng, np.uint32), 3)
+    annealed = float(np.asarray(batch["annealed_alpha"]).reshape(-1)[0])
+    variables = state.variables
+    others = [v for k, v in variables["flat"].items() if k not in state.segments]
+    n_all = state.theta.numel() + sum(int(v.numel()) for v in others)
+    sq = (state.theta.double() ** 2).sum() + sum((v.double() ** 2).sum() for v in others)
+    weight_l2 = (sq / n_all).float()
+    grads = state.grads[:state.theta.numel()]
+    grads.copy_(state.theta).mul_(2.0 * flags.weight_decay_mult / n_all)
+    distributed.allreduce_mean_([grads])
+    if flags.grad_max_val > 0:
+        grads.clamp_(-flags.grad_max_val, flags.grad_max_val)
+    if flags.grad_max_norm > 0:
+        og = [v * (2.0 * flags.weight_decay_mult / n_all) for v in others]
+        if flags.grad_max_val > 0:
+            og = [v.clamp(-flags.grad_max_val, flags.grad_max_val) for v in og]
+        norm = torch.sqrt((grads * grads).sum() + sum((v * v).sum() for v in og))
+        grads.mul_(torch.clamp(flags.grad_max_norm / (1e-7 + norm), max=1.0))
+    state.apply_gradients(grads)
+    zero = torch.zeros((), device=state.theta.device)
+    stats = Stats(loss=zero, psnr=zero, loss_c=zero, psnr_c=zero, weight_l2=weight_l2, loss_sp=0.0, loss_nrm=0.0, annealing_rate=annealed,
+                  coarse_alpha_target=0.0, fine_alpha_target=0.0, loss_bg=zero, loss_bg_c=0.0, loss_bg_smooth=0.0)
+    return state, stats, rng
+
+
 def _all_stage_backward(model: NerfModel, state: TrainState, variables, ctx, dy_c, d_bk_dirs, bwd: int, annealed: float, taps) -> None:
     """Stage all*: d loss / d so3_mlp through the marched path (csrc/ior_train_kernels.inc).  Only the coarse level and the background
     colour reach the path: sample_pdf stops the gradient of everything it returns (rnerf/model_utils.py:406-411), ray_dist is
@@ -174,9 +208,10 @@ def train_step(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], 
     0-dim device tensors (no host synchronisation inside the step)."""
     flags = state.flags if flags is None else flags           # the reference reads the global FLAGS (train.py:52)
     all_stage = flags.stage.startswith("all")
+    if flags.stage.startswith("ior"):
+        return _ior_stage_step(model, rng, state, batch, flags)
     if not (flags.stage.startswith("radiance") or all_stage):
-        raise NotImplementedError("train_step: the radiance* and all* stages are built (the ior* stage's only loss term carries "
-                                  "annealing_rate = 0.0, train.py:156: it trains nothing)")
+        raise NotImplementedError(f"train_step: unknown stage {flags.stage!r}")
     if all_stage and model.stage != flags.stage:
         raise ValueError("stage all*: build the model with the same stage (the march must evaluate so3_mlp)")
     if flags.beta_weight > 0 or flags.sparsity_weight > 0:

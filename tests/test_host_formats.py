@@ -127,9 +127,36 @@ def test_flags_and_lr_schedule():
     assert abs(utils.compute_psnr(0.01) - 20.0) < 1e-9
 
 
+def test_ior_stage_step_is_the_weight_decay_term():
+    """train.py:133-146,156: the ior* stage's data term is multiplied by annealing_rate = 0.0 — the gradient of the trained group
+    (path_sampler, :294-301) is 2 wd theta / n_all, applied through optax's Adam formula."""
+    from samplenerfro_amd.train import TrainState, train_step
+
+    class _M:
+        num_fine_samples = 128
+        def _flat(self, variables, name, shapes):
+            return variables["flat"][name]
+    pf = syn.init_params_flat(5, fine=True, bias_scale=0.1)
+    so3 = torch.linspace(-0.3, 0.3, 65411)
+    variables = models.make_variables({**{k: torch.from_numpy(v) for k, v in pf.items()}, "so3_mlp": so3.clone()})
+    flags = utils.default_flags(stage="ior", weight_decay_mult=3.0, lr_delay_steps=0, max_steps=100)
+    st = TrainState.create(_M(), variables, flags)
+    assert list(st.segments) == ["so3_mlp"] and st.theta.numel() == 65411
+    st.lr_fn = lambda c: 1e-2
+    st, stats, _ = train_step(_M(), np.array([1, 2], np.uint32), st, {"annealed_alpha": 0.5}, flags)
+    n_all = 65411 + 2 * 595844 + 56963
+    g = 2 * 3.0 * so3.double() / n_all
+    want = so3.double() - 1e-2 * (0.1 * g / 0.1) / (torch.sqrt(0.001 * g * g / 0.001) + 1e-8)
+    assert float((st.theta.double() - want).abs().max()) < 1e-6 and float(stats.loss) == 0.0
+    wl2 = (so3.double() ** 2).sum() + sum((torch.from_numpy(v).double() ** 2).sum() for v in pf.values())
+    assert abs(float(stats.weight_l2) - float(wl2 / n_all)) < 1e-7
+    # the other networks are labelled "zero": untouched
+    assert torch.equal(st.variables["flat"]["coarse_mlp"], torch.from_numpy(pf["coarse_mlp"]))
+
+
 def test_model_rejects_unbuilt_options():
     with pytest.raises(NotImplementedError):
-        models.NerfModel(ndim=[4] * 3, nmin=[-1] * 3, nmax=[1] * 3, grid=np.ones((4, 4, 4), np.float32), stage="ior", device="cpu")
+        models.NerfModel(ndim=[4] * 3, nmin=[-1] * 3, nmax=[1] * 3, grid=np.ones((4, 4, 4), np.float32), stage="nonsense", device="cpu")
     with pytest.raises(NotImplementedError):
         models.NerfModel(ndim=[4] * 3, nmin=[-1] * 3, nmax=[1] * 3, grid=np.ones((4, 4, 4), np.float32), sh_deg=2, device="cpu")
 
