@@ -421,6 +421,14 @@ __device__ __forceinline__ void kstep_mfma(f32x16 (&acc0)[8], f32x16 (&acc1)[8],
 // l = 1..8, set 8 = the rgb-head input), stored word-major uint32[9][4][R][2]: word w holds k-steps 4w..4w+3 (written as soon as
 // they are converted: no register lives across the layer), byte s&3, bit (j>>1) + 4*(j&1) <=> element j of k-step s is non-zero.
 constexpr int SAVE_PE = 0, SAVE_L1 = 4, SAVE_VIEW = 148, SAVE_RGBIN = 150, SAVE_SLOTS = 158, SAVE_MASK = 158, SAVE_TOTAL = 167;
+// Memory layout of the saved operands (and of the dY planes below): TILE-major — [32-row tile][slot][row in tile][half] uint4, so that
+// the slots a wave touches for its 32 rows are consecutive 1 KiB blocks: the training forward / the dgrad write, and the wgrad reads,
+// 16-32 KiB contiguous per (wave, chunk) instead of 1 KiB pieces 16 MB apart (one DRAM page activation per KiB).  The save buffer is
+// [hi plane: SAVE_SLOTS slots][ReLU masks: 36 dword-slots = 576 uint4 per tile][lo plane: SAVE_SLOTS slots (hi + lo mode only)].
+__host__ __device__ constexpr size_t sv_mask0(long long R) { return (size_t)(R / 32) * SAVE_SLOTS * 64; }                  // uint4 units
+__host__ __device__ constexpr size_t sv_lo0(long long R) { return sv_mask0(R) + (size_t)(R / 32) * 576; }
+__host__ __device__ constexpr size_t sv_addr(int q, long long t32, int m, int h) { return (((size_t)t32 * SAVE_SLOTS + q) * 32 + m) * 2 + h; }
+__host__ __device__ constexpr size_t sv_mask_addr(int sw, long long t32, int m, int h) { return (((size_t)t32 * 36 + sw) * 32 + m) * 2 + h; }   // dword units
 
 // non-zero flags of the 8 post-ReLU (non-negative) 16-bit values of one operand: bits 0..3 = even elements, 16..19 = odd elements
 __device__ __forceinline__ uint32_t nz_nibbles(const uint4& o) {
@@ -476,16 +484,17 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
 
     // training forward: keep the hi parts of the operands of slot q (see SAVE_* above); padded rows are written too
     const long long srow0 = (long long)tile * 256 + wave * 64 + m;
+    const long long t32_0 = (long long)tile * 8 + wave * 2;                   // 32-row tile of m-tile 0 (m-tile 1: + 1)
     auto save_ops = [&](int q, const KOps& o) {
       if constexpr (TRAIN != 0) {
 #ifndef RNERF_FWD_NOSAVE      /* profiling ablation */
-        uint4* dst = save + ((size_t)q * save_rows + srow0) * 2 + h;
+        uint4* dst = save + sv_addr(q, t32_0, m, h);
         stream_store(dst, o.h0);
-        stream_store(dst + 64, o.h1);          // m-tile 1 = rows + 32
-        if constexpr (TRAIN == 2) {            // lo plane: slots SAVE_TOTAL + q
-          uint4* dl = save + ((size_t)(SAVE_TOTAL + q) * save_rows + srow0) * 2 + h;
+        stream_store(dst + (size_t)SAVE_SLOTS * 64, o.h1);          // m-tile 1 = the next 32-row tile
+        if constexpr (TRAIN == 2) {            // lo plane
+          uint4* dl = dst + sv_lo0(save_rows);
           stream_store(dl, o.l0);
-          stream_store(dl + 64, o.l1);
+          stream_store(dl + (size_t)SAVE_SLOTS * 64, o.l1);
         }
 #endif
       }
@@ -500,9 +509,9 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
         if ((s & 3) == 0) { mw0 = nz_byte(nib0); mw1 = nz_byte(nib1); }
         else { mw0 |= nz_byte(nib0) << (8 * (s & 3)); mw1 |= nz_byte(nib1) << (8 * (s & 3)); }
         if ((s & 3) == 3) {      // word-major: a wave's 64 dwords are contiguous (full-line writes)
-          uint32_t* dst = (uint32_t*)(save + (size_t)SAVE_MASK * save_rows * 2) + ((size_t)(set * 4 + (s >> 2)) * save_rows + srow0) * 2 + h;
+          uint32_t* dst = (uint32_t*)(save + sv_mask0(save_rows)) + sv_mask_addr(set * 4 + (s >> 2), t32_0, m, h);
           __builtin_nontemporal_store(mw0, dst);
-          __builtin_nontemporal_store(mw1, dst + 64);
+          __builtin_nontemporal_store(mw1, dst + 36 * 64);
         }
       }
     };
@@ -869,6 +878,7 @@ template <int BWD> struct Bwd {
 };
 // dy buffer: uint4[DY_SLOTS * NP][R][2] operand planes (hi, then lo), then float row_scale[R] and uint32 m_ref bits (F16 modes)
 __host__ __device__ constexpr size_t dy_plane_uint4(long long R, int np) { return (size_t)DY_SLOTS * np * (size_t)R * 2; }
+__host__ __device__ constexpr size_t dy_addr(int q, long long t32, int m, int h) { return (((size_t)t32 * DY_SLOTS + q) * 32 + m) * 2 + h; }     // tile-major, see sv_addr
 
 template <int BWD>
 __global__ void __launch_bounds__(256, 1)
@@ -900,6 +910,7 @@ nerfmlp_dgrad_kernel(const char* __restrict__ packed_bwd, const float* __restric
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const bool has_next_tile = tile + (int)gridDim.x < n_tiles;
     const long long srow0 = (long long)tile * 256 + wave * 64 + m;
+    const long long t32_0 = (long long)tile * 8 + wave * 2;
     float4 g[2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
@@ -924,23 +935,23 @@ nerfmlp_dgrad_kernel(const char* __restrict__ packed_bwd, const float* __restric
 
     auto dy_store = [&](int q, const KOps& o) {
 #ifndef RNERF_DGRAD_NOSTORE   /* profiling ablation */
-      uint4* dst = dy + ((size_t)q * save_rows + srow0) * 2 + h;
+      uint4* dst = dy + dy_addr(q, t32_0, m, h);
       stream_store(dst, o.h0);
-      stream_store(dst + 64, o.h1);
+      stream_store(dst + (size_t)DY_SLOTS * 64, o.h1);
       if constexpr (BW::NP == 2) {
-        uint4* dl = dy + ((size_t)(DY_SLOTS + q) * save_rows + srow0) * 2 + h;
+        uint4* dl = dst + dy_plane_uint4(save_rows, 1);
         stream_store(dl, o.l0);
-        stream_store(dl + 64, o.l1);
+        stream_store(dl + (size_t)DY_SLOTS * 64, o.l1);
       }
 #endif
     };
     // ReLU masks: one uint4 of non-zero flags per (row, half) per layer (SAVE_MASK), fetched one layer ahead
     auto mask_at = [&](int set, uint4& a, uint4& b) {
-      const uint32_t* src = (const uint32_t*)(saved + (size_t)SAVE_MASK * save_rows * 2) + ((size_t)(set * 4) * save_rows + srow0) * 2 + h;
-      const size_t ws = (size_t)save_rows * 2;
+      const uint32_t* src = (const uint32_t*)(saved + sv_mask0(save_rows)) + sv_mask_addr(set * 4, t32_0, m, h);
+      constexpr size_t ws = 64, mt1 = 36 * 64;          // next mask word of the set / the wave's second 32-row tile
 #define RNERF_NTL(P) __builtin_nontemporal_load(P)
       a = make_uint4(RNERF_NTL(src), RNERF_NTL(src + ws), RNERF_NTL(src + 2 * ws), RNERF_NTL(src + 3 * ws));
-      b = make_uint4(RNERF_NTL(src + 64), RNERF_NTL(src + ws + 64), RNERF_NTL(src + 2 * ws + 64), RNERF_NTL(src + 3 * ws + 64));
+      b = make_uint4(RNERF_NTL(src + mt1), RNERF_NTL(src + ws + mt1), RNERF_NTL(src + 2 * ws + mt1), RNERF_NTL(src + 3 * ws + mt1));
 #undef RNERF_NTL
     };
     // operands of k-step s from the state (prev0 / st1): x = (state + dsig * wadd) * 1[mask != 0]
@@ -1151,13 +1162,15 @@ __device__ __forceinline__ void wgrad_body(const uint4* __restrict__ saved, cons
   for (int b = 0; b < NT; ++b) acc[b] = zero;
   uint4 opr[NOP];
   auto load_chunk = [&](int chunk) {
-    const size_t row2 = ((size_t)chunk * 128 + rw * 32 + m) * 2 + h;
+    const long long t32 = (long long)chunk * 4 + rw;
     if (grp == 0) {
+      const uint4* base = saved + sv_addr(qx, t32, m, h);
 #pragma unroll
-      for (int t = 0; t < 2 * KT; ++t) opr[t] = stream_load(saved + (size_t)(qx + t) * R * 2 + row2);
+      for (int t = 0; t < 2 * KT; ++t) opr[t] = stream_load(base + t * 64);
     } else {
+      const uint4* base = dy + dy_addr(qd, t32, m, h);
 #pragma unroll
-      for (int t = 0; t < 2 * NT; ++t) opr[t] = t < KSd ? stream_load(dy + (size_t)(qd + t) * R * 2 + row2) : z4;
+      for (int t = 0; t < 2 * NT; ++t) opr[t] = t < KSd ? stream_load(base + t * 64) : z4;
     }
   };
   if (g < n_chunks) load_chunk(g);
@@ -1262,27 +1275,30 @@ __device__ __forceinline__ void wgrad_body_f16(const uint4* __restrict__ saved, 
   for (int b = 0; b < NT; ++b) acc[b] = zero;
   uint4 opr[NOP];
   float4 scq[4];
-  const uint4* __restrict__ src = side == 0 ? saved + (size_t)(part * SAVE_TOTAL + qx) * R * 2 : dy + (size_t)(part * DY_SLOTS + qd) * R * 2;
+  const uint4* __restrict__ src = side == 0 ? saved + (part ? sv_lo0(R) : 0) + (size_t)qx * 64 : dy + (part ? dy_plane_uint4(R, 1) : 0) + (size_t)qd * 64;
+  const size_t tile_stride = (size_t)(side == 0 ? SAVE_SLOTS : DY_SLOTS) * 64;      // uint4 per 32-row tile
   constexpr int NLOAD_X = 2 * KT, NLOAD_D = KSd < 2 * NT ? KSd : 2 * NT;
   auto load_chunk = [&](int chunk) {
     const size_t row0 = (size_t)chunk * W::CH + rg * 32;
-    const uint4* base = src + (row0 + m) * 2 + h;
+    const uint4* base = src + (row0 >> 5) * tile_stride + m * 2 + h;
+    // the row scales first: they are consumed before the first operand, and loads retire in issue order (waiting for the LAST load
+    // of a chunk would serialise the transposition behind the whole chunk)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) scq[q] = *(const float4*)(rs + row0 + 8 * q + 4 * h);
 #pragma unroll
     for (int t = 0; t < NOP; ++t) {
       // slots beyond this side's count are clamped to its last slot (loaded, never used): no predicate on the load
       const int tx = t < NLOAD_X ? t : NLOAD_X - 1, td = t < NLOAD_D ? t : NLOAD_D - 1;
-      opr[t] = stream_load(base + (size_t)(side == 0 ? tx : td) * R * 2);
+      opr[t] = stream_load(base + (size_t)(side == 0 ? tx : td) * 64);
     }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) scq[q] = *(const float4*)(rs + row0 + 8 * q + 4 * h);
   };
   if (g < n_chunks) load_chunk(g);
   for (int chunk = g; chunk < n_chunks; chunk += G) {
     const bool ok = (long long)chunk * W::CH + rg * 32 + m < total_rows;
-    float sc[16];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) { sc[4 * q] = scq[q].x * inv_mref; sc[4 * q + 1] = scq[q].y * inv_mref; sc[4 * q + 2] = scq[q].z * inv_mref; sc[4 * q + 3] = scq[q].w * inv_mref; }
     if (side == 0) {
+      float sc[16];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { sc[4 * q] = scq[q].x * inv_mref; sc[4 * q + 1] = scq[q].y * inv_mref; sc[4 * q + 2] = scq[q].z * inv_mref; sc[4 * q + 3] = scq[q].w * inv_mref; }
 #pragma unroll
       for (int t = 0; t < KT; ++t) {
         f32x16 d = mfma16<true>(opr[2 * t], il, zero);
