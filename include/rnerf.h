@@ -172,8 +172,10 @@ int rnerf_so3_query(const float* table, const rnerf_grid* g, const float* so3_pa
                     const float* condition, int64_t n, float* out4, float* pred_grad, void* stream);
 
 /* ---- E1/E2 with stage "all*": the march with grad = where(|grad n| > 1e-3, pred_grad, grad n) (rnerf/eikonal_utils.py:34-39).
- * Outputs as rnerf_march (path_ior nullable). */
-int rnerf_march_all(const float* table, const rnerf_grid* g, const float* so3_params, const float* window10, const float* origins,
+ * Outputs as rnerf_march (path_ior nullable).  so3_packed: device scratch of rnerf_so3_packed_bytes() bytes — the call packs the so3
+ * parameters into the f16 hi + lo A-operand stream of the in-march MLP (3 x v_mfma_f32_32x32x16_f16 per tile, fp32 accumulate). */
+size_t rnerf_so3_packed_bytes(void);
+int rnerf_march_all(const float* table, const rnerf_grid* g, const float* so3_params, void* so3_packed, const float* window10, const float* origins,
                     const float* viewdirs, int32_t B, double near, double far, int32_t num_nodes, float* path_pd, float* path_dr,
                     float* path_ior, void* stream);
 
@@ -266,7 +268,7 @@ int rnerf_bkgd_backward(const float* params, const void* save, const float* d_ou
  *                            samples, sample_of_node int32[N] (-1 = the node is no sample) -> v4 float4[np], the cotangent of raw per pair;
  *   rnerf_nerfmlp_input_grad: d loss / d (position, direction) of every row of a NerfMLP level from the dgrad's dy buffer (F16 modes):
  *                            through pos_enc into Dense_0, the skip concat of Dense_5 and the view layer Dense_10. */
-int rnerf_march_all_train(const float* table, const rnerf_grid* g, const float* so3_params, const float* window10, const float* origins,
+int rnerf_march_all_train(const float* table, const rnerf_grid* g, const float* so3_params, void* so3_packed, const float* window10, const float* origins,
                           const float* viewdirs, int32_t B, double near, double far, int32_t num_nodes, float* path_pd, float* path_dr,
                           float* path_rdn, int32_t* pair_count, int32_t pair_cap, int32_t* pair_id, float* pair_x, float* pair_g,
                           int32_t* pair_of_node, void* stream);

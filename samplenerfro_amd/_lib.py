@@ -71,14 +71,15 @@ SIGNATURES = {
     "rnerf_nerfmlp_wgrad": (C.c_int, [C.c_int, C.c_int, _vp, _vp, _i64, _vp, _vp, _vp]),
     "rnerf_voxelize": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _GP, _i32, _dbl, _dbl, _vp, _vp, _vp, _vp]),
     "rnerf_so3_query": (C.c_int, [_vp, _GP, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
-    "rnerf_march_all": (C.c_int, [_vp, _GP, _vp, _vp, _vp, _vp, _i32, _dbl, _dbl, _i32, _vp, _vp, _vp, _vp]),
+    "rnerf_march_all": (C.c_int, [_vp, _GP, _vp, _vp, _vp, _vp, _vp, _i32, _dbl, _dbl, _i32, _vp, _vp, _vp, _vp]),
     "rnerf_generate_rays": (C.c_int, [_vp, _i32, _dbl, _dbl, _dbl, _dbl, _dbl, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "rnerf_stratified_u": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
     "rnerf_bkgd_save_bytes": (C.c_size_t, [_i64]),
     "rnerf_bkgd_dy_bytes": (C.c_size_t, [_i64]),
     "rnerf_bkgd_forward_train": (C.c_int, [_vp, _vp, _i32, _i64, _dbl, _vp, _vp, _vp]),
     "rnerf_bkgd_backward": (C.c_int, [_vp, _vp, _vp, _i64, _dbl, _vp, _vp, _vp, _vp]),
-    "rnerf_march_all_train": (C.c_int, [_vp, _GP, _vp, _vp, _vp, _vp, _i32, _dbl, _dbl, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "rnerf_march_all_train": (C.c_int, [_vp, _GP, _vp, _vp, _vp, _vp, _vp, _i32, _dbl, _dbl, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "rnerf_so3_packed_bytes": (C.c_size_t, []),
     "rnerf_so3_save_bytes": (C.c_size_t, [_i64]),
     "rnerf_so3_dy_bytes": (C.c_size_t, [_i64]),
     "rnerf_so3_forward_train": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp]),

@@ -1677,6 +1677,130 @@ __device__ __forceinline__ void so3_eval(const float* __restrict__ params, float
   for (int c = 0; c < 3; ++c) raw[c] = o[c] + __shfl_xor(o[c], 32) + params[so3_boff(4) + c];
 }
 
+// ---- so3_mlp on the 16-bit matrix cores (f16 hi + lo split of both operands, 3 MFMAs per tile, fp32 accumulate: the arithmetic of the
+// NerfMLP engine) for the march of stage "all*", where it runs once per node: 384 v_mfma_f32_32x32x16_f16 per 32 rays instead of 1014
+// v_mfma_f32_32x32x2_f32, and the weights arrive as coalesced 1 KiB A-operand blocks instead of one dword per lane and MFMA.
+// Transposed chain as in nerfmlp_fwd_kernel: lane (ray m, half h) holds outputs n = 32 t + (r & 3) + 8 (r >> 2) + 4 h in acc[t][r] and feeds
+// k-step s, slot j of the next layer with feature 16 s + 8 (j >> 2) + 4 h + (j & 3) = acc[s >> 1][8 (s & 1) + j].
+// Packed stream: layers 0..3, k-steps (4, 8, 8, 12: Dense_3 = 8 previous + 4 encoding), 4 n-tiles; block = 64 lanes x uint4 hi, then lo.
+constexpr int SO3_KS[4] = {4, 8, 8, 12};
+__host__ __device__ constexpr int so3_blocks_before(int l) { int o = 0; for (int i = 0; i < l; ++i) o += SO3_KS[i] * 4; return o; }
+constexpr int kSo3Blocks = so3_blocks_before(4);                 // 128 blocks x 2 KiB
+constexpr float SO3_WSCALE = 256.f;                              // keeps the lo parts of the f16 split normal (as Prec<F16X3>::WSCALE)
+// encoding feature fed by (k-step s, half h, slot j) of an encoding block: annealed_pos_enc index 6 d + 3 is_cos + c, or -1 (zero padding)
+__host__ __device__ constexpr int so3_enc_feature(int s, int h, int j) { const int f = 16 * s + 8 * (j >> 2) + 4 * h + (j & 3); return f < 60 ? f : -1; }
+
+__global__ void so3_pack16_kernel(const float* __restrict__ params, uint4* __restrict__ packed) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= kSo3Blocks * 64) return;
+  const int blk = gid >> 6, lane = gid & 63;
+  int l = 0;
+  while (l < 3 && blk >= so3_blocks_before(l + 1)) ++l;
+  const int rel = blk - so3_blocks_before(l), s = rel / 4, t = rel % 4;
+  const int n_out = 32 * t + (lane & 31), h = lane >> 5;
+  float w[8];
+  for (int j = 0; j < 8; ++j) {
+    int row;                                                      // input row of Dense_l's kernel
+    if (l == 0) row = so3_enc_feature(s, h, j);
+    else if (l == 3 && s >= 8) { const int f = so3_enc_feature(s - 8, h, j); row = f < 0 ? -1 : 128 + f; }
+    else row = 16 * s + 8 * (j >> 2) + 4 * h + (j & 3);
+    w[j] = row < 0 ? 0.f : params[so3_koff(l) + row * 128 + n_out] * SO3_WSCALE;
+  }
+  uint32_t hi[4], lo[4];
+  for (int p = 0; p < 4; ++p) split2<true>(w[2 * p], w[2 * p + 1], hi[p], lo[p]);
+  packed[(size_t)blk * 128 + lane] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+  packed[(size_t)blk * 128 + 64 + lane] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+}
+
+struct So3Ops { uint4 h, l; };
+__device__ __forceinline__ So3Ops so3_split_ops(const float (&x)[8]) {
+  uint32_t hh[4], ll[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) split2<true>(x[2 * p], x[2 * p + 1], hh[p], ll[p]);
+  So3Ops o; o.h = make_uint4(hh[0], hh[1], hh[2], hh[3]); o.l = make_uint4(ll[0], ll[1], ll[2], ll[3]);
+  return o;
+}
+// acc[t] (+)= W-block(k-step) x operands, 4 n-tiles x 3 passes
+template <bool FIRST>
+__device__ __forceinline__ void so3_kstep16(f32x16 (&acc)[4], const uint4* __restrict__ blk, const So3Ops& b, int lane) {
+  const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const uint4 ah = blk[(size_t)t * 128 + lane], al = blk[(size_t)t * 128 + 64 + lane];
+    acc[t] = mfma16<true>(ah, b.h, FIRST ? zero : acc[t]);
+    acc[t] = mfma16<true>(ah, b.l, acc[t]);
+    acc[t] = mfma16<true>(al, b.h, acc[t]);
+  }
+}
+
+// raw axis-angle of one point per lane pair, fp32-grade (f16 x 3); all 64 lanes must call it.  packed: so3_pack16_kernel's stream.
+__device__ __forceinline__ void so3_eval16(const uint4* __restrict__ packed, const float* __restrict__ params, float px, float py, float pz,
+                                           const So3Window& win, int lane, float (&raw)[3]) {
+  const int h = lane >> 5;
+  const float HALF_PI = 1.5707963705062866f;
+  const float pc[3] = {px, py, pz};
+  So3Ops enc[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int f0 = 16 * s + 8 * (j >> 2) + (j & 3);                      // feature of half 0; half 1: + 4
+      const int f = f0 + 4 * h;
+      // f = 6 d + 3 is_cos + c: all four (f0, f0 + 4) cases are resolved from the lane's half at run time
+      const int d = f / 6, jj = f % 6, c = jj % 3;
+      const float x = c == 0 ? pc[0] : (c == 1 ? pc[1] : pc[2]);
+      const float xb = fmul(x, (float)(1 << (d < 10 ? d : 0)));
+      const float e = fmul(sinf(jj >= 3 ? fadd(xb, HALF_PI) : xb), win.w[d < 10 ? d : 0]);
+      v[j] = f < 60 ? e : 0.f;
+    }
+    enc[s] = so3_split_ops(v);
+  }
+  constexpr float INV = 1.0f / SO3_WSCALE;
+  f32x16 acc[4];
+  // Dense_0
+#pragma unroll
+  for (int s = 0; s < 4; ++s) { if (s == 0) so3_kstep16<true>(acc, packed + (size_t)(so3_blocks_before(0) + 4 * s) * 128, enc[s], lane); else so3_kstep16<false>(acc, packed + (size_t)(so3_blocks_before(0) + 4 * s) * 128, enc[s], lane); }
+  auto hidden_ops = [&](int s, const float* __restrict__ bias) -> So3Ops {     // ReLU(acc / scale + bias) of the 8 features of k-step s
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int n = 16 * s + 8 * (j >> 2) + 4 * h + (j & 3);
+      v[j] = fmaxf(fmaf(acc[s >> 1][8 * (s & 1) + j], INV, bias[n]), 0.f);
+    }
+    return so3_split_ops(v);
+  };
+#pragma unroll 1
+  for (int l = 1; l <= 3; ++l) {
+    const float* __restrict__ bias = params + (l == 1 ? so3_boff(0) : (l == 2 ? so3_boff(1) : so3_boff(2)));
+    So3Ops x[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) x[s] = hidden_ops(s, bias);
+    const uint4* __restrict__ base = packed + (size_t)(l == 1 ? so3_blocks_before(1) : (l == 2 ? so3_blocks_before(2) : so3_blocks_before(3))) * 128;
+    so3_kstep16<true>(acc, base, x[0], lane);
+#pragma unroll
+    for (int s = 1; s < 8; ++s) so3_kstep16<false>(acc, base + (size_t)(4 * s) * 128, x[s], lane);
+    if (l == 3) {                                                    // skip concat: the encoding again (rnerf/model_utils.py:131-132)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) so3_kstep16<false>(acc, base + (size_t)(4 * (8 + s)) * 128, enc[s], lane);
+    }
+  }
+  // Dense_4 (128 -> 3) on the VALU in fp32
+  const float* __restrict__ b3 = params + so3_boff(3);
+  const float* __restrict__ k4 = params + so3_koff(4);
+  float o[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int f = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+      const float v = fmaxf(fmaf(acc[t][r], INV, b3[f]), 0.f);
+      o[0] = fmaf(v, k4[f * 3 + 0], o[0]); o[1] = fmaf(v, k4[f * 3 + 1], o[1]); o[2] = fmaf(v, k4[f * 3 + 2], o[2]);
+    }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) raw[c] = o[c] + __shfl_xor(o[c], 32) + params[so3_boff(4) + c];
+}
+
 // pred_grad = a (cos(t) v + sin(t) e x v + (1 - cos(t)) (e . v) e),  e = raw / |raw|, v = g / |g| with safe norms (ior_utils.py:305-312)
 __device__ __forceinline__ void so3_rotate(const float (&raw)[3], const float (&g)[3], float (&pred)[3]) {
   const float theta = fsqrt(fmaxf(fadd(fadd(fmul(raw[0], raw[0]), fmul(raw[1], raw[1])), fmul(raw[2], raw[2])), 1e-6f));
@@ -1712,7 +1836,7 @@ __global__ void __launch_bounds__(64) so3_query_kernel(const float4* __restrict_
 // E1/E2 with stage "all": one wave = 32 rays (both lane halves carry the ray state; the MLP needs the whole wave), the so3 MLP is
 // evaluated at every node.  Weights stream from L2 (262 KB per step per wave).
 __global__ void __launch_bounds__(64) march_all_kernel(const float4* __restrict__ table, GridParams gp, const float* __restrict__ params,
-                                                       So3Window win, const float* __restrict__ origins, const float* __restrict__ viewdirs,
+                                                       const uint4* __restrict__ packed16, So3Window win, const float* __restrict__ origins, const float* __restrict__ viewdirs,
                                                        int B, float near, float step, int num_nodes, float4* __restrict__ path_pd,
                                                        float4* __restrict__ path_dr, float4* __restrict__ path_ior,
                                                        // training record (nullable): raw direction + n per node, and the compacted list of
@@ -1754,7 +1878,7 @@ __global__ void __launch_bounds__(64) march_all_kernel(const float4* __restrict_
     float pred[3] = {0.f, 0.f, 0.f};
     if (__builtin_amdgcn_ballot_w64(use) != 0) {     // pred_grad is only selected where |grad n| > 1e-3: outside the object's boundary
       float raw[3];                                   // shell no ray of the wave needs the MLP (wave-uniform branch, same results)
-      so3_eval(params, p[0], p[1], p[2], win, m, h, raw);
+      so3_eval16(packed16, params, p[0], p[1], p[2], win, lane, raw);
       so3_rotate(raw, g, pred);
     }
     const float s = fdiv(step, c.x);
@@ -2325,18 +2449,21 @@ extern "C" int rnerf_so3_query(const float* table, const rnerf_grid* g, const fl
   return RNERF_OK;
 }
 
-extern "C" int rnerf_march_all(const float* table, const rnerf_grid* g, const float* so3_params, const float* window10, const float* origins,
+extern "C" size_t rnerf_so3_packed_bytes(void) { return (size_t)kSo3Blocks * 128 * sizeof(uint4); }
+
+extern "C" int rnerf_march_all(const float* table, const rnerf_grid* g, const float* so3_params, void* so3_packed, const float* window10, const float* origins,
                                const float* viewdirs, int32_t B, double near, double far, int32_t num_nodes, float* path_pd, float* path_dr,
                                float* path_ior, void* stream) {
-  RNERF_CHECK_ARG(table && g && so3_params && window10 && origins && viewdirs && path_pd && path_dr, "rnerf_march_all: null pointer");
+  RNERF_CHECK_ARG(table && g && so3_params && so3_packed && window10 && origins && viewdirs && path_pd && path_dr, "rnerf_march_all: null pointer");
   RNERF_CHECK_ARG(B > 0 && num_nodes >= 2, "rnerf_march_all: need B > 0 and num_nodes >= 2");
   GridParams gp;
   RNERF_CHECK_ARG(make_grid_params(g, &gp), "rnerf_march_all: bad grid");
   So3Window w;
   for (int i = 0; i < 10; ++i) w.w[i] = window10[i];
   const float stepf = (float)((far - near) / (num_nodes - 1));  // models.py:122
-  hipLaunchKernelGGL(march_all_kernel, dim3((unsigned)((B + 31) / 32)), dim3(64), 0, (hipStream_t)stream, (const float4*)table, gp, so3_params, w,
-                     origins, viewdirs, B, (float)near, stepf, num_nodes, (float4*)path_pd, (float4*)path_dr, (float4*)path_ior,
+  hipLaunchKernelGGL(so3_pack16_kernel, dim3((kSo3Blocks * 64 + 255) / 256), dim3(256), 0, (hipStream_t)stream, so3_params, (uint4*)so3_packed);
+  hipLaunchKernelGGL(march_all_kernel, dim3((unsigned)((B + 31) / 32)), dim3(64), 0, (hipStream_t)stream, (const float4*)table, gp, so3_params,
+                     (const uint4*)so3_packed, w, origins, viewdirs, B, (float)near, stepf, num_nodes, (float4*)path_pd, (float4*)path_dr, (float4*)path_ior,
                      (float4*)nullptr, (int*)nullptr, 0, (int2*)nullptr, (float4*)nullptr, (float4*)nullptr, (int*)nullptr);
   RNERF_CHECK_LAUNCH();
   return RNERF_OK;

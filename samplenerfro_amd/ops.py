@@ -321,28 +321,57 @@ def so3_query(table: torch.Tensor, spec: Grid, so3_flat: torch.Tensor, pts: torc
     return out, pred
 
 
+def _shell_order(table: torch.Tensor, spec: Grid, o: torch.Tensor, v: torch.Tensor, near: float, far: float, num_nodes: int):
+    """Permutation that groups rays whose paths meet the boundary shell (|grad n| > 1e-3, where so3_mlp is evaluated) over the same
+    node range.  The all* march evaluates the MLP for a 32-ray wave whenever ANY of its rays is in the shell, so coherent waves need
+    several times fewer evaluations.  The shell interval of a ray is read off a cheap pre-march without so3 (the paths differ only by
+    the so3 rotation, irrelevant for grouping); rays are results-independent, so the order changes no value."""
+    _, _, ior, _ = march(table, spec, o, v, near, far, num_nodes, want_ior=True)
+    g = ior[..., 1:4]
+    m = (g * g).sum(-1) > 1e-6                                       # [N, B]
+    hit = m.any(0)
+    first = torch.argmax(m.to(torch.uint8), 0)
+    last = num_nodes - 1 - torch.argmax(torch.flip(m, [0]).to(torch.uint8), 0)
+    key = torch.where(hit, (first // 16) * num_nodes + last, torch.full_like(first, 2 * num_nodes * num_nodes))
+    return torch.argsort(key, stable=True)
+
+
 def march_all(table: torch.Tensor, spec: Grid, so3_flat: torch.Tensor, origins: torch.Tensor, viewdirs: torch.Tensor, near: float, far: float,
-              num_nodes: int, annealed_alpha: float = 1.0, want_ior: bool = False):
+              num_nodes: int, annealed_alpha: float = 1.0, want_ior: bool = False, coherent: bool = True):
     """E1/E2 with stage "all*" (rnerf/eikonal_utils.py:34-39). -> path_pd [N,B,4], path_dr [N,B,4], ior?"""
     lib = _lib.load()
     o = _chk(origins, "origins"); v = _chk(viewdirs, "viewdirs")
     B = o.shape[0]
+    if coherent and B > 64:
+        perm = _shell_order(table, spec, o, v, near, far, num_nodes)
+        pd, dr, ior = march_all(table, spec, so3_flat, o[perm].contiguous(), v[perm].contiguous(), near, far, num_nodes, annealed_alpha, want_ior, False)
+        inv = torch.empty_like(perm); inv[perm] = torch.arange(B, device=perm.device)
+        return pd[:, inv].contiguous(), dr[:, inv].contiguous(), (ior[:, inv].contiguous() if ior is not None else None)
     pd = torch.empty((num_nodes, B, 4), dtype=torch.float32, device=o.device)
     dr = torch.empty_like(pd)
     ior = torch.empty_like(pd) if want_ior else None
     w = so3_window(annealed_alpha)
-    check(lib.rnerf_march_all(ptr(table), C.byref(spec), ptr(_chk(so3_flat, "so3_flat")), w.ctypes.data_as(C.c_void_p), ptr(o), ptr(v), B,
+    packed = torch.empty(lib.rnerf_so3_packed_bytes(), dtype=torch.uint8, device=o.device)
+    check(lib.rnerf_march_all(ptr(table), C.byref(spec), ptr(_chk(so3_flat, "so3_flat")), ptr(packed), w.ctypes.data_as(C.c_void_p), ptr(o), ptr(v), B,
                               float(near), float(far), int(num_nodes), ptr(pd), ptr(dr), ptr(ior), current_stream()), "rnerf_march_all")
     return pd, dr, ior
 
 
 def march_all_train(table: torch.Tensor, spec: Grid, so3_flat: torch.Tensor, origins: torch.Tensor, viewdirs: torch.Tensor, near: float, far: float,
-                    num_nodes: int, annealed_alpha: float = 1.0, pair_cap: Optional[int] = None):
+                    num_nodes: int, annealed_alpha: float = 1.0, pair_cap: Optional[int] = None, coherent: bool = True):
     """rnerf_march_all_train: the stage "all*" march + the record its backward needs.  Returns a dict (pairs trimmed to their count:
     this reads the device counter, i.e. synchronises once per step)."""
     lib = _lib.load()
     o = _chk(origins, "origins"); v = _chk(viewdirs, "viewdirs")
     B, N, dev = o.shape[0], int(num_nodes), o.device
+    if coherent and B > 64:
+        perm = _shell_order(table, spec, o, v, near, far, N)
+        rec = march_all_train(table, spec, so3_flat, o[perm].contiguous(), v[perm].contiguous(), near, far, N, annealed_alpha, pair_cap, False)
+        inv = torch.empty_like(perm); inv[perm] = torch.arange(B, device=dev)
+        for k in ("path_pd", "path_dr", "path_rdn", "pair_of_node"):
+            rec[k] = rec[k][:, inv].contiguous()
+        rec["pair_id"][:, 0] = perm[rec["pair_id"][:, 0].long()].to(torch.int32)
+        return rec
     cap = int(pair_cap) if pair_cap else N * B
     pd = torch.empty((N, B, 4), dtype=torch.float32, device=dev); dr = torch.empty_like(pd); rdn = torch.empty_like(pd)
     count = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -350,7 +379,8 @@ def march_all_train(table: torch.Tensor, spec: Grid, so3_flat: torch.Tensor, ori
     pair_x = torch.empty((cap, 4), dtype=torch.float32, device=dev); pair_g = torch.empty_like(pair_x)
     pair_of_node = torch.empty((N, B), dtype=torch.int32, device=dev)
     w = so3_window(annealed_alpha)
-    check(lib.rnerf_march_all_train(ptr(table), C.byref(spec), ptr(_chk(so3_flat, "so3_flat")), w.ctypes.data_as(C.c_void_p), ptr(o), ptr(v), B,
+    packed = torch.empty(lib.rnerf_so3_packed_bytes(), dtype=torch.uint8, device=dev)
+    check(lib.rnerf_march_all_train(ptr(table), C.byref(spec), ptr(_chk(so3_flat, "so3_flat")), ptr(packed), w.ctypes.data_as(C.c_void_p), ptr(o), ptr(v), B,
                                     float(near), float(far), N, ptr(pd), ptr(dr), ptr(rdn), ptr(count), cap, ptr(pair_id), ptr(pair_x), ptr(pair_g),
                                     ptr(pair_of_node), current_stream()), "rnerf_march_all_train")
     n = int(count.item())
