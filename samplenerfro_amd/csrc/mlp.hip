@@ -77,8 +77,11 @@ constexpr int AUX_FLOATS = 3208;
 
 template <int PREC>
 struct Prec {
-  static constexpr bool F16 = (PREC == RNERF_PREC_F16X3 || PREC == RNERF_PREC_F16);
-  static constexpr int NP = (PREC == RNERF_PREC_F16X3 || PREC == RNERF_PREC_BF16X3) ? 2 : 1;
+  static constexpr bool F16 = (PREC == RNERF_PREC_F16X3 || PREC == RNERF_PREC_F16 || PREC == RNERF_PREC_F16X2);
+  static constexpr int NP = (PREC == RNERF_PREC_F16X3 || PREC == RNERF_PREC_BF16X3 || PREC == RNERF_PREC_F16X2) ? 2 : 1;   // parts of a WEIGHT
+  // MFMA passes per tile of a two-part stream: 3 = W_hi x_hi + W_lo x_hi + W_hi x_lo (fp32-grade);
+  // 22 = (W_hi + W_lo) x_hi (f16x2: exact weights, activations rounded to f16 — 2/3 of the matrix work)
+  static constexpr int PASSES = PREC == RNERF_PREC_F16X2 ? 22 : 3;
   // power-of-two weight scale: keeps the lo part of an f16 split out of the f16 subnormal range
   static constexpr float WSCALE = F16 ? 256.f : 1.f;
   static constexpr size_t STREAM_BYTES = (size_t)kTotalBlocks * NP * 1024;
@@ -327,7 +330,7 @@ struct NoWork {
 
 // one n-tile of one k-step: 6 (X3) or 2 MFMAs with the conversion chunks of pair PI in their shadow
 // PASSES (X3 modes): 3 = hi*hi + hi*lo + lo*hi (fp32-grade), 2 = drop the lo(weight) term, 1 = hi*hi only
-template <int PREC, bool FIRST, int PI, typename W, int PASSES = 3>
+template <int PREC, bool FIRST, int PI, typename W, int PASSES = Prec<PREC>::PASSES>
 __device__ __forceinline__ void tile_mfma(f32x16& a0, f32x16& a1, const uint4 ah, const uint4 al, const KOps& b, W& work) {
   using PP = Prec<PREC>;
   const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -380,7 +383,7 @@ struct NoDma { __device__ __forceinline__ void operator()() const {} };
 // number of reads in flight (latency x concurrency), not by the 256 B/clk peak.
 constexpr int FRAG_DEPTH = 4;
 
-template <int PREC, int NT, int KOFF, bool FIRST, typename W, bool NOREAD = false, typename D = NoDma, int PASSES = 3>
+template <int PREC, int NT, int KOFF, bool FIRST, typename W, bool NOREAD = false, typename D = NoDma, int PASSES = Prec<PREC>::PASSES>
 __device__ __forceinline__ void kstep_mfma(f32x16 (&acc0)[8], f32x16 (&acc1)[8], const KOps& b, const char* slab, int lane, W& work, D dma = D()) {
   using PP = Prec<PREC>;
   const uint4* a = (const uint4*)slab + lane + (size_t)KOFF * NT * PP::NP * 64;
@@ -2123,11 +2126,14 @@ __global__ void __launch_bounds__(256) bkgd_wgrad_reduce_kernel(const float* __r
 
 using namespace rnerf;
 
-static bool prec_ok(int p) { return p == RNERF_PREC_F16X3 || p == RNERF_PREC_BF16X3 || p == RNERF_PREC_F16 || p == RNERF_PREC_BF16; }
+static bool prec_ok(int p) {
+  return p == RNERF_PREC_F16X3 || p == RNERF_PREC_BF16X3 || p == RNERF_PREC_F16 || p == RNERF_PREC_BF16 || p == RNERF_PREC_F16X2;
+}
 
 extern "C" size_t rnerf_nerfmlp_packed_bytes(int precision) {
   switch (precision) {
-    case RNERF_PREC_F16X3: return Prec<RNERF_PREC_F16X3>::PACKED_BYTES;
+    case RNERF_PREC_F16X3:
+    case RNERF_PREC_F16X2: return Prec<RNERF_PREC_F16X3>::PACKED_BYTES;       // f16x2 reads the f16x3 stream
     case RNERF_PREC_BF16X3: return Prec<RNERF_PREC_BF16X3>::PACKED_BYTES;
     case RNERF_PREC_F16: return Prec<RNERF_PREC_F16>::PACKED_BYTES;
     case RNERF_PREC_BF16: return Prec<RNERF_PREC_BF16>::PACKED_BYTES;
@@ -2142,7 +2148,8 @@ extern "C" int rnerf_nerfmlp_pack(const float* params, int precision, void* pack
   const int threads = kTotalBlocks * 64, block = 256, grid = (threads + block - 1) / block;
   hipStream_t st = (hipStream_t)stream;
   switch (precision) {
-    case RNERF_PREC_F16X3: hipLaunchKernelGGL(nerfmlp_pack_kernel<RNERF_PREC_F16X3>, dim3(grid), dim3(block), 0, st, params, (char*)packed); break;
+    case RNERF_PREC_F16X3:
+    case RNERF_PREC_F16X2: hipLaunchKernelGGL(nerfmlp_pack_kernel<RNERF_PREC_F16X3>, dim3(grid), dim3(block), 0, st, params, (char*)packed); break;
     case RNERF_PREC_BF16X3: hipLaunchKernelGGL(nerfmlp_pack_kernel<RNERF_PREC_BF16X3>, dim3(grid), dim3(block), 0, st, params, (char*)packed); break;
     case RNERF_PREC_F16: hipLaunchKernelGGL(nerfmlp_pack_kernel<RNERF_PREC_F16>, dim3(grid), dim3(block), 0, st, params, (char*)packed); break;
     default: hipLaunchKernelGGL(nerfmlp_pack_kernel<RNERF_PREC_BF16>, dim3(grid), dim3(block), 0, st, params, (char*)packed); break;
@@ -2221,6 +2228,7 @@ extern "C" int rnerf_nerfmlp_forward(const void* packed, int precision, const fl
   hipStream_t st = (hipStream_t)stream;
   switch (precision) {
     case RNERF_PREC_F16X3: return launch_fwd<RNERF_PREC_F16X3>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, max_workgroups);
+    case RNERF_PREC_F16X2: return launch_fwd<RNERF_PREC_F16X2>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, max_workgroups);
     case RNERF_PREC_BF16X3: return launch_fwd<RNERF_PREC_BF16X3>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, max_workgroups);
     case RNERF_PREC_F16: return launch_fwd<RNERF_PREC_F16>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, max_workgroups);
     default: return launch_fwd<RNERF_PREC_BF16>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, max_workgroups);

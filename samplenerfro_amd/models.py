@@ -10,6 +10,7 @@ parameter tree.  There is no CPU path: tensors must live on a ROCm device.
 from __future__ import annotations
 
 import math
+import weakref
 from typing import Any, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -110,7 +111,7 @@ class NerfModel:
         g = g.to(self.device, torch.float32).reshape(self.ndim)
         # VoxMLP.setup: data = concat([grid, grad]) (rnerf/ior_utils.py:161) — built once on the device
         self.table = ops.grid_build_table(g, self.spec)
-        self._packed: Dict[str, Tuple[int, int, torch.Tensor]] = {}
+        self._packed: Dict[str, Tuple[Any, int, torch.Tensor]] = {}
         self._jit_cache: Dict[bytes, torch.Tensor] = {}
         self._u_lin: Optional[torch.Tensor] = None
         self._side: Optional[torch.cuda.Stream] = None
@@ -138,9 +139,10 @@ class NerfModel:
     def _packed_weights(self, variables, name: str) -> torch.Tensor:
         flat = self._flat(variables, name, NERF_MLP_SHAPES)
         ent = self._packed.get(name)
-        if ent is None or ent[0] != flat.data_ptr() or ent[1] != flat._version:
+        # keyed on the tensor OBJECT (weakly) + its version: a data_ptr key would go stale when a freed buffer's address is reused
+        if ent is None or ent[0]() is not flat or ent[1] != flat._version:
             buf = ops.nerfmlp_pack(flat.detach(), self.precision, ent[2] if ent is not None else None)
-            self._packed[name] = (flat.data_ptr(), flat._version, buf)
+            self._packed[name] = (weakref.ref(flat), flat._version, buf)
         return self._packed[name][2]
 
     # ---- randomness -------------------------------------------------------------------------------------------------------

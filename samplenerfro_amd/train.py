@@ -20,6 +20,7 @@ plain torch arithmetic on that flat buffer: weights and optimiser state stay on 
 """
 from __future__ import annotations
 
+import weakref
 from typing import Any, Dict, Optional
 
 import numpy as np
@@ -120,9 +121,9 @@ def _bwd_packed(model: NerfModel, state: TrainState, name: str, backward: int) -
     cache = model.__dict__.setdefault("_packed_bwd", {})
     flat = state.variables["flat"][name]
     ent = cache.get(name)
-    if ent is None or ent[0] != flat.data_ptr() or ent[1] != flat._version or ent[3] != backward:
+    if ent is None or ent[0]() is not flat or ent[1] != flat._version or ent[3] != backward:
         buf = ops.nerfmlp_pack_bwd(flat, ent[2] if ent is not None else None, backward)
-        cache[name] = (flat.data_ptr(), flat._version, buf, backward)
+        cache[name] = (weakref.ref(flat), flat._version, buf, backward)
     return cache[name][2]
 
 

@@ -179,10 +179,10 @@ def test_bkgd_mlp(scene):
 
 # raw-output tolerance per MLP arithmetic (abs, on raw outputs of magnitude ~1): the X3 modes are the parity-graded
 # ones; the single-MFMA modes are reported with their measured error (SURVEY.md §7 hard part 1).
-MLP_TOL = {"f16x3": 2e-5, "bf16x3": 2e-4, "f16": 2e-2, "bf16": 1e-1}
+MLP_TOL = {"f16x3": 2e-5, "bf16x3": 2e-4, "f16": 2e-2, "bf16": 1e-1, "f16x2": 2e-3}
 
 
-@pytest.mark.parametrize("prec", ["f16x3", "bf16x3", "f16", "bf16"])
+@pytest.mark.parametrize("prec", ["f16x3", "bf16x3", "f16", "bf16", "f16x2"])
 def test_nerf_mlp(scene, prec):
     from samplenerfro_amd import ops
     pf = syn.init_params_flat(7, bias_scale=0.1)
@@ -221,7 +221,7 @@ def test_nerf_mlp_node_indirection(scene):
     np.testing.assert_array_equal(a, b)
 
 
-@pytest.mark.parametrize("prec,fine", [("f16x3", True), ("f16x3", False), ("bf16x3", True)])
+@pytest.mark.parametrize("prec,fine", [("f16x3", True), ("f16x3", False), ("bf16x3", True), ("f16x2", True)])
 def test_model_end_to_end(prec, fine):
     """NerfModel.apply vs the oracle: RGB within 1e-4 abs (north_star), coarse level tighter."""
     from samplenerfro_amd import models, prng
@@ -253,7 +253,37 @@ def test_model_end_to_end(prec, fine):
         # the resample indices agree wherever the coarse weights agree to the last bit; report the match rate
         same = (taps["idx_f"].cpu().numpy().T == otaps["idx_f"]).mean()
         print(f"[{prec}] fine node-index agreement with the oracle (MLP outputs differ in the last bits): {same:.4f}")
-        assert same > 0.98
+        assert same > (0.98 if prec != "f16x2" else 0.9)      # f16x2: coarse weights differ by ~1e-5, more picks flip
+
+
+def test_packed_weight_cache_follows_the_variables():
+    """A second parameter set handed to the same model must be rendered with ITS weights, also when its flat buffer lands on the
+    address a freed one had (the operand-stream cache is keyed on the tensor object + version, not on the address), and an in-place
+    update must re-pack."""
+    from samplenerfro_amd import models, prng
+    from samplenerfro_amd.utils import Rays
+    sc = Scene(B=64, seed=15)
+    model = models.NerfModel(ndim=sc.ndim, nmin=sc.nmin, nmax=sc.nmax, grid=T(sc.grid), near=2.0, far=6.0, num_coarse_samples=8,
+                             num_fine_samples=0, num_path_samples=2)
+    rays = Rays(T(sc.o), None, T(sc.d), None)
+    key = prng.PRNGKey(5)
+    cfg = R.ModelConfig(sc.ndim, sc.nmin, sc.nmax, num_coarse_samples=8, num_fine_samples=0, num_path_samples=2)
+    jitter = np.arange(0, 16, 2) + 1
+    ptrs = set()
+    for seed in (2, 3, 4):
+        pf = syn.init_params_flat(seed, fine=False, bias_scale=0.3)
+        variables = models.make_variables({k: T(v) for k, v in pf.items()})
+        ptrs.add(variables["flat"]["coarse_mlp"].data_ptr())
+        ret, _ = model.apply(variables, key, key, rays, False, jitter=jitter)
+        oret, _ = R.nerf_forward(cfg, syn.params_tree(pf), sc.table, sc.o, sc.d, jitter)
+        assert np.abs(ret[-1][0].cpu().numpy() - oret[-1][0]).max() < 1e-4, seed
+        del variables, ret
+    print("distinct addresses of the three flat buffers:", len(ptrs))
+    variables = models.make_variables({k: T(v) for k, v in pf.items()})
+    a = model.apply(variables, key, key, rays, False, jitter=jitter)[0][-1][0].clone()
+    variables["flat"]["coarse_mlp"].mul_(1.25)
+    b = model.apply(variables, key, key, rays, False, jitter=jitter)[0][-1][0]
+    assert (a - b).abs().max() > 1e-3
 
 
 def test_render_image_chunks():
