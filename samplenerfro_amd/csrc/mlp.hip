@@ -21,6 +21,8 @@
 
 #include <stdlib.h>
 #include <type_traits>
+#include <vector>
+#include <stdio.h>
 
 namespace rnerf {
 
@@ -203,6 +205,16 @@ __device__ __forceinline__ float pe_sin(float a) {
 __device__ __forceinline__ void glds16(const char* gsrc, unsigned lds_off) {
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_off) : "memory");
+}
+// the same with the non-temporal policy: operand streams that are read exactly once (wgrad)
+__device__ __forceinline__ void glds16_nt(const char* gsrc, unsigned lds_off) {
+  unsigned keep;
+#ifdef RNERF_WGTR_NO_NT
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+#else
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+#endif
                : "=&s"(keep) : "v"(gsrc), "s"(lds_off) : "memory");
 }
 // vmcnt(0) as the BUILTIN (imm: vmcnt=0, expcnt=7, lgkmcnt=15): hipcc folds an explicit s_waitcnt into its own scoreboard,
@@ -1232,156 +1244,186 @@ __device__ __forceinline__ void wgrad_body(const uint4* __restrict__ saved, cons
   if (wave < NT && h == 0) pbias[wave * 32 + m] = accb[0];
 }
 
-// ---- wgrad of the row-normalised f16 modes (RNERF_BWD_F16: NP = 1, RNERF_BWD_F16X2: NP = 2) -----------------------------------------
-// Same scheme as wgrad_body (transposition on the matrix cores, fragments through LDS, wave w accumulates k-tile w), with
-//   * f16 operands: X^T as saved by the forward (exact), scaled per row by m_row / m_ref (a power of two <= 1: exact; rows whose
-//     gradient is many orders below the largest underflow harmlessly), dY^T = the normalised gradients of the dgrad chain;
-//   * NP = 2: hi and lo parts of both operands, 3 MFMAs per product (hi*hi + hi*lo + lo*hi: ~2^-22 relative), 64-row chunks
-//     (2 row groups x 66 KiB of fragments); NP = 1: 128-row chunks (4 x 34 KiB);
-//   * the bias row sum_rows m_row dY^[row][n] through an A operand holding the row scales (the "ones" row of the bf16 body).
-// LDS slots (1 KiB) of a row group: X^T hi [0,16), X^T lo [16,32) if NP = 2, dY^T hi [16 NP, 16 NP + 16), dY^T lo, then 2 scale slots.
-template <int NP> struct WgF16 {
-  static constexpr int ROWG = NP == 2 ? 2 : 4, CH = 32 * ROWG, RG_SLOTS = 32 * NP + 2, RG_BYTES = RG_SLOTS * 1024, LDS = ROWG * RG_BYTES;
+// ---- wgrad of the row-normalised f16 modes (RNERF_BWD_F16: NP = 1, RNERF_BWD_F16X2: NP = 2): no transposition phase ------------------------
+// The saved tensors are row-major per slot ([row][half][8 features] = 32 B per row); an MFMA operand wants, per lane, 8 ROWS of one
+// feature.  gfx950's LDS transpose read (ds_read_b64_tr_b16: within a 16-lane group, destination lane i, element j receives element
+// (i & 3) of the 8 bytes addressed by source lane 4 j + (i >> 2); probed by tools/ubench/tr_read.hip) does that on the way out of LDS, so
+//   * the operand slots travel HBM -> LDS by DMA (global_load_lds_dwordx4, no registers), 16 rows (one MFMA k-step) at a time, through a
+//     ring of 4 (hi + lo) or 8 steps: all but one in flight while one is consumed — the kernel is paced by HBM (intensity 192 flop/B in the hi + lo mode);
+//   * one DMA instruction builds one 1 KiB "block" = 16 rows x 32 features (two slots: a k-tile of X or an n-tile of dY) as
+//     [row r][slot parity a][32 B]: lane L = 4 r + 2 a + h fetches the 16 B (slot 2 t + a, row r, half h).  A transpose read of a
+//     32-lane half then covers 256 contiguous bytes: conflict-free;
+//   * A operand of k-tile t: lane (m = l & 31, kh = l >> 5) reads rows 8 kh .. 8 kh + 7 of feature position m (= 16 a + p, p the position in
+//     the slot's row — the order wgrad_reduce_kernel already undoes) with two transpose reads; B operands of dY the same way;
+//   * the per-row scale m_row / m_ref (a power of two <= 1) multiplies the X operands as packed f16 (exact above the subnormal range; rows
+//     that far below the largest carry nothing, as before); the bias row sum_rows m_row dY^[row][n] is an MFMA whose A operand holds the
+//     scales in row m = 0;
+//   * 8 waves = WK x WN, each accumulating TK x TN output tiles over all rows of its workgroup: per k-step TK + TN operand fetches feed
+//     TK TN MFMAs (x 3 in the hi + lo mode).
+// (Round 2's first form transposed on the matrix cores like wgrad_body below, through registers and LDS writes: 3.5 ms for the hi + lo
+// mode on the bench workload against 2.2 ms for this one, which runs at ~5.2 TB/s of operand stream.)
+template <int KT, int NT> struct WgTrShape {
+  static constexpr int WK = KT >= 8 ? (NT >= 4 ? 4 : 8) : (KT >= 4 ? 4 : KT);
+  static constexpr int WN = (8 / WK) < NT ? (8 / WK) : NT;
+  static constexpr int TK = KT / WK, TN = NT / WN;
+  static_assert(WK * TK == KT && WN * TN == NT && WK * WN <= 8, "tile split");
 };
+template <int NP> constexpr int wgtr_nbuf() { return NP == 2 ? 4 : 8; }       // ring depth: what fits 160 KiB
+template <int NP> constexpr int wgtr_lds_bytes() { return wgtr_nbuf<NP>() * ((8 + 8) * NP + 1) * 1024; }
 
-__device__ __forceinline__ void pack_rows_f16(const f32x16& d, uint4& u0, uint4& u1) {
-  u0 = make_uint4(pack2<true>(d[0], d[1]), pack2<true>(d[2], d[3]), pack2<true>(d[4], d[5]), pack2<true>(d[6], d[7]));
-  u1 = make_uint4(pack2<true>(d[8], d[9]), pack2<true>(d[10], d[11]), pack2<true>(d[12], d[13]), pack2<true>(d[14], d[15]));
+__device__ __forceinline__ half8 tr_read8(const char* p) {      // rows k .. k+3 at p, rows k+4 .. k+7 at p + 256 (4 rows x 64 B)
+  typedef short short4v __attribute__((ext_vector_type(4)));
+  typedef short short8v __attribute__((ext_vector_type(8)));
+  typedef __attribute__((address_space(3))) short4v lds_short4;
+  const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4*)p);
+  const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4*)(p + 256));
+  return __builtin_bit_cast(half8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+__device__ __forceinline__ f32x16 mfma_h8(const half8 a, const half8 b, const f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+  __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
+  asm volatile("" ::: "memory");
 }
 
 template <int NP, int KT, int KSd>
-__device__ __forceinline__ void wgrad_body_f16(const uint4* __restrict__ saved, const uint4* __restrict__ dy, long long R, long long total_rows,
-                                                int n_chunks, float* __restrict__ pg, float* __restrict__ pbias, int qx, int qd, int g, int G,
-                                                char* smem) {
-  using W = WgF16<NP>;
+__device__ __forceinline__ void wgrad_body_tr(const uint4* __restrict__ saved, const uint4* __restrict__ dy, long long R, float* __restrict__ pg,
+                                               float* __restrict__ pbias, int qx, int qd, int g, int G, char* smem) {
   constexpr int NT = (KSd + 1) / 2;
-  constexpr int NOP = 2 * (KT > NT ? KT : NT);
+  using SH = WgTrShape<KT, NT>;
+  constexpr int TK = SH::TK, TN = SH::TN;
+  constexpr int NBLK = (KT + NT) * NP, NDMA = (NBLK + 7) / 8, STEP_BYTES = (NBLK + 1) * 1024;   // + the row-scale block (64 B used)
+  constexpr int WGTR_NBUF = wgtr_nbuf<NP>(), AHEAD = WGTR_NBUF - 1;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // 8 waves = (side: X slots / dY slots) x (row group) x (NP = 2: hi plane / lo plane).  Every wave runs the SAME compile-time slot loop;
-  // what differs between waves is only a base pointer and an LDS offset (run-time predicates around the loads would make hipcc guard
-  // each of them with a branch and a vmcnt(0)).
-  const int side = wave >> 2;
-  const int rg = NP == 2 ? ((wave >> 1) & 1) : (wave & 3);
-  const int part = NP == 2 ? (wave & 1) : 0;
-  const int m = lane & 31, h = lane >> 5;
+  const int wk = wave / SH::WN, wn = wave % SH::WN;
+  const bool active = wave < SH::WK * SH::WN;
   const float* __restrict__ rs = (const float*)(dy + dy_plane_uint4(R, NP));
   const float mref = rs[R];                                     // written by the dgrad's atomicMax
   const float inv_mref = mref > 0.f ? 1.0f / mref : 0.f;        // m_ref is a power of two: exact
-  uint4* myT = (uint4*)(smem + rg * W::RG_BYTES) + lane + (size_t)(side * 16 * NP + part * 16) * 64;
-  uint4* mySc = (uint4*)(smem + rg * W::RG_BYTES) + lane + (size_t)(32 * NP) * 64;
-  const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  const uint4 il = shifted_identity<true>(lane, 0), ih = shifted_identity<true>(lane, 1);
-  const uint4 z4 = make_uint4(0, 0, 0, 0);
-  f32x16 acc[NT], accb = zero;
+  // DMA roles: block b = wave + 8 i (clamped: a surplus instruction re-fetches the last block, same bytes to the same place)
+  const uint4* src[NDMA];
+  size_t tstride[NDMA];
+  unsigned lds_blk[NDMA];
+  {
+    const int r = lane >> 2, a = (lane >> 1) & 1, h = lane & 1;
 #pragma unroll
-  for (int b = 0; b < NT; ++b) acc[b] = zero;
-  uint4 opr[NOP];
-  float4 scq[4];
-  const uint4* __restrict__ src = side == 0 ? saved + (part ? sv_lo0(R) : 0) + (size_t)qx * 64 : dy + (part ? dy_plane_uint4(R, 1) : 0) + (size_t)qd * 64;
-  const size_t tile_stride = (size_t)(side == 0 ? SAVE_SLOTS : DY_SLOTS) * 64;      // uint4 per 32-row tile
-  constexpr int NLOAD_X = 2 * KT, NLOAD_D = KSd < 2 * NT ? KSd : 2 * NT;
-  auto load_chunk = [&](int chunk) {
-    const size_t row0 = (size_t)chunk * W::CH + rg * 32;
-    const uint4* base = src + (row0 >> 5) * tile_stride + m * 2 + h;
-    // the row scales first: they are consumed before the first operand, and loads retire in issue order (waiting for the LAST load
-    // of a chunk would serialise the transposition behind the whole chunk)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) scq[q] = *(const float4*)(rs + row0 + 8 * q + 4 * h);
-#pragma unroll
-    for (int t = 0; t < NOP; ++t) {
-      // slots beyond this side's count are clamped to its last slot (loaded, never used): no predicate on the load
-      const int tx = t < NLOAD_X ? t : NLOAD_X - 1, td = t < NLOAD_D ? t : NLOAD_D - 1;
-      opr[t] = stream_load(base + (size_t)(side == 0 ? tx : td) * 64);
+    for (int i = 0; i < NDMA; ++i) {
+      int b = wave + 8 * i;
+      b = b < NBLK ? b : NBLK - 1;
+      const int t = b / NP, part = b % NP;
+      if (t < KT) {
+        src[i] = saved + (part ? sv_lo0(R) : 0) + sv_addr(qx + 2 * t + a, 0, r, h);
+        tstride[i] = (size_t)SAVE_SLOTS * 64;
+      } else {
+        const int slot = 2 * (t - KT) + a;
+        src[i] = dy + (part ? dy_plane_uint4(R, 1) : 0) + dy_addr(qd + (slot < KSd ? slot : KSd - 1), 0, r, h);
+        tstride[i] = (size_t)DY_SLOTS * 64;
+      }
+      lds_blk[i] = (unsigned)b * 1024u;
     }
+  }
+  // the 16 row scales of a step ride the same ring (every VMEM operation of the loop is a DMA: one counter discipline): wave 0 fetches
+  // them as one more DMA instruction, lanes 0..3 carry 4 floats each (the other lanes repeat them)
+  const float* rs_src = rs + 4 * (lane & 3);
+  const long long n_t32 = R / 32;
+  const int my_tiles = g < n_t32 ? (int)((n_t32 - 1 - g) / G) + 1 : 0;
+  const int n_steps = 2 * my_tiles;
+  auto issue = [&](int s) {                                     // DMA of local step s into ring slot s & 3 (steps past the end: the last one again)
+    const int sc = s < n_steps ? s : n_steps - 1;
+    const size_t t32 = (size_t)g + (size_t)(sc >> 1) * G;
+    const unsigned ring = (unsigned)(s & (WGTR_NBUF - 1)) * STEP_BYTES;
+#pragma unroll
+    for (int i = 0; i < NDMA; ++i)
+      glds16_nt((const char*)(src[i] + t32 * tstride[i] + (sc & 1) * 32), __builtin_amdgcn_readfirstlane(ring + lds_blk[i]));
+    if (wave == 0) glds16_nt((const char*)(rs_src + t32 * 32 + (sc & 1) * 16), __builtin_amdgcn_readfirstlane(ring + NBLK * 1024u));
   };
-  if (g < n_chunks) load_chunk(g);
-  for (int chunk = g; chunk < n_chunks; chunk += G) {
-    const bool ok = (long long)chunk * W::CH + rg * 32 + m < total_rows;
-    if (side == 0) {
-      float sc[16];
+  const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  f32x16 acc[TK][TN], accb = zero;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { sc[4 * q] = scq[q].x * inv_mref; sc[4 * q + 1] = scq[q].y * inv_mref; sc[4 * q + 2] = scq[q].z * inv_mref; sc[4 * q + 3] = scq[q].w * inv_mref; }
+  for (int i = 0; i < TK; ++i)
 #pragma unroll
-      for (int t = 0; t < KT; ++t) {
-        f32x16 d = mfma16<true>(opr[2 * t], il, zero);
-        d = mfma16<true>(opr[2 * t + 1], ih, d);
+    for (int j = 0; j < TN; ++j) acc[i][j] = zero;
+  if (n_steps > 0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) d[r] *= sc[r];
-        uint4 u0, u1;
-        pack_rows_f16(d, u0, u1);
-        myT[(2 * t) * 64] = u0; myT[(2 * t + 1) * 64] = u1;
-      }
-      if (part == 0) {                                          // the row scales as an A operand: row m = 0 holds them, the others 0
-        f32x16 d;
+    for (int s = 0; s < AHEAD; ++s) issue(s);
+    // lane part of every transpose-read address: row (8 kh + (i >> 2)) * 64 + slot parity a * 32 + (i & 3) * 8, i = lane & 15
+    const unsigned lane_off = (unsigned)((8 * (lane >> 5) + ((lane & 15) >> 2)) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8);
+    const int kh = lane >> 5;
+    for (int s = 0; s < n_steps; ++s) {
+      if (wave == 0) wait_vmcnt<(AHEAD - 1) * (NDMA + 1)>(); else
+      wait_vmcnt<(AHEAD - 1) * NDMA>();                         // this wave's part of step s has landed (the later steps may be in flight)
+      __syncthreads();                                          // ... everybody's has, and everybody is done with the ring slot of step s - 1
+      issue(s + AHEAD);
+      if (active) {
+        const char* ring0 = smem + (s & (WGTR_NBUF - 1)) * STEP_BYTES;
+        const char* ring = ring0 + lane_off;
+        const float4 s0 = *(const float4*)(ring0 + NBLK * 1024 + kh * 32), s1 = *(const float4*)(ring0 + NBLK * 1024 + kh * 32 + 16);
+        const half8 sc8 = {(_Float16)(s0.x * inv_mref), (_Float16)(s0.y * inv_mref), (_Float16)(s0.z * inv_mref), (_Float16)(s0.w * inv_mref),
+                           (_Float16)(s1.x * inv_mref), (_Float16)(s1.y * inv_mref), (_Float16)(s1.z * inv_mref), (_Float16)(s1.w * inv_mref)};
+        half8 ah[TK], al[TK], bh[TN], bl[TN];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) d[r] = m == 0 ? sc[r] : 0.f;
-        uint4 u0, u1;
-        pack_rows_f16(d, u0, u1);
-        mySc[0] = u0; mySc[64] = u1;
-      }
-    } else {
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const uint4 a0 = ok ? opr[2 * t] : z4, a1 = (ok && 2 * t + 1 < KSd) ? opr[2 * t + 1] : z4;   // padded rows / slots must not contribute
-        f32x16 d = mfma16<true>(a0, il, zero);
-        d = mfma16<true>(a1, ih, d);
-        uint4 u0, u1;
-        pack_rows_f16(d, u0, u1);
-        myT[(2 * t) * 64] = u0; myT[(2 * t + 1) * 64] = u1;
-      }
-    }
-    __syncthreads();
-    if (chunk + G < n_chunks) load_chunk(chunk + G);
-    if (wave < KT || wave < NT) {
-#pragma unroll 1
-      for (int v = 0; v < W::ROWG; ++v) {
-        const uint4* T = (const uint4*)(smem + v * W::RG_BYTES) + lane;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          if (wave < KT) {
-            const uint4 ah = T[(2 * wave + u) * 64];
-            uint4 al = z4;
-            if constexpr (NP == 2) al = T[(16 + 2 * wave + u) * 64];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-              const uint4 bh = T[(16 * NP + 2 * nt + u) * 64];
-              acc[nt] = mfma16<true>(ah, bh, acc[nt]);
-              if constexpr (NP == 2) {
-                acc[nt] = mfma16<true>(ah, T[(48 + 2 * nt + u) * 64], acc[nt]);
-                acc[nt] = mfma16<true>(al, bh, acc[nt]);
-              }
-            }
-          }
-          if (wave < NT) {
-            const uint4 sv = T[(32 * NP + u) * 64];
-            accb = mfma16<true>(sv, T[(16 * NP + 2 * wave + u) * 64], accb);
-            if constexpr (NP == 2) accb = mfma16<true>(sv, T[(48 + 2 * wave + u) * 64], accb);
-          }
+        for (int i = 0; i < TK; ++i) {
+          const char* p = ring + (wk * TK + i) * NP * 1024;
+          ah[i] = tr_read8(p) * sc8;
+          if constexpr (NP == 2) al[i] = tr_read8(p + 1024) * sc8;
         }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const char* p = ring + (KT + wn * TN + j) * NP * 1024;
+          bh[j] = tr_read8(p);
+          if constexpr (NP == 2) bl[j] = tr_read8(p + 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < TK; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = mfma_h8(ah[i], bh[j], acc[i][j]);
+        if constexpr (NP == 2) {
+#pragma unroll
+          for (int i = 0; i < TK; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = mfma_h8(ah[i], bl[j], acc[i][j]);
+#pragma unroll
+          for (int i = 0; i < TK; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = mfma_h8(al[i], bh[j], acc[i][j]);
+        }
+        // bias row: wave (wk, wn) owns it for n-tile wn TN + wk (every n-tile has one owner when WK >= TN)
+        static_assert(SH::WK >= TN, "bias owners");
+        half8 ab;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) ab[k] = (lane & 31) == 0 ? sc8[k] : (_Float16)0;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          if (wk == j) {
+            accb = mfma_h8(ab, bh[j], accb);
+            if constexpr (NP == 2) accb = mfma_h8(ab, bl[j], accb);
+          }
       }
     }
-    __syncthreads();
+    wait_vmcnt<0>();                                            // the surplus prefetches must not outlive the workgroup's LDS
   }
   constexpr size_t ldn = (size_t)NT * 32;
-  if (wave < KT) {
+  const int m = lane & 31, h = lane >> 5;
+  if (active) {
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
+    for (int i = 0; i < TK; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
-        pg[(size_t)(wave * 32 + i) * ldn + nt * 32 + m] = acc[nt][r];
-      }
-    }
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+          pg[(size_t)((wk * TK + i) * 32 + row) * ldn + (wn * TN + j) * 32 + m] = acc[i][j][r];
+        }
+    if (wk < TN && h == 0) pbias[(wn * TN + wk) * 32 + m] = accb[0];
   }
-  if (wave < NT && h == 0) pbias[wave * 32 + m] = accb[0];
 }
 
 template <int NP>
 __global__ void __launch_bounds__(512)
-nerfmlp_wgrad_f16_kernel(const uint4* __restrict__ saved, const uint4* __restrict__ dy, long long R, long long total_rows, int n_chunks,
-                          float* __restrict__ workspace, const WgradTable tab) {
+nerfmlp_wgrad_tr_kernel(const uint4* __restrict__ saved, const uint4* __restrict__ dy, long long R, float* __restrict__ workspace, const WgradTable tab,
+                        long long* __restrict__ trace) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (trace && threadIdx.x == 0) trace[2 * blockIdx.x] = (long long)__builtin_amdgcn_s_memrealtime();
   int j = 0;
   while ((int)blockIdx.x >= tab.wg0[j + 1]) ++j;
   const int qx = tab.qx[j], KSx = tab.KSx[j], qd = tab.qd[j], KSd = tab.KSd[j];
@@ -1390,7 +1432,11 @@ nerfmlp_wgrad_f16_kernel(const uint4* __restrict__ saved, const uint4* __restric
   float* pg = workspace + tab.poff[j] + (size_t)g * (size_t)KT * 32 * NT * 32;
   float* pb = workspace + tab.pboff[j] + (size_t)g * NT * 32;
 #define RNERF_WGRAD_CASE(KT_, KSD_)                                                                                                 \
-  if (KSx == 2 * (KT_) && KSd == (KSD_)) { wgrad_body_f16<NP, KT_, KSD_>(saved, dy, R, total_rows, n_chunks, pg, pb, qx, qd, g, G, smem); return; }
+  if (KSx == 2 * (KT_) && KSd == (KSD_)) {                                                                                          \
+    wgrad_body_tr<NP, KT_, KSD_>(saved, dy, R, pg, pb, qx, qd, g, G, smem);                                                         \
+    if (trace && threadIdx.x == 0) trace[2 * blockIdx.x + 1] = (long long)__builtin_amdgcn_s_memrealtime();                         \
+    return;                                                                                                                         \
+  }
   RNERF_WGRAD_CASE(8, 16) RNERF_WGRAD_CASE(2, 16) RNERF_WGRAD_CASE(8, 1) RNERF_WGRAD_CASE(8, 8) RNERF_WGRAD_CASE(1, 8) RNERF_WGRAD_CASE(4, 1)
 #undef RNERF_WGRAD_CASE
   __builtin_trap();
@@ -2326,17 +2372,19 @@ static const WgradPlan kWgradPlan[15] = {
     {SAVE_RGBIN, 8, DY_HEADS, 1, {11, 1, 0, 2, 4, 1, 1}},
     {0, 0, 0, 0, {0, 0, 0, 0, 0, 0, 0}}};
 
-static size_t build_wgrad_table(int cus, WgradTable& t) {
+// legacy = the bf16 body (MFMA transposition): shares by MFMA count, 4 rounds of workgroups; otherwise the transpose-read bodies, paced
+// by HBM: shares by bytes streamed per row, 2 rounds (measured with RNERF_WGRAD_TRACE: all jobs' workgroups finish within 10 %)
+static size_t build_wgrad_table(int cus, WgradTable& t, bool legacy) {
   int n = 0;
   double cost[16], total = 0;
   for (; kWgradPlan[n].KSx != 0; ++n) {
     const WgradJob& jb = kWgradPlan[n].job;
-    cost[n] = 2.0 * jb.KT * jb.NT + 2 * (jb.KT + jb.NT) + 16;   // accumulate MFMAs + transposition MFMAs + a fixed part per chunk
+    cost[n] = legacy ? 2.0 * jb.KT * jb.NT + 2 * (jb.KT + jb.NT) + 16 : jb.KT + jb.NT + 1;
     total += cost[n];
   }
   t.n = n;
-  static const int mult = getenv("RNERF_WGRAD_MULT") ? atoi(getenv("RNERF_WGRAD_MULT")) : 4;
-  const int budget = mult * cus;                             // rounds of one-per-CU workgroups
+  static const int mult_env = getenv("RNERF_WGRAD_MULT") ? atoi(getenv("RNERF_WGRAD_MULT")) : 0;
+  const int budget = (mult_env > 0 ? mult_env : (legacy ? 4 : 2)) * cus;       // rounds of one-per-CU workgroups
   size_t off = 0;
   int wg = 0;
   for (int i = 0; i < n; ++i) {
@@ -2358,9 +2406,22 @@ static int device_cus() {
   return cus;
 }
 
+struct WgradTables { WgradTable legacy, tr; size_t partial_floats; int max_wgs; };
+static const WgradTables& wgrad_tables() {
+  static WgradTables w;
+  static bool ready = false;
+  if (!ready) {
+    const size_t a = build_wgrad_table(device_cus(), w.legacy, true), b = build_wgrad_table(device_cus(), w.tr, false);
+    w.partial_floats = a > b ? a : b;
+    w.max_wgs = w.legacy.wg0[w.legacy.n] > w.tr.wg0[w.tr.n] ? w.legacy.wg0[w.legacy.n] : w.tr.wg0[w.tr.n];
+    ready = true;
+  }
+  return w;
+}
+
 extern "C" size_t rnerf_nerfmlp_wgrad_workspace_bytes(void) {
-  WgradTable t;
-  return build_wgrad_table(device_cus(), t) * sizeof(float);
+  const WgradTables& w = wgrad_tables();
+  return w.partial_floats * sizeof(float) + (size_t)w.max_wgs * 2 * sizeof(long long);       // + the RNERF_WGRAD_TRACE slots
 }
 
 extern "C" int rnerf_nerfmlp_wgrad(int fwd_precision, int backward, const void* save, const void* dy, int64_t rows, float* grads, void* workspace,
@@ -2369,35 +2430,50 @@ extern "C" int rnerf_nerfmlp_wgrad(int fwd_precision, int backward, const void* 
   RNERF_CHECK_ARG(fwd_precision == RNERF_PREC_F16X3, "rnerf_nerfmlp_wgrad: forward precision must be f16x3");
   RNERF_CHECK_ARG(bwd_ok(backward), "rnerf_nerfmlp_wgrad: unknown backward mode %d", backward);
   RNERF_CHECK_ARG(rows >= 1, "rnerf_nerfmlp_wgrad: rows must be >= 1");
-  static WgradTable tab;
+  const WgradTables& w = wgrad_tables();
   static bool ready = false;
   if (!ready) {
-    build_wgrad_table(device_cus(), tab);
     RNERF_CHECK_HIP(hipFuncSetAttribute((const void*)nerfmlp_wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
-    RNERF_CHECK_HIP(hipFuncSetAttribute((const void*)nerfmlp_wgrad_f16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, WgF16<1>::LDS));
-    RNERF_CHECK_HIP(hipFuncSetAttribute((const void*)nerfmlp_wgrad_f16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, WgF16<2>::LDS));
+    RNERF_CHECK_HIP(hipFuncSetAttribute((const void*)nerfmlp_wgrad_tr_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, wgtr_lds_bytes<1>()));
+    RNERF_CHECK_HIP(hipFuncSetAttribute((const void*)nerfmlp_wgrad_tr_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, wgtr_lds_bytes<2>()));
     ready = true;
   }
   const long long R = (rows + 255) / 256 * 256;
   hipStream_t st = (hipStream_t)stream;
   const float* out_scale = nullptr;
+  // RNERF_WGRAD_TRACE=1 (profiling aid): per-workgroup start / end times behind the partials -> per-job spans on stderr (synchronises)
+  static const bool tracing = getenv("RNERF_WGRAD_TRACE") != nullptr;
+  long long* trace = tracing ? (long long*)((char*)workspace + w.partial_floats * sizeof(float)) : nullptr;
+  const WgradTable& tab = backward == RNERF_BWD_BF16 ? w.legacy : w.tr;
   if (backward == RNERF_BWD_BF16) {
     const int n_chunks = (int)((rows + 127) / 128);
     hipLaunchKernelGGL(nerfmlp_wgrad_kernel<true>, dim3(tab.wg0[tab.n]), dim3(512), 131072, st, (const uint4*)save, (const uint4*)dy, R,
                        (long long)rows, n_chunks, (float*)workspace, tab);
   } else if (backward == RNERF_BWD_F16) {
-    const int n_chunks = (int)((rows + WgF16<1>::CH - 1) / WgF16<1>::CH);
-    hipLaunchKernelGGL(nerfmlp_wgrad_f16_kernel<1>, dim3(tab.wg0[tab.n]), dim3(512), WgF16<1>::LDS, st, (const uint4*)save, (const uint4*)dy, R,
-                       (long long)rows, n_chunks, (float*)workspace, tab);
+    hipLaunchKernelGGL(nerfmlp_wgrad_tr_kernel<1>, dim3(tab.wg0[tab.n]), dim3(512), wgtr_lds_bytes<1>(), st, (const uint4*)save, (const uint4*)dy, R,
+                       (float*)workspace, tab, trace);
     out_scale = (const float*)((const uint4*)dy + dy_plane_uint4(R, 1)) + R;
   } else {
-    const int n_chunks = (int)((rows + WgF16<2>::CH - 1) / WgF16<2>::CH);
-    hipLaunchKernelGGL(nerfmlp_wgrad_f16_kernel<2>, dim3(tab.wg0[tab.n]), dim3(512), WgF16<2>::LDS, st, (const uint4*)save, (const uint4*)dy, R,
-                       (long long)rows, n_chunks, (float*)workspace, tab);
+    hipLaunchKernelGGL(nerfmlp_wgrad_tr_kernel<2>, dim3(tab.wg0[tab.n]), dim3(512), wgtr_lds_bytes<2>(), st, (const uint4*)save, (const uint4*)dy, R,
+                       (float*)workspace, tab, trace);
     out_scale = (const float*)((const uint4*)dy + dy_plane_uint4(R, 2)) + R;
   }
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(256, tab.n), dim3(256), 0, st, (const float*)workspace, tab, grads, out_scale);
   RNERF_CHECK_LAUNCH();
+  if (trace && backward != RNERF_BWD_BF16) {
+    const int n_wg = tab.wg0[tab.n];
+    std::vector<long long> h(2 * (size_t)n_wg);
+    RNERF_CHECK_HIP(hipStreamSynchronize(st));
+    RNERF_CHECK_HIP(hipMemcpy(h.data(), trace, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+    long long t0 = h[0];
+    for (int i = 0; i < n_wg; ++i) t0 = h[2 * i] < t0 ? h[2 * i] : t0;
+    for (int j = 0; j < tab.n; ++j) {
+      long long a = -1, b = 0; double busy = 0;
+      for (int i = tab.wg0[j]; i < tab.wg0[j + 1]; ++i) { a = (a < 0 || h[2 * i] < a) ? h[2 * i] : a; b = h[2 * i + 1] > b ? h[2 * i + 1] : b; busy += (double)(h[2 * i + 1] - h[2 * i]); }
+      fprintf(stderr, "[wgrad trace] job %2d (KT %d NT %d) wgs %4d  first start %9lld  last end %9lld  mean wg ticks (100 MHz) %7.0f\n", j, tab.job[j].KT, tab.job[j].NT,
+              tab.wg0[j + 1] - tab.wg0[j], a - t0, b - t0, busy / (tab.wg0[j + 1] - tab.wg0[j]));
+    }
+  }
   return RNERF_OK;
 }
 
