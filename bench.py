@@ -354,7 +354,7 @@ def main():
         wgrad_bytes = (8 * 32 + 2 * 20 + 17 + 24 + 10 + 9) * R_pad * 32 * (2 if args.backward == "f32" else 1)   # sum over the 14 jobs of (X slots + dY slots) x R x 32 B (x 2: hi + lo)
         for name, ms, flop, bound, byt in (("nerfmlp_fwd_kernel<train>", t_f, MLP_FLOP_PER_ROW * rows, "mfma", None),
                                            ("nerfmlp_dgrad_kernel", t_d, 2 * 557696 * rows, "mfma", None),
-                                           ("nerfmlp_wgrad_kernel", t_w, MLP_FLOP_PER_ROW * rows, "hbm", wgrad_bytes)):
+                                           ("nerfmlp_wgrad_kernel" if args.backward == "bf16" else "nerfmlp_wgrad_tr_kernel", t_w, MLP_FLOP_PER_ROW * rows, "hbm", wgrad_bytes)):
             if bound == "mfma":
                 train_kernels.append({"kernel": name, "bound": "mfma", "achieved": flop / (ms * 1e-3) / 1e12, "peak": PEAK_MFMA_16BIT / 1e12,
                                       "unit": "TFLOP/s", "frac": flop / (ms * 1e-3) / PEAK_MFMA_16BIT, "avg_launch_ms": ms,

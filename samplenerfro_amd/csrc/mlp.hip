@@ -475,6 +475,11 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
   size_t off = 0;   // stream offset of the next slab to prefetch
   float prof_dma = 0.f, prof_bar = 0.f, prof_tot = 0.f, prof_n = 0.f;
   unsigned long long prof_last = __builtin_amdgcn_s_memtime();
+  // dbg & 256: shader clocks per phase of a tile (PH(k) books the time since the previous mark on phase k):
+  //   0 row loads  1 layer 0 (encoding slabs)  2 first k-step of a hidden layer (incl. its operand conversion)  3 k-steps 1..15
+  //   4 layer end (state to registers / LDS)  5 skip-concat slabs  6 sigma head  7 view layer  8 rgb head + store
+  float prof_ph[12] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#define PH(K) do { if constexpr ((dbg & 256) != 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); prof_ph[K] += (float)(t_ - prof_last); prof_last = t_; } } while (0)
 
   if ((int)blockIdx.x < n_tiles) { if (!(dbg & 1)) issue_slab<SLAB>(packed, 0u, wave, lane); off = SLAB; }
   slab_wait_dma();
@@ -482,6 +487,12 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
 
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const bool has_next_tile = tile + (int)gridDim.x < n_tiles;
+    // The aux vectors (biases, head weights) are read at lane-dependent but tile-invariant addresses.  Left alone, hipcc hoists the ~100
+    // 64-bit per-lane addresses out of the tile loop, spills them, and in the heads / the view layer reloads each one from scratch right
+    // before its load, one after the other (measured: 52 k clocks for the rgb head, 5.4 k per view-layer slab).  An opaque per-tile copy
+    // of the base keeps the address arithmetic next to the loads (scalar base + lane offset + immediate).
+    const float* __restrict__ auxt = aux;
+    asm volatile("" : "+s"(auxt));
     long long row[2]; bool row_ok[2];
     float4 pd[2], dr[2];
 #pragma unroll
@@ -496,6 +507,7 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
     }
 
     f32x16 acc0[8], acc1[8], prev0[8];
+    PH(0);
 
     // training forward: keep the hi parts of the operands of slot q (see SAVE_* above); padded rows are written too
     const long long srow0 = (long long)tile * 256 + wave * 64 + m;
@@ -628,13 +640,15 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
         SLAB_DONE();
         cur = nxt;
       }
+      PH(1);
       layer_end();
+      PH(4);
     }
 
     // ---- layers 1..8: Dense_1..Dense_7 (inputs ReLU'd; Dense_5 also takes the skip concat), Dense_9 = bottleneck
 #pragma unroll 1
     for (int l = 1; l <= 8; ++l) {
-      const float* __restrict__ bias = aux + AUX_BIAS + 256 * (l - 1);
+      const float* __restrict__ bias = auxt + AUX_BIAS + 256 * (l - 1);
       KOps cur = prev_ops(0, bias, 0.f);
       float bnext[8];
       load_bias8(1, bias, bnext);
@@ -660,9 +674,10 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
         if constexpr (S + 2 < 16) { _Pragma("unroll") for (int j = 0; j < 8; ++j) bnext[j] = bnn[j]; }               \
         SLAB_DONE();                                                                                                 \
       }
-      RNERF_KSTEP(0) RNERF_KSTEP(1) RNERF_KSTEP(2) RNERF_KSTEP(3) RNERF_KSTEP(4) RNERF_KSTEP(5) RNERF_KSTEP(6) RNERF_KSTEP(7)
+      RNERF_KSTEP(0) PH(2); RNERF_KSTEP(1) RNERF_KSTEP(2) RNERF_KSTEP(3) RNERF_KSTEP(4) RNERF_KSTEP(5) RNERF_KSTEP(6) RNERF_KSTEP(7)
       RNERF_KSTEP(8) RNERF_KSTEP(9) RNERF_KSTEP(10) RNERF_KSTEP(11) RNERF_KSTEP(12) RNERF_KSTEP(13) RNERF_KSTEP(14) RNERF_KSTEP(15)
 #undef RNERF_KSTEP
+      PH(3);
       if (l == 5) {   // skip concat: [x, inputs] (rnerf/model_utils.py:68-69)
         cur = enc_ops(pd, 0, 30);
 #pragma unroll
@@ -674,14 +689,15 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
           SLAB_DONE();
           cur = nxt;
         }
+        PH(5);
       }
       if (l == 7) {   // sigma head (Dense_8, rnerf/model_utils.py:70) on the fp32 trunk output relu(acc + b7), once per tile
-        const float* __restrict__ b7 = aux + AUX_BIAS + 256 * 7;
+        const float* __restrict__ b7 = auxt + AUX_BIAS + 256 * 7;
 #pragma unroll
         for (int t = 0; t < 8; ++t)
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
-            const float4 bb = *(const float4*)(b7 + 32 * t + 8 * g + 4 * h), ww = *(const float4*)(aux + AUX_WSIG + 32 * t + 8 * g + 4 * h);
+            const float4 bb = *(const float4*)(b7 + 32 * t + 8 * g + 4 * h), ww = *(const float4*)(auxt + AUX_WSIG + 32 * t + 8 * g + 4 * h);
             const float bv[4] = {bb.x, bb.y, bb.z, bb.w}, wv[4] = {ww.x, ww.y, ww.z, ww.w};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -689,13 +705,15 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
               sig1 = fmaf(fmaxf(fmaf(acc1[t][4 * g + i], INV_SCALE, bv[i]), 0.f), wv[i], sig1);
             }
           }
+        PH(6);
       }
       layer_end();
+      PH(4);
     }
 
     // ---- view layer: [bottleneck(256) (no activation), pos_enc(dir, 0, 4) (27)] -> 128 (Dense_10)  (rnerf/models.py:289-294)
     {
-      const float* __restrict__ bias = aux + AUX_BIAS + 256 * 8;
+      const float* __restrict__ bias = auxt + AUX_BIAS + 256 * 8;
       KOps c0 = prev_ops(0, bias, NEG_INF);
       KOps c1 = prev_ops(1, bias, NEG_INF);
 #pragma unroll
@@ -720,11 +738,12 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
       SLAB_PREFETCH(has_next_tile);
       if (!(dbg & 2)) { kstep_mfma<PREC, 4, 0, false>(acc0, acc1, c0, smem + buf * SLAB, lane, nowork); kstep_mfma<PREC, 4, 1, false>(acc0, acc1, c1, smem + buf * SLAB, lane, nowork); }
       SLAB_DONE();
+      PH(7);
     }
 
     // ---- heads: sigma (Dense_8, accumulated above) and rgb (Dense_11) on the fp32 view-layer output
     {
-      const float* __restrict__ b9 = aux + AUX_BIAS + 256 * 9;
+      const float* __restrict__ b9 = auxt + AUX_BIAS + 256 * 9;
       float p0[3] = {0.f, 0.f, 0.f}, p1[3] = {0.f, 0.f, 0.f};
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
@@ -733,7 +752,7 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
         for (int g = 0; g < 4; ++g) {
           const int n = 32 * t + 8 * g + 4 * h;
           const float4 bb = *(const float4*)(b9 + n);
-          const float4 wr = *(const float4*)(aux + AUX_WRGB + n), wg = *(const float4*)(aux + AUX_WRGB + 128 + n), wb = *(const float4*)(aux + AUX_WRGB + 256 + n);
+          const float4 wr = *(const float4*)(auxt + AUX_WRGB + n), wg = *(const float4*)(auxt + AUX_WRGB + 128 + n), wb = *(const float4*)(auxt + AUX_WRGB + 256 + n);
           const float bv[4] = {bb.x, bb.y, bb.z, bb.w}, wrv[4] = {wr.x, wr.y, wr.z, wr.w}, wgv[4] = {wg.x, wg.y, wg.z, wg.w}, wbv[4] = {wb.x, wb.y, wb.z, wb.w};
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
@@ -761,11 +780,11 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
           }
         }
       }
-      const float bsig = aux[AUX_BSIG];
+      const float bsig = auxt[AUX_BSIG];
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        p0[c] = p0[c] + __shfl_xor(p0[c], 32) + aux[AUX_BRGB + c];
-        p1[c] = p1[c] + __shfl_xor(p1[c], 32) + aux[AUX_BRGB + c];
+        p0[c] = p0[c] + __shfl_xor(p0[c], 32) + auxt[AUX_BRGB + c];
+        p1[c] = p1[c] + __shfl_xor(p1[c], 32) + auxt[AUX_BRGB + c];
       }
       sig0 = sig0 + __shfl_xor(sig0, 32) + bsig;
       sig1 = sig1 + __shfl_xor(sig1, 32) + bsig;
@@ -773,6 +792,7 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
         if (row_ok[0]) out_raw[row[0]] = make_float4(p0[0], p0[1], p0[2], sig0);
         if (row_ok[1]) out_raw[row[1]] = make_float4(p1[0], p1[1], p1[2], sig1);
       }
+      PH(8);
     }
 #undef SLAB_PREFETCH
 #undef SLAB_DONE
@@ -780,6 +800,13 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
   if constexpr ((dbg & 64) != 0) {
     if (lane == 0) out_raw[blockIdx.x * 4 + wave] = make_float4(prof_tot, prof_dma, prof_bar, prof_n);
   }
+  if constexpr ((dbg & 256) != 0) {
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) out_raw[(blockIdx.x * 4 + wave) * 3 + i] = make_float4(prof_ph[4 * i], prof_ph[4 * i + 1], prof_ph[4 * i + 2], prof_ph[4 * i + 3]);
+    }
+  }
+#undef PH
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -2232,6 +2259,7 @@ static int launch_fwd(const void* packed, const float* rows_pd, const float* row
     case 64: return launch_fwd_dbg<PREC, 64>(packed, rows_pd, rows_dr, node_of_sample, B, total_rows, out_raw, st, nullptr, max_wg);
     case 32: return launch_fwd_dbg<PREC, 32>(packed, rows_pd, rows_dr, node_of_sample, B, total_rows, out_raw, st, nullptr, max_wg);
     case 29: return launch_fwd_dbg<PREC, 29>(packed, rows_pd, rows_dr, node_of_sample, B, total_rows, out_raw, st, nullptr, max_wg);
+    case 256: return launch_fwd_dbg<PREC, 256>(packed, rows_pd, rows_dr, node_of_sample, B, total_rows, out_raw, st, nullptr, max_wg);
     default: break;
   }
 #endif

@@ -29,3 +29,12 @@ if os.environ.get('RNERF_MLP_DEBUG') == '64':
     print(f"slabs/wave={n:.0f}  cycles/slab total={prof[:,0].sum()/prof[:,3].sum():.0f}  dma-wait={prof[:,1].sum()/prof[:,3].sum():.0f}  barrier-wait={prof[:,2].sum()/prof[:,3].sum():.0f}")
     w = prof.reshape(-1, 4, 4)
     print("per-wave-slot barrier wait:", [round(float(w[:, k, 2].sum()/w[:, k, 3].sum())) for k in range(4)], " dma:", [round(float(w[:, k, 1].sum()/w[:, k, 3].sum())) for k in range(4)])
+
+if os.environ.get('RNERF_MLP_DEBUG') == '256':
+    prof = out.reshape(-1, 4)[:256 * 4 * 3].cpu().numpy().reshape(-1, 12)[:, :9]
+    names = ["row loads", "layer 0 (PE slabs)", "hidden k-step 0 (+conversion)", "hidden k-steps 1..15", "layer end", "skip slabs", "sigma head", "view layer", "rgb head + store"]
+    tot = prof.sum()
+    per_tile = prof.sum(0) / prof.shape[0] / 8          # 8 tiles per workgroup on this workload
+    for n, v in zip(names, per_tile):
+        print(f"  {n:32s} {v:9.0f} clk/tile  {100 * v / per_tile.sum():5.1f} %")
+    print(f"  total {per_tile.sum():.0f} clk/tile; MFMA floor 145 slabs x 1536 = {145 * 1536}")
