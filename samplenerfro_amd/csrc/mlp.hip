@@ -338,6 +338,45 @@ struct NoWork {
   __device__ __forceinline__ void chunk() {}
 };
 
+// Work of the LAST k-step of a layer (the layer seam), in the shadow of its MFMAs: once the MFMAs of tile t have been issued, tile
+// t - 1 is final, so in tile t's slots
+//   * its m-tile 0 outputs move to prev0[t - 1], its m-tile 1 outputs to the wave's LDS state (128 register moves + 32 ds_write_b128
+//     per wave, which used to run after the k-step with the matrix pipe idle), and
+//   * the operands of the NEXT layer's k-step 0 (features 0..15 = tile 0, registers 0..7) are converted from the final accumulators
+//     (used to be prev_ops(0) at the head of the next layer, exposed together with its bias load).
+// Tile 7 is handed over by finish() after the k-step.
+template <int PREC, bool MASK>
+struct SeamWork {
+  f32x16 (&acc0)[8];
+  f32x16 (&acc1)[8];
+  f32x16 (&prev0)[8];
+  float4* st1;
+  PrevConv<PREC, 0, MASK> cv;      // pairs 0..3: m-tile 0 from acc0[0], pairs 4..7: m-tile 1 from acc1[0]
+  __device__ __forceinline__ SeamWork(f32x16 (&a0)[8], f32x16 (&a1)[8], f32x16 (&p0)[8], float4* s1) : acc0(a0), acc1(a1), prev0(p0), st1(s1), cv(a0[0]) {}
+  template <int C, int T>
+  __device__ __forceinline__ void move() {            // piece C of the hand-over of tile T
+    if constexpr (C == 0) prev0[T] = acc0[T];
+    else st1[(T * 4 + C - 1) * 64] = make_float4(acc1[T][4 * (C - 1)], acc1[T][4 * (C - 1) + 1], acc1[T][4 * (C - 1) + 2], acc1[T][4 * (C - 1) + 3]);
+  }
+  template <int C, int Q>
+  __device__ __forceinline__ void conv() {
+    if constexpr (C == 0 && Q >= 4) { cv.v1[2 * (Q & 3)] = acc1[0][2 * (Q & 3)]; cv.v1[2 * (Q & 3) + 1] = acc1[0][2 * (Q & 3) + 1]; }
+    cv.template chunk<C, Q>();
+  }
+  template <int C, int PI>
+  __device__ __forceinline__ void chunk() {
+    if constexpr (PI >= 1) {
+      move<C, PI - 1>();
+      conv<C, PI - 1>();
+      // pair 7 after pair 6 (PrevConv keeps ONE pair in flight: x0 / x1)
+      if constexpr (PI == 7 && C == 4) { conv<0, 7>(); conv<1, 7>(); conv<2, 7>(); conv<3, 7>(); conv<4, 7>(); }
+    }
+  }
+  __device__ __forceinline__ void finish() {
+    move<0, 7>(); move<1, 7>(); move<2, 7>(); move<3, 7>(); move<4, 7>();
+  }
+};
+
 #define RNERF_PIN() __builtin_amdgcn_sched_barrier(0)
 
 // one n-tile of one k-step: 6 (X3) or 2 MFMAs with the conversion chunks of pair PI in their shadow
@@ -614,34 +653,32 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
     buf ^= 1;                                                                                                        \
   } while (0)
 
-    // end of a 256-wide layer: m-tile 0 outputs stay in registers (prev0), m-tile 1 outputs go to this wave's LDS region
-    auto layer_end = [&]() {
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        prev0[t] = acc0[t];
-#pragma unroll
-        for (int rq = 0; rq < 4; ++rq)
-          st1[(t * 4 + rq) * 64] = make_float4(acc1[t][4 * rq], acc1[t][4 * rq + 1], acc1[t][4 * rq + 2], acc1[t][4 * rq + 3]);
-      }
-    };
-
     float sig0 = 0.f, sig1 = 0.f;
 
     // ---- layer 0: pos_enc(pos, 0, 10) (63) -> 256 (Dense_0)  (rnerf/models.py:257)
+    KOps cur;                                   // operands of the next k-step; across a layer seam: k-step 0 of the next layer (SeamWork)
     {
-      KOps cur = enc_ops(pd, 0, 30);
+      cur = enc_ops(pd, 0, 30);
+      SeamWork<PREC, TRAIN != 0> seam(acc0, acc1, prev0, st1);
+      seam.cv.floor_v = 0.f;
+      load_bias8(0, auxt + AUX_BIAS, seam.cv.b);
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         save_ops(SAVE_PE + s, cur);
         SLAB_PREFETCH(true);   // glds first: it is a scheduling boundary, conversion + MFMAs must share the region after it
         KOps nxt = cur;
         if (s + 1 < 4) nxt = enc_ops(pd, s + 1, 30);
-        if (!(dbg & 2)) { if (s == 0) kstep_mfma<PREC, 8, 0, true>(acc0, acc1, cur, smem + buf * SLAB, lane, nowork); else kstep_mfma<PREC, 8, 0, false>(acc0, acc1, cur, smem + buf * SLAB, lane, nowork); }
+        if (!(dbg & 2)) {
+          if (s == 0) kstep_mfma<PREC, 8, 0, true>(acc0, acc1, cur, smem + buf * SLAB, lane, nowork);
+          else if (s < 3) kstep_mfma<PREC, 8, 0, false>(acc0, acc1, cur, smem + buf * SLAB, lane, nowork);
+          else kstep_mfma<PREC, 8, 0, false>(acc0, acc1, cur, smem + buf * SLAB, lane, seam);
+        }
         SLAB_DONE();
         cur = nxt;
       }
       PH(1);
-      layer_end();
+      seam.finish();
+      cur = seam.cv.result();
       PH(4);
     }
 
@@ -649,9 +686,13 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
 #pragma unroll 1
     for (int l = 1; l <= 8; ++l) {
       const float* __restrict__ bias = auxt + AUX_BIAS + 256 * (l - 1);
-      KOps cur = prev_ops(0, bias, 0.f);
       float bnext[8];
       load_bias8(1, bias, bnext);
+      // the seam of this layer: hand-over of the outputs + conversion of the next layer's k-step 0 (bias of THIS layer; the bottleneck
+      // Dense_9 = layer 8 has no activation), run by the layer's last k-step
+      SeamWork<PREC, TRAIN != 0> seam(acc0, acc1, prev0, st1);
+      seam.cv.floor_v = l == 8 ? NEG_INF : 0.f;
+      load_bias8(0, bias + 256, seam.cv.b);
 #define RNERF_KSTEP(S)                                                                                              \
       {                                                                                                              \
         save_ops(SAVE_L1 + 16 * (l - 1) + S, cur);                                                                   \
@@ -669,7 +710,9 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
           cur = cv.result();                                                                                         \
           save_mask(l - 1, S + 1, cv.nz[0], cv.nz[1]); }                                                             \
         } else {                                                                                                     \
-          if (!(dbg & 2)) kstep_mfma<PREC, 8, 0, false>(acc0, acc1, cur, smem + buf * SLAB, lane, nowork, dma);      \
+          /* also for l == 5, whose last k-step is the 4th skip slab: that one runs the seam again on the final sums (no branch here: */ \
+          /* a run-time choice of the work functor splits the accumulators' live ranges and hipcc spills them around it) */ \
+          if (!(dbg & 2)) kstep_mfma<PREC, 8, 0, false, SeamWork<PREC, TRAIN != 0>, false, decltype(dma)>(acc0, acc1, cur, smem + buf * SLAB, lane, seam, dma); \
         }                                                                                                            \
         if constexpr (S + 2 < 16) { _Pragma("unroll") for (int j = 0; j < 8; ++j) bnext[j] = bnn[j]; }               \
         SLAB_DONE();                                                                                                 \
@@ -685,36 +728,41 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
           SLAB_PREFETCH(true);
           KOps nxt = cur;
           if (s + 1 < 4) nxt = enc_ops(pd, s + 1, 30);
-          if (!(dbg & 2)) kstep_mfma<PREC, 8, 0, false>(acc0, acc1, cur, smem + buf * SLAB, lane, nowork);
+          if (!(dbg & 2)) {
+            if (s < 3) kstep_mfma<PREC, 8, 0, false>(acc0, acc1, cur, smem + buf * SLAB, lane, nowork);
+            else kstep_mfma<PREC, 8, 0, false>(acc0, acc1, cur, smem + buf * SLAB, lane, seam);
+          }
           SLAB_DONE();
           cur = nxt;
         }
         PH(5);
       }
-      if (l == 7) {   // sigma head (Dense_8, rnerf/model_utils.py:70) on the fp32 trunk output relu(acc + b7), once per tile
-        const float* __restrict__ b7 = auxt + AUX_BIAS + 256 * 7;
+      seam.finish();
+      cur = seam.cv.result();
+      PH(4);
+      if (l == 7) {   // sigma head (Dense_8, rnerf/model_utils.py:70) on the fp32 trunk output relu(x + b7), once per tile; x = the state
+        const float* __restrict__ b7 = auxt + AUX_BIAS + 256 * 7;      // the seam just handed over (prev0 / this wave's LDS region)
 #pragma unroll
         for (int t = 0; t < 8; ++t)
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             const float4 bb = *(const float4*)(b7 + 32 * t + 8 * g + 4 * h), ww = *(const float4*)(auxt + AUX_WSIG + 32 * t + 8 * g + 4 * h);
-            const float bv[4] = {bb.x, bb.y, bb.z, bb.w}, wv[4] = {ww.x, ww.y, ww.z, ww.w};
+            const float4 s1v = st1[(t * 4 + g) * 64];
+            const float bv[4] = {bb.x, bb.y, bb.z, bb.w}, wv[4] = {ww.x, ww.y, ww.z, ww.w}, x1v[4] = {s1v.x, s1v.y, s1v.z, s1v.w};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-              sig0 = fmaf(fmaxf(fmaf(acc0[t][4 * g + i], INV_SCALE, bv[i]), 0.f), wv[i], sig0);
-              sig1 = fmaf(fmaxf(fmaf(acc1[t][4 * g + i], INV_SCALE, bv[i]), 0.f), wv[i], sig1);
+              sig0 = fmaf(fmaxf(fmaf(prev0[t][4 * g + i], INV_SCALE, bv[i]), 0.f), wv[i], sig0);
+              sig1 = fmaf(fmaxf(fmaf(x1v[i], INV_SCALE, bv[i]), 0.f), wv[i], sig1);
             }
           }
         PH(6);
       }
-      layer_end();
-      PH(4);
     }
 
     // ---- view layer: [bottleneck(256) (no activation), pos_enc(dir, 0, 4) (27)] -> 128 (Dense_10)  (rnerf/models.py:289-294)
     {
       const float* __restrict__ bias = auxt + AUX_BIAS + 256 * 8;
-      KOps c0 = prev_ops(0, bias, NEG_INF);
+      KOps c0 = cur;                             // converted by layer 8's seam
       KOps c1 = prev_ops(1, bias, NEG_INF);
 #pragma unroll
       for (int sl = 0; sl < 8; ++sl) {
