@@ -75,7 +75,8 @@ constexpr int AUX_WSIG = 2560;         // Dense_8 kernel [256]
 constexpr int AUX_BSIG = 2816;         // Dense_8 bias (+3 pad)
 constexpr int AUX_WRGB = 2820;         // Dense_11 kernel transposed [3][128]
 constexpr int AUX_BRGB = 3204;         // Dense_11 bias (+1 pad)
-constexpr int AUX_FLOATS = 3208;
+constexpr int AUX_ZERO = 3208;         // 256 zeros: the sigma weights of every layer but the trunk output (PrevConv SIG)
+constexpr int AUX_FLOATS = 3464;
 
 template <int PREC>
 struct Prec {
@@ -241,6 +242,14 @@ __device__ __forceinline__ uint32_t pk_min1(uint32_t w) {
   return r;
 }
 
+// 16-byte load through an explicitly GLOBAL pointer (a pointer that went through an asm operand is generic to hipcc: flat_load + 64-bit
+// address arithmetic per load)
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 gload4(const float* p) {
+  const f32x4v v = *(const __attribute__((address_space(1))) f32x4v*)p;
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+
 struct KOps { uint4 h0, l0, h1, l1; };
 
 // streaming accesses of the training tensors (written once, read once by a later kernel): keep them out of the L2 working set
@@ -277,9 +286,13 @@ __device__ __forceinline__ void split8(const float (&x)[8], uint4& hi, uint4& lo
 // ~5 independent VALU ops in that shadow).  hipcc does not build this interleave by itself (it emits the ~110 VALU ops as
 // one clump ahead of the 48 MFMAs and the matrix pipe idles), so the order is written out and pinned with sched_barrier.
 //   pair pi in [0,8): m-tile pi>>2, value pair pi&3 -> chunk 0: bias+scale+ReLU, chunk 1: hi + residual, chunk 2: lo
-template <int PREC, int S, bool MASK = false>
+// SIG: also accumulate sg0/sg1 += x * ws[j] (the sigma head, Dense_8, rides on the conversion of the trunk output that feeds Dense_9: the
+// same relu(acc / scale + b) values; for every other layer ws points at zeros — no branch in the shared loop body).
+template <int PREC, int S, bool MASK = false, bool SIG = false>
 struct PrevConv {
   using PP = Prec<PREC>;
+  float ws[8];
+  float sg0 = 0.f, sg1 = 0.f;
   uint32_t nz[2] = {0, 0};   // MASK (training forward): non-zero flags of the 8 hi values per m-tile, bits p and 16 + p for pair p
   const f32x16& p0;   // m-tile 0: the accumulator registers holding features 32*(S>>1) .. +31 of the previous layer
   float v1[8];        // m-tile 1: raw accumulator values of the 8 features of k-step S (from LDS)
@@ -287,13 +300,17 @@ struct PrevConv {
   __device__ __forceinline__ PrevConv(const f32x16& p) : p0(p) {}
   float floor_v;   // 0 (ReLU) or -inf (bottleneck: no activation)
   uint32_t hi[2][4], lo[2][4];
-  float x0, x1;
+  // the pair in flight, per m-tile (a 4-tile k-step runs one pair of each m-tile at a time: PairOfPairs).  Four scalars, not arrays:
+  // the inline asm below takes them by "+v", and an array member whose element goes into an asm operand stays in memory (scratch)
+  float x0m0, x1m0, x0m1, x1m1;
 
   // five dependent stages of one value pair, one stage per MFMA slot (each stage = 1-2 independent VALU ops)
   template <int C, int PI>
   __device__ __forceinline__ void chunk() {
     constexpr int mt = PI >> 2, p = PI & 3;
     constexpr float INV_SCALE = 1.0f / PP::WSCALE;
+    float& x0 = mt == 0 ? x0m0 : x0m1;
+    float& x1 = mt == 0 ? x1m0 : x1m1;
     if constexpr (C == 0) {
       const float r0 = mt == 0 ? p0[8 * (S & 1) + 2 * p] : v1[2 * p];
       const float r1 = mt == 0 ? p0[8 * (S & 1) + 2 * p + 1] : v1[2 * p + 1];
@@ -302,6 +319,13 @@ struct PrevConv {
     } else if constexpr (C == 1) {
       x0 = fmaxf(x0, floor_v);
       x1 = fmaxf(x1, floor_v);
+      if constexpr (SIG) {
+        // volatile asm: as plain fmaf() the two FMAs are sunk below the residual stage (which overwrites x0 / x1 in place), and the
+        // copies of x0 / x1 that keeps alive are spilled — 16 scratch stores per k-step
+        float& sg = mt == 0 ? sg0 : sg1;
+        asm volatile("v_fmac_f32_e32 %0, %1, %2" : "+v"(sg) : "v"(x0), "v"(ws[2 * p]));
+        asm volatile("v_fmac_f32_e32 %0, %1, %2" : "+v"(sg) : "v"(x1), "v"(ws[2 * p + 1]));
+      }
     } else if constexpr (C == 2) {
       hi[mt][p] = pack2<PP::F16>(x0, x1);
     } else if constexpr (C == 3) {
@@ -337,6 +361,16 @@ struct NoWork {
   template <int C, int PI>
   __device__ __forceinline__ void chunk() {}
 };
+// a k-step of 4 tiles (the view layer's N = 128) has half the MFMA slots: tile T carries pair T of BOTH m-tiles
+template <typename W>
+struct PairOfPairs {
+  W& w;
+  __device__ __forceinline__ PairOfPairs(W& w_) : w(w_) {}
+  template <int C, int PI>
+  __device__ __forceinline__ void chunk() {
+    if constexpr (PI < 4) { w.template chunk<C, PI>(); w.template chunk<C, PI + 4>(); }
+  }
+};
 
 // Work of the LAST k-step of a layer (the layer seam), in the shadow of its MFMAs: once the MFMAs of tile t have been issued, tile
 // t - 1 is final, so in tile t's slots
@@ -351,10 +385,12 @@ struct SeamWork {
   f32x16 (&acc1)[8];
   f32x16 (&prev0)[8];
   float4* st1;
-  PrevConv<PREC, 0, MASK> cv;      // pairs 0..3: m-tile 0 from acc0[0], pairs 4..7: m-tile 1 from acc1[0]
+  PrevConv<PREC, 0, MASK, true> cv;      // pairs 0..3: m-tile 0 from acc0[0], pairs 4..7: m-tile 1 from acc1[0]
   __device__ __forceinline__ SeamWork(f32x16 (&a0)[8], f32x16 (&a1)[8], f32x16 (&p0)[8], float4* s1) : acc0(a0), acc1(a1), prev0(p0), st1(s1), cv(a0[0]) {}
   template <int C, int T>
   __device__ __forceinline__ void move() {            // piece C of the hand-over of tile T
+    // (the m-tile 0 moves are plain assignments: hipcc sinks them to the head of the next layer, ~1 k clocks per layer; pinning them here
+    // with volatile v_accvgpr_read asm made the allocator spill in the steady k-steps: 1.57 -> 1.79 ms)
     if constexpr (C == 0) prev0[T] = acc0[T];
     else st1[(T * 4 + C - 1) * 64] = make_float4(acc1[T][4 * (C - 1)], acc1[T][4 * (C - 1) + 1], acc1[T][4 * (C - 1) + 2], acc1[T][4 * (C - 1) + 3]);
   }
@@ -662,6 +698,7 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
       SeamWork<PREC, TRAIN != 0> seam(acc0, acc1, prev0, st1);
       seam.cv.floor_v = 0.f;
       load_bias8(0, auxt + AUX_BIAS, seam.cv.b);
+      load_bias8(0, auxt + AUX_ZERO, seam.cv.ws);
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         save_ops(SAVE_PE + s, cur);
@@ -682,39 +719,48 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
       PH(4);
     }
 
+    // bias / sigma weights of the conversion that runs in the shadow of the next hidden k-step (fetched one slab ahead, across layers too)
+    float bnext[8], wnext[8];
+    load_bias8(1, auxt + AUX_BIAS, bnext);
+    load_bias8(1, auxt + AUX_ZERO, wnext);
+
     // ---- layers 1..8: Dense_1..Dense_7 (inputs ReLU'd; Dense_5 also takes the skip concat), Dense_9 = bottleneck
 #pragma unroll 1
     for (int l = 1; l <= 8; ++l) {
       const float* __restrict__ bias = auxt + AUX_BIAS + 256 * (l - 1);
-      float bnext[8];
-      load_bias8(1, bias, bnext);
       // the seam of this layer: hand-over of the outputs + conversion of the next layer's k-step 0 (bias of THIS layer; the bottleneck
       // Dense_9 = layer 8 has no activation), run by the layer's last k-step
       SeamWork<PREC, TRAIN != 0> seam(acc0, acc1, prev0, st1);
       seam.cv.floor_v = l == 8 ? NEG_INF : 0.f;
-      load_bias8(0, bias + 256, seam.cv.b);
+      // sigma head (Dense_8, rnerf/model_utils.py:70) = sum over the trunk output x7 = the inputs of layer 8: k-step 0 in layer 7's seam,
+      // k-steps 1..15 in layer 8's conversions.  (The seam's bias / sigma weights are fetched at k-step 13: 16 registers less in the steady state.)
+      const float* __restrict__ wseam = auxt + (l == 7 ? AUX_WSIG : AUX_ZERO);
+      const float* __restrict__ wsel = auxt + (l == 8 ? AUX_WSIG : AUX_ZERO);
 #define RNERF_KSTEP(S)                                                                                              \
       {                                                                                                              \
         save_ops(SAVE_L1 + 16 * (l - 1) + S, cur);                                                                   \
         if constexpr (TRAIN != 0 && S == 0) save_mask(l - 1, 0, nz_nibbles(cur.h0), nz_nibbles(cur.h1));                  \
-        float bnn[8];                                                                                                \
-        if constexpr (S + 2 < 16) load_bias8(S + 2, bias, bnn);   /* consumed in the NEXT slab */                     \
+        if constexpr (S == 13) { load_bias8(0, bias + 256, seam.cv.b); load_bias8(0, wseam, seam.cv.ws); }           \
+        float bnn[8], wnn[8];                                                                                        \
+        if constexpr (S + 2 < 16) { load_bias8(S + 2, bias, bnn); load_bias8(S + 2, wsel, wnn); }   /* consumed in the NEXT slab */ \
+        else if constexpr (S == 14) { load_bias8(1, bias + 256, bnn); load_bias8(1, wseam, wnn); }   /* k-step 1 of the NEXT layer */ \
         auto dma = [&]() { SLAB_PREFETCH(true); };                                                                   \
         if constexpr (S + 1 < 16) {                                                                                  \
-          PrevConv<PREC, S + 1, TRAIN != 0> cv(prev0[(S + 1) >> 1]);                                                      \
+          PrevConv<PREC, S + 1, TRAIN != 0, true> cv(prev0[(S + 1) >> 1]);                                           \
           cv.floor_v = 0.f;                                                                                          \
-          _Pragma("unroll") for (int j = 0; j < 8; ++j) cv.b[j] = bnext[j];                                          \
+          _Pragma("unroll") for (int j = 0; j < 8; ++j) { cv.b[j] = bnext[j]; cv.ws[j] = wnext[j]; }                 \
           load_state8(S + 1, cv.v1);                                                                                 \
           if (dbg & 8) { kstep_mfma<PREC, 8, 0, S == 0, NoWork, (dbg & 16) != 0>(acc0, acc1, cur, smem + buf * SLAB, lane, nowork, dma); } \
-          else { if (!(dbg & 2)) kstep_mfma<PREC, 8, 0, S == 0, PrevConv<PREC, S + 1, TRAIN != 0>, (dbg & 16) != 0, decltype(dma)>(acc0, acc1, cur, smem + buf * SLAB, lane, cv, dma);              \
+          else { if (!(dbg & 2)) kstep_mfma<PREC, 8, 0, S == 0, PrevConv<PREC, S + 1, TRAIN != 0, true>, (dbg & 16) != 0, decltype(dma)>(acc0, acc1, cur, smem + buf * SLAB, lane, cv, dma);              \
           cur = cv.result();                                                                                         \
+          sig0 += cv.sg0; sig1 += cv.sg1;                                                                            \
           save_mask(l - 1, S + 1, cv.nz[0], cv.nz[1]); }                                                             \
         } else {                                                                                                     \
           /* also for l == 5, whose last k-step is the 4th skip slab: that one runs the seam again on the final sums (no branch here: */ \
           /* a run-time choice of the work functor splits the accumulators' live ranges and hipcc spills them around it) */ \
           if (!(dbg & 2)) kstep_mfma<PREC, 8, 0, false, SeamWork<PREC, TRAIN != 0>, false, decltype(dma)>(acc0, acc1, cur, smem + buf * SLAB, lane, seam, dma); \
         }                                                                                                            \
-        if constexpr (S + 2 < 16) { _Pragma("unroll") for (int j = 0; j < 8; ++j) bnext[j] = bnn[j]; }               \
+        if constexpr (S + 2 <= 16) { _Pragma("unroll") for (int j = 0; j < 8; ++j) { bnext[j] = bnn[j]; wnext[j] = wnn[j]; } } \
         SLAB_DONE();                                                                                                 \
       }
       RNERF_KSTEP(0) PH(2); RNERF_KSTEP(1) RNERF_KSTEP(2) RNERF_KSTEP(3) RNERF_KSTEP(4) RNERF_KSTEP(5) RNERF_KSTEP(6) RNERF_KSTEP(7)
@@ -740,23 +786,7 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
       seam.finish();
       cur = seam.cv.result();
       PH(4);
-      if (l == 7) {   // sigma head (Dense_8, rnerf/model_utils.py:70) on the fp32 trunk output relu(x + b7), once per tile; x = the state
-        const float* __restrict__ b7 = auxt + AUX_BIAS + 256 * 7;      // the seam just handed over (prev0 / this wave's LDS region)
-#pragma unroll
-        for (int t = 0; t < 8; ++t)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const float4 bb = *(const float4*)(b7 + 32 * t + 8 * g + 4 * h), ww = *(const float4*)(auxt + AUX_WSIG + 32 * t + 8 * g + 4 * h);
-            const float4 s1v = st1[(t * 4 + g) * 64];
-            const float bv[4] = {bb.x, bb.y, bb.z, bb.w}, wv[4] = {ww.x, ww.y, ww.z, ww.w}, x1v[4] = {s1v.x, s1v.y, s1v.z, s1v.w};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              sig0 = fmaf(fmaxf(fmaf(prev0[t][4 * g + i], INV_SCALE, bv[i]), 0.f), wv[i], sig0);
-              sig1 = fmaf(fmaxf(fmaf(x1v[i], INV_SCALE, bv[i]), 0.f), wv[i], sig1);
-            }
-          }
-        PH(6);
-      }
+      sig0 += seam.cv.sg0; sig1 += seam.cv.sg1;
     }
 
     // ---- view layer: [bottleneck(256) (no activation), pos_enc(dir, 0, 4) (27)] -> 128 (Dense_10)  (rnerf/models.py:289-294)
@@ -764,21 +794,43 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
       const float* __restrict__ bias = auxt + AUX_BIAS + 256 * 8;
       KOps c0 = cur;                             // converted by layer 8's seam
       KOps c1 = prev_ops(1, bias, NEG_INF);
-#pragma unroll
-      for (int sl = 0; sl < 8; ++sl) {
-        save_ops(SAVE_L1 + 16 * 8 + 2 * sl, c0);
-        save_ops(SAVE_L1 + 16 * 8 + 2 * sl + 1, c1);
-        SLAB_PREFETCH(true);
-        KOps n0 = c0, n1 = c1;
-        if (sl + 1 < 8) { n0 = prev_ops(2 * sl + 2, bias, NEG_INF); n1 = prev_ops(2 * sl + 3, bias, NEG_INF); }
-        else { n0 = enc_ops(dr, 0, 12); n1 = enc_ops(dr, 1, 12); }
-        if (!(dbg & 2)) {
-          if (sl == 0) kstep_mfma<PREC, 4, 0, true>(acc0, acc1, c0, smem + buf * SLAB, lane, nowork); else kstep_mfma<PREC, 4, 0, false>(acc0, acc1, c0, smem + buf * SLAB, lane, nowork);
-          kstep_mfma<PREC, 4, 1, false>(acc0, acc1, c1, smem + buf * SLAB, lane, nowork);
-        }
-        SLAB_DONE();
-        c0 = n0; c1 = n1;
+      float bA[8], bB[8];                        // biases of the two k-steps converted in the shadow of the current slab
+      load_bias8(2, bias, bA);
+      load_bias8(3, bias, bB);
+#define RNERF_VSLAB(SL)                                                                                              \
+      {                                                                                                              \
+        save_ops(SAVE_L1 + 16 * 8 + 2 * SL, c0);                                                                     \
+        save_ops(SAVE_L1 + 16 * 8 + 2 * SL + 1, c1);                                                                 \
+        SLAB_PREFETCH(true);                                                                                         \
+        if constexpr (SL + 1 < 8) {                                                                                  \
+          float bA2[8], bB2[8];                                                                                      \
+          if constexpr (SL + 2 < 8) { load_bias8(2 * SL + 4, bias, bA2); load_bias8(2 * SL + 5, bias, bB2); }        \
+          PrevConv<PREC, 2 * SL + 2, false> cvA(prev0[SL + 1]);                                                      \
+          PrevConv<PREC, 2 * SL + 3, false> cvB(prev0[SL + 1]);                                                      \
+          cvA.floor_v = NEG_INF; cvB.floor_v = NEG_INF;                                                              \
+          _Pragma("unroll") for (int j = 0; j < 8; ++j) { cvA.b[j] = bA[j]; cvB.b[j] = bB[j]; }                      \
+          load_state8(2 * SL + 2, cvA.v1);                                                                           \
+          load_state8(2 * SL + 3, cvB.v1);                                                                           \
+          PairOfPairs<decltype(cvA)> wA(cvA);                                                                        \
+          PairOfPairs<decltype(cvB)> wB(cvB);                                                                        \
+          if (!(dbg & 2)) {                                                                                          \
+            kstep_mfma<PREC, 4, 0, SL == 0>(acc0, acc1, c0, smem + buf * SLAB, lane, wA);                            \
+            kstep_mfma<PREC, 4, 1, false>(acc0, acc1, c1, smem + buf * SLAB, lane, wB);                              \
+          }                                                                                                          \
+          c0 = cvA.result(); c1 = cvB.result();                                                                      \
+          if constexpr (SL + 2 < 8) { _Pragma("unroll") for (int j = 0; j < 8; ++j) { bA[j] = bA2[j]; bB[j] = bB2[j]; } } \
+        } else {                                                                                                     \
+          const KOps n0 = enc_ops(dr, 0, 12), n1 = enc_ops(dr, 1, 12);                                               \
+          if (!(dbg & 2)) {                                                                                          \
+            kstep_mfma<PREC, 4, 0, false>(acc0, acc1, c0, smem + buf * SLAB, lane, nowork);                          \
+            kstep_mfma<PREC, 4, 1, false>(acc0, acc1, c1, smem + buf * SLAB, lane, nowork);                          \
+          }                                                                                                          \
+          c0 = n0; c1 = n1;                                                                                          \
+        }                                                                                                            \
+        SLAB_DONE();                                                                                                 \
       }
+      RNERF_VSLAB(0) RNERF_VSLAB(1) RNERF_VSLAB(2) RNERF_VSLAB(3) RNERF_VSLAB(4) RNERF_VSLAB(5) RNERF_VSLAB(6) RNERF_VSLAB(7)
+#undef RNERF_VSLAB
       // last slab of the tile (the two view-encoding k-steps): prefetch the first slab of the next tile (stream restarts)
       save_ops(SAVE_VIEW, c0);
       save_ops(SAVE_VIEW + 1, c1);
@@ -791,16 +843,29 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
 
     // ---- heads: sigma (Dense_8, accumulated above) and rgb (Dense_11) on the fp32 view-layer output
     {
-      const float* __restrict__ b9 = auxt + AUX_BIAS + 256 * 9;
+      // the 16 weight / bias vectors of n-tile t + 1 are fetched while n-tile t is reduced (left to itself hipcc loads two vectors, waits,
+      // uses them, loads the next two: 32 exposed round trips, 18 k clocks per tile)
+      const float* __restrict__ hw = auxt + 4 * h;
+      auto head_load = [&](int t, float4 (&W)[16]) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = 32 * t + 8 * g;
+          W[4 * g] = gload4(hw + AUX_BIAS + 256 * 9 + n);
+          W[4 * g + 1] = gload4(hw + AUX_WRGB + n); W[4 * g + 2] = gload4(hw + AUX_WRGB + 128 + n); W[4 * g + 3] = gload4(hw + AUX_WRGB + 256 + n);
+        }
+      };
       float p0[3] = {0.f, 0.f, 0.f}, p1[3] = {0.f, 0.f, 0.f};
+      float4 Wc[16];
+      head_load(0, Wc);
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
+        float4 Wn[16];
+        if (t + 1 < 4) head_load(t + 1, Wn);
+        RNERF_PIN();
         float rv0[16], rv1[16];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const int n = 32 * t + 8 * g + 4 * h;
-          const float4 bb = *(const float4*)(b9 + n);
-          const float4 wr = *(const float4*)(auxt + AUX_WRGB + n), wg = *(const float4*)(auxt + AUX_WRGB + 128 + n), wb = *(const float4*)(auxt + AUX_WRGB + 256 + n);
+          const float4 bb = Wc[4 * g], wr = Wc[4 * g + 1], wg = Wc[4 * g + 2], wb = Wc[4 * g + 3];
           const float bv[4] = {bb.x, bb.y, bb.z, bb.w}, wrv[4] = {wr.x, wr.y, wr.z, wr.w}, wgv[4] = {wg.x, wg.y, wg.z, wg.w}, wbv[4] = {wb.x, wb.y, wb.z, wb.w};
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
@@ -810,6 +875,10 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
             p1[0] = fmaf(v1, wrv[i], p1[0]); p1[1] = fmaf(v1, wgv[i], p1[1]); p1[2] = fmaf(v1, wbv[i], p1[2]);
             rv0[4 * g + i] = v0; rv1[4 * g + i] = v1;
           }
+        }
+        if (t + 1 < 4) {
+#pragma unroll
+          for (int q = 0; q < 16; ++q) Wc[q] = Wn[q];
         }
         if constexpr (TRAIN != 0) {   // rgb-head input (ReLU'd view-layer output) in operand-slot order: k-step 2t + half, slot j = reg & 7
 #pragma unroll
