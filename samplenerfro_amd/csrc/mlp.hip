@@ -1066,6 +1066,15 @@ nerfmlp_dgrad_kernel(const char* __restrict__ packed_bwd, const float* __restric
   __syncthreads();
 
   float mref = 0.f;
+  // -DRNERF_DGRAD_PROFILE (ablation build): clocks per phase of a tile, written over the head of the dy buffer (results are garbage)
+  //   0 rows + head gradients  1 first k-step operands of a layer (grad_ops(0), masks)  2 k-steps  3 layer end  4 dY_0 record
+#ifdef RNERF_DGRAD_PROFILE
+  float dprof[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  unsigned long long dlast = __builtin_amdgcn_s_memtime();
+#define DPH(K) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); dprof[K] += (float)(t_ - dlast); dlast = t_; } while (0)
+#else
+#define DPH(K) do {} while (0)
+#endif
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const bool has_next_tile = tile + (int)gridDim.x < n_tiles;
     const long long srow0 = (long long)tile * 256 + wave * 64 + m;
@@ -1174,7 +1183,9 @@ nerfmlp_dgrad_kernel(const char* __restrict__ packed_bwd, const float* __restric
           }
           acc0[t][r] = a; acc1[t][r] = b;
         }
+      DPH(0);
       layer_end();
+      DPH(3);
     }
 
     // ---- dgrad of MFMA layer 9 (Dense_10): k-steps over its 128 outputs; state masked by the saved rgb-head input
@@ -1182,6 +1193,7 @@ nerfmlp_dgrad_kernel(const char* __restrict__ packed_bwd, const float* __restric
       uint4 ma, mb;
       mask_at(8, ma, mb);
       KOps cur = grad_ops(0, true, ma, mb, nullptr);
+      DPH(1);
 #define RNERF_DG_KSTEP(S, NSTEPS, SLOT0, PREFETCH_STMT)                                                                       \
       {                                                                                                                         \
         dy_store((SLOT0) + S, cur);                                                                                             \
@@ -1192,9 +1204,12 @@ nerfmlp_dgrad_kernel(const char* __restrict__ packed_bwd, const float* __restric
             const float4 u0 = st1[(((S + 1) >> 1) * 4 + 2 * ((S + 1) & 1)) * 64], u1 = st1[(((S + 1) >> 1) * 4 + 2 * ((S + 1) & 1) + 1) * 64]; \
             cv.v1[0] = u0.x; cv.v1[1] = u0.y; cv.v1[2] = u0.z; cv.v1[3] = u0.w; cv.v1[4] = u1.x; cv.v1[5] = u1.y; cv.v1[6] = u1.z; cv.v1[7] = u1.w; \
           }                                                                                                                     \
-          _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                                       \
-            const float wv = wadd ? wadd[16 * (S + 1) + 8 * (j >> 2) + 4 * h + (j & 3)] : 0.f;                                  \
-            cv.t0[j] = g[0].w * wv; cv.t1[j] = g[1].w * wv;                                                                     \
+          if (wadd) {   /* ONE test per k-step (per value it was 8 branches), two vector loads; only layer 7 takes it */         \
+            const float4 wa = *(const float4*)(wadd + 16 * (S + 1) + 4 * h), wb = *(const float4*)(wadd + 16 * (S + 1) + 8 + 4 * h); \
+            const float wv[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};                                               \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) { cv.t0[j] = g[0].w * wv[j]; cv.t1[j] = g[1].w * wv[j]; }             \
+          } else {                                                                                                              \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) { cv.t0[j] = 0.f; cv.t1[j] = 0.f; }                                   \
           }                                                                                                                     \
           cv.w0 = ((S + 1) >> 2) == 0 ? ma.x : (((S + 1) >> 2) == 1 ? ma.y : (((S + 1) >> 2) == 2 ? ma.z : ma.w));             \
           cv.w1 = ((S + 1) >> 2) == 0 ? mb.x : (((S + 1) >> 2) == 1 ? mb.y : (((S + 1) >> 2) == 2 ? mb.z : mb.w));             \
@@ -1212,7 +1227,9 @@ nerfmlp_dgrad_kernel(const char* __restrict__ packed_bwd, const float* __restric
         RNERF_DG_KSTEP(4, 8, DY_L9, SLAB_PREFETCH(true)) RNERF_DG_KSTEP(5, 8, DY_L9, SLAB_PREFETCH(true))
         RNERF_DG_KSTEP(6, 8, DY_L9, SLAB_PREFETCH(true)) RNERF_DG_KSTEP(7, 8, DY_L9, SLAB_PREFETCH(true))
       }
+      DPH(2);
       layer_end();
+      DPH(3);
     }
 
     // ---- dgrad of MFMA layers 8..1: dY_l = (dX_{l+1} [+ d sigma * w_sigma for l = 7]) * 1[X_{l+1} > 0]  (no mask for the bottleneck l = 8)
@@ -1226,6 +1243,7 @@ nerfmlp_dgrad_kernel(const char* __restrict__ packed_bwd, const float* __restric
       mask_at(l - 1, nma, nmb);
       KOps cur = grad_ops(0, true, ma, mb, wadd);
       const int slot0 = 16 * l;
+      DPH(1);
 #define RNERF_DG_PF(S) do { if ((S) == 15 && l == 1) { if (has_next_tile) off = 0; SLAB_PREFETCH(has_next_tile); } else SLAB_PREFETCH(true); } while (0)
       RNERF_DG_KSTEP(0, 16, slot0, RNERF_DG_PF(0)) RNERF_DG_KSTEP(1, 16, slot0, RNERF_DG_PF(1)) RNERF_DG_KSTEP(2, 16, slot0, RNERF_DG_PF(2))
       RNERF_DG_KSTEP(3, 16, slot0, RNERF_DG_PF(3)) RNERF_DG_KSTEP(4, 16, slot0, RNERF_DG_PF(4)) RNERF_DG_KSTEP(5, 16, slot0, RNERF_DG_PF(5))
@@ -1234,7 +1252,9 @@ nerfmlp_dgrad_kernel(const char* __restrict__ packed_bwd, const float* __restric
       RNERF_DG_KSTEP(12, 16, slot0, RNERF_DG_PF(12)) RNERF_DG_KSTEP(13, 16, slot0, RNERF_DG_PF(13)) RNERF_DG_KSTEP(14, 16, slot0, RNERF_DG_PF(14))
       RNERF_DG_KSTEP(15, 16, slot0, RNERF_DG_PF(15))
 #undef RNERF_DG_PF
+      DPH(2);
       layer_end();
+      DPH(3);
     }
 #undef RNERF_DG_KSTEP
 
@@ -1244,6 +1264,7 @@ nerfmlp_dgrad_kernel(const char* __restrict__ packed_bwd, const float* __restric
       const KOps o = grad_ops(s, true, nma, nmb, nullptr);
       dy_store(s, o);
     }
+    DPH(4);
 #undef SLAB_PREFETCH
 #undef SLAB_DONE
   }
@@ -1253,6 +1274,14 @@ nerfmlp_dgrad_kernel(const char* __restrict__ packed_bwd, const float* __restric
     if (lane == 0 && mref > 0.f)
       atomicMax((unsigned int*)((float*)(dy + dy_plane_uint4(save_rows, BW::NP)) + save_rows), __builtin_bit_cast(unsigned int, mref));
   }
+#ifdef RNERF_DGRAD_PROFILE
+  if (lane == 0) {
+    float4* pr = (float4*)dy + (blockIdx.x * 4 + wave) * 2;
+    pr[0] = make_float4(dprof[0], dprof[1], dprof[2], dprof[3]);
+    pr[1] = make_float4(dprof[4], dprof[5], dprof[6], dprof[7]);
+  }
+#endif
+#undef DPH
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -36,3 +36,11 @@ print("forward        %.3f ms" % timeit(lambda: ops.nerfmlp_forward(packed, P, p
 print("forward_train  %.3f ms" % timeit(lambda: lib.rnerf_nerfmlp_forward_train(packed.data_ptr(), P, pd.data_ptr(), dr.data_ptr(), None, S, B, raw.data_ptr(), save.data_ptr(), BW, None)))
 print("dgrad          %.3f ms" % timeit(lambda: ops.nerfmlp_backward(pbwd, packed, P, save, d_raw, rows, dy=dy, stages="d", backward=BW)))
 print("wgrad+reduce   %.3f ms" % timeit(lambda: ops.nerfmlp_backward(pbwd, packed, P, save, d_raw, rows, grads=grads, workspace=ws, dy=dy, stages="w", backward=BW)))
+
+if os.environ.get("DGRAD_PROFILE"):       # library built with -DRNERF_DGRAD_PROFILE (tools/r02/build_ablate.sh)
+    ops.nerfmlp_backward(pbwd, packed, P, save, d_raw, rows, dy=dy, stages="d", backward=BW); torch.cuda.synchronize()
+    pr = dy[:256 * 4 * 32].view(torch.float32).reshape(-1, 8).cpu().numpy()[:, :5]
+    per_tile = pr.sum(0) / pr.shape[0] / (rows / 256 / 256)
+    for n, v in zip(["rows + head gradients", "first operands of a layer (grad_ops(0), masks)", "k-steps", "layer end", "dY_0 record"], per_tile):
+        print(f"  {n:48s} {v:9.0f} clk/tile {100 * v / per_tile.sum():5.1f} %")
+    print(f"  total {per_tile.sum():.0f} clk/tile")
