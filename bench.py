@@ -351,7 +351,10 @@ def main():
         t_d = timed(lambda: ops.nerfmlp_backward(pbwd, packed, model.precision, save_t, d_raw, rows, dy=dy_t, stages="d", backward=BW))
         t_w = timed(lambda: ops.nerfmlp_backward(pbwd, packed, model.precision, save_t, d_raw, rows, grads=g_t, workspace=ws_t, dy=dy_t, stages="w", backward=BW))
         R_pad = (rows + 255) // 256 * 256
-        wgrad_bytes = (8 * 32 + 2 * 20 + 17 + 24 + 10 + 9) * R_pad * 32 * (2 if args.backward == "f32" else 1)   # sum over the 14 jobs of (X slots + dY slots) x R x 32 B (x 2: hi + lo)
+        # sum over the wgrad jobs of (X slots + dY slots) x R x 32 B (x 2: hi + lo).  f16 modes: 11 jobs (the Dense_5 / Dense_10 concat rows and
+        # the sigma head share their operand streams with the main block: 316 slot planes); bf16 body: 14 single-segment jobs (356)
+        wgrad_slots = (8 * 32 + 2 * 20 + 17 + 24 + 10 + 9) if args.backward == "bf16" else (20 + 4 * 32 + 36 + 2 * 32 + 33 + 26 + 9)
+        wgrad_bytes = wgrad_slots * R_pad * 32 * (2 if args.backward == "f32" else 1)
         for name, ms, flop, bound, byt in (("nerfmlp_fwd_kernel<train>", t_f, MLP_FLOP_PER_ROW * rows, "mfma", None),
                                            ("nerfmlp_dgrad_kernel", t_d, 2 * 557696 * rows, "mfma", None),
                                            ("nerfmlp_wgrad_kernel" if args.backward == "bf16" else "nerfmlp_wgrad_tr_kernel", t_w, MLP_FLOP_PER_ROW * rows, "hbm", wgrad_bytes)):

@@ -1314,11 +1314,17 @@ struct WgradJob {
   int row_off;    // kernel row offset of this X block (256 for the concat parts)
   int dkind;      // 0 = layer outputs (prev_feature order), 1 = sigma head (slot 0 of the head grads), 2 = rgb head (slots 1..3)
   int KT, NT, write_bias;
+  // merged jobs of the transpose-read kernel (an operand stream that two Dense blocks share is read once): the k-tiles from KTa on are
+  // a second X segment (xkind2 / row_off2: the concat rows of the same Dense), the n-tiles from NTa on a second dY segment (dense2 /
+  // dkind2: the sigma head beside Dense_9).  Single-segment jobs have KTa = KT, NTa = NT.
+  int KTa, xkind2, row_off2, NTa, dense2, dkind2;
+  int bias_sigma;  // rgb-head job: column 0 of its bias row is the sigma head's bias gradient (Dense_8), written from here
 };
-// all jobs of one NerfMLP in ONE launch: workgroups [wg0[j], wg0[j+1]) belong to job j (shares proportional to its MFMA count)
+// all jobs of one NerfMLP in ONE launch: workgroups [wg0[j], wg0[j+1]) belong to job j
 struct WgradTable {
   int n;
   int qx[16], KSx[16], qd[16], KSd[16], wg0[17];
+  int qx2[16], qd2[16], KSd2[16];         // slot bases of the second segments, k-steps of the second dY segment
   long long poff[16], pboff[16];          // float offsets of the job's partial blocks in the workspace
   WgradJob job[16];
 };
@@ -1435,14 +1441,16 @@ __device__ __forceinline__ void wgrad_body(const uint4* __restrict__ saved, cons
 //     TK TN MFMAs (x 3 in the hi + lo mode).
 // (Round 2's first form transposed on the matrix cores like wgrad_body below, through registers and LDS writes: 3.5 ms for the hi + lo
 // mode on the bench workload against 2.2 ms for this one, which runs at ~5.2 TB/s of operand stream.)
+// NT == 9 (Dense_9 + the sigma head): the 8 x 8 split, and the ninth n-tile as ONE extra tile per wave (k-tile 2 wk + wn, one of its own)
 template <int KT, int NT> struct WgTrShape {
-  static constexpr int WK = KT >= 8 ? (NT >= 4 ? 4 : 8) : (KT >= 4 ? 4 : KT);
-  static constexpr int WN = (8 / WK) < NT ? (8 / WK) : NT;
-  static constexpr int TK = KT / WK, TN = NT / WN;
-  static_assert(WK * TK == KT && WN * TN == NT && WK * WN <= 8, "tile split");
+  static constexpr int EXTRA = NT == 9 ? 1 : 0, NTR = NT - EXTRA;
+  static constexpr int WK = KT == 10 ? 2 : (KT == 9 ? 3 : (KT >= 8 ? (NTR >= 4 ? 4 : 8) : (KT >= 4 ? 4 : KT)));
+  static constexpr int WN = (8 / WK) < NTR ? (8 / WK) : NTR;
+  static constexpr int TK = KT / WK, TN = NTR / WN;
+  static_assert(WK * TK == KT && WN * TN == NTR && WK * WN <= 8 && (!EXTRA || (TK == 2 && WN == 2)), "tile split");
 };
 template <int NP> constexpr int wgtr_nbuf() { return NP == 2 ? 4 : 8; }       // ring depth: what fits 160 KiB
-template <int NP> constexpr int wgtr_lds_bytes() { return wgtr_nbuf<NP>() * ((8 + 8) * NP + 1) * 1024; }
+template <int NP> constexpr int wgtr_lds_bytes() { return wgtr_nbuf<NP>() * ((10 + 8) * NP + 1) * 1024; }       // largest job: 10 k-tiles + 8 n-tiles
 
 __device__ __forceinline__ half8 tr_read8(const char* p) {      // rows k .. k+3 at p, rows k+4 .. k+7 at p + 256 (4 rows x 64 B)
   typedef short short4v __attribute__((ext_vector_type(4)));
@@ -1458,10 +1466,11 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("" ::: "memory");
 }
 
-template <int NP, int KT, int KSd>
+struct WgTrSegs { int qx, KTa, qx2, qd, NTa, KSd, qd2, KSd2; };    // slot bases / extents of the (up to two) X and dY segments of a job
+
+template <int NP, int KT, int NT>
 __device__ __forceinline__ void wgrad_body_tr(const uint4* __restrict__ saved, const uint4* __restrict__ dy, long long R, float* __restrict__ pg,
-                                               float* __restrict__ pbias, int qx, int qd, int g, int G, char* smem) {
-  constexpr int NT = (KSd + 1) / 2;
+                                               float* __restrict__ pbias, const WgTrSegs sg, int g, int G, char* smem) {
   using SH = WgTrShape<KT, NT>;
   constexpr int TK = SH::TK, TN = SH::TN;
   constexpr int NBLK = (KT + NT) * NP, NDMA = (NBLK + 7) / 8, STEP_BYTES = (NBLK + 1) * 1024;   // + the row-scale block (64 B used)
@@ -1485,11 +1494,14 @@ __device__ __forceinline__ void wgrad_body_tr(const uint4* __restrict__ saved, c
       b = b < NBLK ? b : NBLK - 1;
       const int t = b / NP, part = b % NP;
       if (t < KT) {
-        src[i] = saved + (part ? sv_lo0(R) : 0) + sv_addr(qx + 2 * t + a, 0, r, h);
+        const int slot = t < sg.KTa ? sg.qx + 2 * t + a : sg.qx2 + 2 * (t - sg.KTa) + a;
+        src[i] = saved + (part ? sv_lo0(R) : 0) + sv_addr(slot, 0, r, h);
         tstride[i] = (size_t)SAVE_SLOTS * 64;
-      } else {
-        const int slot = 2 * (t - KT) + a;
-        src[i] = dy + (part ? dy_plane_uint4(R, 1) : 0) + dy_addr(qd + (slot < KSd ? slot : KSd - 1), 0, r, h);
+      } else {     // a slot beyond the segment's k-steps repeats its last one: those columns are dropped by the reduction
+        const int nt = t - KT;
+        const int rel = nt < sg.NTa ? 2 * nt + a : 2 * (nt - sg.NTa) + a;
+        const int slot = nt < sg.NTa ? sg.qd + (rel < sg.KSd ? rel : sg.KSd - 1) : sg.qd2 + (rel < sg.KSd2 ? rel : sg.KSd2 - 1);
+        src[i] = dy + (part ? dy_plane_uint4(R, 1) : 0) + dy_addr(slot, 0, r, h);
         tstride[i] = (size_t)DY_SLOTS * 64;
       }
       lds_blk[i] = (unsigned)b * 1024u;
@@ -1511,7 +1523,7 @@ __device__ __forceinline__ void wgrad_body_tr(const uint4* __restrict__ saved, c
     if (wave == 0) glds16_nt((const char*)(rs_src + t32 * 32 + (sc & 1) * 16), __builtin_amdgcn_readfirstlane(ring + NBLK * 1024u));
   };
   const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  f32x16 acc[TK][TN], accb = zero;
+  f32x16 acc[TK][TN], accb = zero, acce = zero;            // acce: the extra tile (k-tile wk TK + wn) x (n-tile NT - 1)
 #pragma unroll
   for (int i = 0; i < TK; ++i)
 #pragma unroll
@@ -1533,7 +1545,7 @@ __device__ __forceinline__ void wgrad_body_tr(const uint4* __restrict__ saved, c
         const float4 s0 = *(const float4*)(ring0 + NBLK * 1024 + kh * 32), s1 = *(const float4*)(ring0 + NBLK * 1024 + kh * 32 + 16);
         const half8 sc8 = {(_Float16)(s0.x * inv_mref), (_Float16)(s0.y * inv_mref), (_Float16)(s0.z * inv_mref), (_Float16)(s0.w * inv_mref),
                            (_Float16)(s1.x * inv_mref), (_Float16)(s1.y * inv_mref), (_Float16)(s1.z * inv_mref), (_Float16)(s1.w * inv_mref)};
-        half8 ah[TK], al[TK], bh[TN], bl[TN];
+        half8 ah[TK], al[TK], bh[TN], bl[TN], beh, bel;
 #pragma unroll
         for (int i = 0; i < TK; ++i) {
           const char* p = ring + (wk * TK + i) * NP * 1024;
@@ -1546,10 +1558,24 @@ __device__ __forceinline__ void wgrad_body_tr(const uint4* __restrict__ saved, c
           bh[j] = tr_read8(p);
           if constexpr (NP == 2) bl[j] = tr_read8(p + 1024);
         }
+        if constexpr (SH::EXTRA) {
+          const char* p = ring + (KT + NT - 1) * NP * 1024;
+          beh = tr_read8(p);
+          if constexpr (NP == 2) bel = tr_read8(p + 1024);
+        }
 #pragma unroll
         for (int i = 0; i < TK; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j) acc[i][j] = mfma_h8(ah[i], bh[j], acc[i][j]);
+        if constexpr (SH::EXTRA) {          // wn picks which of the wave's two k-tiles (a select on registers, no branch)
+          const half8 aeh = wn ? ah[1] : ah[0];
+          acce = mfma_h8(aeh, beh, acce);
+          if constexpr (NP == 2) {
+            const half8 ael = wn ? al[1] : al[0];
+            acce = mfma_h8(aeh, bel, acce);
+            acce = mfma_h8(ael, beh, acce);
+          }
+        }
         if constexpr (NP == 2) {
 #pragma unroll
           for (int i = 0; i < TK; ++i)
@@ -1560,7 +1586,8 @@ __device__ __forceinline__ void wgrad_body_tr(const uint4* __restrict__ saved, c
 #pragma unroll
             for (int j = 0; j < TN; ++j) acc[i][j] = mfma_h8(al[i], bh[j], acc[i][j]);
         }
-        // bias row: wave (wk, wn) owns it for n-tile wn TN + wk (every n-tile has one owner when WK >= TN)
+        // bias row: wave (wk, wn) owns it for n-tile wn TN + wk, wk < TN (the 9th n-tile of the Dense_9 + sigma job has no owner: the
+        // sigma bias comes out of the rgb-head job, which reads the same head-gradient slot)
         static_assert(SH::WK >= TN, "bias owners");
         half8 ab;
 #pragma unroll
@@ -1587,6 +1614,13 @@ __device__ __forceinline__ void wgrad_body_tr(const uint4* __restrict__ saved, c
           const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
           pg[(size_t)((wk * TK + i) * 32 + row) * ldn + (wn * TN + j) * 32 + m] = acc[i][j][r];
         }
+    if constexpr (SH::EXTRA) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        pg[(size_t)((wk * TK + wn) * 32 + row) * ldn + (NT - 1) * 32 + m] = acce[r];
+      }
+    }
     if (wk < TN && h == 0) pbias[(wn * TN + wk) * 32 + m] = accb[0];
   }
 }
@@ -1599,18 +1633,19 @@ nerfmlp_wgrad_tr_kernel(const uint4* __restrict__ saved, const uint4* __restrict
   if (trace && threadIdx.x == 0) trace[2 * blockIdx.x] = (long long)__builtin_amdgcn_s_memrealtime();
   int j = 0;
   while ((int)blockIdx.x >= tab.wg0[j + 1]) ++j;
-  const int qx = tab.qx[j], KSx = tab.KSx[j], qd = tab.qd[j], KSd = tab.KSd[j];
+  const WgradJob job = tab.job[j];
   const int g = blockIdx.x - tab.wg0[j], G = tab.wg0[j + 1] - tab.wg0[j];
-  const int KT = KSx >> 1, NT = (KSd + 1) >> 1;
+  const int KT = job.KT, NT = job.NT;
   float* pg = workspace + tab.poff[j] + (size_t)g * (size_t)KT * 32 * NT * 32;
   float* pb = workspace + tab.pboff[j] + (size_t)g * NT * 32;
-#define RNERF_WGRAD_CASE(KT_, KSD_)                                                                                                 \
-  if (KSx == 2 * (KT_) && KSd == (KSD_)) {                                                                                          \
-    wgrad_body_tr<NP, KT_, KSD_>(saved, dy, R, pg, pb, qx, qd, g, G, smem);                                                         \
+  const WgTrSegs sg = {tab.qx[j], job.KTa, tab.qx2[j], tab.qd[j], job.NTa, tab.KSd[j], tab.qd2[j], tab.KSd2[j]};
+#define RNERF_WGRAD_CASE(KT_, NT_)                                                                                                  \
+  if (KT == (KT_) && NT == (NT_)) {                                                                                                 \
+    wgrad_body_tr<NP, KT_, NT_>(saved, dy, R, pg, pb, sg, g, G, smem);                                                              \
     if (trace && threadIdx.x == 0) trace[2 * blockIdx.x + 1] = (long long)__builtin_amdgcn_s_memrealtime();                         \
     return;                                                                                                                         \
   }
-  RNERF_WGRAD_CASE(8, 16) RNERF_WGRAD_CASE(2, 16) RNERF_WGRAD_CASE(8, 1) RNERF_WGRAD_CASE(8, 8) RNERF_WGRAD_CASE(1, 8) RNERF_WGRAD_CASE(4, 1)
+  RNERF_WGRAD_CASE(8, 8) RNERF_WGRAD_CASE(2, 8) RNERF_WGRAD_CASE(10, 8) RNERF_WGRAD_CASE(8, 9) RNERF_WGRAD_CASE(9, 4) RNERF_WGRAD_CASE(4, 1)
 #undef RNERF_WGRAD_CASE
   __builtin_trap();
 }
@@ -1644,12 +1679,17 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
   const float* __restrict__ partial_bias = workspace + tab.pboff[jb];
   const int ldn = job.NT * 32, rows = job.KT * 32;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  const int in_dim = nerf_dense(job.dense).in, out_dim = nerf_dense(job.dense).out;
-  auto out_feature = [&](int J) -> int {
-    const int nt = J >> 5, c = J & 31, a = c >> 4, hh = (c >> 3) & 1, j = c & 7;
-    if (job.dkind == 0) { const int n = prev_feature(2 * nt + a, hh, j); return n < out_dim ? n : -1; }
+  // column J of the partial -> (Dense index, output feature) through the dY segment it lies in
+  auto out_feature = [&](int J, int& dense) -> int {
+    int nt = J >> 5;
+    const int c = J & 31, a = c >> 4, hh = (c >> 3) & 1, j = c & 7;
+    const bool segb = nt >= job.NTa;
+    const int dkind = segb ? job.dkind2 : job.dkind;
+    dense = segb ? job.dense2 : job.dense;
+    if (segb) nt -= job.NTa;
+    if (dkind == 0) { const int n = prev_feature(2 * nt + a, hh, j); return n < nerf_dense(dense).out ? n : -1; }
     if (a != 0 || hh != 0 || nt != 0) return -1;
-    if (job.dkind == 1) return j == 0 ? 0 : -1;
+    if (dkind == 1) return j == 0 ? 0 : -1;
     return (j >= 1 && j <= 3) ? j - 1 : -1;
   };
   auto sum_over = [&](const float* __restrict__ p, size_t stride) -> float {
@@ -1661,17 +1701,25 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
   };
   if (e < rows * ldn) {
     const int I = e / ldn, J = e % ldn;
-    const int kt = I >> 5, c = I & 31, a = c >> 4, hh = (c >> 3) & 1, j = c & 7, s = 2 * kt + a;
-    int fin = job.xkind == 1 ? prev_feature(s, hh, j) : (job.xkind == 0 ? pe_feature(8 * s + j, hh) : view_feature(8 * s + j, hh));
-    const int fout = out_feature(J);
+    int kt = I >> 5;
+    const int c = I & 31, a = c >> 4, hh = (c >> 3) & 1, j = c & 7;
+    const bool segb = kt >= job.KTa;
+    const int xkind = segb ? job.xkind2 : job.xkind, row_off = segb ? job.row_off2 : job.row_off;
+    if (segb) kt -= job.KTa;
+    const int s = 2 * kt + a;
+    int fin = xkind == 1 ? prev_feature(s, hh, j) : (xkind == 0 ? pe_feature(8 * s + j, hh) : view_feature(8 * s + j, hh));
+    int dense;
+    const int fout = out_feature(J, dense);
     if (fin >= 0 && fout >= 0) {
-      fin += job.row_off;
-      if (fin < in_dim) grads[nerf_koff(job.dense) + fin * out_dim + fout] = sum_over(partial + e, (size_t)rows * ldn) * osc;
+      fin += row_off;
+      if (fin < nerf_dense(dense).in) grads[nerf_koff(dense) + fin * nerf_dense(dense).out + fout] = sum_over(partial + e, (size_t)rows * ldn) * osc;
     }
   }
   if (job.write_bias && e < ldn) {
-    const int fout = out_feature(e);
-    if (fout >= 0) grads[nerf_boff(job.dense) + fout] = sum_over(partial_bias + e, (size_t)ldn) * osc;
+    int dense;
+    const int fout = out_feature(e, dense);
+    if (fout >= 0 && (e >> 5) < job.NTa) grads[nerf_boff(dense) + fout] = sum_over(partial_bias + e, (size_t)ldn) * osc;
+    if (job.bias_sigma && e == 0) grads[nerf_boff(8)] = sum_over(partial_bias, (size_t)ldn) * osc;      // column 0 of the head slot = d raw_sigma
   }
 }
 
@@ -2533,26 +2581,44 @@ extern "C" int rnerf_nerfmlp_dgrad(const void* packed_bwd, const void* packed_fw
   return launch_dgrad<RNERF_BWD_BF16>(packed_bwd, fwd_aux, save, d_raw, rows, dy, st);
 }
 
-// the 15 wgrad jobs of one NerfMLP: {x slot base, x k-steps, dy slot base, dy k-steps, job}
-struct WgradPlan { int qx, KSx, qd, KSd; WgradJob job; };
+// the wgrad jobs of one NerfMLP: {x slot base, x k-steps, dy slot base, dy k-steps, job, second-segment bases}
+struct WgradPlan { int qx, KSx, qd, KSd; WgradJob job; int qx2, qd2, KSd2; };
+static constexpr WgradJob job1(int dense, int xkind, int row_off, int dkind, int KT, int NT, int wb, int bias_sigma = 0) {
+  return WgradJob{dense, xkind, row_off, dkind, KT, NT, wb, KT, 0, 0, NT, 0, 0, bias_sigma};
+}
+// 14 single-segment jobs: the bf16 body (MFMA transposition)
 static const WgradPlan kWgradPlan[15] = {
-    {SAVE_PE, 4, 0, 16, {0, 0, 0, 0, 2, 8, 1}},
-    {SAVE_L1 + 0, 16, 16, 16, {1, 1, 0, 0, 8, 8, 1}},   {SAVE_L1 + 16, 16, 32, 16, {2, 1, 0, 0, 8, 8, 1}},
-    {SAVE_L1 + 32, 16, 48, 16, {3, 1, 0, 0, 8, 8, 1}},  {SAVE_L1 + 48, 16, 64, 16, {4, 1, 0, 0, 8, 8, 1}},
-    {SAVE_L1 + 64, 16, 80, 16, {5, 1, 0, 0, 8, 8, 1}},  {SAVE_PE, 4, 80, 16, {5, 0, 256, 0, 2, 8, 0}},
-    {SAVE_L1 + 80, 16, 96, 16, {6, 1, 0, 0, 8, 8, 1}},  {SAVE_L1 + 96, 16, 112, 16, {7, 1, 0, 0, 8, 8, 1}},
-    {SAVE_L1 + 112, 16, 128, 16, {9, 1, 0, 0, 8, 8, 1}}, {SAVE_L1 + 112, 16, DY_HEADS, 1, {8, 1, 0, 1, 8, 1, 1}},
-    {SAVE_L1 + 128, 16, DY_L9, 8, {10, 1, 0, 0, 8, 4, 1}}, {SAVE_VIEW, 2, DY_L9, 8, {10, 2, 256, 0, 1, 4, 0}},
-    {SAVE_RGBIN, 8, DY_HEADS, 1, {11, 1, 0, 2, 4, 1, 1}},
-    {0, 0, 0, 0, {0, 0, 0, 0, 0, 0, 0}}};
+    {SAVE_PE, 4, 0, 16, job1(0, 0, 0, 0, 2, 8, 1), 0, 0, 0},
+    {SAVE_L1 + 0, 16, 16, 16, job1(1, 1, 0, 0, 8, 8, 1), 0, 0, 0},   {SAVE_L1 + 16, 16, 32, 16, job1(2, 1, 0, 0, 8, 8, 1), 0, 0, 0},
+    {SAVE_L1 + 32, 16, 48, 16, job1(3, 1, 0, 0, 8, 8, 1), 0, 0, 0},  {SAVE_L1 + 48, 16, 64, 16, job1(4, 1, 0, 0, 8, 8, 1), 0, 0, 0},
+    {SAVE_L1 + 64, 16, 80, 16, job1(5, 1, 0, 0, 8, 8, 1), 0, 0, 0},  {SAVE_PE, 4, 80, 16, job1(5, 0, 256, 0, 2, 8, 0), 0, 0, 0},
+    {SAVE_L1 + 80, 16, 96, 16, job1(6, 1, 0, 0, 8, 8, 1), 0, 0, 0},  {SAVE_L1 + 96, 16, 112, 16, job1(7, 1, 0, 0, 8, 8, 1), 0, 0, 0},
+    {SAVE_L1 + 112, 16, 128, 16, job1(9, 1, 0, 0, 8, 8, 1), 0, 0, 0}, {SAVE_L1 + 112, 16, DY_HEADS, 1, job1(8, 1, 0, 1, 8, 1, 1), 0, 0, 0},
+    {SAVE_L1 + 128, 16, DY_L9, 8, job1(10, 1, 0, 0, 8, 4, 1), 0, 0, 0}, {SAVE_VIEW, 2, DY_L9, 8, job1(10, 2, 256, 0, 1, 4, 0), 0, 0, 0},
+    {SAVE_RGBIN, 8, DY_HEADS, 1, job1(11, 1, 0, 2, 4, 1, 1), 0, 0, 0},
+    {0, 0, 0, 0, job1(0, 0, 0, 0, 0, 0, 0), 0, 0, 0}};
+// 11 jobs of the transpose-read kernel: an operand stream that two Dense blocks share is read once —
+//   Dense_5 = [previous layer | position encoding] rows against dY_5 (10 k-tiles), Dense_10 = [bottleneck | view encoding] rows against
+//   dY_9 (9 k-tiles), Dense_9 and the sigma head Dense_8 against the trunk output (8 + 1 n-tiles; the sigma bias comes from the rgb job)
+static const WgradPlan kWgradPlanTr[12] = {
+    {SAVE_PE, 4, 0, 16, job1(0, 0, 0, 0, 2, 8, 1), 0, 0, 0},
+    {SAVE_L1 + 0, 16, 16, 16, job1(1, 1, 0, 0, 8, 8, 1), 0, 0, 0},   {SAVE_L1 + 16, 16, 32, 16, job1(2, 1, 0, 0, 8, 8, 1), 0, 0, 0},
+    {SAVE_L1 + 32, 16, 48, 16, job1(3, 1, 0, 0, 8, 8, 1), 0, 0, 0},  {SAVE_L1 + 48, 16, 64, 16, job1(4, 1, 0, 0, 8, 8, 1), 0, 0, 0},
+    {SAVE_L1 + 64, 20, 80, 16, WgradJob{5, 1, 0, 0, 10, 8, 1, /*KTa*/ 8, /*xkind2*/ 0, /*row_off2*/ 256, /*NTa*/ 8, 0, 0, 0}, SAVE_PE, 0, 0},
+    {SAVE_L1 + 80, 16, 96, 16, job1(6, 1, 0, 0, 8, 8, 1), 0, 0, 0},  {SAVE_L1 + 96, 16, 112, 16, job1(7, 1, 0, 0, 8, 8, 1), 0, 0, 0},
+    {SAVE_L1 + 112, 16, 128, 16, WgradJob{9, 1, 0, 0, 8, 9, 1, 8, 0, 0, /*NTa*/ 8, /*dense2*/ 8, /*dkind2*/ 1, 0}, 0, DY_HEADS, 1},
+    {SAVE_L1 + 128, 18, DY_L9, 8, WgradJob{10, 1, 0, 0, 9, 4, 1, /*KTa*/ 8, /*xkind2*/ 2, /*row_off2*/ 256, 4, 0, 0, 0}, SAVE_VIEW, 0, 0},
+    {SAVE_RGBIN, 8, DY_HEADS, 1, job1(11, 1, 0, 2, 4, 1, 1, /*bias_sigma*/ 1), 0, 0, 0},
+    {0, 0, 0, 0, job1(0, 0, 0, 0, 0, 0, 0), 0, 0, 0}};
 
 // legacy = the bf16 body (MFMA transposition): shares by MFMA count, 4 rounds of workgroups; otherwise the transpose-read bodies, paced
 // by HBM: shares by bytes streamed per row, 2 rounds (measured with RNERF_WGRAD_TRACE: all jobs' workgroups finish within 10 %)
 static size_t build_wgrad_table(int cus, WgradTable& t, bool legacy) {
+  const WgradPlan* plan = legacy ? kWgradPlan : kWgradPlanTr;
   int n = 0;
   double cost[16], total = 0;
-  for (; kWgradPlan[n].KSx != 0; ++n) {
-    const WgradJob& jb = kWgradPlan[n].job;
+  for (; plan[n].KSx != 0; ++n) {
+    const WgradJob& jb = plan[n].job;
     cost[n] = legacy ? 2.0 * jb.KT * jb.NT + 2 * (jb.KT + jb.NT) + 16 : jb.KT + jb.NT + 1;
     total += cost[n];
   }
@@ -2562,10 +2628,11 @@ static size_t build_wgrad_table(int cus, WgradTable& t, bool legacy) {
   size_t off = 0;
   int wg = 0;
   for (int i = 0; i < n; ++i) {
-    const WgradPlan& p = kWgradPlan[i];
+    const WgradPlan& p = plan[i];
     int share = (int)(budget * cost[i] / total + 0.5);
     if (share < 8) share = 8;
     t.qx[i] = p.qx; t.KSx[i] = p.KSx; t.qd[i] = p.qd; t.KSd[i] = p.KSd; t.job[i] = p.job;
+    t.qx2[i] = p.qx2; t.qd2[i] = p.qd2; t.KSd2[i] = p.KSd2;
     t.wg0[i] = wg; wg += share;
     t.poff[i] = (long long)off; off += (size_t)share * p.job.KT * 32 * p.job.NT * 32;
     t.pboff[i] = (long long)off; off += (size_t)share * p.job.NT * 32;
@@ -2632,7 +2699,9 @@ extern "C" int rnerf_nerfmlp_wgrad(int fwd_precision, int backward, const void* 
                        (float*)workspace, tab, trace);
     out_scale = (const float*)((const uint4*)dy + dy_plane_uint4(R, 2)) + R;
   }
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(256, tab.n), dim3(256), 0, st, (const float*)workspace, tab, grads, out_scale);
+  int max_elems = 0;
+  for (int j = 0; j < tab.n; ++j) max_elems = tab.job[j].KT * tab.job[j].NT * 1024 > max_elems ? tab.job[j].KT * tab.job[j].NT * 1024 : max_elems;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((max_elems + 255) / 256, tab.n), dim3(256), 0, st, (const float*)workspace, tab, grads, out_scale);
   RNERF_CHECK_LAUNCH();
   if (trace && backward != RNERF_BWD_BF16) {
     const int n_wg = tab.wg0[tab.n];
