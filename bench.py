@@ -347,7 +347,7 @@ def main():
 
         jp = jit.data_ptr()
         t_f = timed(lambda: lib.rnerf_nerfmlp_forward_train(packed.data_ptr(), model.precision, path_pd.data_ptr(), path_dr.data_ptr(), jp, S, B,
-                                                            raw_t.data_ptr(), save_t.data_ptr(), BW, _lib.current_stream()))
+                                                            raw_t.data_ptr(), save_t.data_ptr(), BW, 0, _lib.current_stream()))
         t_d = timed(lambda: ops.nerfmlp_backward(pbwd, packed, model.precision, save_t, d_raw, rows, dy=dy_t, stages="d", backward=BW))
         t_w = timed(lambda: ops.nerfmlp_backward(pbwd, packed, model.precision, save_t, d_raw, rows, grads=g_t, workspace=ws_t, dy=dy_t, stages="w", backward=BW))
         R_pad = (rows + 255) // 256 * 256

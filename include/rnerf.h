@@ -235,7 +235,8 @@ size_t rnerf_nerfmlp_dy_bytes(int64_t rows, int backward);
 size_t rnerf_nerfmlp_bwd_packed_bytes(void);
 size_t rnerf_nerfmlp_wgrad_workspace_bytes(void);
 int rnerf_nerfmlp_forward_train(const void* packed, int precision, const float* rows_pd, const float* rows_dr,
-                                const int32_t* node_of_sample, int32_t S, int32_t B, float* out_raw, void* save, int backward, void* stream);
+                                const int32_t* node_of_sample, int32_t S, int32_t B, float* out_raw, void* save, int backward,
+                                int32_t max_workgroups /* as rnerf_nerfmlp_forward: 0 = one workgroup per CU */, void* stream);
 int rnerf_nerfmlp_pack_bwd(const float* params, int backward, void* packed_bwd, void* stream);
 int rnerf_nerfmlp_dgrad(const void* packed_bwd, const void* packed_fwd, int fwd_precision, int backward, const void* save, const float* d_raw,
                         int64_t rows, void* dy, void* stream);

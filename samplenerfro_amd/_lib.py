@@ -65,7 +65,7 @@ SIGNATURES = {
     "rnerf_nerfmlp_dy_bytes": (C.c_size_t, [_i64, C.c_int]),
     "rnerf_nerfmlp_bwd_packed_bytes": (C.c_size_t, []),
     "rnerf_nerfmlp_wgrad_workspace_bytes": (C.c_size_t, []),
-    "rnerf_nerfmlp_forward_train": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _i32, _i32, _vp, _vp, C.c_int, _vp]),
+    "rnerf_nerfmlp_forward_train": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _i32, _i32, _vp, _vp, C.c_int, _i32, _vp]),
     "rnerf_nerfmlp_pack_bwd": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "rnerf_nerfmlp_dgrad": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _i64, _vp, _vp]),
     "rnerf_nerfmlp_wgrad": (C.c_int, [C.c_int, C.c_int, _vp, _vp, _i64, _vp, _vp, _vp]),

@@ -2512,8 +2512,9 @@ extern "C" size_t rnerf_nerfmlp_save_bytes(int64_t rows, int backward) {
 
 extern "C" int rnerf_nerfmlp_forward_train(const void* packed, int precision, const float* rows_pd, const float* rows_dr,
                                            const int32_t* node_of_sample, int32_t S, int32_t B, float* out_raw, void* save,
-                                           int backward, void* stream) {
+                                           int backward, int32_t max_workgroups, void* stream) {
   RNERF_CHECK_ARG(packed && rows_pd && rows_dr && out_raw && save, "rnerf_nerfmlp_forward_train: null pointer");
+  RNERF_CHECK_ARG(max_workgroups >= 0, "rnerf_nerfmlp_forward_train: max_workgroups must be >= 0");
   RNERF_CHECK_ARG(bwd_ok(backward), "rnerf_nerfmlp_forward_train: unknown backward mode %d", backward);
   // (the bf16x3 forward is an inference-only precision: its 8-bit saved operands would cap every backward mode at bf16 accuracy)
   RNERF_CHECK_ARG(precision == RNERF_PREC_F16X3, "rnerf_nerfmlp_forward_train: the training forward is built for precision f16x3");
@@ -2522,8 +2523,8 @@ extern "C" int rnerf_nerfmlp_forward_train(const void* packed, int precision, co
                   "rnerf_nerfmlp_forward_train: buffers must be 16-byte aligned");
   const long long total = (long long)S * B;
   hipStream_t st = (hipStream_t)stream;
-  if (backward == RNERF_BWD_F16X2) return launch_fwd_dbg<RNERF_PREC_F16X3, 0, 2>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, save);
-  return launch_fwd_dbg<RNERF_PREC_F16X3, 0, 1>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, save);
+  if (backward == RNERF_BWD_F16X2) return launch_fwd_dbg<RNERF_PREC_F16X3, 0, 2>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, save, max_workgroups);
+  return launch_fwd_dbg<RNERF_PREC_F16X3, 0, 1>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, save, max_workgroups);
 }
 
 extern "C" size_t rnerf_nerfmlp_bwd_packed_bytes(void) { return (size_t)kBwdBlocks * 2 * 1024; }

@@ -307,7 +307,8 @@ class NerfModel:
                 out, ctx["save_bkgd"] = ops.bkgd_forward_train(bkgd_flat, both, self.rgb_padding)
                 bkgd, ctx["rgb_env"] = out[:B], out[B:]
             raw_c, ctx["save_c"] = ops.nerfmlp_forward_train(self._packed_weights(variables, "coarse_mlp"), self.precision, path_pd,
-                                                            path_dr, jit, Nc, B, ctx.get("backward", _lib.BWD_F16X2))
+                                                            path_dr, jit, Nc, B, ctx.get("backward", _lib.BWD_F16X2),
+                                                            max_workgroups=self._mlp_wg_limit)
             ctx.update(path_pd=path_pd, path_dr=path_dr, jit=jit, raw_c=raw_c, bkgd=bkgd, B=B)
         rgb, dist, acc, trans, trans_bkgd, weights, alpha = ops.composite(
             raw_c, path_pd, path_dr, jit, Nc, B, bkgd, self.white_bkgd, self.rgb_padding, self.sigma_bias,
@@ -332,7 +333,8 @@ class NerfModel:
                                             max_workgroups=self._mlp_wg_limit)
             else:
                 raw_f, ctx["save_f"] = ops.nerfmlp_forward_train(self._packed_weights(variables, "fine_mlp"), self.precision, rows_pd,
-                                                                rows_dr, None, S, B, ctx.get("backward", _lib.BWD_F16X2))
+                                                                rows_dr, None, S, B, ctx.get("backward", _lib.BWD_F16X2),
+                                                                max_workgroups=self._mlp_wg_limit)
                 ctx.update(rows_pd=rows_pd, rows_dr=rows_dr, raw_f=raw_f)
             rgb, dist, acc, trans, trans_bkgd, w_f, alpha_f = ops.composite(
                 raw_f, rows_pd, rows_dr, None, S, B, bkgd, self.white_bkgd, self.rgb_padding, self.sigma_bias,

@@ -197,14 +197,16 @@ def composite_backward(raw, rows_pd, rows_dr, node_of_sample, S: int, B: int, bk
     return d_raw, d_bkgd
 
 
-def nerfmlp_forward_train(packed, precision: int, rows_pd, rows_dr, node_of_sample, S: int, B: int, backward: int = _lib.BWD_F16X2):
+def nerfmlp_forward_train(packed, precision: int, rows_pd, rows_dr, node_of_sample, S: int, B: int, backward: int = _lib.BWD_F16X2,
+                          max_workgroups: int = 0):
     """Training forward: raw [S,B,4] + the saved operands (uint8 buffer) for the backward kernels (`backward`: _lib.BWD_*)."""
     lib = _lib.load()
     dev = rows_pd.device
     out = torch.empty((S, B, 4), dtype=torch.float32, device=dev)
     save = torch.empty(lib.rnerf_nerfmlp_save_bytes(S * B, int(backward)), dtype=torch.uint8, device=dev)
     check(lib.rnerf_nerfmlp_forward_train(ptr(packed), int(precision), ptr(_chk(rows_pd, "rows_pd")), ptr(_chk(rows_dr, "rows_dr")),
-                                          ptr(node_of_sample), int(S), int(B), ptr(out), ptr(save), int(backward), current_stream()),
+                                          ptr(node_of_sample), int(S), int(B), ptr(out), ptr(save), int(backward), int(max_workgroups),
+                                          current_stream()),
           "rnerf_nerfmlp_forward_train")
     return out, save
 
@@ -220,9 +222,10 @@ def nerfmlp_pack_bwd(params_flat: torch.Tensor, out: Optional[torch.Tensor] = No
 
 def nerfmlp_backward(packed_bwd, packed_fwd, precision: int, save, d_raw: torch.Tensor, rows: int,
                      grads: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None, dy: Optional[torch.Tensor] = None,
-                     stages: str = "dw", backward: int = _lib.BWD_F16X2, return_dy: bool = False) -> torch.Tensor:
+                     stages: str = "dw", backward: int = _lib.BWD_F16X2, return_dy: bool = False, between=None) -> torch.Tensor:
     """d_raw [S,B,4] (d loss / d raw) -> flat fp32 gradient of the NerfMLP parameters (595844 floats).  `backward` (_lib.BWD_*) must be
-    the mode the forward saved for and packed_bwd was packed for."""
+    the mode the forward saved for and packed_bwd was packed for.  between: optional callable run after the dgrad launch and before the
+    wgrad launch (train_step issues the next step's march there)."""
     lib = _lib.load()
     dev = d_raw.device
     dy = torch.empty(lib.rnerf_nerfmlp_dy_bytes(rows, int(backward)), dtype=torch.uint8, device=dev) if dy is None else dy
@@ -231,6 +234,8 @@ def nerfmlp_backward(packed_bwd, packed_fwd, precision: int, save, d_raw: torch.
                                       ptr(dy), current_stream()), "rnerf_nerfmlp_dgrad")
     if "w" not in stages:
         return dy
+    if between is not None:
+        between()
     if grads is None:
         grads = torch.empty(_lib.NERFMLP_PARAMS, dtype=torch.float32, device=dev)
     if workspace is None:

@@ -20,6 +20,7 @@ plain torch arithmetic on that flat buffer: weights and optimiser state stay on 
 """
 from __future__ import annotations
 
+import os
 import weakref
 from typing import Any, Dict, Optional
 
@@ -29,6 +30,10 @@ import torch
 from . import _lib, distributed, ops, prng
 from .models import BKGD_MLP_SHAPES, NERF_MLP_SHAPES, SO3_MLP_SHAPES, NerfModel, make_variables
 from .utils import Rays, Stats, learning_rate_decay
+
+_MARCH_EARLY = os.environ.get("RNERF_MARCH_BEFORE_WGRAD") is not None  # experiment switch, see train_step (measured slower: off)
+# CUs the training forward leaves to the next step's march (issued at the START of the step, see train_step); 0 = march after the wgrad
+_MARCH_RESERVE = int(os.environ.get("RNERF_MARCH_RESERVE_CUS", "0"))
 
 _N_STATS = 8        # loss, loss_c, loss_bg, loss_bg_smooth, weight_l2, (3 spare)
 
@@ -231,8 +236,15 @@ def train_step(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], 
     if flags.bg_smooth_weight > 0:
         ev = batch["env_rays"].viewdirs
         ctx["env_dirs"] = ev.reshape(-1, 3)
+    hold = {}
+    if _MARCH_RESERVE > 0 and next_rays is not None and not all_stage:
+        # the NEXT step's march, issued now: it runs beside this step's training forward, which leaves it _MARCH_RESERVE CUs (a dependent
+        # gather chain: 64 waves, as fast on a few CUs as on many)
+        hold["path"] = model.prefetch_path(next_rays, sync_inputs=True, reserve_cus=_MARCH_RESERVE)
     ret, _loss_sp = model.apply(variables, key_0, key_1, rays, flags.randomized, annealed, jitter=jitter, u_fine=u_fine, ctx=ctx, path=path,
                              taps=forward_taps)
+    if "path" in hold:
+        model.release_reserved_cus()
     B = ctx["B"]
     rgb_f, _, _, trans_f, tb_f = ret[-1]
     rgb_c = ret[0][0] if len(ret) > 1 else None
@@ -260,16 +272,23 @@ def train_step(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], 
         d_raw_c, d_bkgd = ops.composite_backward(ctx["raw_c"], ctx["path_pd"], ctx["path_dr"], ctx["jit"], Nc, B, ctx["bkgd"], rgb_f, pixels,
                                                  trans_f, tb_f, sums, mse_scale, flags.bg_weight * bg_on, rgb_padding=model.rgb_padding,
                                                  sigma_bias=model.sigma_bias, white_bkgd=model.white_bkgd, d_bkgd=d_first, accumulate_bkgd=False)
+    # The march of the NEXT step (it reads neither the trained parameters nor anything of this step) goes to the side stream after the
+    # wgrad, beside the small kernels of the step's tail (background-MLP backward, loss glue, Adam).  Those are ~0.35 ms against 0.7-0.8 ms
+    # of march, so ~0.4 ms of every step still waits for it (rocprof timeline) — but issuing it between the dgrad and the
+    # wgrad (RNERF_MARCH_BEFORE_WGRAD=1), where it would be hidden entirely, costs the HBM-paced wgrad more than that: 6.81 -> 7.18 ms.
+    def issue_next_march():
+        hold["path"] = model.prefetch_path(next_rays, sync_inputs=True, reserve_cus=0) if next_rays is not None else None
+    early = _MARCH_EARLY and next_rays is not None and "path" not in hold
     _, dy_c = ops.nerfmlp_backward(_bwd_packed(model, state, "coarse_mlp", bwd), model._packed_weights(variables, "coarse_mlp"), prec, ctx["save_c"],
-                                   d_raw_c, Nc * B, grads=state.grad_view("coarse_mlp"), backward=bwd, return_dy=True)
+                                   d_raw_c, Nc * B, grads=state.grad_view("coarse_mlp"), backward=bwd, return_dy=True,
+                                   between=issue_next_march if early else None)
     # jax.lax.pmean of the gradients (train.py:166), first part: the NerfMLP segments are final here, their all-reduce (95 % of the
     # bytes) starts now and runs beside the rest of the step; the background-MLP gradients and the stats follow in a small second one
     n_big = state.segments["bkgd_mlp"][0]
     pending = distributed.allreduce_begin(G[:n_big])
-    # The march of the NEXT step (it reads neither the trained parameters nor anything of this step) goes to the side stream here:
-    # it starts when the wgrad above has finished and runs beside the small, latency-bound kernels of the step's tail (background-MLP
-    # backward, loss glue, Adam), which leave most of the chip idle; the big persistent MLP kernels are never shared with it.
-    next_path = model.prefetch_path(next_rays, sync_inputs=True, reserve_cus=0) if next_rays is not None else None
+    if "path" not in hold:
+        issue_next_march()
+    next_path = hold["path"]
     bk_flat = variables["flat"]["bkgd_mlp"]
     g_bk = state.grad_view("bkgd_mlp")
     # ---- env-map smoothness (train.py:127-132): its rows went through the background MLP together with the rays' rows

@@ -33,7 +33,7 @@ def timeit(fn, n=5):
 
 print("backward", os.environ.get("BWD", "f32"), "rows", rows, "save MB", save.numel() / 1e6, "dy MB", dy.numel() / 1e6)
 print("forward        %.3f ms" % timeit(lambda: ops.nerfmlp_forward(packed, P, pd, dr, None, S, B, out=raw)))
-print("forward_train  %.3f ms" % timeit(lambda: lib.rnerf_nerfmlp_forward_train(packed.data_ptr(), P, pd.data_ptr(), dr.data_ptr(), None, S, B, raw.data_ptr(), save.data_ptr(), BW, None)))
+print("forward_train  %.3f ms" % timeit(lambda: lib.rnerf_nerfmlp_forward_train(packed.data_ptr(), P, pd.data_ptr(), dr.data_ptr(), None, S, B, raw.data_ptr(), save.data_ptr(), BW, 0, None)))
 print("dgrad          %.3f ms" % timeit(lambda: ops.nerfmlp_backward(pbwd, packed, P, save, d_raw, rows, dy=dy, stages="d", backward=BW)))
 print("wgrad+reduce   %.3f ms" % timeit(lambda: ops.nerfmlp_backward(pbwd, packed, P, save, d_raw, rows, grads=grads, workspace=ws, dy=dy, stages="w", backward=BW)))
 
