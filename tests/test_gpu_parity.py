@@ -221,6 +221,26 @@ def test_nerf_mlp_node_indirection(scene):
     np.testing.assert_array_equal(a, b)
 
 
+def test_nerf_mlp_workgroup_cap_and_training_forward_agree(scene):
+    """max_workgroups only changes which workgroup walks which tile; the training forward (both save modes) returns the evaluation
+    forward's bits, capped or not."""
+    from samplenerfro_amd import ops
+    pf = syn.init_params_flat(7, bias_scale=0.1)
+    rng = np.random.default_rng(8)
+    B, S = 300, 7                                  # 2100 rows = 9 tiles
+    pd = rng.uniform(-2, 2, (S, B, 4)).astype(F32)
+    dr = np.concatenate([R.safe_l2_normalize(rng.standard_normal((S, B, 3)).astype(F32)), np.zeros((S, B, 1), F32)], -1)
+    packed = ops.nerfmlp_pack(T(pf["coarse_mlp"]), _lib.PREC_F16X3)
+    ref = ops.nerfmlp_forward(packed, _lib.PREC_F16X3, T(pd), T(dr), None, S, B).cpu().numpy()
+    for cap in (1, 4):
+        out = ops.nerfmlp_forward(packed, _lib.PREC_F16X3, T(pd), T(dr), None, S, B, max_workgroups=cap).cpu().numpy()
+        np.testing.assert_array_equal(out, ref)
+    for bwd in (_lib.BWD_F16X2, _lib.BWD_F16):
+        for cap in (0, 2):
+            raw, _save = ops.nerfmlp_forward_train(packed, _lib.PREC_F16X3, T(pd), T(dr), None, S, B, bwd, max_workgroups=cap)
+            np.testing.assert_array_equal(raw.cpu().numpy(), ref)
+
+
 @pytest.mark.parametrize("prec,fine", [("f16x3", True), ("f16x3", False), ("bf16x3", True), ("f16x2", True)])
 def test_model_end_to_end(prec, fine):
     """NerfModel.apply vs the oracle: RGB within 1e-4 abs (north_star), coarse level tighter."""
