@@ -185,17 +185,28 @@ __global__ void nerfmlp_pack_kernel(const float* __restrict__ params, char* __re
 // sin for the positional encoding: 3-constant Cody-Waite reduction by pi/2 (exact products through fma; |a| < ~2^15) and the
 // Cephes sinf/cosf minimax polynomials on [-pi/4, pi/4] (~1 ulp).  ~20 VALU ops instead of the ~100 of the generic ocml
 // sinf with its Payne-Hanek path.  The argument itself is formed exactly like the reference: fl(fl(x * 2^d) + fl(pi/2)).
+// (cut into four dependent stages so that EncWork can issue them one per MFMA slot; pe_sin runs the same stages back to back)
+struct PeSin {
+  float a, k, r, z, sp;
+  __device__ __forceinline__ void s0(float arg) { a = arg; k = rintf(a * 0.63661977236758134f); }
+  __device__ __forceinline__ void s1() {
+    r = fmaf(-k, 1.5707963705062866f, a);
+    r = fmaf(-k, -4.3711388286737929e-08f, r);
+    r = fmaf(-k, -1.7151245100059311e-15f, r);
+    z = r * r;
+  }
+  __device__ __forceinline__ void s2() { sp = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, r, r); }
+  __device__ __forceinline__ float s3() const {
+    const int q = (int)k;
+    const float cp = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f), z * z, fmaf(-0.5f, z, 1.0f));
+    const float v = (q & 1) ? cp : sp;
+    return (q & 2) ? -v : v;
+  }
+};
 __device__ __forceinline__ float pe_sin(float a) {
-  const float k = rintf(a * 0.63661977236758134f);
-  float r = fmaf(-k, 1.5707963705062866f, a);
-  r = fmaf(-k, -4.3711388286737929e-08f, r);
-  r = fmaf(-k, -1.7151245100059311e-15f, r);
-  const int q = (int)k;
-  const float z = r * r;
-  const float sp = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, r, r);
-  const float cp = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f), z * z, fmaf(-0.5f, z, 1.0f));
-  const float v = (q & 1) ? cp : sp;
-  return (q & 2) ? -v : v;
+  PeSin p;
+  p.s0(a); p.s1(); p.s2();
+  return p.s3();
 }
 
 // Weight-stream DMA (global -> LDS, 16 B per lane, 1 KiB per wave-instruction).  Written as inline asm on purpose: for the
@@ -369,6 +380,58 @@ struct PairOfPairs {
   template <int C, int PI>
   __device__ __forceinline__ void chunk() {
     if constexpr (PI < 4) { w.template chunk<C, PI>(); w.template chunk<C, PI + 4>(); }
+  }
+};
+
+// Position-encoding operands of k-step S (slot map pe_feature: slot q = 8 S + j < NSIN is sin(2^(q/3) x_(q%3) + phase(h)), then the
+// identity terms) for both m-tiles, one value pair per MFMA tile like PrevConv: stage 0 argument + reduction index, 1 reduced argument,
+// 2 sine polynomial, 3 cosine polynomial + selection, 4 hi / lo split.  Same arithmetic, same order as enc_ops() / pe_sin().
+template <int PREC, int S, int NSIN>
+struct EncWork {
+  using PP = Prec<PREC>;
+  const float4 (&v)[2];
+  const int h;
+  uint32_t hi[2][4], lo[2][4];
+  PeSin e0, e1;
+  float f0, f1;
+  __device__ __forceinline__ EncWork(const float4 (&v_)[2], int h_) : v(v_), h(h_) {}
+  template <int MT, int Q>
+  __device__ __forceinline__ float coord() const {      // x, y or z of m-tile MT for sine slot Q
+    constexpr int c = Q % 3;
+    return c == 0 ? v[MT].x : (c == 1 ? v[MT].y : v[MT].z);
+  }
+  template <int MT, int Q>
+  __device__ __forceinline__ float plain() const {      // the non-sine slots
+    if constexpr (Q == NSIN) return h ? v[MT].z : v[MT].x;
+    else if constexpr (Q == NSIN + 1) return h ? 0.f : v[MT].y;
+    else return 0.f;
+  }
+  template <int C, int PI>
+  __device__ __forceinline__ void chunk() {
+    constexpr int mt = PI >> 2, p = PI & 3, q0 = 8 * S + 2 * p, q1 = q0 + 1;
+    const float phase = h ? 1.5707963705062866f : 0.0f;   // f32(0.5*pi) (rnerf/model_utils.py:213)
+    if constexpr (C == 0) {
+      if constexpr (q0 < NSIN) e0.s0(fadd(fmul(coord<mt, q0>(), (float)(1 << (q0 / 3))), phase));
+      if constexpr (q1 < NSIN) e1.s0(fadd(fmul(coord<mt, q1>(), (float)(1 << (q1 / 3))), phase));
+    } else if constexpr (C == 1) {
+      if constexpr (q0 < NSIN) e0.s1();
+      if constexpr (q1 < NSIN) e1.s1();
+    } else if constexpr (C == 2) {
+      if constexpr (q0 < NSIN) e0.s2();
+      if constexpr (q1 < NSIN) e1.s2();
+    } else if constexpr (C == 3) {
+      if constexpr (q0 < NSIN) f0 = e0.s3(); else f0 = plain<mt, q0>();
+      if constexpr (q1 < NSIN) f1 = e1.s3(); else f1 = plain<mt, q1>();
+    } else {
+      if constexpr (PP::NP == 2) split2<PP::F16>(f0, f1, hi[mt][p], lo[mt][p]);
+      else { hi[mt][p] = pack2<PP::F16>(f0, f1); lo[mt][p] = 0; }
+    }
+  }
+  __device__ __forceinline__ KOps result() const {
+    KOps o;
+    o.h0 = make_uint4(hi[0][0], hi[0][1], hi[0][2], hi[0][3]); o.l0 = make_uint4(lo[0][0], lo[0][1], lo[0][2], lo[0][3]);
+    o.h1 = make_uint4(hi[1][0], hi[1][1], hi[1][2], hi[1][3]); o.l1 = make_uint4(lo[1][0], lo[1][1], lo[1][2], lo[1][3]);
+    return o;
   }
 };
 
@@ -699,20 +762,21 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
       seam.cv.floor_v = 0.f;
       load_bias8(0, auxt + AUX_BIAS, seam.cv.b);
       load_bias8(0, auxt + AUX_ZERO, seam.cv.ws);
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        save_ops(SAVE_PE + s, cur);
-        SLAB_PREFETCH(true);   // glds first: it is a scheduling boundary, conversion + MFMAs must share the region after it
-        KOps nxt = cur;
-        if (s + 1 < 4) nxt = enc_ops(pd, s + 1, 30);
-        if (!(dbg & 2)) {
-          if (s == 0) kstep_mfma<PREC, 8, 0, true>(acc0, acc1, cur, smem + buf * SLAB, lane, nowork);
-          else if (s < 3) kstep_mfma<PREC, 8, 0, false>(acc0, acc1, cur, smem + buf * SLAB, lane, nowork);
-          else kstep_mfma<PREC, 8, 0, false>(acc0, acc1, cur, smem + buf * SLAB, lane, seam);
-        }
-        SLAB_DONE();
-        cur = nxt;
+      // k-steps 0..2 convert the position-encoding operands of the next k-step in their own MFMA shadows (EncWork), k-step 3 carries the seam
+#define RNERF_PE_KSTEP(S, FIRST_, SAVE_)                                                                             \
+      {                                                                                                              \
+        if (SAVE_) save_ops(SAVE_PE + S, cur);                                                                       \
+        SLAB_PREFETCH(true);   /* glds first: it is a scheduling boundary, conversion + MFMAs must share the region after it */ \
+        if constexpr (S < 3) {                                                                                       \
+          EncWork<PREC, S + 1, 30> ew(pd, h);                                                                        \
+          if (!(dbg & 2)) kstep_mfma<PREC, 8, 0, FIRST_>(acc0, acc1, cur, smem + buf * SLAB, lane, ew);              \
+          cur = ew.result();                                                                                         \
+        } else {                                                                                                     \
+          if (!(dbg & 2)) kstep_mfma<PREC, 8, 0, false>(acc0, acc1, cur, smem + buf * SLAB, lane, seam);             \
+        }                                                                                                            \
+        SLAB_DONE();                                                                                                 \
       }
+      RNERF_PE_KSTEP(0, true, true) RNERF_PE_KSTEP(1, false, true) RNERF_PE_KSTEP(2, false, true) RNERF_PE_KSTEP(3, false, true)
       PH(1);
       seam.finish();
       cur = seam.cv.result();
@@ -769,18 +833,7 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
       PH(3);
       if (l == 5) {   // skip concat: [x, inputs] (rnerf/model_utils.py:68-69)
         cur = enc_ops(pd, 0, 30);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          SLAB_PREFETCH(true);
-          KOps nxt = cur;
-          if (s + 1 < 4) nxt = enc_ops(pd, s + 1, 30);
-          if (!(dbg & 2)) {
-            if (s < 3) kstep_mfma<PREC, 8, 0, false>(acc0, acc1, cur, smem + buf * SLAB, lane, nowork);
-            else kstep_mfma<PREC, 8, 0, false>(acc0, acc1, cur, smem + buf * SLAB, lane, seam);
-          }
-          SLAB_DONE();
-          cur = nxt;
-        }
+        RNERF_PE_KSTEP(0, false, false) RNERF_PE_KSTEP(1, false, false) RNERF_PE_KSTEP(2, false, false) RNERF_PE_KSTEP(3, false, false)
         PH(5);
       }
       seam.finish();
@@ -911,6 +964,7 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
       }
       PH(8);
     }
+#undef RNERF_PE_KSTEP
 #undef SLAB_PREFETCH
 #undef SLAB_DONE
   }
