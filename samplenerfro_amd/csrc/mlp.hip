@@ -1251,7 +1251,7 @@ nerfmlp_dgrad_kernel(const char* __restrict__ packed_bwd, const float* __restric
 #define RNERF_DG_KSTEP(S, NSTEPS, SLOT0, PREFETCH_STMT)                                                                       \
       {                                                                                                                         \
         dy_store((SLOT0) + S, cur);                                                                                             \
-        PREFETCH_STMT;                                                                                                          \
+        auto dma = [&]() { PREFETCH_STMT; };   /* issued after the first two tiles' MFMAs (an LDS-DMA instruction costs ~100 issue cycles) */ \
         if constexpr (S + 1 < NSTEPS) {                                                                                         \
           GradConv<PREC, S + 1, NEED_LO> cv(prev0[(S + 1) >> 1]);                                                                        \
           {                                                                                                                     \
@@ -1267,10 +1267,10 @@ nerfmlp_dgrad_kernel(const char* __restrict__ packed_bwd, const float* __restric
           }                                                                                                                     \
           cv.w0 = ((S + 1) >> 2) == 0 ? ma.x : (((S + 1) >> 2) == 1 ? ma.y : (((S + 1) >> 2) == 2 ? ma.z : ma.w));             \
           cv.w1 = ((S + 1) >> 2) == 0 ? mb.x : (((S + 1) >> 2) == 1 ? mb.y : (((S + 1) >> 2) == 2 ? mb.z : mb.w));             \
-          kstep_mfma<PREC, 8, 0, S == 0, GradConv<PREC, S + 1, NEED_LO>, false, NoDma, DGP>(acc0, acc1, cur, smem + buf * SLAB, lane, cv); \
+          kstep_mfma<PREC, 8, 0, S == 0, GradConv<PREC, S + 1, NEED_LO>, false, decltype(dma), DGP>(acc0, acc1, cur, smem + buf * SLAB, lane, cv, dma); \
           cur = cv.result();                                                                                                    \
         } else {                                                                                                                \
-          kstep_mfma<PREC, 8, 0, false, NoWork, false, NoDma, DGP>(acc0, acc1, cur, smem + buf * SLAB, lane, nowork);  \
+          kstep_mfma<PREC, 8, 0, false, NoWork, false, decltype(dma), DGP>(acc0, acc1, cur, smem + buf * SLAB, lane, nowork, dma);  \
         }                                                                                                                       \
         SLAB_DONE();                                                                                                            \
       }
