@@ -594,7 +594,10 @@ template <int PREC, int dbg, int TRAIN>
 __global__ void __launch_bounds__(256, 1)
 nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ rows_pd, const float4* __restrict__ rows_dr,
                    const int* __restrict__ node_of_sample, int B, long long total_rows, int n_tiles, float4* __restrict__ out_raw,
-                   uint4* __restrict__ save, long long save_rows) {
+                   uint4* __restrict__ save, long long save_rows, int* __restrict__ tileq) {
+  // tileq != nullptr (training forward on a capped grid): tiles beyond the first round are handed out by an atomic counter (tileq[0],
+  // zeroed by the launcher; tileq[1 + workgroup] passes the draw from thread 0 to the other waves) — with fewer workgroups than CUs the
+  // static stride would leave most of the chip idle in a last partial round (2048 tiles over 248 workgroups: 9 rounds instead of 8.26).
   // dbg != 0: profiling ablations, only instantiated with -DRNERF_MLP_ABLATE (results are garbage):
   //   bit0 = skip the weight-stream loads, bit1 = skip ds_read + MFMA, bit2 = skip the barrier.
   // Compile-time on purpose: a runtime branch per k-step would split the scheduling region and stop the compiler from
@@ -623,14 +626,16 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
   slab_wait_dma();
   __syncthreads();
 
-  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const bool has_next_tile = tile + (int)gridDim.x < n_tiles;
+  for (int tile = blockIdx.x; tile < n_tiles;) {
+    if (tileq != nullptr && tid == 0)      // read back by every wave at the end of the tile, ~145 barriers later
+      __hip_atomic_store(tileq + 1 + blockIdx.x, (int)gridDim.x + atomicAdd(tileq, 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // The aux vectors (biases, head weights) are read at lane-dependent but tile-invariant addresses.  Left alone, hipcc hoists the ~100
     // 64-bit per-lane addresses out of the tile loop, spills them, and in the heads / the view layer reloads each one from scratch right
     // before its load, one after the other (measured: 52 k clocks for the rgb head, 5.4 k per view-layer slab).  An opaque per-tile copy
     // of the base keeps the address arithmetic next to the loads (scalar base + lane offset + immediate).
     const float* __restrict__ auxt = aux;
     asm volatile("" : "+s"(auxt));
+    int next_tile = n_tiles;
     long long row[2]; bool row_ok[2];
     float4 pd[2], dr[2];
 #pragma unroll
@@ -887,6 +892,9 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
       // last slab of the tile (the two view-encoding k-steps): prefetch the first slab of the next tile (stream restarts)
       save_ops(SAVE_VIEW, c0);
       save_ops(SAVE_VIEW + 1, c1);
+      next_tile = tileq != nullptr ? __builtin_amdgcn_readfirstlane(__hip_atomic_load(tileq + 1 + blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                                   : tile + (int)gridDim.x;
+      const bool has_next_tile = next_tile < n_tiles;
       if (has_next_tile) off = 0;
       SLAB_PREFETCH(has_next_tile);
       if (!(dbg & 2)) { kstep_mfma<PREC, 4, 0, false>(acc0, acc1, c0, smem + buf * SLAB, lane, nowork); kstep_mfma<PREC, 4, 1, false>(acc0, acc1, c1, smem + buf * SLAB, lane, nowork); }
@@ -967,6 +975,7 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
 #undef RNERF_PE_KSTEP
 #undef SLAB_PREFETCH
 #undef SLAB_DONE
+    tile = next_tile;
   }
   if constexpr ((dbg & 64) != 0) {
     if (lane == 0) out_raw[blockIdx.x * 4 + wave] = make_float4(prof_tot, prof_dma, prof_bar, prof_n);
@@ -2479,6 +2488,12 @@ extern "C" int rnerf_nerfmlp_pack(const float* params, int precision, void* pack
   return RNERF_OK;
 }
 
+// saved operands + masks of `padded` rows; behind them SAVE_QUEUE_BYTES for the dynamic tile queue of a capped training forward
+constexpr size_t SAVE_QUEUE_BYTES = 8192;       // counter + one slot per workgroup (<= 2047 CUs)
+static size_t save_payload_bytes(long long padded, bool with_lo) {
+  return (size_t)(SAVE_TOTAL + (with_lo ? SAVE_SLOTS : 0)) * (size_t)padded * 2 * sizeof(uint4);
+}
+
 static int mlp_debug_flags() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("RNERF_MLP_DEBUG"); v = e ? atoi(e) : 0; }
@@ -2530,9 +2545,14 @@ static int launch_fwd_dbg(const void* packed, const float* rows_pd, const float*
     RNERF_CHECK_HIP(hipFuncSetAttribute((const void*)nerfmlp_fwd_kernel<PREC, DBG, TRAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
+  int* tileq = nullptr;
+  if (TRAIN != 0 && grid < cus && grid < n_tiles) {      // capped training forward: dynamic tile queue in the tail of the save buffer
+    tileq = (int*)((char*)save + save_payload_bytes((long long)n_tiles * 256, TRAIN == 2));
+    RNERF_CHECK_HIP(hipMemsetAsync(tileq, 0, sizeof(int), st));
+  }
   hipLaunchKernelGGL((nerfmlp_fwd_kernel<PREC, DBG, TRAIN>), dim3(grid), dim3(256), lds, st, (const char*)packed, (const float4*)rows_pd,
                      (const float4*)rows_dr, node_of_sample, B, total_rows, n_tiles, (float4*)out_raw, (uint4*)save,
-                     (long long)n_tiles * 256);
+                     (long long)n_tiles * 256, tileq);
   RNERF_CHECK_LAUNCH();
   return RNERF_OK;
 }
@@ -2561,7 +2581,7 @@ static bool bwd_ok(int b) { return b == RNERF_BWD_BF16 || b == RNERF_BWD_F16 || 
 
 extern "C" size_t rnerf_nerfmlp_save_bytes(int64_t rows, int backward) {
   const int64_t padded = (rows + 255) / 256 * 256;
-  return (size_t)(SAVE_TOTAL + (backward == RNERF_BWD_F16X2 ? SAVE_SLOTS : 0)) * (size_t)padded * 2 * sizeof(uint4);
+  return save_payload_bytes(padded, backward == RNERF_BWD_F16X2) + SAVE_QUEUE_BYTES;
 }
 
 extern "C" int rnerf_nerfmlp_forward_train(const void* packed, int precision, const float* rows_pd, const float* rows_dr,

@@ -32,7 +32,10 @@ from .models import BKGD_MLP_SHAPES, NERF_MLP_SHAPES, SO3_MLP_SHAPES, NerfModel,
 from .utils import Rays, Stats, learning_rate_decay
 
 _MARCH_EARLY = os.environ.get("RNERF_MARCH_BEFORE_WGRAD") is not None  # experiment switch, see train_step (measured slower: off)
-# CUs the training forward leaves to the next step's march (issued at the START of the step, see train_step); 0 = march after the wgrad
+# CUs the training forward leaves to the next step's march (issued at the START of the step, see train_step); 0 = march after the wgrad.
+# Measured slower (6.8 -> 7.0 ms): the march's 256 one-wave workgroups are dispatched over ALL CUs, and every MLP workgroup (a whole CU
+# each) waits for the wave on its CU; confining the march with a CU-masked stream (hipExtStreamCreateWithCUMask) serialised the two
+# streams instead (7.6 ms).  Off.
 _MARCH_RESERVE = int(os.environ.get("RNERF_MARCH_RESERVE_CUS", "0"))
 
 _N_STATS = 8        # loss, loss_c, loss_bg, loss_bg_smooth, weight_l2, (3 spare)
