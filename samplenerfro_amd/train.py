@@ -35,7 +35,8 @@ _MARCH_EARLY = os.environ.get("RNERF_MARCH_BEFORE_WGRAD") is not None  # experim
 # CUs the training forward leaves to the next step's march (issued at the START of the step, see train_step); 0 = march after the wgrad.
 # Measured slower (6.8 -> 7.0 ms): the march's 256 one-wave workgroups are dispatched over ALL CUs, and every MLP workgroup (a whole CU
 # each) waits for the wave on its CU; confining the march with a CU-masked stream (hipExtStreamCreateWithCUMask) serialised the two
-# streams instead (7.6 ms).  Off.
+# streams instead (7.6 ms), and packing it into 16-wave workgroups on 16 / 32 CUs makes it bound by those CUs' gather units (9.7 / 7.5 ms):
+# the march wants one wave on EVERY CU, the MLP kernels want every CU whole.  Off.
 _MARCH_RESERVE = int(os.environ.get("RNERF_MARCH_RESERVE_CUS", "0"))
 
 _N_STATS = 8        # loss, loss_c, loss_bg, loss_bg_smooth, weight_l2, (3 spare)
