@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """End-to-end RGB error and kernel time of a two-pass NerfMLP forward against the shipped three-pass f16x3 forward.
 
-    python tools/r02/fwd_passes.py gen out.npz                                   # shipped library: weight sets + their RGB / depth
-    RNERF_LIB=.../var/librnerf_p22.so python tools/r02/fwd_passes.py cmp out.npz  # variant library: same weights, max |delta|
+    python tools/r02/fwd_passes.py gen out.npz              # precision f16x3: weight sets + their RGB / depth
+    PREC=f16x2 python tools/r02/fwd_passes.py cmp out.npz    # the same weights through another forward precision, max |delta|
 
-Variant builds: -DRNERF_FWD_PASSES=22 (exact weights x f16(activations)) and =2 (f16(weights) x exact activations).
+(profiles/r02/fwd_two_pass_error.jsonl was taken with two variant BUILDS of the kernel: "22" = exact weights x f16(activations), which
+became the precision f16x2, and "2" = f16(weights) x exact activations, which was dropped.)
 Workload = bench.py's default (ship_straight: 4096 rays x 128 samples, flat).  Weight sets:
   init     bench.py's initial weights
   trained  the student of a 1000-step teacher/student run from those (train_step, f32 backward)
@@ -20,7 +21,7 @@ import numpy as np
 import torch
 
 import bench
-from samplenerfro_amd import models, ops, prng, synthetic as syn, utils as U
+from samplenerfro_amd import _lib, models, ops, prng, synthetic as syn, utils as U
 from samplenerfro_amd.utils import Rays
 
 dev = torch.device("cuda:0")
@@ -28,7 +29,8 @@ mode, path = sys.argv[1], sys.argv[2]
 steps = int(os.environ.get("STEPS", "1000"))
 cfg = dict(syn.CONFIGS["ship_straight"])
 B = 4096
-model, variables, pf = bench.build_scene(cfg, dev, "f16x3", 0)
+PREC = "f16x3" if mode == "gen" else os.environ.get("PREC", "f16x2")
+model, variables, pf = bench.build_scene(cfg, dev, PREC, 0)
 o, d = syn.sphere_rays(B, seed=syn.SEED + 7)
 rays = Rays(torch.from_numpy(o).to(dev), None, torch.from_numpy(d).to(dev), None)
 key = np.array([0, 1], np.uint32)
@@ -46,12 +48,13 @@ def fwd_ms():
     pd, dr, _, _ = ops.march(model.table, model.spec, rays.origins, rays.viewdirs, model.near, model.far, cfg["S"] * cfg["P"])
     jit = torch.from_numpy(jitter.astype(np.int32)).to(dev)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-    packed = ops.nerfmlp_pack(variables["flat"]["coarse_mlp"], 1)
+    pid = _lib.PRECISIONS[PREC]
+    packed = ops.nerfmlp_pack(variables["flat"]["coarse_mlp"], pid)
     for it in range(3):
         if it == 1:
             ev[0].record()
         for _ in range(10):
-            ops.nerfmlp_forward(packed, 1, pd, dr, jit, cfg["S"], B)
+            ops.nerfmlp_forward(packed, pid, pd, dr, jit, cfg["S"], B)
     ev[1].record(); torch.cuda.synchronize()
     return ev[0].elapsed_time(ev[1]) / 20
 
@@ -103,7 +106,7 @@ if mode == "gen":
     print("three-pass forward kernel ms:", round(fwd_ms(), 4))
 else:
     z = np.load(path)
-    res = {"lib": os.environ.get("RNERF_LIB", "shipped"), "fwd_kernel_ms": round(fwd_ms(), 4)}
+    res = {"precision": PREC, "fwd_kernel_ms": round(fwd_ms(), 4)}
     for name in ("init", "trained", "teacher", "stress"):
         flat = {k.split("/w/")[1]: z[k] for k in z.files if k.startswith(name + "/w/")}
         rgb, dist = render(flat)
