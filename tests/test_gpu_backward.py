@@ -160,3 +160,31 @@ def test_bkgd_mlp_backward():
             off += cnt
             err = np.abs(a - b).max() / np.abs(b).max()
             assert err < 2e-5, f"bkgd Dense_{k} {name}: rel err {err:.3e}"      # exact-fp32 MFMA chain + fp32 atomics
+
+
+@pytest.mark.parametrize("bwd", ["f32", "tf32"])
+def test_nerfmlp_backward_is_reproducible(bwd):
+    """The same inputs give the same bits, run after run (fixed workgroup -> rows assignment, no atomics in the sums): a race in the
+    DMA ring / vmcnt accounting of the transpose-read wgrad, or in the forward's tile hand-over, would show as differences.  Rows with
+    gradients ten orders of magnitude apart, a ragged tile count, and a size that runs the wgrad's ring through many steps."""
+    import torch
+    from samplenerfro_amd import ops, synthetic as syn
+    dev = "cuda:0"
+    BW = _lib.BACKWARDS[bwd]
+    pf = torch.from_numpy(syn.init_params_flat(3, fine=False, bias_scale=0.1)["coarse_mlp"]).to(dev)
+    packed = ops.nerfmlp_pack(pf, _lib.PREC_F16X3)
+    pbwd = ops.nerfmlp_pack_bwd(pf, None, BW)
+    for B, S in ((300, 7), (4096, 9)):
+        g = torch.Generator(device=dev).manual_seed(1)
+        pd = torch.rand((S, B, 4), device=dev, generator=g) * 2 - 1
+        dr = torch.nn.functional.normalize(torch.randn((S, B, 4), device=dev, generator=g), dim=-1)
+        d_raw = torch.randn((S, B, 4), device=dev, generator=g) * torch.exp(torch.randn((S, B, 1), device=dev, generator=g) * 3)
+        ref = None
+        for _ in range(8):
+            raw, save = ops.nerfmlp_forward_train(packed, _lib.PREC_F16X3, pd, dr, None, S, B, BW)
+            grads = ops.nerfmlp_backward(pbwd, packed, _lib.PREC_F16X3, save, d_raw, S * B, backward=BW)
+            assert torch.isfinite(grads).all()
+            if ref is None:
+                ref = (raw.clone(), grads.clone())
+            else:
+                assert torch.equal(ref[0], raw) and torch.equal(ref[1], grads)
