@@ -2597,6 +2597,10 @@ extern "C" int rnerf_nerfmlp_forward_train(const void* packed, int precision, co
                   "rnerf_nerfmlp_forward_train: buffers must be 16-byte aligned");
   const long long total = (long long)S * B;
   hipStream_t st = (hipStream_t)stream;
+#ifdef RNERF_MLP_ABLATE      /* RNERF_MLP_DEBUG=256: per-phase clocks of the training forward (hi + lo saves) */
+  if (backward == RNERF_BWD_F16X2 && mlp_debug_flags() == 256)
+    return launch_fwd_dbg<RNERF_PREC_F16X3, 256, 2>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, save, max_workgroups);
+#endif
   if (backward == RNERF_BWD_F16X2) return launch_fwd_dbg<RNERF_PREC_F16X3, 0, 2>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, save, max_workgroups);
   return launch_fwd_dbg<RNERF_PREC_F16X3, 0, 1>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, save, max_workgroups);
 }

@@ -31,6 +31,9 @@ if os.environ.get('RNERF_MLP_DEBUG') == '64':
     print("per-wave-slot barrier wait:", [round(float(w[:, k, 2].sum()/w[:, k, 3].sum())) for k in range(4)], " dma:", [round(float(w[:, k, 1].sum()/w[:, k, 3].sum())) for k in range(4)])
 
 if os.environ.get('RNERF_MLP_DEBUG') == '256':
+    if os.environ.get('TRAIN'):           # the training forward (hi + lo saves) instead of the evaluation forward
+        out, _save = ops.nerfmlp_forward_train(packed, _lib.PRECISIONS[prec], pd, dr, None, S, B, _lib.BWD_F16X2)
+        torch.cuda.synchronize()
     prof = out.reshape(-1, 4)[:256 * 4 * 3].cpu().numpy().reshape(-1, 12)[:, :9]
     names = ["row loads", "layer 0 (PE slabs)", "hidden k-step 0 (+conversion)", "hidden k-steps 1..15", "layer end", "skip slabs", "sigma head", "view layer", "rgb head + store"]
     tot = prof.sum()
