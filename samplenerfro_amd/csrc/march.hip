@@ -69,6 +69,10 @@ __global__ void __launch_bounds__(64) march_kernel(const float* __restrict__ tab
     const unsigned z0 = quad_bcast_i<2>(i0) * 16u + cofs, z1 = quad_bcast_i<2>(i1) * 16u + cofs;
     const unsigned bx0 = __umul24(x0, s1), bx1 = __umul24(x1, s1);
     const unsigned b00 = bx0 + __umul24(y0, s2), b10 = bx1 + __umul24(y0, s2), b01 = bx0 + __umul24(y1, s2), b11 = bx1 + __umul24(y1, s2);
+#if defined(RNERF_MARCH_ABL) && (RNERF_MARCH_ABL & 1)   /* profiling ablation: no gathers */
+    for (int i_ = 0; i_ < 8; ++i_) o.c[i_] = __uint_as_float(0x3f800000u + ((b00 + z0 + b11 + z1) & 1u));
+    return;
+#endif
     o.c[0] = *(const float*)(tabc + (b00 + z0)); o.c[1] = *(const float*)(tabc + (b10 + z0));
     o.c[2] = *(const float*)(tabc + (b00 + z1)); o.c[3] = *(const float*)(tabc + (b10 + z1));
     o.c[4] = *(const float*)(tabc + (b01 + z0)); o.c[5] = *(const float*)(tabc + (b11 + z0));
@@ -92,12 +96,18 @@ __global__ void __launch_bounds__(64) march_kernel(const float* __restrict__ tab
   // one step; cn = corners of this step, nx = where the corners of step k+2 are gathered to
   auto one_step = [&](int k, Corners& cn, Corners& nx) {
     // ---- VoxMLP._linear3 addressing (ior_utils.py:188-211): one coordinate per lane
+#if defined(RNERF_MARCH_ABL) && (RNERF_MARCH_ABL & 4)   /* profiling ablation: f32 multiply instead of the f64 product */
+    const float x = fmul(fsub(p, nmin_q), (float)rcp_q);
+#else
     const float x = div_const(fsub(p, nmin_q), rcp_q);
+#endif
     const float fx = floorf(x);
     const int i = (int)fx;
     const float t = fsub(x, fx);                   // (x - x0) / (x1 - x0), divisor exactly 1
     const int i0 = clampi(i, 0, dim_q - 1), i1 = clampi(i + 1, 0, dim_q - 1);
+#if !(defined(RNERF_MARCH_ABL) && (RNERF_MARCH_ABL & 8))   /* profiling ablation: no misprediction check */
     if (__builtin_amdgcn_ballot_w64(i0 != cn.i0 || i1 != cn.i1) != 0) gather(i0, i1, cn);     // mispredicted somewhere in the wave
+#endif
     // ---- speculative gather for step k+2
     const float dx = fsub(x, x_prev);
     predict(fadd(x, fadd(dx, dx)), nx);
@@ -127,7 +137,11 @@ __global__ void __launch_bounds__(64) march_kernel(const float* __restrict__ tab
     if (WANT_IOR) { *out_ior = c; out_ior += node_stride; }
     // ---- OneEikonalStep (eikonal_utils.py:41-45)
     const float n = quad_bcast<3>(c);
+#if defined(RNERF_MARCH_ABL) && (RNERF_MARCH_ABL & 2)   /* profiling ablation: no IEEE division on the chain */
+    const float s = fmul(step, n);
+#else
     const float s = fdiv(step, n);
+#endif
     const float np = fadd(p, fmul(s, d));
     d = fadd(d, fmul(step, c));
     rt = fadd(rt, fsqrt(quad_sumsq3(fsub(p, np))));
