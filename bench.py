@@ -170,6 +170,29 @@ def cpu_train_step(R, mc, pf, params, table, o, d, jitter, cfg, fine, seed):
     return B / dt, dt
 
 
+def relaunch_for_gpus(args):
+    """`--gpus N` is the contract, not a label: one process per GPU.  Started bare (`python bench.py --gpus N`, no launcher in the
+    environment) with N > 1, this process becomes the launcher: it starts `python -m torch.distributed.run --nproc-per-node N bench.py
+    <same arguments>` as a CHILD (never an exec, and before anything here touches the GPU), relays the child's output — rank 0's one
+    JSON line — and exits with its return code.  Started under a launcher (WORLD_SIZE set), the world size must equal --gpus."""
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if env_world is None:
+        if args.gpus == 1:
+            return
+        import socket
+        import subprocess
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        raise SystemExit(subprocess.run(cmd, env=env).returncode)
+    if int(env_world) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={env_world} ranks; "
+                         "they must agree (the line's n_gpus is the number of ranks that ran)")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -202,6 +225,7 @@ def main():
     ap.add_argument("--mode", choices=["train", "forward"], default="train",
                     help="train: the whole optimisation step (BASELINE metric 'rays/sec (train step)'); forward: the render pass only")
     args = ap.parse_args()
+    relaunch_for_gpus(args)
     if args.pipeline is None:
         args.pipeline = args.mode == "train"
     if args.cpu_rays is None:
@@ -217,7 +241,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a ROCm GPU (the hot path has no CPU implementation)")
+        raise SystemExit(f"bench.py needs a ROCm GPU (the hot path has no CPU implementation) [rank {rank} of {world}]")
     # one process per GPU (RCCL).  RNERF_DIST_BACKEND=gloo lets the tests drive this very branch with two ranks on one device
     backend = os.environ.get("RNERF_DIST_BACKEND", "nccl")
     local_rank = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
@@ -276,7 +300,7 @@ def main():
         return model.apply(variables, key, key, rays, False, path=h)
 
     def barrier():
-        if world > 1:
+        if D.active():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -485,6 +509,10 @@ def main():
             line["roofline_forward_kernel"] = line["roofline"]
             line["roofline"] = max(train_kernels, key=lambda t: t["avg_launch_ms"])
             line["roofline_train_kernels"] = train_kernels
+        line["collectives"] = {"backend": (dist.get_backend() if dist.is_initialized() else None), "ranks": world,
+                               "per_step": ("none" if not (train and D.active()) else
+                                            "one all-reduce(mean) of the flat gradient + stats buffer, in two pieces (NerfMLP segments async behind "
+                                            "the wgrad; background MLP + stats after its backward)")}
         if pmc_meta is not None:
             line["pmc_profile"] = pmc_meta
         if other_modes:
@@ -505,7 +533,7 @@ def main():
             line["cpu_baseline"] = {"value": cpu_rps, "unit": "rays/s", "cores": used, "host_cpus": os.cpu_count(), "kind": "port",
                                     "sample": f"{args.cpu_rays} rays of the same workload, {what} (threaded BLAS); 1 warm-up + median of 3 passes, {cpu_dt:.1f} s each"}
         print(json.dumps(line))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

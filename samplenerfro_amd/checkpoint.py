@@ -191,11 +191,15 @@ def params_to_state_dict(variables: Dict[str, Any], step: int = 0, train_state=N
         for which in ("mu", "nu"):
             if name in trained:
                 src = None
-                if train_state is not None and name in getattr(train_state, "segments", {}):
-                    lo, hi = train_state.segments[name]
+                # the params tree calls the IoR group "path_sampler" (rnerf/models.py:121-131); its flat segment is "so3_mlp"
+                seg = "so3_mlp" if name == "path_sampler" else name
+                if train_state is not None and seg in getattr(train_state, "segments", {}):
+                    lo, hi = train_state.segments[seg]
                     from .models import flat_to_tree
-                    shapes = BKGD_MLP_SHAPES if name == "bkgd_mlp" else NERF_MLP_SHAPES
+                    shapes = {"bkgd_mlp": BKGD_MLP_SHAPES, "so3_mlp": SO3_MLP_SHAPES}.get(seg, NERF_MLP_SHAPES)
                     src = _np_tree(flat_to_tree(getattr(train_state, which)[lo:hi], shapes))
+                    if name == "path_sampler":
+                        src = {"scan": {"idx_model": {"so3_mlp": src}}}
                 moments[which][name] = src if src is not None else _zeros_like(tree)
             else:
                 moments[which][name] = _masked_like(tree, False)

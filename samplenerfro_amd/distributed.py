@@ -26,13 +26,25 @@ def init(backend: Optional[str] = None) -> Tuple[int, int]:
     if torch.cuda.is_available():
         # one process per GPU: bind before anything allocates (NerfModel defaults to the current device; RCCL needs distinct devices)
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or _force()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world
+
+
+def _force() -> bool:
+    """RNERF_FORCE_DIST=1: bring the process group up and issue every collective of the path even with ONE rank — how the RCCL
+    code path (group init on the device, the asynchronous gradient all-reduce and its stream hand-over, barrier, max) is executed on a
+    one-GPU box (tests/test_gpu_rccl.py).  Arithmetically a no-op: the sum over one rank divided by one."""
+    return os.environ.get("RNERF_FORCE_DIST") == "1"
+
+
+def active() -> bool:
+    """True when the collectives of the path are to be issued: more than one rank, or a forced one-rank group."""
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _force())
 
 
 def world() -> Tuple[int, int]:
@@ -60,7 +72,7 @@ def allreduce_mean_(buffers: Sequence[torch.Tensor], extra: Optional[torch.Tenso
     All buffers are flattened into ONE contiguous tensor so a step costs a single all-reduce (5.26 MB for the reference
     network: latency-bound over xGMI, so fewer, larger messages win)."""
     rank, w = world()
-    if w == 1:
+    if not active():
         return
     parts = [b.reshape(-1) for b in buffers] + ([extra.reshape(-1)] if extra is not None else [])
     if len(parts) == 1 and parts[0].is_contiguous():             # the train step keeps gradients + stats in one buffer already
@@ -76,12 +88,12 @@ def allreduce_mean_(buffers: Sequence[torch.Tensor], extra: Optional[torch.Tenso
         off += p.numel()
 
 
-def allreduce_begin(buf: torch.Tensor):
+def allreduce_begin(buf: torch.Tensor, force: bool = False):
     """Start the SUM all-reduce of a contiguous flat buffer without blocking the issuing stream (returns None on one rank).
     The train step starts the NerfMLP gradients (95 % of the bytes) right behind the last wgrad, so the collective runs beside
-    the background-MLP backward and the loss tail instead of after them."""
-    rank, w = world()
-    if w == 1:
+    the background-MLP backward and the loss tail instead of after them.  force: issue the collective even in a one-rank group
+    (tests/test_gpu_rccl.py drives RCCL itself that way on a one-GPU box)."""
+    if not (active() or (force and dist.is_available() and dist.is_initialized())):
         return None
     return dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
 
@@ -95,8 +107,7 @@ def allreduce_end_mean_(handle, buf: torch.Tensor) -> None:
 
 
 def max_over_ranks(x: float, device=None) -> float:
-    rank, w = world()
-    if w == 1:
+    if not active():
         return x
     t = torch.tensor([x], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

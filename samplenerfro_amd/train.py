@@ -117,12 +117,20 @@ class TrainState:
                     buf[lo:hi].copy_(m[name])
         except (KeyError, TypeError, ValueError):
             pass                                            # weights-only checkpoint: the moments restart from zero
+        # parameters outside theta (the frozen path_sampler of the radiance stages) come from the checkpoint too; the cached sum of
+        # their squares (weight_l2, norm clipping) is keyed on the tensor and its version, so it follows this copy
+        frozen = flat_from_params(find_params(state), self.theta.device, ("so3_mlp",)) if "so3_mlp" not in self.segments else {}
+        cur = self.variables.get("flat", {}).get("so3_mlp")
+        if "so3_mlp" in frozen and cur is not None:
+            cur.copy_(frozen["so3_mlp"])
+        self.frozen_sq = None
         return self
 
     def load_state_dict(self, d: Dict[str, Any]) -> None:
         self.step = int(d["step"])
         for k in ("theta", "mu", "nu"):
             getattr(self, k).copy_(d[k])
+        self.frozen_sq = None
 
 
 def _bwd_packed(model: NerfModel, state: TrainState, name: str, backward: int) -> torch.Tensor:
@@ -310,9 +318,12 @@ def train_step(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], 
     # ---- weight_l2 over ALL variables, the frozen path_sampler included (train.py:147-153), and the Stats scalars: they ride in the
     #      tail of the gradient buffer, one all-reduce for both (train.py:166-167)
     n_theta = state.theta.numel()
-    if state.frozen_sq is None:
-        so3 = variables.get("flat", {}).get("so3_mlp") if "so3_mlp" not in state.segments else None      # trained in stage all*: part of theta
-        state.frozen_sq = (float((so3.double() ** 2).sum()) if so3 is not None else 0.0, so3.numel() if so3 is not None else 0)   # once
+    so3 = variables.get("flat", {}).get("so3_mlp") if "so3_mlp" not in state.segments else None      # trained in stage all*: part of theta
+    fkey = (id(so3), so3._version) if so3 is not None else None
+    if state.frozen_sq is None or state.frozen_sq[2] != fkey or (so3 is not None and state.frozen_sq[3]() is not so3):
+        # cached per (tensor object, version): restore_flax / graft_pretrained / an in-place load of new so3 weights invalidate it
+        state.frozen_sq = (float((so3.double() ** 2).sum()) if so3 is not None else 0.0, so3.numel() if so3 is not None else 0, fkey,
+                           weakref.ref(so3) if so3 is not None else None)
     n_all = n_theta + state.frozen_sq[1]
     st = G[n_theta:]
     ops.train_stats(sums, B, rgb_c is not None, bg_on, env_sum, ps, on, state.theta, state.frozen_sq[0], n_all, st)

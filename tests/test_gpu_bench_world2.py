@@ -31,3 +31,19 @@ def test_bench_two_ranks(scaling):
     assert d["metric"] == "rays/sec (train step)" and d["unit"] == "rays/s" and d["value"] > 0
     assert abs(d["value"] - 2 * per * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]      # whole-job rays / max-over-ranks time
     assert d["roofline"]["frac"] > 0 and d["config"]["backward_precision"] == "f32"
+
+
+@pytest.mark.timeout(600)
+def test_bench_gpus_flag_launches_the_ranks_itself():
+    """`python bench.py --gpus 2` WITHOUT a launcher (how the driver starts N = 1, and what a bare --gpus 8 must not silently turn into one
+    rank): bench.py becomes the launcher, starts two ranks as children and relays rank 0's line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(RNERF_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "example", "--rays", "256",
+           "--no-frame", "--no-cpu-baseline", "--no-extra"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=560)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["rays_per_gpu"] == 256 and d["value"] > 0

@@ -185,3 +185,56 @@ def test_train_state_resumes_from_a_reference_checkpoint(tmp_path):
     out = checkpoint.params_to_state_dict(st.variables, st.step, st)
     mu = out["opt_state"]["inner_states"]["adam_lr_scheduler"]["inner_state"]["0"]["mu"]["params"]["bkgd_mlp"]["Dense_0"]["kernel"]
     assert np.array_equal(mu, _pattern((27, 128), 1300) * np.float32(1e-3))
+
+
+@pytest.mark.parametrize("stage", ["ior", "all"])
+def test_so3_moments_survive_save_and_restore(tmp_path, stage):
+    """Stages ior* / all* train path_sampler (train.py:294-310): its Adam moments live in the flat segment "so3_mlp" and must come
+    back out under opt_state[...]["params"]["path_sampler"]["scan"]["idx_model"]["so3_mlp"] — and in again through restore_flax."""
+    from samplenerfro_amd.train import TrainState
+
+    class _M:
+        num_fine_samples = 128
+        def _flat(self, variables, name, shapes):
+            return variables["flat"][name]
+    pf = syn.init_params_flat(5, fine=True, bias_scale=0.1)
+    so3 = torch.linspace(-0.3, 0.3, 65411)
+    mk = lambda: models.make_variables({**{k: torch.from_numpy(v.copy()) for k, v in pf.items()}, "so3_mlp": so3.clone()})
+    flags = utils.default_flags(stage=stage)
+    st = TrainState.create(_M(), mk(), flags)
+    g = torch.Generator().manual_seed(3)
+    st.mu.copy_(torch.randn(st.mu.shape, generator=g)); st.nu.copy_(torch.rand(st.nu.shape, generator=g)); st.step = 11
+    path = checkpoint.save_checkpoint(str(tmp_path / stage), st.variables, st.step, st, stage=stage)
+    sd = checkpoint.restore_checkpoint(path)
+    adam = sd["opt_state"]["inner_states"]["adam_lr_scheduler"]["inner_state"]["0"]
+    lo, hi = st.segments["so3_mlp"]
+    k0 = adam["mu"]["params"]["path_sampler"]["scan"]["idx_model"]["so3_mlp"]["Dense_0"]["kernel"]
+    assert np.array_equal(np.asarray(k0), st.mu[lo:lo + 60 * 128].reshape(60, 128).numpy())
+    if stage == "ior":                                   # the radiance networks are labelled "zero" there: masked, no moments
+        assert adam["mu"]["params"]["coarse_mlp"]["Dense_0"]["kernel"] in ({}, None) or len(adam["mu"]["params"]["coarse_mlp"]["Dense_0"]["kernel"]) == 0
+    st2 = TrainState.create(_M(), mk(), flags)
+    st2.restore_flax(sd)
+    assert st2.step == 11 and torch.equal(st2.mu, st.mu) and torch.equal(st2.nu, st.nu) and torch.equal(st2.theta, st.theta)
+
+
+def test_frozen_so3_norm_follows_a_restore():
+    """weight_l2 and the norm clip run over ALL variables, the frozen path_sampler included (train.py:147-153,174-180): the cached sum of
+    its squares must follow restore_flax / an in-place change of the so3 weights."""
+    from samplenerfro_amd.train import TrainState
+
+    class _M:
+        num_fine_samples = 0
+        def _flat(self, variables, name, shapes):
+            return variables["flat"][name]
+    pf = syn.init_params_flat(5, fine=False, bias_scale=0.1)
+    variables = models.make_variables({**{k: torch.from_numpy(v.copy()) for k, v in pf.items()}, "so3_mlp": torch.zeros(65411)})
+    st = TrainState.create(_M(), variables, utils.default_flags())
+    so3 = st.variables["flat"]["so3_mlp"]
+    import weakref
+    st.frozen_sq = (0.0, so3.numel(), (id(so3), so3._version), weakref.ref(so3))          # what a first step caches
+    donor = models.make_variables({**{k: torch.from_numpy(v.copy()) for k, v in pf.items()}, "so3_mlp": torch.full((65411,), 0.5)})
+    st.restore_flax(checkpoint.params_to_state_dict(donor, 3))
+    assert st.frozen_sq is None and float(st.variables["flat"]["so3_mlp"][0]) == 0.5
+    st.frozen_sq = (1.0, so3.numel(), (id(so3), so3._version), weakref.ref(so3))
+    so3.mul_(2.0)                                                                        # an in-place load bumps the version
+    assert st.frozen_sq[2] != (id(so3), so3._version)
