@@ -290,6 +290,111 @@ int rnerf_march_adjoint(const float* table, const rnerf_grid* g, const float* pa
 int rnerf_nerfmlp_input_grad(const float* params, int backward, const void* dy, const float* rows_pd, const float* rows_dr,
                              const int32_t* node_of_sample, int32_t S, int32_t B, float* d_pos4, float* d_dir4, void* stream);
 
+/* ====================================================================================================================================
+ * Whole-path entry points ("rnerf_forward / rnerf_backward + a workspace-size query").  They sequence the stage launchers
+ * above exactly as NerfModel.__call__ (rnerf/models.py:220-535) and train_step (train.py:58-183) do, on ONE stream, from caller-owned
+ * device buffers, with no host round trip in between — so a host in any language drives the path with one call per ray batch, and a
+ * whole step can be captured into one launch graph (rnerf_graph_*).  Every random number of the path comes from DEVICE-resident
+ * jax.random keys (rnerf_rng_*), which is what makes the step capturable.
+ * ==================================================================================================================================== */
+
+/* What NerfModel closes over (attributes rnerf/models.py:42-90, setup :91-137).  Plain data; pointers are device pointers. */
+typedef struct rnerf_model {
+  const float* table;          /* float4[G^3] written by rnerf_grid_build_table (VoxMLP.setup, rnerf/ior_utils.py:139-172) */
+  rnerf_grid grid;
+  double near, far;            /* rnerf/models.py:122 */
+  int32_t num_coarse;          /* N_c  (num_coarse_samples) */
+  int32_t num_fine;            /* N_f  (num_fine_samples; 0 = single level, rnerf/models.py:368) */
+  int32_t num_path;            /* P    (num_path_samples): N = N_c * P eikonal nodes */
+  int32_t precision;           /* enum rnerf_precision of packed_coarse / packed_fine */
+  int32_t white_bkgd;          /* rnerf/model_utils.py:307-308 */
+  int32_t bd_cut;              /* != 0: the fine level's trans / trans_rgb_bkgd are the bd_cut_dist pair (rnerf/models.py:479-524) */
+  double rgb_padding, sigma_bias;   /* rnerf/models.py:78-79 */
+  double bd_cut_bbox[6];       /* min xyz, max xyz (rnerf/models.py:485-497) */
+  const void* packed_coarse;   /* rnerf_nerfmlp_pack of coarse_mlp */
+  const void* packed_fine;     /* rnerf_nerfmlp_pack of fine_mlp (NULL when num_fine == 0) */
+  const float* bkgd_params;    /* float[RNERF_BKGDMLP_PARAMS] */
+} rnerf_model;
+
+/* Level outputs, struct-of-arrays in one buffer of 9*B floats (the 5-tuple of rnerf/models.py:359-361,532-535):
+ * [0,3B) comp_rgb[B][3] | [3B,4B) distance[B] | [4B,5B) acc[B] | [5B,6B) trans[B] | [6B,9B) trans_rgb_bkgd[B][3]. */
+#define RNERF_LEVEL_FLOATS 9
+
+/* ---- device-resident jax.random keys (threefry2x32; pinned by tests/test_prng.py against values JAX publishes).
+ * rnerf_rng_split3     : train_step's `rng, key_0, key_1 = random.split(rng, 3)` (train.py:74): rng_state uint32[2] is advanced in place,
+ *                        keys4 uint32[4] receives (key_0, key_1).
+ * rnerf_rng_forward    : the key chain of NerfModel.__call__: `key, rng_0 = split(rng_0)`; jitter = arange(0, N, P) (+ randint(key, [N_c],
+ *                        0, P) when use_random_choice — also in eval, rnerf/models.py:240-242); `key, rng_1 = split(rng_1)` -> key_u, the key of
+ *                        the stratified draws (rnerf/model_utils.py:345-354).  keys4 = (rng_0, rng_1); jitter int32[N_c]; key_u uint32[2].
+ * rnerf_stratified_u_dev: rnerf_stratified_u with the key read from device memory. */
+int rnerf_rng_split3(uint32_t* rng_state, uint32_t* keys4, void* stream);
+int rnerf_rng_forward(const uint32_t* keys4, int32_t num_coarse, int32_t num_path, int32_t use_random_choice, int32_t* jitter, uint32_t* key_u,
+                      void* stream);
+int rnerf_stratified_u_dev(const uint32_t* key_dev, int32_t B, int32_t num_fine, float* u, void* stream);
+
+/* ---- NerfModel.__call__ (rnerf/models.py:220-535; callers train.py:247, eval.py:97) for one batch of B rays: march -> background MLP on the
+ * last coarse direction -> PE + coarse NerfMLP -> compositing [-> resampling -> PE + fine NerfMLP -> compositing (-> bd_cut pair)].
+ * origins, viewdirs: float[B][3].  jitter: device int32[N_c] (rnerf_rng_forward, or any strictly increasing node indices).
+ * u_fine (num_fine > 0): device float[N_f] shared by all rays (u_per_ray = 0; randomized=False: linspace(0, 1-eps, N_f)) or float[N_f][B].
+ * out_coarse / out_fine: float[RNERF_LEVEL_FLOATS * B] (out_fine unused when num_fine == 0).
+ * path_pd / path_dr (nullable, both or none): a path record float4[N][B] marched earlier for these rays (rnerf_march) — the march is
+ * skipped; otherwise it runs here into the workspace.  workspace: rnerf_forward_workspace_bytes(m, B) bytes, 256-byte aligned.
+ * max_workgroups: as rnerf_nerfmlp_forward. */
+size_t rnerf_forward_workspace_bytes(const rnerf_model* m, int32_t B);
+int rnerf_forward(const rnerf_model* m, const float* origins, const float* viewdirs, int32_t B, const int32_t* jitter, const float* u_fine,
+                  int32_t u_per_ray, const float* path_pd, const float* path_dr, float* out_coarse, float* out_fine, void* workspace,
+                  int32_t max_workgroups, void* stream);
+
+/* ---- train_step.loss_fn + jax.value_and_grad (train.py:75-164) for the radiance stages: the training forward of every level, the loss
+ * reductions, and the backward kernels down to the flat gradient.  theta: the flat fp32 parameter buffer [coarse_mlp | fine_mlp (if
+ * num_fine > 0) | bkgd_mlp] (RNERF_NERFMLP_PARAMS, RNERF_NERFMLP_PARAMS, RNERF_BKGDMLP_PARAMS floats; m->packed_* / m->bkgd_params are
+ * ignored: the operand streams are packed from theta inside the call).  grads: float[n_theta + 8]: d loss / d theta of THIS rank's rays
+ * (before the mean over ranks, train.py:166; without the weight-decay term, which rnerf_adam_update adds) followed by the 8 stats scalars
+ * of rnerf_train_stats.  pixels float[B][3]; env_dirs float[ps*ps][3] (bg_smooth_weight > 0).
+ * keys4 (device uint32[4] = key_0, key_1 of rnerf_rng_split3) drives the jitter and the stratified draws; jitter_override / u_override
+ * (nullable) inject them instead (parity tests).  path_pd / path_dr as in rnerf_forward. */
+typedef struct rnerf_train_cfg {
+  int32_t backward;            /* enum rnerf_backward */
+  int32_t randomized;          /* FLAGS.randomized (rnerf/utils.py:131): stratified fine draws */
+  int32_t use_random_choice;   /* rnerf/models.py:89 */
+  int32_t bg_patch_size;       /* ps (0: no env-map smoothness term) */
+  double bg_weight, bg_smooth_weight, annealed_alpha;     /* train.py:90-92,127-132 */
+  double frozen_sq;            /* sum of squares / count of the variables outside theta (the frozen path_sampler): weight_l2, train.py:147-153 */
+  int64_t frozen_count;
+} rnerf_train_cfg;
+size_t rnerf_train_workspace_bytes(const rnerf_model* m, const rnerf_train_cfg* c, int32_t B);
+int rnerf_train_forward_backward(const rnerf_model* m, const rnerf_train_cfg* c, const float* theta, const float* origins, const float* viewdirs,
+                                 const float* pixels, const float* env_dirs, int32_t B, const uint32_t* keys4, const int32_t* jitter_override,
+                                 const float* u_override, int32_t u_per_ray, const float* path_pd, const float* path_dr, float* grads,
+                                 void* workspace, int32_t max_workgroups, void* stream);
+
+/* ---- train.py:169-183 + optax.adam behind multi_transform (:312-317) on the flat buffers: weight-decay gradient 2 wd theta / n_all,
+ * value clip, global-norm clip (over theta's gradient and the frozen variables' weight-decay gradient, frozen_params nullable),
+ * Adam with bias correction and the reference's learning-rate schedule (rnerf/utils.py:490-528) evaluated on the device from the
+ * device-resident step counter, which is incremented.  scratch: device float[RNERF_ADAM_SCRATCH_FLOATS]. */
+#define RNERF_ADAM_SCRATCH_FLOATS 2052
+typedef struct rnerf_adam_cfg {
+  double lr_init, lr_final, lr_delay_mult;
+  int64_t max_steps, lr_delay_steps;
+  double b1, b2, eps;
+  double weight_decay_mult, grad_max_val, grad_max_norm;
+  int64_t n_all;               /* number of variables weight_l2 averages over (theta + frozen) */
+  double lr_override;          /* > 0: constant learning rate (tests) */
+} rnerf_adam_cfg;
+int rnerf_adam_update(const rnerf_adam_cfg* c, float* theta, float* mu, float* nu, float* grads, int64_t n_theta, const float* frozen_params,
+                      int64_t n_frozen, int32_t* step_counter, float* scratch, void* stream);
+
+/* ---- one launch graph per step (hipGraph): begin capture on `stream`, issue any sequence of the calls above on it (and on streams forked
+ * from it through rnerf_fork / rnerf_join), end -> an executable graph that replays the whole sequence with one launch. */
+int rnerf_graph_begin(void* stream);
+int rnerf_graph_end(void* stream, void** graph_exec);
+int rnerf_graph_launch(void* graph_exec, void* stream);
+int rnerf_graph_destroy(void* graph_exec);
+/* side-stream helpers usable inside and outside capture: rnerf_fork makes `side` wait for everything issued on `main` so far;
+ * rnerf_join makes `main` wait for everything issued on `side` so far (event pair owned by the library, per (main, side) call). */
+int rnerf_fork(void* main_stream, void* side_stream);
+int rnerf_join(void* main_stream, void* side_stream);
+
 #ifdef __cplusplus
 }
 #endif

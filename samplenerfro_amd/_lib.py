@@ -38,8 +38,33 @@ class Grid(C.Structure):
         return g
 
 
+class Model(C.Structure):
+    """rnerf_model (include/rnerf.h): what NerfModel closes over (rnerf/models.py:42-137), for the whole-path entry points."""
+    _fields_ = [("table", C.c_void_p), ("grid", Grid), ("near", C.c_double), ("far", C.c_double), ("num_coarse", C.c_int32),
+                ("num_fine", C.c_int32), ("num_path", C.c_int32), ("precision", C.c_int32), ("white_bkgd", C.c_int32), ("bd_cut", C.c_int32),
+                ("rgb_padding", C.c_double), ("sigma_bias", C.c_double), ("bd_cut_bbox", C.c_double * 6), ("packed_coarse", C.c_void_p),
+                ("packed_fine", C.c_void_p), ("bkgd_params", C.c_void_p)]
+
+
+class TrainCfg(C.Structure):
+    """rnerf_train_cfg: the loss terms of train_step.loss_fn that the shipped configs switch on (train.py:75-162)."""
+    _fields_ = [("backward", C.c_int32), ("randomized", C.c_int32), ("use_random_choice", C.c_int32), ("bg_patch_size", C.c_int32),
+                ("bg_weight", C.c_double), ("bg_smooth_weight", C.c_double), ("annealed_alpha", C.c_double), ("frozen_sq", C.c_double),
+                ("frozen_count", C.c_int64)]
+
+
+class AdamCfg(C.Structure):
+    """rnerf_adam_cfg: optax.adam + the reference's learning-rate schedule and gradient clipping (train.py:169-183,312-317)."""
+    _fields_ = [("lr_init", C.c_double), ("lr_final", C.c_double), ("lr_delay_mult", C.c_double), ("max_steps", C.c_int64),
+                ("lr_delay_steps", C.c_int64), ("b1", C.c_double), ("b2", C.c_double), ("eps", C.c_double), ("weight_decay_mult", C.c_double),
+                ("grad_max_val", C.c_double), ("grad_max_norm", C.c_double), ("n_all", C.c_int64), ("lr_override", C.c_double)]
+
+
+LEVEL_FLOATS = 9
+ADAM_SCRATCH_FLOATS = 2052
 _vp, _i32, _i64, _dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
 _GP = C.POINTER(Grid)
+_MP, _TP, _AP = C.POINTER(Model), C.POINTER(TrainCfg), C.POINTER(AdamCfg)
 
 # name -> (restype, argtypes); must list every symbol declared in include/rnerf.h
 SIGNATURES = {
@@ -88,6 +113,21 @@ SIGNATURES = {
     "rnerf_march_adjoint": (C.c_int, [_vp, _GP, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _dbl, _dbl, _i32, _vp, _vp]),
     "rnerf_nerfmlp_input_grad": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
     "rnerf_resample": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    # whole-path entry points (csrc/pipeline.hip)
+    "rnerf_rng_split3": (C.c_int, [_vp, _vp, _vp]),
+    "rnerf_rng_forward": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "rnerf_stratified_u_dev": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
+    "rnerf_forward_workspace_bytes": (C.c_size_t, [_MP, _i32]),
+    "rnerf_forward": (C.c_int, [_MP, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "rnerf_train_workspace_bytes": (C.c_size_t, [_MP, _TP, _i32]),
+    "rnerf_train_forward_backward": (C.c_int, [_MP, _TP, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "rnerf_adam_update": (C.c_int, [_AP, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
+    "rnerf_graph_begin": (C.c_int, [_vp]),
+    "rnerf_graph_end": (C.c_int, [_vp, C.POINTER(C.c_void_p)]),
+    "rnerf_graph_launch": (C.c_int, [_vp, _vp]),
+    "rnerf_graph_destroy": (C.c_int, [_vp]),
+    "rnerf_fork": (C.c_int, [_vp, _vp]),
+    "rnerf_join": (C.c_int, [_vp, _vp]),
 }
 
 _lib: Optional[C.CDLL] = None

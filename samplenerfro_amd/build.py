@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "librnerf.so")
-SOURCES = ["grid.hip", "march.hip", "render.hip", "mlp.hip"]
+SOURCES = ["grid.hip", "march.hip", "render.hip", "mlp.hip", "pipeline.hip"]
 # -ffp-contract=off + correctly rounded div/sqrt: the march/lookup/resample kernels reproduce the reference's
 # individually rounded fp32 op order so that integer indices are bit-exact against the oracle.
 # -fno-slp-vectorize: hipcc's SLP pass packs adjacent scalar fp32 ops into v_pk_{mul,add,fma}_f32.  Beside MFMAs they are slower than

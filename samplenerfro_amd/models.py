@@ -9,7 +9,9 @@ parameter tree.  There is no CPU path: tensors must live on a ROCm device.
 """
 from __future__ import annotations
 
+import ctypes as C
 import math
+import os
 import weakref
 from typing import Any, Dict, List, Optional, Sequence, Tuple
 
@@ -116,6 +118,10 @@ class NerfModel:
         self._u_lin: Optional[torch.Tensor] = None
         self._side: Optional[torch.cuda.Stream] = None
         self._mlp_wg_limit = 0
+        # whole_path: apply() goes through rnerf_forward (one C call per batch); RNERF_STAGED=1 keeps the stage-by-stage host sequence
+        self.whole_path = os.environ.get("RNERF_STAGED") != "1"
+        self._ws: Dict[Tuple[str, int], torch.Tensor] = {}
+        self._key_cache: Dict[bytes, torch.Tensor] = {}
 
     # ---- parameters -------------------------------------------------------------------------------------------------------
     def init(self, key, **unused) -> Dict[str, Any]:
@@ -237,6 +243,93 @@ class NerfModel:
         """Give the CUs reserved by prefetch_path(reserve_cus > 0) back to the MLP kernels."""
         self._mlp_wg_limit = 0
 
+    # ---- the whole path in one call (csrc/pipeline.hip) ------------------------------------------------------------------------
+    def c_model(self, variables=None) -> "_lib.Model":
+        """The rnerf_model descriptor of this model (+ the packed weights of `variables`, when given)."""
+        m = _lib.Model()
+        m.table = self.table.data_ptr()
+        m.grid = self.spec
+        m.near, m.far = self.near, self.far
+        m.num_coarse, m.num_fine, m.num_path = self.num_coarse_samples, self.num_fine_samples, self.num_path_samples
+        m.precision, m.white_bkgd = int(self.precision), int(self.white_bkgd)
+        m.rgb_padding, m.sigma_bias = self.rgb_padding, self.sigma_bias
+        m.bd_cut = int(self.bd_cut_dist is not None and self.num_fine_samples > 0)
+        if m.bd_cut:
+            for i, v in enumerate(self._bd_cut_bbox()):
+                m.bd_cut_bbox[i] = float(v)
+        if variables is not None:
+            m.packed_coarse = self._packed_weights(variables, "coarse_mlp").data_ptr()
+            if self.num_fine_samples > 0:
+                m.packed_fine = self._packed_weights(variables, "fine_mlp").data_ptr()
+            m.bkgd_params = self._flat(variables, "bkgd_mlp", BKGD_MLP_SHAPES).detach().data_ptr()
+        return m
+
+    def _workspace(self, kind: str, nbytes: int) -> torch.Tensor:
+        """One cached scratch buffer per kind ("fwd" / "train"), grown on demand (calls on one stream are ordered, so it is reused)."""
+        t = self._ws.get(kind)
+        if t is None or t.numel() < nbytes:
+            t = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+            self._ws[kind] = t
+        return t
+
+    def _keys_dev(self, *keys) -> torch.Tensor:
+        """jax.random keys as a device uint32 vector (pinned staging, asynchronous copy, cached by value like the jitter)."""
+        k = np.ascontiguousarray(np.concatenate([np.asarray(x, np.uint32).reshape(2) for x in keys]))
+        b = k.tobytes()
+        t = self._key_cache.get(b)
+        if t is None:
+            if len(self._key_cache) > 64:
+                self._key_cache.clear()
+            pin = torch.from_numpy(k.view(np.int32)).pin_memory()
+            t = (pin, pin.to(self.device, non_blocking=True))
+            self._key_cache[b] = t
+        return t[1]
+
+    def _forward_whole(self, variables, rng_0, rng_1, rays: Rays, randomized: bool, jitter, u_fine, path):
+        """NerfModel.__call__ through rnerf_forward: the keys go to the device, every stage is sequenced there."""
+        lib = _lib.load()
+        o, v = ops._chk(rays.origins, "origins"), ops._chk(rays.viewdirs, "viewdirs")
+        B, Nc, Nf = o.shape[0], self.num_coarse_samples, self.num_fine_samples
+        st = _lib.current_stream()
+        m = self.c_model(variables)
+        keys = None
+        if jitter is None:
+            keys = self._keys_dev(rng_0, rng_1)
+            jit = torch.empty(Nc, dtype=torch.int32, device=self.device)
+            key_u = torch.empty(2, dtype=torch.int32, device=self.device)
+            _lib.check(lib.rnerf_rng_forward(keys.data_ptr(), Nc, self.num_path_samples, int(self.use_random_choice), jit.data_ptr(), key_u.data_ptr(), st),
+                       "rnerf_rng_forward")
+        else:
+            jit = self._jitter_dev(jitter)
+        u, per_ray = None, 0
+        if Nf > 0:
+            if u_fine is not None:
+                u = ops._chk(u_fine, "u_fine"); per_ray = 1 if u.dim() == 2 else 0
+            elif not randomized:
+                u = self.make_u(None, B, False)
+            else:
+                if jitter is not None:          # the key chain was not run on the device: derive the stratified key on the host
+                    key, _ = prng.split(np.asarray(rng_1, np.uint32))
+                    u = self.make_u(key, B, True)
+                else:
+                    u = torch.empty((Nf, B), dtype=torch.float32, device=self.device)
+                    _lib.check(lib.rnerf_stratified_u_dev(key_u.data_ptr(), B, Nf, u.data_ptr(), st), "rnerf_stratified_u_dev")
+                per_ray = 1
+        pd = dr = None
+        if path is not None:
+            if path.batch != B:
+                raise ValueError("path handle was marched for a different batch size")
+            cur = torch.cuda.current_stream()
+            cur.wait_event(path.event)
+            pd, dr = path.pd, path.dr
+            pd.record_stream(cur); dr.record_stream(cur)
+        ws = self._workspace("fwd", lib.rnerf_forward_workspace_bytes(C.byref(m), B))
+        out_c = torch.empty(_lib.LEVEL_FLOATS * B, dtype=torch.float32, device=self.device)
+        out_f = torch.empty(_lib.LEVEL_FLOATS * B, dtype=torch.float32, device=self.device) if Nf > 0 else None
+        _lib.check(lib.rnerf_forward(C.byref(m), o.data_ptr(), v.data_ptr(), B, jit.data_ptr(), _lib.ptr(u), per_ray, _lib.ptr(pd), _lib.ptr(dr),
+                                     out_c.data_ptr(), _lib.ptr(out_f), ws.data_ptr(), int(self._mlp_wg_limit), st), "rnerf_forward")
+        return [level_views(t, B) for t in (out_c, out_f) if t is not None]
+
     # ---- forward ------------------------------------------------------------------------------------------------------------
     def apply(self, variables, *args, method=None, **kwargs):
         """flax-style entry: model.apply(variables, rng_0, rng_1, rays, randomized[, annealed_alpha]) or
@@ -256,6 +349,10 @@ class NerfModel:
         if origins.dim() != 2 or origins.shape[-1] != 3:
             raise ValueError("rays.origins must be [B, 3]")
         B = origins.shape[0]
+        if ctx is None and taps is None and self.whole_path and self.stage.startswith("radiance") and not self.use_online_sparsity:
+            # the product path: ONE call into librnerf.so (rnerf_forward) sequences every stage on the device; the stage-by-stage
+            # code below is the same sequence with taps, kept for the parity tests and for the variants rnerf_forward does not cover
+            return self._forward_whole(variables, rng_0, rng_1, rays, randomized, jitter, u_fine, path), 0.0
         Nc, Nf, N = self.num_coarse_samples, self.num_fine_samples, self.num_samples
         key, rng_0 = prng.split(np.asarray(rng_0, np.uint32))
         want_ior = self.use_online_sparsity or (taps is not None and not (ctx is not None and self.stage.startswith("all")))
@@ -422,6 +519,11 @@ class NerfModel:
             loss_sp = loss_sp + (alpha - fine_alpha_target).abs().mean()
             next_f = alpha.mean()
         return loss_sp, next_c, next_f
+
+
+def level_views(out: torch.Tensor, B: int):
+    """The 5-tuple of one level (rnerf/models.py:359-361) as views of a RNERF_LEVEL_FLOATS * B output buffer."""
+    return (out[:3 * B].view(B, 3), out[3 * B:4 * B], out[4 * B:5 * B], out[5 * B:6 * B].view(B, 1), out[6 * B:9 * B].view(B, 3))
 
 
 class PathHandle:

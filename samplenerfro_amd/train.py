@@ -20,6 +20,7 @@ plain torch arithmetic on that flat buffer: weights and optimiser state stay on 
 """
 from __future__ import annotations
 
+import ctypes as C
 import os
 import weakref
 from typing import Any, Dict, Optional
@@ -57,6 +58,17 @@ class TrainState:
         self.grads = torch.zeros(theta.numel() + _N_STATS, dtype=torch.float32, device=theta.device)   # + the stats vector
         self.frozen_sq: Optional[torch.Tensor] = None
         self.next_path = None          # PathHandle of the next step's rays when train_step was given next_rays
+        self._lr_fn_default = lr_fn    # the reference schedule (rnerf_adam_update evaluates it on the device; a replaced lr_fn is passed by value)
+        # device-resident optimiser state of rnerf_adam_update: the update count and its scratch (learning rate, bias corrections, clip)
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=theta.device) if theta.is_cuda else None
+        self._step_dev_value = 0
+        self.adam_scratch = torch.zeros(_lib.ADAM_SCRATCH_FLOATS, dtype=torch.float32, device=theta.device) if theta.is_cuda else None
+
+    def sync_step_counter(self) -> None:
+        """Make the device-resident update count equal to self.step (they drift apart when the host sets step: restore, tests)."""
+        if self.step_dev is not None and self._step_dev_value != self.step:
+            self.step_dev.fill_(int(self.step))
+            self._step_dev_value = self.step
 
     @classmethod
     def create(cls, model: NerfModel, variables: Dict[str, Any], flags) -> "TrainState":
@@ -216,6 +228,107 @@ def _all_stage_backward(model: NerfModel, state: TrainState, variables, ctx, dy_
         taps.update(a_pos=a_pos, a_dir=a_dir, n_pairs=n, v_pairs=v)
 
 
+def frozen_sq_of(state: TrainState, variables):
+    """(sum of squares, count, cache key, weak reference) of the variables outside theta — the frozen path_sampler of the radiance stages —
+    for weight_l2 / the norm clip (train.py:147-153,174-180); cached per (tensor object, version)."""
+    so3 = variables.get("flat", {}).get("so3_mlp") if "so3_mlp" not in state.segments else None      # trained in stage all*: part of theta
+    fkey = (id(so3), so3._version) if so3 is not None else None
+    if state.frozen_sq is None or state.frozen_sq[2] != fkey or (so3 is not None and state.frozen_sq[3]() is not so3):
+        # restore_flax / graft_pretrained / an in-place load of new so3 weights invalidate it
+        state.frozen_sq = (float((so3.double() ** 2).sum()) if so3 is not None else 0.0, so3.numel() if so3 is not None else 0, fkey,
+                           weakref.ref(so3) if so3 is not None else None)
+    return state.frozen_sq
+
+
+def train_cfg(model: NerfModel, state: TrainState, flags, annealed: float) -> "_lib.TrainCfg":
+    c = _lib.TrainCfg()
+    c.backward = backward_mode(flags, model)
+    c.randomized, c.use_random_choice = int(bool(flags.randomized)), int(model.use_random_choice)
+    c.bg_patch_size = int(flags.bg_patch_size) if flags.bg_smooth_weight > 0 else 0
+    c.bg_weight, c.bg_smooth_weight, c.annealed_alpha = float(flags.bg_weight), float(flags.bg_smooth_weight), float(annealed)
+    fs = frozen_sq_of(state, state.variables)
+    c.frozen_sq, c.frozen_count = fs[0], fs[1]
+    return c
+
+
+def adam_cfg(state: TrainState, flags, lr_override: float = 0.0) -> "_lib.AdamCfg":
+    a = _lib.AdamCfg()
+    a.lr_init, a.lr_final, a.lr_delay_mult = float(flags.lr_init), float(flags.lr_final), float(flags.lr_delay_mult)
+    a.max_steps, a.lr_delay_steps = int(flags.max_steps), int(flags.lr_delay_steps)
+    a.b1, a.b2, a.eps = 0.9, 0.999, 1e-8
+    a.weight_decay_mult, a.grad_max_val, a.grad_max_norm = float(flags.weight_decay_mult), float(flags.grad_max_val), float(flags.grad_max_norm)
+    a.n_all = state.theta.numel() + frozen_sq_of(state, state.variables)[1]
+    a.lr_override = float(lr_override)
+    return a
+
+
+def _train_step_whole(model: NerfModel, rng, state: TrainState, batch, flags, jitter, u_fine, path, next_rays):
+    """train_step for the radiance stages through the whole-path entry points (include/rnerf.h, csrc/pipeline.hip)."""
+    lib = _lib.load()
+    rng, key_0, key_1 = prng.split(np.asarray(rng, np.uint32), 3)
+    annealed = float(np.asarray(batch["annealed_alpha"]).reshape(-1)[0])
+    rays: Rays = batch["rays"]
+    o, v = ops._chk(rays.origins, "origins"), ops._chk(rays.viewdirs, "viewdirs")
+    pixels = ops._chk(batch["pixels"][..., :3].contiguous(), "pixels")
+    B = o.shape[0]
+    env = None
+    if flags.bg_smooth_weight > 0:
+        env = ops._chk(batch["env_rays"].viewdirs.reshape(-1, 3), "env_rays.viewdirs")
+        if env.shape[0] != flags.bg_patch_size ** 2:
+            raise ValueError("env_rays.viewdirs must hold bg_patch_size^2 directions")
+    m = model.c_model()
+    c = train_cfg(model, state, flags, annealed)
+    st = _lib.current_stream()
+    keys = model._keys_dev(key_0, key_1)
+    jit = model._jitter_dev(jitter) if jitter is not None else None
+    u, per_ray = None, 0
+    if u_fine is not None:
+        u = ops._chk(u_fine, "u_fine"); per_ray = 1 if u.dim() == 2 else 0
+    pd = dr = None
+    if path is not None:
+        if path.batch != B:
+            raise ValueError("path handle was marched for a different batch size")
+        cur = torch.cuda.current_stream()
+        cur.wait_event(path.event)
+        pd, dr = path.pd, path.dr
+        pd.record_stream(cur); dr.record_stream(cur)
+    ws = model._workspace("train", lib.rnerf_train_workspace_bytes(C.byref(m), C.byref(c), B))
+    G = state.grads
+    n_theta = state.theta.numel()
+    _lib.check(lib.rnerf_train_forward_backward(C.byref(m), C.byref(c), state.theta.data_ptr(), o.data_ptr(), v.data_ptr(), pixels.data_ptr(), _lib.ptr(env), B,
+                                                keys.data_ptr(), _lib.ptr(jit), _lib.ptr(u), per_ray, _lib.ptr(pd), _lib.ptr(dr), G.data_ptr(), ws.data_ptr(),
+                                                int(model._mlp_wg_limit), st), "rnerf_train_forward_backward")
+    # the march of the NEXT step goes to the side stream now: it runs beside the all-reduce and the optimiser update
+    next_path = model.prefetch_path(next_rays, sync_inputs=True, reserve_cus=0) if next_rays is not None else None
+    distributed.allreduce_mean_([G])                   # jax.lax.pmean of gradients and stats (train.py:166-167): one flat buffer
+    default_lr = state._lr_fn_default is state.lr_fn
+    a = adam_cfg(state, flags, 0.0 if default_lr else float(state.lr_fn(state.step)))
+    state.sync_step_counter()
+    fs = frozen_sq_of(state, state.variables)
+    frozen = state.variables["flat"].get("so3_mlp") if fs[1] > 0 else None
+    _lib.check(lib.rnerf_adam_update(C.byref(a), state.theta.data_ptr(), state.mu.data_ptr(), state.nu.data_ptr(), G.data_ptr(), n_theta, _lib.ptr(frozen),
+                                     fs[1], state.step_dev.data_ptr(), state.adam_scratch.data_ptr(), st), "rnerf_adam_update")
+    state.step += 1
+    state._step_dev_value = state.step
+    _bump(state.theta)
+    s8 = G[n_theta:]
+    two = model.num_fine_samples > 0
+    stats = Stats(loss=s8[0], psnr=s8[6], loss_c=s8[1], psnr_c=(s8[7] if two else 0.0), weight_l2=s8[4], loss_sp=0.0, loss_nrm=0.0,
+                  annealing_rate=annealed, coarse_alpha_target=0.0, fine_alpha_target=0.0, loss_bg=flags.bg_weight * s8[2], loss_bg_c=0.0,
+                  loss_bg_smooth=s8[3])
+    state.next_path = next_path
+    return state, stats, rng
+
+
+def _bump(t: torch.Tensor) -> None:
+    """librnerf.so updated `t` in place behind PyTorch's back: bump its version counter so that caches keyed on it (the packed MFMA
+    operand streams of the staged path, frozen_sq) see the change."""
+    try:
+        torch._C._autograd._unsafe_set_version_counter([t], [t._version + 1])
+    except (AttributeError, TypeError):
+        t.add_(0)
+
+
 def train_step(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], flags=None, *, jitter=None, u_fine=None,
                taps: Optional[dict] = None, path=None, next_rays: Optional[Rays] = None, forward_taps: Optional[dict] = None):
     """One optimisation step (train.py:58-183).  batch: {"rays": Rays of [B,3], "pixels": [B,>=3], "annealed_alpha": float,
@@ -234,6 +347,10 @@ def train_step(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], 
         raise ValueError("stage all*: build the model with the same stage (the march must evaluate so3_mlp)")
     if flags.beta_weight > 0 or flags.sparsity_weight > 0:
         pass        # both are multiplied by annealing_rate = 0.0 (train.py:156): no contribution to loss or gradient
+    if not all_stage and taps is None and forward_taps is None and getattr(model, "whole_path", False):
+        # the product path: the whole forward + backward is ONE call into librnerf.so (rnerf_train_forward_backward), the update another
+        # (rnerf_adam_update); what follows below is the same sequence stage by stage, with taps (parity tests, stage all*)
+        return _train_step_whole(model, rng, state, batch, flags, jitter, u_fine, path, next_rays)
     rng, key_0, key_1 = prng.split(np.asarray(rng, np.uint32), 3)
     annealed = float(np.asarray(batch["annealed_alpha"]).reshape(-1)[0])
     rays: Rays = batch["rays"]
@@ -318,12 +435,7 @@ def train_step(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], 
     # ---- weight_l2 over ALL variables, the frozen path_sampler included (train.py:147-153), and the Stats scalars: they ride in the
     #      tail of the gradient buffer, one all-reduce for both (train.py:166-167)
     n_theta = state.theta.numel()
-    so3 = variables.get("flat", {}).get("so3_mlp") if "so3_mlp" not in state.segments else None      # trained in stage all*: part of theta
-    fkey = (id(so3), so3._version) if so3 is not None else None
-    if state.frozen_sq is None or state.frozen_sq[2] != fkey or (so3 is not None and state.frozen_sq[3]() is not so3):
-        # cached per (tensor object, version): restore_flax / graft_pretrained / an in-place load of new so3 weights invalidate it
-        state.frozen_sq = (float((so3.double() ** 2).sum()) if so3 is not None else 0.0, so3.numel() if so3 is not None else 0, fkey,
-                           weakref.ref(so3) if so3 is not None else None)
+    frozen_sq_of(state, variables)
     n_all = n_theta + state.frozen_sq[1]
     st = G[n_theta:]
     ops.train_stats(sums, B, rgb_c is not None, bg_on, env_sum, ps, on, state.theta, state.frozen_sq[0], n_all, st)

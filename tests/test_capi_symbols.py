@@ -44,3 +44,30 @@ def test_argument_errors_do_not_need_a_gpu(lib_path):
     rc = lib.rnerf_grid_build_table(ctypes.c_void_p(16), ctypes.c_void_p(32), ctypes.byref(g), None)
     assert rc == -1 and b"dims" in lib.rnerf_last_error()
     assert lib.rnerf_march(None, ctypes.byref(g), None, None, 4, 2.0, 6.0, 8, None, None, None, None, None) == -1
+
+
+def test_whole_path_structs_match_the_header_layout(lib_path):
+    """ctypes mirrors of rnerf_model / rnerf_train_cfg: the workspace queries read num_coarse / num_fine / num_path / bd_cut / backward
+    / bg_patch_size out of them on the host — the sizes must move exactly as the fields say."""
+    lib = _lib.load()
+    m = _lib.Model()
+    m.num_coarse, m.num_fine, m.num_path = 64, 0, 12
+    assert lib.rnerf_forward_workspace_bytes(ctypes.byref(m), 0) == 0
+    a = lib.rnerf_forward_workspace_bytes(ctypes.byref(m), 512)
+    path = 2 * 64 * 12 * 512 * 16
+    assert path < a < path + 64 * 512 * 24 + 512 * 64
+    m.num_fine = 128
+    b = lib.rnerf_forward_workspace_bytes(ctypes.byref(m), 512)
+    assert b - a >= 192 * 512 * (16 + 16 + 16 + 4)                       # fine rows (pd, dr), raw, merged depths
+    m.bd_cut = 1
+    assert lib.rnerf_forward_workspace_bytes(ctypes.byref(m), 512) - b >= 2 * 9 * 512 * 4
+    c = _lib.TrainCfg()
+    c.backward = _lib.BWD_F16
+    t1 = lib.rnerf_train_workspace_bytes(ctypes.byref(m), ctypes.byref(c), 512)
+    c.backward = _lib.BWD_F16X2
+    t2 = lib.rnerf_train_workspace_bytes(ctypes.byref(m), ctypes.byref(c), 512)
+    assert t2 > t1 > b                                                   # hi + lo saves / dY planes
+    c.bg_smooth_weight, c.bg_patch_size = 1.0, 128
+    assert lib.rnerf_train_workspace_bytes(ctypes.byref(m), ctypes.byref(c), 512) > t2
+    rc = lib.rnerf_adam_update(None, None, None, None, None, 0, None, 0, None, None, None)
+    assert rc == -1 and b"rnerf_adam_update" in lib.rnerf_last_error()
