@@ -28,6 +28,7 @@ MLP_FLOP_PER_ROW = 2 * 593408          # NerfMLP MACs*2 per sample row (BASELINE
 BKGD_FLOP_PER_RAY = 2 * 56448
 PEAK_MFMA_16BIT = 2.5e15               # dense bf16/f16 MFMA peak (MI355X_MICROARCH.md)
 PEAK_HBM = 8.0e12
+CPU_WARMUP, CPU_TIMED = 3, 5           # cpu_baseline: 3 warm-up + 5 timed passes, median
 PRECISION_NOTES = {
     "f16x3": "fp32 operands split into hi + lo f16 parts, 3 MFMAs per product, fp32 accumulate (fp32-grade: |dRGB| ~1e-6 vs the oracle)",
     "bf16x3": "fp32 operands split into hi + lo bf16 parts, 3 MFMAs per product, fp32 accumulate",
@@ -86,14 +87,14 @@ def cpu_baseline(cfg, pf, fine, sample_rays, seed, train=False):
     jitter = np.arange(0, mc.num_samples, cfg["P"]) + (cfg["P"] // 2)
     params = syn.params_tree(pf)
     times = []
-    for it in range(1 + 3):                  # one warm-up (thread pools, page faults, BLAS autotuning) + 3 timed: the median is reported
+    for it in range(CPU_WARMUP + CPU_TIMED):   # warm-up passes (thread pools, page faults, BLAS autotuning), then the median of the timed ones
         if train:
             _, dt = cpu_train_step(R, mc, pf, params, table, o, d, jitter, cfg, fine, seed)
         else:
             t0 = time.perf_counter()
             R.nerf_forward(mc, params, table, o, d, jitter)
             dt = time.perf_counter() - t0
-        if it > 0:
+        if it >= CPU_WARMUP:
             times.append(dt)
     dt = float(np.median(times))
     return sample_rays / dt, dt
@@ -193,6 +194,116 @@ def relaunch_for_gpus(args):
                          "they must agree (the line's n_gpus is the number of ranks that ran)")
 
 
+class Stepper:
+    """One training (or forward) step of a workload, repeated.  Training in the radiance stages replays the step's launch graph
+    (samplenerfro_amd.graph.GraphTrainStep: one hipGraphLaunch per step, the next step's march on a side branch); --no-graph issues the
+    kernels one by one through train_step."""
+
+    def __init__(self, args, cfg, model, variables, rays, key, B, world, rank, fine, device, backward, mode, stage, pipeline, graph):
+        import torch
+        from samplenerfro_amd import utils as U
+        self.args, self.model, self.variables, self.rays, self.key, self.mode = args, model, variables, rays, key, mode
+        self.train = mode == "train"
+        self.pipeline, self.graph, self.h, self.rng, self.g = pipeline, graph and self.train and stage == "radiance", None, key, None
+        if not self.train:
+            return
+        # the shipped configs' loss terms (configs/*.yaml): bg_weight 0.025, bg_smooth_weight 1.0 on a 128x128 env-map patch,
+        # randomized stratified resampling, Adam with the reference schedule; pixels are synthetic
+        from samplenerfro_amd import synthetic as syn
+        from samplenerfro_amd.train import TrainState
+        self.flags = U.default_flags(num_coarse_samples=cfg["S"], num_fine_samples=fine, num_path_samples=cfg["P"], white_bkgd=False,
+                                     bg_weight=0.025, bg_smooth_weight=1.0, bg_patch_size=128, use_online_sparsity=False, randomized=True,
+                                     near=cfg["near"], far=cfg["far"], batch_size=B * world, backward_precision=backward, stage=stage)
+        self.tstate = TrainState.create(model, variables, self.flags)
+        gen = np.random.default_rng(syn.SEED + 1000 + rank)
+        ev_d = gen.standard_normal((self.flags.bg_patch_size, self.flags.bg_patch_size, 3)).astype(np.float32)
+        ev_d /= np.linalg.norm(ev_d, axis=-1, keepdims=True)
+        self.batch = {"rays": rays, "pixels": torch.from_numpy(gen.uniform(0, 1, (B, 3)).astype(np.float32)).to(device), "annealed_alpha": 0.5,
+                      "env_rays": U.Rays(None, None, torch.from_numpy(ev_d).to(device), None)}
+        if self.graph:
+            from samplenerfro_amd.graph import GraphTrainStep
+            self.g = GraphTrainStep(model, self.tstate, self.flags, B, key, env_rays=self.batch["env_rays"], annealed_alpha=0.5, prefetch=pipeline)
+            self.g.load(self.batch)
+            for _ in range(3):                       # eager warm-up step + the capture of both slots' graphs, outside every timed region
+                self.step()
+
+    def step(self, last=False):
+        if self.g is not None:
+            if self.pipeline:
+                self.g.load_next(self.batch)       # the rays of the step after (their march is a side branch of this step's graph)
+            return self.g.step().loss
+        if self.train:
+            from samplenerfro_amd.train import train_step
+            # the march of step k+1 is issued on the side stream behind the backward of step k
+            _, stats, self.rng = train_step(self.model, self.rng, self.tstate, self.batch, self.flags, path=self.h,
+                                            next_rays=self.rays if (self.pipeline and not last) else None)
+            self.h = self.tstate.next_path
+            return stats.loss
+        m, a = self.model, self.args
+        h = self.h if self.pipeline else None
+        if self.pipeline and h is None:
+            h = m.prefetch_path(self.rays, sync_inputs=False, reserve_cus=a.reserve_cus)
+        self.h = m.prefetch_path(self.rays, sync_inputs=False, reserve_cus=a.reserve_cus) if (self.pipeline and not last) else None
+        ret, _ = m.apply(self.variables, self.key, self.key, self.rays, False, path=h)
+        return ret[-1][0]
+
+    def close(self):
+        if self.g is not None:
+            self.g.close()
+        self.g = self.tstate = None
+        self.model._ws.clear()
+
+
+def timed_steps(stepper, warmup, steps, barrier, D, device):
+    import torch
+    for i in range(warmup):
+        stepper.step(last=(i == warmup - 1))
+    barrier()
+    t0 = time.perf_counter()
+    out = None
+    for i in range(steps):
+        out = stepper.step(last=(i == steps - 1))
+    barrier()
+    dt = D.max_over_ranks(time.perf_counter() - t0, device)
+    assert bool(torch.isfinite(out).all())
+    return dt
+
+
+def pmc_lookup(workload, fine, B, mode, backward, rnerf_cus):
+    """HBM bytes and SQ / GRBM counters per launch from the committed rocprofv3 --pmc passes of THIS command (tools/r03/pmc_all.sh; PMC
+    counters cannot be read from inside the process).  The JSON is stamped with the sha of the kernel sources and of bench.py it was taken
+    with: a stale stamp (or no profile of this workload) leaves every counter-derived field null."""
+    import hashlib
+    tag = ("%s_f%d_%s" % (workload, fine, mode if mode == "forward" else "train_" + backward))
+    rel = os.path.join("profiles", "r03", "pmc_%s.json" % tag)
+    path = os.path.join(ROOT, rel)
+    if B != 4096 or not os.path.exists(path):
+        return {}, {}, None
+    try:
+        pj = json.load(open(path))
+        sha = lambda q: hashlib.sha256(open(q, "rb").read()).hexdigest()[:16]
+        now = {f: sha(os.path.join(ROOT, "samplenerfro_amd", "csrc", f)) for f in pj.get("csrc_sha16", {})}
+        fresh = bool(now) and now == pj.get("csrc_sha16")
+        meta = {"file": rel, "head": pj.get("head"), "bench_py_sha16": pj.get("bench_py_sha16"), "kernels_unchanged_since": fresh}
+        traffic, sq = {}, {}
+        if fresh:
+            for k, v in pj["counters"].items():
+                name = k.split("::")[-1]
+                if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+                    # KiB -> bytes; wide (16 B/lane) streaming reads are reported at half their size on gfx950 (MI355X_MICROARCH.md, HBM):
+                    # doubled for the MLP kernels (weight DMA / saved-operand streams); the march's gathers stay as reported
+                    ff = 2.0 if "nerfmlp" in k else 1.0
+                    traffic[name] = 1024.0 * (ff * v["FETCH_SIZE"]["mean"] + v["WRITE_SIZE"]["mean"])
+                if "SQ_VALU_MFMA_BUSY_CYCLES" in v and "GRBM_GUI_ACTIVE" in v:
+                    gui = v["GRBM_GUI_ACTIVE"]["mean"] / float(pj.get("xcd_instances", 8))     # reported summed over the XCDs' GRBM instances
+                    sq[name] = {"mfma_busy_frac": v["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"] / (4.0 * rnerf_cus * gui),
+                                "effective_clock_ghz": gui / v["avg_ns"]["mean"] if "avg_ns" in v else None,
+                                "wave_wait_frac": (v["SQ_WAIT_ANY"]["mean"] / v["SQ_WAVE_CYCLES"]["mean"]) if "SQ_WAIT_ANY" in v and "SQ_WAVE_CYCLES" in v else None}
+        return traffic, sq, meta
+    except Exception:
+        return {}, {}, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -204,15 +315,16 @@ def main():
     ap.add_argument("--rays", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pipeline", dest="pipeline", action="store_true", default=None,
-                    help="issue the march of step k+1 on a side stream (train: beside the small tail kernels of step k, default ON; "
+                    help="march of step k+1 beside step k (train: a side branch of the step's graph / the side stream, default ON; "
                          "forward: beside the MLP on reserved CUs, default OFF)")
     ap.add_argument("--no-pipeline", dest="pipeline", action="store_false", help="every step runs its stages strictly in sequence")
+    ap.add_argument("--no-graph", dest="graph", action="store_false", help="train: issue the step's kernels one by one instead of replaying its launch graph")
     ap.add_argument("--no-extra", dest="extra", action="store_false",
-                    help="skip the short timing of the other backward modes (train mode)")
+                    help="skip the short timings of the other backward modes and of the other workload variants (train mode)")
     ap.add_argument("--no-frame", dest="frame", action="store_false",
                     help="skip the 800x800 full-frame render (ms/frame, the second part of BASELINE's metric; ~1 s)")
-    ap.add_argument("--reserve-cus", type=int, default=32, help="CUs kept free of MLP workgroups for the overlapped march")
-    ap.add_argument("--cpu-rays", type=int, default=None, help="rays in the CPU baseline sample (default 8192 forward / 1536 train)")
+    ap.add_argument("--reserve-cus", type=int, default=32, help="CUs kept free of MLP workgroups for the overlapped march (forward mode)")
+    ap.add_argument("--cpu-rays", type=int, default=None, help="rays in the CPU baseline sample (default 4096 forward / 512 train)")
     ap.add_argument("--backward", choices=["f32", "tf32", "bf16"], default="f32",
                     help="arithmetic of the NerfMLP backward: f32 = hi + lo f16 parts (fp32-grade, the reference differentiates in fp32; "
                          "default), tf32 = f16 parts (11-bit significand), bf16 = 8-bit significand (round 1's arithmetic)")
@@ -229,7 +341,7 @@ def main():
     if args.pipeline is None:
         args.pipeline = args.mode == "train"
     if args.cpu_rays is None:
-        args.cpu_rays = 4096 if args.mode == "forward" else 768
+        args.cpu_rays = 4096 if args.mode == "forward" else 512
 
     import torch
     import torch.distributed as dist
@@ -258,64 +370,47 @@ def main():
         if B % world:
             raise SystemExit("--scaling strong: the global batch must be divisible by the number of ranks (train.py:196)")
         B //= world
+    t_scene = time.perf_counter()
     model, variables, pf = build_scene(cfg, device, args.precision, fine, args.stage)
+    torch.cuda.synchronize()
+    t_scene = time.perf_counter() - t_scene
     if args.stage == "all":
         args.pipeline = False           # the all* march reads the so3 parameters of the current step: no cross-step prefetch
     # weak scaling: every rank marches its own B rays (different seed per rank), grid + weights replicated
     o, d = syn.sphere_rays(B, seed=syn.SEED + rank)
     rays = Rays(torch.from_numpy(o).to(device), None, torch.from_numpy(d).to(device), None)
     key = prng.split(prng.PRNGKey(syn.SEED), world)[rank]      # one key per device (train.py:338-339)
-
-    # Software pipeline across steps: the march of batch k+1 (latency-bound, no matrix cores) runs on a side stream
-    # while the MLP/compositing phase of batch k (MFMA-bound) runs on the main stream.  Every step still does its whole
-    # work inside the timed region (the first march is issued after the opening barrier).
-    state = {"h": None, "rng": key}
     train = args.mode == "train"
-    if train:
-        # the shipped configs' loss terms (configs/*.yaml): bg_weight 0.025, bg_smooth_weight 1.0 on a 128x128 env-map patch,
-        # randomized stratified resampling, Adam with the reference schedule; pixels are synthetic
-        from samplenerfro_amd import utils as U
-        from samplenerfro_amd.train import TrainState, train_step
-        flags = U.default_flags(num_coarse_samples=cfg["S"], num_fine_samples=fine, num_path_samples=cfg["P"], white_bkgd=False,
-                                bg_weight=0.025, bg_smooth_weight=1.0, bg_patch_size=128, use_online_sparsity=False, randomized=True,
-                                near=cfg["near"], far=cfg["far"], batch_size=B * world, backward_precision=args.backward, stage=args.stage)
-        tstate = TrainState.create(model, variables, flags)
-        gen = np.random.default_rng(syn.SEED + 1000 + rank)
-        ev_d = gen.standard_normal((flags.bg_patch_size, flags.bg_patch_size, 3)).astype(np.float32)
-        ev_d /= np.linalg.norm(ev_d, axis=-1, keepdims=True)
-        batch = {"rays": rays, "pixels": torch.from_numpy(gen.uniform(0, 1, (B, 3)).astype(np.float32)).to(device), "annealed_alpha": 0.5,
-                 "env_rays": Rays(None, None, torch.from_numpy(ev_d).to(device), None)}
-
-    def step(last=False):
-        if train:
-            # the march of step k+1 is issued right after the forward of step k and runs beside its backward kernels
-            _, stats, state["rng"] = train_step(model, state["rng"], tstate, batch, flags, path=state["h"],
-                                                next_rays=rays if (args.pipeline and not last) else None)
-            state["h"] = tstate.next_path
-            return [(stats.loss.reshape(1),)], None
-        h = state["h"] if args.pipeline else None
-        if args.pipeline and h is None:
-            h = model.prefetch_path(rays, sync_inputs=False, reserve_cus=args.reserve_cus)
-        state["h"] = model.prefetch_path(rays, sync_inputs=False, reserve_cus=args.reserve_cus) if (args.pipeline and not last) else None
-        return model.apply(variables, key, key, rays, False, path=h)
 
     def barrier():
         if D.active():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(last=(i == args.warmup - 1))
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        ret, _ = step(last=(i == args.steps - 1))
-    barrier()
-    dt = time.perf_counter() - t0
-    dt = D.max_over_ranks(dt, device)
-    assert torch.isfinite(ret[-1][0]).all()
+    # ---- the headline: W untimed warm-up steps, then exactly K timed steps between barriers, max over ranks --------------------------
+    # Every step does its whole work inside the timed region; with the pipeline on, step k also marches the rays of step k+1 (one march
+    # per step either way: the first timed step consumes the march the last warm-up step issued, the last one issues one nobody reads).
+    stepper = Stepper(args, cfg, model, variables, rays, key, B, world, rank, fine, device, args.backward, args.mode, args.stage, args.pipeline, args.graph)
+    dt = timed_steps(stepper, args.warmup, args.steps, barrier, D, device)
+    graph_used = stepper.g is not None
 
-    # ---- per-kernel roofline of the dominant kernel (PE + NerfMLP), HIP events on the launch stream --------------------
+    other_modes = None
+    if train and args.extra:
+        # the same step with the other backward arithmetics (5 steps each, after 2 warm-up steps), for the record in the same line
+        other_modes = {}
+        stepper.close()
+        for name in ("f32", "tf32", "bf16"):
+            if name == args.backward or (args.stage == "all" and name == "bf16"):
+                continue
+            s2 = Stepper(args, cfg, model, variables, rays, key, B, world, rank, fine, device, name, args.mode, args.stage, args.pipeline, args.graph)
+            dt_m = timed_steps(s2, 2, 5, barrier, D, device)
+            s2.close()
+            other_modes[name] = {"ms_per_step": 1e3 * dt_m / 5, "rays_per_s": B * world * 5 / dt_m}
+    stepper.close()
+    del stepper
+    torch.cuda.empty_cache()
+
+    # ---- per-kernel roofline of the dominant kernels, HIP events on the launch stream ----------------------------------------------
     from samplenerfro_amd import ops, _lib
     rnerf_cus = _lib.load().rnerf_device_cus()
     S = cfg["S"]
@@ -324,26 +419,22 @@ def main():
     jit = model._jitter_dev(model.make_jitter(key))
     packed = model._packed_weights(variables, "coarse_mlp")
     reps = max(5, min(args.steps, 20))
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
-    out = None
-    ops.nerfmlp_forward(packed, model.precision, path_pd, path_dr, jit, S, B)
-    torch.cuda.synchronize()
-    ev[0].record()
-    for i in range(reps):
-        out = ops.nerfmlp_forward(packed, model.precision, path_pd, path_dr, jit, S, B, out=out)
-        ev[i + 1].record()
-    torch.cuda.synchronize()
-    mlp_ms = float(np.mean([ev[i].elapsed_time(ev[i + 1]) for i in range(reps)]))
+
+    def timed(fn):
+        fn(); torch.cuda.synchronize()
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+        e[0].record()
+        for i in range(reps):
+            fn(); e[i + 1].record()
+        torch.cuda.synchronize()
+        return float(np.mean([e[i].elapsed_time(e[i + 1]) for i in range(reps)]))
+
+    out_raw = torch.empty((S, B, 4), dtype=torch.float32, device=device)
+    mlp_ms = timed(lambda: ops.nerfmlp_forward(packed, model.precision, path_pd, path_dr, jit, S, B, out=out_raw))
     mlp_flops = MLP_FLOP_PER_ROW * S * B
     mlp_achieved = mlp_flops / (mlp_ms * 1e-3)
     # march kernel (HBM-bound by its algorithmic gather bytes: 8 corners x 16 B per step)
-    ev2 = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
-    ev2[0].record()
-    for i in range(reps):
-        ops.march(model.table, model.spec, rays.origins, rays.viewdirs, cfg["near"], cfg["far"], N, out=(path_pd, path_dr))
-        ev2[i + 1].record()
-    torch.cuda.synchronize()
-    march_ms = float(np.mean([ev2[i].elapsed_time(ev2[i + 1]) for i in range(reps)]))
+    march_ms = timed(lambda: ops.march(model.table, model.spec, rays.origins, rays.viewdirs, cfg["near"], cfg["far"], N, out=(path_pd, path_dr)))
     march_bytes = B * (N * 128 + 24)
     march_achieved = march_bytes / (march_ms * 1e-3)
 
@@ -359,16 +450,6 @@ def main():
         dy_t = torch.empty(lib.rnerf_nerfmlp_dy_bytes(rows, BW), dtype=torch.uint8, device=device)
         ws_t = torch.empty(lib.rnerf_nerfmlp_wgrad_workspace_bytes(), dtype=torch.uint8, device=device)
         g_t = torch.empty(_lib.NERFMLP_PARAMS, device=device)
-
-        def timed(fn):
-            fn(); torch.cuda.synchronize()
-            e = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
-            e[0].record()
-            for i in range(reps):
-                fn(); e[i + 1].record()
-            torch.cuda.synchronize()
-            return float(np.mean([e[i].elapsed_time(e[i + 1]) for i in range(reps)]))
-
         jp = jit.data_ptr()
         t_f = timed(lambda: lib.rnerf_nerfmlp_forward_train(packed.data_ptr(), model.precision, path_pd.data_ptr(), path_dr.data_ptr(), jp, S, B,
                                                             raw_t.data_ptr(), save_t.data_ptr(), BW, 0, _lib.current_stream()))
@@ -379,47 +460,23 @@ def main():
         # the sigma head share their operand streams with the main block: 316 slot planes); bf16 body: 14 single-segment jobs (356)
         wgrad_slots = (8 * 32 + 2 * 20 + 17 + 24 + 10 + 9) if args.backward == "bf16" else (20 + 4 * 32 + 36 + 2 * 32 + 33 + 26 + 9)
         wgrad_bytes = wgrad_slots * R_pad * 32 * (2 if args.backward == "f32" else 1)
-        for name, ms, flop, bound, byt in (("nerfmlp_fwd_kernel<train>", t_f, MLP_FLOP_PER_ROW * rows, "mfma", None),
-                                           ("nerfmlp_dgrad_kernel", t_d, 2 * 557696 * rows, "mfma", None),
-                                           ("nerfmlp_wgrad_kernel" if args.backward == "bf16" else "nerfmlp_wgrad_tr_kernel", t_w, MLP_FLOP_PER_ROW * rows, "hbm", wgrad_bytes)):
-            if bound == "mfma":
-                train_kernels.append({"kernel": name, "bound": "mfma", "achieved": flop / (ms * 1e-3) / 1e12, "peak": PEAK_MFMA_16BIT / 1e12,
-                                      "unit": "TFLOP/s", "frac": flop / (ms * 1e-3) / PEAK_MFMA_16BIT, "avg_launch_ms": ms,
-                                      "algorithmic_flop_per_launch": flop})
-            else:
-                train_kernels.append({"kernel": name, "bound": "hbm", "achieved": byt / (ms * 1e-3) / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
-                                      "frac": byt / (ms * 1e-3) / PEAK_HBM, "avg_launch_ms": ms, "algorithmic_bytes_per_launch": byt,
-                                      "algorithmic_flop_per_launch": flop})
+        # the MLP phase is MFMA-bound and its algorithmic work is 2 x 593 408 FLOP per row (forward and wgrad) / 2 x 557 696
+        # (dgrad: the encodings take no gradient).  The saved-operand / dY planes the kernels stream through HBM are an implementation
+        # choice (like the path record): reported next to it as `operand_stream`, never as the algorithmic fraction.
+        for name, ms, flop, byt in (("nerfmlp_fwd_kernel<train>", t_f, MLP_FLOP_PER_ROW * rows, None),
+                                    ("nerfmlp_dgrad_kernel", t_d, 2 * 557696 * rows, None),
+                                    ("nerfmlp_wgrad_kernel" if args.backward == "bf16" else "nerfmlp_wgrad_tr_kernel", t_w, MLP_FLOP_PER_ROW * rows, wgrad_bytes)):
+            tk = {"kernel": name, "bound": "mfma", "achieved": flop / (ms * 1e-3) / 1e12, "peak": PEAK_MFMA_16BIT / 1e12,
+                  "unit": "TFLOP/s", "frac": flop / (ms * 1e-3) / PEAK_MFMA_16BIT, "avg_launch_ms": ms, "algorithmic_flop_per_launch": flop}
+            if byt is not None:
+                tk["operand_stream"] = {"operand_stream_bytes": byt, "GB_per_s": byt / (ms * 1e-3) / 1e9, "frac_of_hbm_peak": byt / (ms * 1e-3) / PEAK_HBM,
+                                        "note": "hi + lo f16 planes of the saved activations and of dY, read once: what paces this kernel (an "
+                                                "implementation choice, not algorithmic bytes)"}
+            train_kernels.append(tk)
         del raw_t, save_t, dy_t, ws_t
+        torch.cuda.empty_cache()
 
-    # HBM bytes and SQ / GRBM counters per launch come from rocprofv3 --pmc passes of THIS command (tools/r02/pmc_all.sh; PMC counters
-    # cannot be read from inside the process).  The committed JSON is stamped with the sha of bench.py and csrc/mlp.hip it was taken
-    # with; `traffic` / `counters` are null / absent when no profile of this workload exists or its stamp is stale.
-    traffic, sq, pmc_meta = {}, {}, None
-    try:
-        import hashlib
-        if args.workload == "ship_straight" and fine == 0 and B == 4096:
-            tag = args.mode if args.mode == "forward" else "train_" + args.backward
-            pj = json.load(open(os.path.join(ROOT, "profiles", "r02", "pmc_%s.json" % tag)))
-            sha = lambda q: hashlib.sha256(open(q, "rb").read()).hexdigest()[:16]
-            fresh = pj.get("mlp_hip_sha16") == sha(os.path.join(ROOT, "samplenerfro_amd", "csrc", "mlp.hip"))
-            pmc_meta = {"file": "profiles/r02/pmc_%s.json" % tag, "head": pj.get("head"), "bench_py_sha16": pj.get("bench_py_sha16"),
-                        "kernels_unchanged_since": bool(fresh)}
-            for k, v in pj["counters"].items():
-                name = k.split("::")[-1]
-                if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
-                    # KiB -> bytes; wide (16 B/lane) streaming reads are reported at half their size on gfx950 (MI355X_MICROARCH.md, HBM):
-                    # doubled for the MLP kernels (weight DMA / saved-operand streams); the march's 4-byte gathers stay as reported
-                    ff = 2.0 if "nerfmlp" in k else 1.0
-                    traffic[name] = 1024.0 * (ff * v["FETCH_SIZE"]["mean"] + v["WRITE_SIZE"]["mean"])
-                if "SQ_VALU_MFMA_BUSY_CYCLES" in v and "GRBM_GUI_ACTIVE" in v:
-                    gui = v["GRBM_GUI_ACTIVE"]["mean"] / float(pj.get("xcd_instances", 8))     # reported summed over the XCDs' GRBM instances
-                    # measured matrix-pipe occupancy: MFMA-busy cycles (summed over SIMDs) / (SIMDs x GPU-active cycles of the launch)
-                    sq[name] = {"mfma_busy_frac": v["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"] / (4.0 * rnerf_cus * gui),
-                                "effective_clock_ghz": gui / v["avg_ns"]["mean"] if "avg_ns" in v else None,
-                                "wave_wait_frac": (v["SQ_WAIT_ANY"]["mean"] / v["SQ_WAVE_CYCLES"]["mean"]) if "SQ_WAIT_ANY" in v and "SQ_WAVE_CYCLES" in v else None}
-    except Exception:
-        traffic, sq = {}, {}
+    traffic, sq, pmc_meta = pmc_lookup(args.workload, fine, B, args.mode, args.backward, rnerf_cus)
 
     def traffic_of(prefix):
         for k, v in traffic.items():
@@ -432,25 +489,48 @@ def main():
             if k.startswith(prefix):
                 return v
         return None
-    other_modes = None
-    if train and args.extra:
-        # the same step with the other backward arithmetics (5 steps each, after 2 warm-up steps), for the record in the same line
-        other_modes = {}
-        for name in ("f32", "tf32", "bf16"):
-            if name == args.backward or (args.stage == "all" and name == "bf16"):
-                continue
-            flags.backward_precision = name
-            state["h"] = None
-            for i in range(2):
-                step(last=(i == 1))
-            barrier()
-            t1 = time.perf_counter()
-            for i in range(5):
-                step(last=(i == 4))
-            barrier()
-            dt_m = D.max_over_ranks(time.perf_counter() - t1, device)
-            other_modes[name] = {"ms_per_step": 1e3 * dt_m / 5, "rays_per_s": B * world * 5 / dt_m}
-        flags.backward_precision = args.backward
+
+    # ---- the harder variants of the same metric, in the same driver-run record ------------------------------------
+    variants = None
+    if train and args.extra and args.stage == "radiance" and args.workload == "ship_straight" and args.rays is None and args.fine is None:
+        variants = {}
+
+        def run_variant(tag, vcfg, vmodel, vvars, vfine, vB, note):
+            ov, dv = syn.sphere_rays(vB, seed=syn.SEED + rank)
+            vrays = Rays(torch.from_numpy(ov).to(device), None, torch.from_numpy(dv).to(device), None)
+            sv = Stepper(args, vcfg, vmodel, vvars, vrays, key, vB, world, rank, vfine, device, args.backward, "train", "radiance", args.pipeline, args.graph)
+            dtv = timed_steps(sv, 2, 5, barrier, D, device)
+            sv.close()
+            torch.cuda.empty_cache()
+            variants[tag] = {"ms_per_step": 1e3 * dtv / 5, "rays_per_s": vB * world * 5 / dtv, "rays_per_gpu": vB, "coarse": vcfg["S"], "fine": vfine,
+                             "what": note}
+
+        vm = models_with_fine(model, cfg, 256, device, args.precision)
+        run_variant("ship_straight_128+256", cfg, vm[0], vm[1], 256, 4096, "BASELINE configs[1], hierarchical (N_f = 2S: 512 MLP rows per ray)")
+        del vm
+        del model, variables
+        torch.cuda.empty_cache()
+        rcfg = dict(syn.CONFIGS["ship_refractive"])
+        t0 = time.perf_counter()
+        rmodel, rvars, _ = build_scene(rcfg, device, args.precision, 0, "radiance")
+        torch.cuda.synchronize()
+        t_refr = time.perf_counter() - t0
+        run_variant("ship_refractive_128", rcfg, rmodel, rvars, 0, 4096, "BASELINE configs[2]: 512^3 sphere grid after the (9, 3.0) prefilter; the speculative "
+                    "march mispredicts where rays bend")
+        vm = models_with_fine(rmodel, rcfg, 256, device, args.precision)
+        run_variant("ship_refractive_128+256", rcfg, vm[0], vm[1], 256, 4096, "BASELINE configs[2], hierarchical")
+        del vm, rmodel, rvars
+        torch.cuda.empty_cache()
+        dcfg = dict(syn.CONFIGS["dolphin_train"])
+        dmodel, dvars, _ = build_scene(dcfg, device, args.precision, dcfg["F"], "radiance")
+        for vB, note in ((4096, "BASELINE configs[3] on one GPU: 64 + 128 samples, 256^3 grid, global batch 4096"),
+                         (1024, "the reference's default batch (configs/example.yaml:20)"), (512, "one GPU's shard of 4096 rays over 8 GPUs")):
+            run_variant("dolphin_train_%d" % vB, dcfg, dmodel, dvars, dcfg["F"], vB, note)
+        del dmodel, dvars
+        torch.cuda.empty_cache()
+        variants["scene_build_s"] = {"ship_straight (table only)": t_scene, "ship_refractive (sphere + (9, 3.0) prefilter + table, 512^3)": t_refr}
+        model, variables, pf = build_scene(cfg, device, args.precision, fine, args.stage)
+
     frame = None
     if args.frame:
         # ms/frame @ 800x800 (BASELINE.json metric 2): pinhole rays of the example camera looking at the volume, rendered in
@@ -474,6 +554,7 @@ def main():
     if rank == 0:
         total_rays = B * args.steps * world
         rows_per_ray = S + (S + fine if fine > 0 else 0)
+        flop_per_ray_fwd = rows_per_ray * MLP_FLOP_PER_ROW + BKGD_FLOP_PER_RAY
         line = {
             "metric": "rays/sec (train step)" if train else "rays/sec (forward render pass)", "value": total_rays / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": args.scaling,
@@ -488,7 +569,9 @@ def main():
                            "f32": "row-normalised f16 hi + lo parts of every saved activation and gradient (22 bits), 3 MFMAs per product: within 1e-5 of max|g| vs float64",
                            "tf32": "row-normalised f16 parts (11-bit significand), 1-2 MFMAs per product: ~1e-3 of max|g| on small batches, ~1e-5 at this size",
                            "bf16": "bf16 parts (8-bit significand), round 1's arithmetic: ~6e-3 of max|g| on small batches"}[args.backward]),
-                       "pipeline": ("none" if not args.pipeline else ("march(k+1) on a side stream beside the tail of step k (bkgd backward, Adam)" if train
+                       "launch": ("one hipGraph launch per step (key split, march branch, forward, backward, Adam: csrc/pipeline.hip)" if graph_used
+                                  else "kernels issued one by one from the host"),
+                       "pipeline": ("none" if not args.pipeline else ("march(k+1) on a side branch beside the tail of step k" if train
                                                                           else "march(k+1) on a side stream overlaps MLP(k)"))},
             "roofline": {"kernel": "nerfmlp_fwd_kernel", "bound": "mfma", "achieved": mlp_achieved / 1e12, "peak": PEAK_MFMA_16BIT / 1e12,
                          "unit": "TFLOP/s", "frac": mlp_achieved / PEAK_MFMA_16BIT, "traffic": traffic_of("nerfmlp_fwd_kernel<1, 0, 0>"),
@@ -501,7 +584,7 @@ def main():
                                "algorithmic_bytes_per_launch": march_bytes},
         }
         if train:
-            # the dominant kernel of a train step is the training forward (the forward + the operand/mask stores for the backward)
+            # the dominant kernel of a train step: the longest of training forward / dgrad / wgrad (algorithmic FLOP against the MFMA peak)
             fk = "nerfmlp_fwd_kernel<1, 0, 2>" if args.backward == "f32" else "nerfmlp_fwd_kernel<1, 0, 1>"
             for tk, pref in zip(train_kernels, (fk, "nerfmlp_dgrad_kernel", "nerfmlp_wgrad")):
                 tk["traffic"] = traffic_of(pref)
@@ -509,14 +592,21 @@ def main():
             line["roofline_forward_kernel"] = line["roofline"]
             line["roofline"] = max(train_kernels, key=lambda t: t["avg_launch_ms"])
             line["roofline_train_kernels"] = train_kernels
+            # the whole step against the MFMA peak: SURVEY §8(d)'s algorithmic FLOP (forward + dgrad + wgrad ~ 3 x forward) / ms_per_step
+            step_flop = 3.0 * flop_per_ray_fwd * B
+            line["roofline_step"] = {"bound": "mfma", "algorithmic_flop_per_step": step_flop, "achieved": step_flop / (dt / args.steps) / 1e12,
+                                     "peak": PEAK_MFMA_16BIT / 1e12, "unit": "TFLOP/s", "frac": step_flop / (dt / args.steps) / PEAK_MFMA_16BIT,
+                                     "note": "3 x (mlp_rows_per_ray x 1 186 816 + 112 896) FLOP per ray; the fp32-grade modes issue 3 MFMAs per product, "
+                                             "so MFMA issue is ~3 x this fraction (DESIGN.md §4: the 3-pass floor)"}
         line["collectives"] = {"backend": (dist.get_backend() if dist.is_initialized() else None), "ranks": world,
                                "per_step": ("none" if not (train and D.active()) else
-                                            "one all-reduce(mean) of the flat gradient + stats buffer, in two pieces (NerfMLP segments async behind "
-                                            "the wgrad; background MLP + stats after its backward)")}
+                                            "one all-reduce(mean) of the flat gradient + stats buffer between the backward graph and the update graph")}
         if pmc_meta is not None:
             line["pmc_profile"] = pmc_meta
         if other_modes:
             line["other_backward_modes"] = other_modes
+        if variants:
+            line["variants"] = variants
         if frame is not None:
             line["frame"] = frame
         if not args.no_cpu_baseline and args.stage == "radiance":      # (the oracle legs below restate the radiance stage)
@@ -531,10 +621,24 @@ def main():
             used = torch.get_num_threads() if train else blas
             line["parity"] = parity_vs_oracle(model, pf, cfg, fine, device)
             line["cpu_baseline"] = {"value": cpu_rps, "unit": "rays/s", "cores": used, "host_cpus": os.cpu_count(), "kind": "port",
-                                    "sample": f"{args.cpu_rays} rays of the same workload, {what} (threaded BLAS); 1 warm-up + median of 3 passes, {cpu_dt:.1f} s each"}
+                                    "sample": f"{args.cpu_rays} rays of the same workload, {what} (threaded BLAS); {CPU_WARMUP} warm-up + median of "
+                                              f"{CPU_TIMED} timed passes, {cpu_dt:.1f} s each"}
         print(json.dumps(line))
     if dist.is_initialized():
         dist.destroy_process_group()
+
+
+def models_with_fine(model, cfg, fine, device, precision):
+    """The same scene with num_fine_samples = `fine`: shares the (up to 2 GB) IoR table of `model` instead of rebuilding it."""
+    import copy
+    import torch
+    from samplenerfro_amd import models, synthetic as syn
+    m2 = copy.copy(model)
+    m2.num_fine_samples = fine
+    m2.fine_step_size = (m2.far - m2.near) / (m2.num_coarse_samples + fine)
+    m2._packed, m2._jit_cache, m2._ws, m2._key_cache, m2._u_lin, m2._side = {}, {}, {}, {}, None, None
+    pf = syn.init_params_flat(0, fine=True)
+    return m2, models.make_variables({k: torch.from_numpy(v).to(device) for k, v in pf.items()})
 
 
 if __name__ == "__main__":

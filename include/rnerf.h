@@ -362,11 +362,22 @@ typedef struct rnerf_train_cfg {
   double frozen_sq;            /* sum of squares / count of the variables outside theta (the frozen path_sampler): weight_l2, train.py:147-153 */
   int64_t frozen_count;
 } rnerf_train_cfg;
+/* The march of the NEXT batch (it reads neither the parameters nor anything of this step): when `next` is given, its rays are marched on
+ * next->side_stream, forked from `stream` right behind the last NerfMLP wgrad, so that the latency-bound march runs beside the small
+ * kernels of the step's tail.  The caller joins (rnerf_join(stream, side_stream)) before it reads next->path_* — inside a captured graph:
+ * before rnerf_graph_end. */
+typedef struct rnerf_prefetch {
+  const float* origins;        /* float[B][3] of the next batch */
+  const float* viewdirs;
+  float* path_pd;              /* float4[N][B] each: where the next batch's path record goes */
+  float* path_dr;
+  void* side_stream;
+} rnerf_prefetch;
 size_t rnerf_train_workspace_bytes(const rnerf_model* m, const rnerf_train_cfg* c, int32_t B);
 int rnerf_train_forward_backward(const rnerf_model* m, const rnerf_train_cfg* c, const float* theta, const float* origins, const float* viewdirs,
                                  const float* pixels, const float* env_dirs, int32_t B, const uint32_t* keys4, const int32_t* jitter_override,
                                  const float* u_override, int32_t u_per_ray, const float* path_pd, const float* path_dr, float* grads,
-                                 void* workspace, int32_t max_workgroups, void* stream);
+                                 void* workspace, int32_t max_workgroups, const rnerf_prefetch* next, void* stream);
 
 /* ---- train.py:169-183 + optax.adam behind multi_transform (:312-317) on the flat buffers: weight-decay gradient 2 wd theta / n_all,
  * value clip, global-norm clip (over theta's gradient and the frozen variables' weight-decay gradient, frozen_params nullable),

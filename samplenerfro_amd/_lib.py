@@ -60,6 +60,11 @@ class AdamCfg(C.Structure):
                 ("grad_max_val", C.c_double), ("grad_max_norm", C.c_double), ("n_all", C.c_int64), ("lr_override", C.c_double)]
 
 
+class Prefetch(C.Structure):
+    """rnerf_prefetch: the next batch's march on a side stream, forked behind the last wgrad of rnerf_train_forward_backward."""
+    _fields_ = [("origins", C.c_void_p), ("viewdirs", C.c_void_p), ("path_pd", C.c_void_p), ("path_dr", C.c_void_p), ("side_stream", C.c_void_p)]
+
+
 LEVEL_FLOATS = 9
 ADAM_SCRATCH_FLOATS = 2052
 _vp, _i32, _i64, _dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
@@ -120,7 +125,7 @@ SIGNATURES = {
     "rnerf_forward_workspace_bytes": (C.c_size_t, [_MP, _i32]),
     "rnerf_forward": (C.c_int, [_MP, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "rnerf_train_workspace_bytes": (C.c_size_t, [_MP, _TP, _i32]),
-    "rnerf_train_forward_backward": (C.c_int, [_MP, _TP, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "rnerf_train_forward_backward": (C.c_int, [_MP, _TP, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, C.POINTER(Prefetch), _vp]),
     "rnerf_adam_update": (C.c_int, [_AP, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
     "rnerf_graph_begin": (C.c_int, [_vp]),
     "rnerf_graph_end": (C.c_int, [_vp, C.POINTER(C.c_void_p)]),

@@ -432,7 +432,7 @@ extern "C" size_t rnerf_train_workspace_bytes(const rnerf_model* m, const rnerf_
 extern "C" int rnerf_train_forward_backward(const rnerf_model* m, const rnerf_train_cfg* c, const float* theta, const float* origins, const float* viewdirs,
                                             const float* pixels, const float* env_dirs, int32_t B, const uint32_t* keys4, const int32_t* jitter_override,
                                             const float* u_override, int32_t u_per_ray, const float* path_pd, const float* path_dr, float* grads,
-                                            void* workspace, int32_t max_workgroups, void* stream) {
+                                            void* workspace, int32_t max_workgroups, const rnerf_prefetch* next, void* stream) {
   RNERF_TRY(check_model(m, B, "rnerf_train_forward_backward"));
   RNERF_CHECK_ARG(c && theta && pixels && grads && workspace, "rnerf_train_forward_backward: null pointer");
   RNERF_CHECK_ARG(keys4 || (jitter_override && (m->num_fine == 0 || u_override || !c->randomized)),
@@ -515,6 +515,12 @@ extern "C" int rnerf_train_forward_backward(const rnerf_model* m, const rnerf_tr
   RNERF_TRY(rnerf_nerfmlp_pack_bwd(th_c, bwd, t.packed_bwd, stream));
   RNERF_TRY(rnerf_nerfmlp_dgrad(t.packed_bwd, t.packed_c, prec, bwd, t.save_c, t.d_raw, (int64_t)Nc * B, t.dy, stream));
   RNERF_TRY(rnerf_nerfmlp_wgrad(prec, bwd, t.save_c, t.dy, (int64_t)Nc * B, g_c, t.wgrad_ws, stream));
+  if (next) {      // the next batch's march: beside the tail below (background-MLP backward, loss glue) and whatever the caller issues after
+    RNERF_CHECK_ARG(next->origins && next->viewdirs && next->path_pd && next->path_dr && next->side_stream, "rnerf_train_forward_backward: incomplete rnerf_prefetch");
+    RNERF_TRY(rnerf_fork(stream, next->side_stream));
+    RNERF_TRY(rnerf_march(m->table, &m->grid, next->origins, next->viewdirs, B, m->near, m->far, N, next->path_pd, next->path_dr, nullptr, nullptr,
+                          next->side_stream));
+  }
   const double env_on = c->annealed_alpha > 0 ? 1.0 : 0.0;
   if (smooth) RNERF_TRY(rnerf_env_smooth_backward(rgb_env, ps, c->bg_smooth_weight * env_on, t.d_all + (size_t)3 * B, t.env_sum, stream));
   RNERF_TRY(rnerf_bkgd_backward(th_b, t.save_bk, t.d_all, (int64_t)B + M, m->rgb_padding, t.dy_bk, g_b, nullptr, stream));

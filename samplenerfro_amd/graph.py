@@ -101,13 +101,15 @@ class GraphTrainStep:
         _lib.check(lib.rnerf_rng_split3(self.rng_state.data_ptr(), self.keys4.data_ptr(), st), "rnerf_rng_split3")
         if not self.prefetch:
             self._march(slot, st)
+        nxt = None
+        if self.prefetch:          # the march of the other slot: forked behind the last wgrad inside the call, joined by the caller
+            nxt = _lib.Prefetch(self.origins[1 - slot].data_ptr(), self.viewdirs[1 - slot].data_ptr(), self.path_pd[1 - slot].data_ptr(),
+                                self.path_dr[1 - slot].data_ptr(), sd)
         _lib.check(lib.rnerf_train_forward_backward(C.byref(self.m), C.byref(self.c), self.state.theta.data_ptr(), self.origins[slot].data_ptr(),
                                                     self.viewdirs[slot].data_ptr(), self.pixels[slot].data_ptr(), _lib.ptr(self.env), self.B,
                                                     self.keys4.data_ptr(), None, None, 0, self.path_pd[k].data_ptr(), self.path_dr[k].data_ptr(),
-                                                    self.state.grads.data_ptr(), self.ws.data_ptr(), 0, st), "rnerf_train_forward_backward")
-        if self.prefetch:
-            _lib.check(lib.rnerf_fork(st, sd), "rnerf_fork")
-            self._march(1 - slot, sd)
+                                                    self.state.grads.data_ptr(), self.ws.data_ptr(), 0, C.byref(nxt) if nxt is not None else None, st),
+                   "rnerf_train_forward_backward")
 
     def _issue_back(self) -> None:
         s = self.state

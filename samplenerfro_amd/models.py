@@ -239,6 +239,23 @@ class NerfModel:
             ev.record(self._side)
         return PathHandle(pd, dr, ior, ev, rays.origins.shape[0])
 
+    def prefetch_slot(self, rays: Rays):
+        """A PathHandle whose march rnerf_train_forward_backward issues itself (rnerf_prefetch): buffers + descriptor; the caller records
+        handle.event on the side stream after the call."""
+        if not self.stage.startswith("radiance"):
+            raise NotImplementedError("prefetch: the all* march depends on the so3_mlp parameters")
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        o, v = ops._chk(rays.origins, "origins"), ops._chk(rays.viewdirs, "viewdirs")
+        B = o.shape[0]
+        pd = torch.empty((self.num_samples, B, 4), dtype=torch.float32, device=self.device)
+        dr = torch.empty_like(pd)
+        for t in (o, v, pd, dr):
+            t.record_stream(self._side)
+        h = PathHandle(pd, dr, None, torch.cuda.Event(), B)
+        h.keep = (o, v)
+        return h, _lib.Prefetch(o.data_ptr(), v.data_ptr(), pd.data_ptr(), dr.data_ptr(), self._side.cuda_stream)
+
     def release_reserved_cus(self) -> None:
         """Give the CUs reserved by prefetch_path(reserve_cus > 0) back to the MLP kernels."""
         self._mlp_wg_limit = 0

@@ -295,11 +295,16 @@ def _train_step_whole(model: NerfModel, rng, state: TrainState, batch, flags, ji
     ws = model._workspace("train", lib.rnerf_train_workspace_bytes(C.byref(m), C.byref(c), B))
     G = state.grads
     n_theta = state.theta.numel()
+    # the march of the NEXT step goes to the model's side stream, forked behind the last wgrad inside the call: it runs beside the
+    # background-MLP backward, the loss tail, the all-reduce and the optimiser update
+    nxt, next_path = None, None
+    if next_rays is not None:
+        next_path, nxt = model.prefetch_slot(next_rays)
     _lib.check(lib.rnerf_train_forward_backward(C.byref(m), C.byref(c), state.theta.data_ptr(), o.data_ptr(), v.data_ptr(), pixels.data_ptr(), _lib.ptr(env), B,
                                                 keys.data_ptr(), _lib.ptr(jit), _lib.ptr(u), per_ray, _lib.ptr(pd), _lib.ptr(dr), G.data_ptr(), ws.data_ptr(),
-                                                int(model._mlp_wg_limit), st), "rnerf_train_forward_backward")
-    # the march of the NEXT step goes to the side stream now: it runs beside the all-reduce and the optimiser update
-    next_path = model.prefetch_path(next_rays, sync_inputs=True, reserve_cus=0) if next_rays is not None else None
+                                                int(model._mlp_wg_limit), C.byref(nxt) if nxt is not None else None, st), "rnerf_train_forward_backward")
+    if next_path is not None:
+        next_path.event.record(model._side)
     distributed.allreduce_mean_([G])                   # jax.lax.pmean of gradients and stats (train.py:166-167): one flat buffer
     default_lr = state._lr_fn_default is state.lr_fn
     a = adam_cfg(state, flags, 0.0 if default_lr else float(state.lr_fn(state.step)))

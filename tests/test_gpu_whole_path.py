@@ -137,13 +137,20 @@ def test_whole_train_step_equals_the_staged_sequence(Nf, bd_cut, bwd):
             taps = None if whole else {}
             state, stats, rng = train_step(model, rng, state, batch, flags, taps=taps)
             gs.append(state.grads[:state.theta.numel()].clone() if whole else taps["grads"])
+            if i == 0:
+                theta1 = state.theta.clone()
             losses.append([float(stats.loss), float(stats.loss_c), float(stats.loss_bg), float(stats.loss_bg_smooth), float(stats.weight_l2), float(stats.psnr)])
-        out[whole] = (gs, losses, state.theta.clone(), rng, state.step)
+        out[whole] = (gs, losses, state.theta.clone(), rng, state.step, theta1)
     assert torch.equal(out[True][0][0], out[False][0][0])                       # first step: same parameters in, same gradient bits out
     assert np.allclose(out[True][1], out[False][1], rtol=2e-6, atol=1e-7)
     assert np.array_equal(out[True][3], out[False][3]) and out[True][4] == out[False][4] == 3
+    # same gradient bits into the first update: the two Adam implementations (rnerf_adam_update / torch elementwise) differ by rounding only
+    lr0 = flags.lr_init * flags.lr_delay_mult
+    assert (out[True][5] - out[False][5]).abs().max().item() < 1e-5 * lr0
+    # later steps start from parameters that differ in the last bit; Adam turns noise-level gradient entries into lr-sized updates, so
+    # the parameters are only compared against the sum of the learning rates (tests/test_gpu_train_2rank.py makes the same point)
     d = (out[True][2] - out[False][2]).abs().max().item()
-    assert d < 2e-6, d                                                           # three updates of ~lr each: only the Adam arithmetic's rounding differs
+    assert d < 3 * flags.lr_init, d
     for a, b in zip(out[True][0][1:], out[False][0][1:]):
         assert (a - b).abs().max().item() <= 2e-4 * b.abs().max().item()
 
