@@ -372,6 +372,7 @@ typedef struct rnerf_prefetch {
   float* path_pd;              /* float4[N][B] each: where the next batch's path record goes */
   float* path_dr;
   void* side_stream;
+  int32_t beside_wgrad;        /* != 0: fork BEFORE the last wgrad instead of behind it (the march co-resident with the wgrad's waves) */
 } rnerf_prefetch;
 size_t rnerf_train_workspace_bytes(const rnerf_model* m, const rnerf_train_cfg* c, int32_t B);
 int rnerf_train_forward_backward(const rnerf_model* m, const rnerf_train_cfg* c, const float* theta, const float* origins, const float* viewdirs,

@@ -62,7 +62,8 @@ class AdamCfg(C.Structure):
 
 class Prefetch(C.Structure):
     """rnerf_prefetch: the next batch's march on a side stream, forked behind the last wgrad of rnerf_train_forward_backward."""
-    _fields_ = [("origins", C.c_void_p), ("viewdirs", C.c_void_p), ("path_pd", C.c_void_p), ("path_dr", C.c_void_p), ("side_stream", C.c_void_p)]
+    _fields_ = [("origins", C.c_void_p), ("viewdirs", C.c_void_p), ("path_pd", C.c_void_p), ("path_dr", C.c_void_p), ("side_stream", C.c_void_p),
+                ("beside_wgrad", C.c_int32)]
 
 
 LEVEL_FLOATS = 9

@@ -229,6 +229,13 @@ __device__ __forceinline__ void glds16_nt(const char* gsrc, unsigned lds_off) {
 #endif
                : "=&s"(keep) : "v"(gsrc), "s"(lds_off) : "memory");
 }
+// the same with a wave-uniform 64-bit base (SGPR pair) + a 32-bit per-lane byte offset: the address arithmetic of a stream that advances
+// by a uniform stride runs on the scalar unit and the lane part costs one VGPR instead of two
+__device__ __forceinline__ void glds16_nt_s(const char* sbase, unsigned voff, unsigned lds_off) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_off) : "memory");
+}
 // vmcnt(0) as the BUILTIN (imm: vmcnt=0, expcnt=7, lgkmcnt=15): hipcc folds an explicit s_waitcnt into its own scoreboard,
 // so it also knows that every load it tracks itself (bias prefetch) has landed and emits no stricter wait later.
 __device__ __forceinline__ void slab_wait_dma() { __builtin_amdgcn_s_waitcnt(0x0F70); asm volatile("" ::: "memory"); }
@@ -1512,6 +1519,9 @@ template <int KT, int NT> struct WgTrShape {
   static constexpr int TK = KT / WK, TN = NTR / WN;
   static_assert(WK * TK == KT && WN * TN == NTR && WK * WN <= 8 && (!EXTRA || (TK == 2 && WN == 2)), "tile split");
 };
+#ifndef RNERF_WGTR_NCH
+#define RNERF_WGTR_NCH 2      /* n-tiles of B fragments fetched at a time when the A side is resident */
+#endif
 template <int NP> constexpr int wgtr_nbuf() { return NP == 2 ? 4 : 8; }       // ring depth: what fits 160 KiB
 template <int NP> constexpr int wgtr_lds_bytes() { return wgtr_nbuf<NP>() * ((10 + 8) * NP + 1) * 1024; }       // largest job: 10 k-tiles + 8 n-tiles
 
@@ -1545,9 +1555,11 @@ __device__ __forceinline__ void wgrad_body_tr(const uint4* __restrict__ saved, c
   const float* __restrict__ rs = (const float*)(dy + dy_plane_uint4(R, NP));
   const float mref = rs[R];                                     // written by the dgrad's atomicMax
   const float inv_mref = mref > 0.f ? 1.0f / mref : 0.f;        // m_ref is a power of two: exact
-  // DMA roles: block b = wave + 8 i (clamped: a surplus instruction re-fetches the last block, same bytes to the same place)
-  const uint4* src[NDMA];
-  size_t tstride[NDMA];
+  // DMA roles: block b = wave + 8 i (clamped: a surplus instruction re-fetches the last block, same bytes to the same place).  The
+  // source address of a block is (wave-uniform base of its slot pair and part, advanced by a uniform stride per 32-row tile: SGPRs) +
+  // (lane part: row r, slot parity a, half h: one 32-bit VGPR per block)
+  const char* sbase[NDMA];
+  unsigned tstride[NDMA], voff[NDMA];
   unsigned lds_blk[NDMA];
   {
     const int r = lane >> 2, a = (lane >> 1) & 1, h = lane & 1;
@@ -1556,17 +1568,25 @@ __device__ __forceinline__ void wgrad_body_tr(const uint4* __restrict__ saved, c
       int b = wave + 8 * i;
       b = b < NBLK ? b : NBLK - 1;
       const int t = b / NP, part = b % NP;
+      int slot0, slot1;              // the slots lane parity a = 0 / 1 fetch
+      const uint4* base;
       if (t < KT) {
-        const int slot = t < sg.KTa ? sg.qx + 2 * t + a : sg.qx2 + 2 * (t - sg.KTa) + a;
-        src[i] = saved + (part ? sv_lo0(R) : 0) + sv_addr(slot, 0, r, h);
-        tstride[i] = (size_t)SAVE_SLOTS * 64;
+        slot0 = t < sg.KTa ? sg.qx + 2 * t : sg.qx2 + 2 * (t - sg.KTa);
+        slot1 = slot0 + 1;
+        base = saved + (part ? sv_lo0(R) : 0);
+        tstride[i] = (unsigned)(SAVE_SLOTS * 64 * sizeof(uint4));
       } else {     // a slot beyond the segment's k-steps repeats its last one: those columns are dropped by the reduction
         const int nt = t - KT;
-        const int rel = nt < sg.NTa ? 2 * nt + a : 2 * (nt - sg.NTa) + a;
-        const int slot = nt < sg.NTa ? sg.qd + (rel < sg.KSd ? rel : sg.KSd - 1) : sg.qd2 + (rel < sg.KSd2 ? rel : sg.KSd2 - 1);
-        src[i] = dy + (part ? dy_plane_uint4(R, 1) : 0) + dy_addr(slot, 0, r, h);
-        tstride[i] = (size_t)DY_SLOTS * 64;
+        const int rel = nt < sg.NTa ? 2 * nt : 2 * (nt - sg.NTa);
+        const int qb = nt < sg.NTa ? sg.qd : sg.qd2, ks = nt < sg.NTa ? sg.KSd : sg.KSd2;
+        slot0 = qb + (rel < ks ? rel : ks - 1);
+        slot1 = qb + (rel + 1 < ks ? rel + 1 : ks - 1);
+        base = dy + (part ? dy_plane_uint4(R, 1) : 0);
+        tstride[i] = (unsigned)(DY_SLOTS * 64 * sizeof(uint4));
       }
+      static_assert(sv_addr(1, 0, 0, 0) == dy_addr(1, 0, 0, 0) && sv_addr(0, 0, 1, 1) == dy_addr(0, 0, 1, 1), "one lane-offset formula for both tensors");
+      sbase[i] = (const char*)(base + sv_addr(__builtin_amdgcn_readfirstlane(slot0), 0, 0, 0));
+      voff[i] = (unsigned)((sv_addr(a ? __builtin_amdgcn_readfirstlane(slot1 - slot0) : 0, 0, r, h)) * sizeof(uint4));
       lds_blk[i] = (unsigned)b * 1024u;
     }
   }
@@ -1582,11 +1602,12 @@ __device__ __forceinline__ void wgrad_body_tr(const uint4* __restrict__ saved, c
     const unsigned ring = (unsigned)(s & (WGTR_NBUF - 1)) * STEP_BYTES;
 #pragma unroll
     for (int i = 0; i < NDMA; ++i)
-      glds16_nt((const char*)(src[i] + t32 * tstride[i] + (sc & 1) * 32), __builtin_amdgcn_readfirstlane(ring + lds_blk[i]));
+      glds16_nt_s(sbase[i] + t32 * tstride[i] + (sc & 1) * (32 * sizeof(uint4)), voff[i], __builtin_amdgcn_readfirstlane(ring + lds_blk[i]));
     if (wave == 0) glds16_nt((const char*)(rs_src + t32 * 32 + (sc & 1) * 16), __builtin_amdgcn_readfirstlane(ring + NBLK * 1024u));
   };
   const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  f32x16 acc[TK][TN], accb = zero, acce = zero;            // acce: the extra tile (k-tile wk TK + wn) x (n-tile NT - 1)
+  f32x16 acc[TK][TN], acce = zero;                         // acce: the extra tile (k-tile wk TK + wn) x (n-tile NT - 1)
+  float accb = 0.f;                                        // bias row: this lane's share of sum_rows (m_row / m_ref) dY^[row][n] (VALU dot products)
 #pragma unroll
   for (int i = 0; i < TK; ++i)
 #pragma unroll
@@ -1608,59 +1629,102 @@ __device__ __forceinline__ void wgrad_body_tr(const uint4* __restrict__ saved, c
         const float4 s0 = *(const float4*)(ring0 + NBLK * 1024 + kh * 32), s1 = *(const float4*)(ring0 + NBLK * 1024 + kh * 32 + 16);
         const half8 sc8 = {(_Float16)(s0.x * inv_mref), (_Float16)(s0.y * inv_mref), (_Float16)(s0.z * inv_mref), (_Float16)(s0.w * inv_mref),
                            (_Float16)(s1.x * inv_mref), (_Float16)(s1.y * inv_mref), (_Float16)(s1.z * inv_mref), (_Float16)(s1.w * inv_mref)};
-        half8 ah[TK], al[TK], bh[TN], bl[TN], beh, bel;
-#pragma unroll
-        for (int i = 0; i < TK; ++i) {
-          const char* p = ring + (wk * TK + i) * NP * 1024;
-          ah[i] = tr_read8(p) * sc8;
-          if constexpr (NP == 2) al[i] = tr_read8(p + 1024) * sc8;
-        }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const char* p = ring + (KT + wn * TN + j) * NP * 1024;
-          bh[j] = tr_read8(p);
-          if constexpr (NP == 2) bl[j] = tr_read8(p + 1024);
-        }
+        // Operands are fetched and consumed in chunks so that the live set beside the TK x TN accumulators stays small enough for
+        // RNERF_WGRAD_VGPRS without spilling: the smaller operand side stays resident for the step, the other side streams through in
+        // chunks (A fragments one k-tile at a time when TK > TN, else B fragments NCH n-tiles at a time).
+        half8 beh, bel;
         if constexpr (SH::EXTRA) {
           const char* p = ring + (KT + NT - 1) * NP * 1024;
           beh = tr_read8(p);
           if constexpr (NP == 2) bel = tr_read8(p + 1024);
         }
-#pragma unroll
-        for (int i = 0; i < TK; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = mfma_h8(ah[i], bh[j], acc[i][j]);
-        if constexpr (SH::EXTRA) {          // wn picks which of the wave's two k-tiles (a select on registers, no branch)
-          const half8 aeh = wn ? ah[1] : ah[0];
-          acce = mfma_h8(aeh, beh, acce);
-          if constexpr (NP == 2) {
-            const half8 ael = wn ? al[1] : al[0];
-            acce = mfma_h8(aeh, bel, acce);
-            acce = mfma_h8(ael, beh, acce);
-          }
-        }
-        if constexpr (NP == 2) {
-#pragma unroll
-          for (int i = 0; i < TK; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = mfma_h8(ah[i], bl[j], acc[i][j]);
-#pragma unroll
-          for (int i = 0; i < TK; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = mfma_h8(al[i], bh[j], acc[i][j]);
-        }
-        // bias row: wave (wk, wn) owns it for n-tile wn TN + wk, wk < TN (the 9th n-tile of the Dense_9 + sigma job has no owner: the
-        // sigma bias comes out of the rgb-head job, which reads the same head-gradient slot)
         static_assert(SH::WK >= TN, "bias owners");
-        half8 ab;
+        auto read_a = [&](int i, half8& h, half8& l) {
+          const char* p = ring + (wk * TK + i) * NP * 1024;
+          h = tr_read8(p) * sc8;
+          if constexpr (NP == 2) l = tr_read8(p + 1024) * sc8;
+        };
+        auto read_b = [&](int j, half8& h, half8& l) {
+          const char* p = ring + (KT + wn * TN + j) * NP * 1024;
+          h = tr_read8(p);
+          if constexpr (NP == 2) l = tr_read8(p + 1024);
+        };
+        // bias row: wave (wk, wn) owns it for n-tile wn TN + wk, wk < TN (the 9th n-tile of the Dense_9 + sigma job has no owner: the
+        // sigma bias comes out of the rgb-head job, which reads the same head-gradient slot).  A B fragment holds, per lane, 8 rows of one
+        // column and sc8 the scales of the same 8 rows: four v_dot2_f32_f16 per fragment instead of an MFMA with a one-row A operand and
+        // a 16-register accumulator (the kernel has to stay within RNERF_WGRAD_VGPRS).
+        auto dot8 = [&](const half8& x, float c) -> float {
+          typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 #pragma unroll
-        for (int k = 0; k < 8; ++k) ab[k] = (lane & 31) == 0 ? sc8[k] : (_Float16)0;
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
+          for (int k = 0; k < 4; ++k) c = __builtin_amdgcn_fdot2(half2v{sc8[2 * k], sc8[2 * k + 1]}, half2v{x[2 * k], x[2 * k + 1]}, c, false);
+          return c;
+        };
+        auto bias_row = [&](int j, const half8& h, const half8& l) {
           if (wk == j) {
-            accb = mfma_h8(ab, bh[j], accb);
-            if constexpr (NP == 2) accb = mfma_h8(ab, bl[j], accb);
+            accb = dot8(h, accb);
+            if constexpr (NP == 2) accb = dot8(l, accb);
           }
+        };
+        half8 ae_h, ae_l;                   // the A fragments of the extra tile's k-tile (EXTRA: TK == 2, A side resident)
+        if constexpr (TK > TN) {            // B resident, A streams
+          half8 bh[TN], bl[TN];
+#pragma unroll
+          for (int j = 0; j < TN; ++j) read_b(j, bh[j], bl[j]);
+          half8 an_h, an_l;
+          read_a(0, an_h, an_l);
+#pragma unroll
+          for (int i = 0; i < TK; ++i) {
+            const half8 ah = an_h, al = an_l;
+            if (i + 1 < TK) read_a(i + 1, an_h, an_l);         // the next k-tile's fragments are on their way while this one's MFMAs issue
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = mfma_h8(ah, bh[j], acc[i][j]);
+            if constexpr (NP == 2) {
+#pragma unroll
+              for (int j = 0; j < TN; ++j) acc[i][j] = mfma_h8(ah, bl[j], acc[i][j]);
+#pragma unroll
+              for (int j = 0; j < TN; ++j) acc[i][j] = mfma_h8(al, bh[j], acc[i][j]);
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < TN; ++j) bias_row(j, bh[j], bl[j]);
+        } else {                            // A resident, B streams in chunks of NCH n-tiles
+          constexpr int NCH = RNERF_WGTR_NCH < TN ? RNERF_WGTR_NCH : TN;
+          static_assert(TN % NCH == 0, "n-tile chunks");
+          half8 ah[TK], al[TK];
+#pragma unroll
+          for (int i = 0; i < TK; ++i) read_a(i, ah[i], al[i]);
+#pragma unroll
+          for (int c = 0; c < TN / NCH; ++c) {
+            half8 bh[NCH], bl[NCH];
+#pragma unroll
+            for (int jj = 0; jj < NCH; ++jj) read_b(c * NCH + jj, bh[jj], bl[jj]);
+#pragma unroll
+            for (int i = 0; i < TK; ++i)
+#pragma unroll
+              for (int jj = 0; jj < NCH; ++jj) acc[i][c * NCH + jj] = mfma_h8(ah[i], bh[jj], acc[i][c * NCH + jj]);
+            if constexpr (NP == 2) {
+#pragma unroll
+              for (int i = 0; i < TK; ++i)
+#pragma unroll
+                for (int jj = 0; jj < NCH; ++jj) acc[i][c * NCH + jj] = mfma_h8(ah[i], bl[jj], acc[i][c * NCH + jj]);
+#pragma unroll
+              for (int i = 0; i < TK; ++i)
+#pragma unroll
+                for (int jj = 0; jj < NCH; ++jj) acc[i][c * NCH + jj] = mfma_h8(al[i], bh[jj], acc[i][c * NCH + jj]);
+            }
+#pragma unroll
+            for (int jj = 0; jj < NCH; ++jj) bias_row(c * NCH + jj, bh[jj], bl[jj]);
+          }
+          if constexpr (SH::EXTRA) { ae_h = wn ? ah[1] : ah[0]; if constexpr (NP == 2) ae_l = wn ? al[1] : al[0]; }
+        }
+        if constexpr (SH::EXTRA) {          // wn picks which of the wave's two k-tiles (a select on registers, no branch)
+          static_assert(!SH::EXTRA || TK <= TN, "the extra tile reads the resident A fragments");
+          acce = mfma_h8(ae_h, beh, acce);
+          if constexpr (NP == 2) {
+            acce = mfma_h8(ae_h, bel, acce);
+            acce = mfma_h8(ae_l, beh, acce);
+          }
+        }
       }
     }
     wait_vmcnt<0>();                                            // the surplus prefetches must not outlive the workgroup's LDS
@@ -1684,12 +1748,19 @@ __device__ __forceinline__ void wgrad_body_tr(const uint4* __restrict__ saved, c
         pg[(size_t)((wk * TK + wn) * 32 + row) * ldn + (NT - 1) * 32 + m] = acce[r];
       }
     }
-    if (wk < TN && h == 0) pbias[(wn * TN + wk) * 32 + m] = accb[0];
+    const float bsum = accb + __shfl_xor(accb, 32);          // the two 8-row halves of a k-step live in lanes m and m + 32
+    if (wk < TN && h == 0) pbias[(wn * TN + wk) * 32 + m] = bsum;
   }
 }
 
+// At most 224 VGPRs per wave: two of these waves per SIMD then leave 64 registers — one wave of the march kernel — on every SIMD, so
+// the next batch's march (a latency-bound chain that needs a wave slot on every CU, no LDS) can be co-resident with this HBM-paced kernel
+// instead of waiting for whole CUs to drain.
+#ifndef RNERF_WGRAD_VGPRS
+#define RNERF_WGRAD_VGPRS 112   /* the attribute counts half of the unified VGPR + AGPR file on gfx90a+: 112 -> 224 registers */
+#endif
 template <int NP>
-__global__ void __launch_bounds__(512)
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(RNERF_WGRAD_VGPRS)))
 nerfmlp_wgrad_tr_kernel(const uint4* __restrict__ saved, const uint4* __restrict__ dy, long long R, float* __restrict__ workspace, const WgradTable tab,
                         long long* __restrict__ trace) {
   extern __shared__ __attribute__((aligned(16))) char smem[];

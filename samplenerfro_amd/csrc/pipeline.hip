@@ -514,13 +514,15 @@ extern "C" int rnerf_train_forward_backward(const rnerf_model* m, const rnerf_tr
   }
   RNERF_TRY(rnerf_nerfmlp_pack_bwd(th_c, bwd, t.packed_bwd, stream));
   RNERF_TRY(rnerf_nerfmlp_dgrad(t.packed_bwd, t.packed_c, prec, bwd, t.save_c, t.d_raw, (int64_t)Nc * B, t.dy, stream));
-  RNERF_TRY(rnerf_nerfmlp_wgrad(prec, bwd, t.save_c, t.dy, (int64_t)Nc * B, g_c, t.wgrad_ws, stream));
-  if (next) {      // the next batch's march: beside the tail below (background-MLP backward, loss glue) and whatever the caller issues after
+  auto march_next = [&]() -> int {      // the next batch's march on the side stream, forked from `stream` here
     RNERF_CHECK_ARG(next->origins && next->viewdirs && next->path_pd && next->path_dr && next->side_stream, "rnerf_train_forward_backward: incomplete rnerf_prefetch");
     RNERF_TRY(rnerf_fork(stream, next->side_stream));
-    RNERF_TRY(rnerf_march(m->table, &m->grid, next->origins, next->viewdirs, B, m->near, m->far, N, next->path_pd, next->path_dr, nullptr, nullptr,
-                          next->side_stream));
-  }
+    return rnerf_march(m->table, &m->grid, next->origins, next->viewdirs, B, m->near, m->far, N, next->path_pd, next->path_dr, nullptr, nullptr,
+                       next->side_stream);
+  };
+  if (next && next->beside_wgrad) RNERF_TRY(march_next());
+  RNERF_TRY(rnerf_nerfmlp_wgrad(prec, bwd, t.save_c, t.dy, (int64_t)Nc * B, g_c, t.wgrad_ws, stream));
+  if (next && !next->beside_wgrad) RNERF_TRY(march_next());     // beside the tail below (background-MLP backward, loss glue) and the update
   const double env_on = c->annealed_alpha > 0 ? 1.0 : 0.0;
   if (smooth) RNERF_TRY(rnerf_env_smooth_backward(rgb_env, ps, c->bg_smooth_weight * env_on, t.d_all + (size_t)3 * B, t.env_sum, stream));
   RNERF_TRY(rnerf_bkgd_backward(th_b, t.save_bk, t.d_all, (int64_t)B + M, m->rgb_padding, t.dy_bk, g_b, nullptr, stream));

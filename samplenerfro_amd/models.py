@@ -254,7 +254,8 @@ class NerfModel:
             t.record_stream(self._side)
         h = PathHandle(pd, dr, None, torch.cuda.Event(), B)
         h.keep = (o, v)
-        return h, _lib.Prefetch(o.data_ptr(), v.data_ptr(), pd.data_ptr(), dr.data_ptr(), self._side.cuda_stream)
+        return h, _lib.Prefetch(o.data_ptr(), v.data_ptr(), pd.data_ptr(), dr.data_ptr(), self._side.cuda_stream,
+                                 int(os.environ.get("RNERF_MARCH_BESIDE_WGRAD", "1")))
 
     def release_reserved_cus(self) -> None:
         """Give the CUs reserved by prefetch_path(reserve_cus > 0) back to the MLP kernels."""
