@@ -2454,29 +2454,37 @@ __global__ void __launch_bounds__(256) bkgd_wgrad_kernel(const float* __restrict
   const bool bias = u.boff >= 0;
   const int NT = (u.nout + 31) / 32;
   const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  f32x16 acc[4] = {zero, zero, zero, zero}, accb[4] = {zero, zero, zero, zero};
-  const float onesA = m == 0 ? 1.f : 0.f;
+  f32x16 acc[4] = {zero, zero, zero, zero};
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};               // bias row: this lane's share of sum_rows dY[row][its column] (plain VALU adds)
   const long long r0 = (long long)blockIdx.x * 256 + wave * 64;
   // unconditional loads from clamped addresses + selects: with run-time predicates around the loads hipcc emits a branch and a
-  // vmcnt(0) per load, which serialises them; the n-tile count and the bias row are compile-time instances
+  // vmcnt(0) per load, which serialises them; the n-tile count and the bias row are compile-time instances.
+  // With 4 n-tiles (a 128-wide dY) n-tile nt is the columns {4 m + nt}: one 16-byte load per lane and row feeds all four MFMAs
+  // (the kernel is bound by the latency of its operand loads, not by the matrix pipe).
   const int kc = k < u.kin ? k : u.kin - 1;
   auto rows = [&](auto nt_c, auto bias_c) {
     constexpr int NTC = decltype(nt_c)::value;
     constexpr bool BIAS = decltype(bias_c)::value;
-#pragma unroll 8
+#pragma unroll 16
     for (int i = 0; i < 32; ++i) {
       const long long rr = r0 + 2 * i + h;
       const bool ok = rr < n;
       const size_t rc = (size_t)(ok ? rr : n - 1);
       const float av = X[rc * u.ldx + kc];
       const float a = (ok && k < u.kin) ? av : 0.f;
+      if constexpr (NTC == 4) {
+        const float4 bv = *(const float4*)(dY + rc * 128 + 4 * m);
+        const float b[4] = {ok ? bv.x : 0.f, ok ? bv.y : 0.f, ok ? bv.z : 0.f, ok ? bv.w : 0.f};
 #pragma unroll
-      for (int nt = 0; nt < NTC; ++nt) {
-        const int nn = 32 * nt + m;
-        const float bv = dY[rc * u.ldy + (nn < u.nout ? nn : u.nout - 1)];
-        const float b = (ok && nn < u.nout) ? bv : 0.f;
-        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[nt], 0, 0, 0);
-        if constexpr (BIAS) accb[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(onesA, b, accb[nt], 0, 0, 0);
+        for (int nt = 0; nt < 4; ++nt) {
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[nt], acc[nt], 0, 0, 0);
+          if constexpr (BIAS) bsum[nt] += b[nt];
+        }
+      } else {
+        const float bv = dY[rc * u.ldy + (m < u.nout ? m : u.nout - 1)];
+        const float b = (ok && m < u.nout) ? bv : 0.f;
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[0], 0, 0, 0);
+        if constexpr (BIAS) bsum[0] += b;
       }
     }
   };
@@ -2488,13 +2496,14 @@ __global__ void __launch_bounds__(256) bkgd_wgrad_kernel(const float* __restrict
     if (nt < NT) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) red[wave][nt][r * 64 + lane] = acc[nt][r];
-      if (h == 0) red[wave][nt][1024 + m] = accb[nt][0];
+      const float bs = bsum[nt] + __shfl_xor(bsum[nt], 32);        // even + odd rows
+      if (h == 0) red[wave][nt][1024 + m] = bs;
     }
   __syncthreads();
   const int nt = wave;                                // wave w sums n-tile w over the 4 waves
   if (nt < NT) {
     float* pg = partial + (size_t)blockIdx.x * SmallNet<KIND>::NPARAMS;
-    const int nn = 32 * nt + m;
+    const int nn = NT == 4 ? 4 * m + nt : m;          // the column this lane's accumulator entries belong to
     if (nn < u.nout) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {

@@ -498,6 +498,15 @@ extern "C" int rnerf_train_forward_backward(const rnerf_model* m, const rnerf_tr
   const double bg_on = (c->bg_weight > 0 && c->annealed_alpha > 0) ? 1.0 : 0.0;
   const double mse_scale = 2.0 / (3.0 * B);
   RNERF_CHECK_HIP(hipMemsetAsync(grads, 0, (size_t)(n_theta + 8) * sizeof(float), st));
+  // The next batch's march on the side stream, forked from `stream` at the call.  With beside_wgrad it is issued right before the LARGEST
+  // wgrad of the step (the fine level's when there is one): the wgrad keeps 64 registers free on every SIMD (RNERF_WGRAD_VGPRS), so the
+  // march's waves are co-resident with it and the whole march hides behind that HBM-paced kernel.
+  auto march_next = [&]() -> int {
+    RNERF_CHECK_ARG(next->origins && next->viewdirs && next->path_pd && next->path_dr && next->side_stream, "rnerf_train_forward_backward: incomplete rnerf_prefetch");
+    RNERF_TRY(rnerf_fork(stream, next->side_stream));
+    return rnerf_march(m->table, &m->grid, next->origins, next->viewdirs, B, m->near, m->far, N, next->path_pd, next->path_dr, nullptr, nullptr,
+                       next->side_stream);
+  };
   // ---- backward, last level first ----
   float* d_first = t.d_all;                      // rows [0,B): d loss / d bkgd of the rays; rows [B,B+M): the env-map patch
   if (Nf > 0) {
@@ -505,6 +514,7 @@ extern "C" int rnerf_train_forward_backward(const rnerf_model* m, const rnerf_tr
                                        mse_scale, c->bg_weight * bg_on, t.d_raw, d_first, 0, m->white_bkgd, m->bd_cut ? m->bd_cut_bbox : nullptr, stream));
     RNERF_TRY(rnerf_nerfmlp_pack_bwd(th_f, bwd, t.packed_bwd, stream));
     RNERF_TRY(rnerf_nerfmlp_dgrad(t.packed_bwd, t.packed_f, prec, bwd, t.save_f, t.d_raw, (int64_t)S * B, t.dy, stream));
+    if (next && next->beside_wgrad) RNERF_TRY(march_next());
     RNERF_TRY(rnerf_nerfmlp_wgrad(prec, bwd, t.save_f, t.dy, (int64_t)S * B, g_f, t.wgrad_ws, stream));
     RNERF_TRY(rnerf_composite_backward(f.raw_c, path_pd, path_dr, jitter, Nc, B, bkgd, m->rgb_padding, m->sigma_bias, lc.rgb, pixels, nullptr, nullptr, nullptr,
                                        mse_scale, 0.0, t.d_raw, d_first, 1, m->white_bkgd, nullptr, stream));
@@ -514,13 +524,7 @@ extern "C" int rnerf_train_forward_backward(const rnerf_model* m, const rnerf_tr
   }
   RNERF_TRY(rnerf_nerfmlp_pack_bwd(th_c, bwd, t.packed_bwd, stream));
   RNERF_TRY(rnerf_nerfmlp_dgrad(t.packed_bwd, t.packed_c, prec, bwd, t.save_c, t.d_raw, (int64_t)Nc * B, t.dy, stream));
-  auto march_next = [&]() -> int {      // the next batch's march on the side stream, forked from `stream` here
-    RNERF_CHECK_ARG(next->origins && next->viewdirs && next->path_pd && next->path_dr && next->side_stream, "rnerf_train_forward_backward: incomplete rnerf_prefetch");
-    RNERF_TRY(rnerf_fork(stream, next->side_stream));
-    return rnerf_march(m->table, &m->grid, next->origins, next->viewdirs, B, m->near, m->far, N, next->path_pd, next->path_dr, nullptr, nullptr,
-                       next->side_stream);
-  };
-  if (next && next->beside_wgrad) RNERF_TRY(march_next());
+  if (next && next->beside_wgrad && Nf == 0) RNERF_TRY(march_next());
   RNERF_TRY(rnerf_nerfmlp_wgrad(prec, bwd, t.save_c, t.dy, (int64_t)Nc * B, g_c, t.wgrad_ws, stream));
   if (next && !next->beside_wgrad) RNERF_TRY(march_next());     // beside the tail below (background-MLP backward, loss glue) and the update
   const double env_on = c->annealed_alpha > 0 ? 1.0 : 0.0;
