@@ -224,13 +224,14 @@ class Stepper:
             from samplenerfro_amd.graph import GraphTrainStep
             self.g = GraphTrainStep(model, self.tstate, self.flags, B, key, env_rays=self.batch["env_rays"], annealed_alpha=0.5, prefetch=pipeline)
             self.g.load(self.batch)
+            self.g.load_next(self.batch)              # the synthetic batch is resident in both static slots: steps copy nothing
             for _ in range(3):                       # eager warm-up step + the capture of both slots' graphs, outside every timed region
                 self.step()
 
     def step(self, last=False):
         if self.g is not None:
-            if self.pipeline:
-                self.g.load_next(self.batch)       # the rays of the step after (their march is a side branch of this step's graph)
+            # the rays of the step after are already in the other static slot (a loader would write them there: GraphTrainStep.next_buffers);
+            # their march is a side branch of this step's graph
             return self.g.step().loss
         if self.train:
             from samplenerfro_amd.train import train_step

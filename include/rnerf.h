@@ -200,10 +200,10 @@ int rnerf_loss_reduce(const float* rgb_c, const float* rgb_f, const float* trans
 /* ---- T1 (scalar tail of loss_fn).  rnerf_env_smooth_backward: the env-map smoothness term of train.py:127-130 on the patch
  * rgb_env float[ps][ps][3]: d_out float[ps*ps][3] = grad_scale * d mean(0.5 dv^2 + 0.5 dh^2) / d rgb_env; *loss_sum (device) =
  * the un-normalised sum.  rnerf_train_stats: utils.Stats scalars (train.py:147-162) into stats8 (device float[8], zeroed by the
- * caller): [0] loss, [1] loss_c, [2] loss_bg, [3] loss_bg_smooth, [4] weight_l2 = (sum theta^2 + frozen_sq) / n_all, [6] psnr,
+ * caller): [0] loss, [1] loss_c, [2] loss_bg = bg_scale * sums2 / (sums3 + 1) with bg_scale = bg_weight * 1[annealed_alpha > 0], [3] loss_bg_smooth, [4] weight_l2 = (sum theta^2 + frozen_sq) / n_all, [6] psnr,
  * [7] psnr_c; sums = rnerf_loss_reduce's output. */
 int rnerf_env_smooth_backward(const float* rgb_env, int32_t ps, double grad_scale, float* d_out, float* loss_sum, void* stream);
-int rnerf_train_stats(const float* sums, int32_t B, int32_t two_levels, double bg_on, const float* env_loss_sum, int32_t ps, double env_on,
+int rnerf_train_stats(const float* sums, int32_t B, int32_t two_levels, double bg_scale, const float* env_loss_sum, int32_t ps, double env_on,
                       const float* theta, int64_t n_theta, double frozen_sq, int64_t n_all, float* stats8, void* stream);
 
 /* ---- T1 (backward of V1 + activations): d loss / d raw of one level, replacing jax.value_and_grad through
@@ -383,7 +383,9 @@ int rnerf_train_forward_backward(const rnerf_model* m, const rnerf_train_cfg* c,
 /* ---- train.py:169-183 + optax.adam behind multi_transform (:312-317) on the flat buffers: weight-decay gradient 2 wd theta / n_all,
  * value clip, global-norm clip (over theta's gradient and the frozen variables' weight-decay gradient, frozen_params nullable),
  * Adam with bias correction and the reference's learning-rate schedule (rnerf/utils.py:490-528) evaluated on the device from the
- * device-resident step counter, which is incremented.  scratch: device float[RNERF_ADAM_SCRATCH_FLOATS]. */
+ * device-resident step counter, which is incremented.  scratch: device float[RNERF_ADAM_SCRATCH_FLOATS]; after the call scratch[3]
+ * holds the number of non-finite (inf / NaN) gradient entries the update met (0 in a healthy step: the f16 backward modes normalise every
+ * row's gradient chain to 2^10 of headroom, a row that exceeds it overflows to inf — the count makes that visible). */
 #define RNERF_ADAM_SCRATCH_FLOATS 2052
 typedef struct rnerf_adam_cfg {
   double lr_init, lr_final, lr_delay_mult;

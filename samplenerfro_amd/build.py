@@ -16,10 +16,13 @@ LIB = os.path.join(LIBDIR, "librnerf.so")
 SOURCES = ["grid.hip", "march.hip", "render.hip", "mlp.hip", "pipeline.hip"]
 # -ffp-contract=off + correctly rounded div/sqrt: the march/lookup/resample kernels reproduce the reference's
 # individually rounded fp32 op order so that integer indices are bit-exact against the oracle.
-# -fno-slp-vectorize: hipcc's SLP pass packs adjacent scalar fp32 ops into v_pk_{mul,add,fma}_f32.  Beside MFMAs they are slower than
-# the scalar forms (MI355X_MICROARCH.md: +22..26 cycles per gap), and in the f16 dgrad kernel the packed forms produced wrong values
-# in a few lanes, differently from run to run (round 2: v_pk_fma_f32 with SGPR operands between inline-asm and MFMA instructions;
-# the same source is exact without the pass — tools/r02/dy_debug.py).
+# -fno-slp-vectorize: a performance choice first — hipcc's SLP pass packs adjacent scalar fp32 ops into v_pk_{mul,add,fma}_f32, which beside
+# MFMAs are slower than the scalar forms (MI355X_MICROARCH.md: +22..26 cycles per gap).  It also keeps the schedule away from a hazard class
+# LLVM cannot see: the one-line asm VALU statements in the MFMA shadows are opaque to its hazard recognizer, so no wait states are inserted
+# between them and a dependent MFMA.  Round 2 met wrong values in a few lanes, run-to-run different, in one SLP-on schedule of the f16
+# dgrad; tools/hazard_check.py scans the ISA of a build for the two hazard patterns (tests/test_hazards.py runs it on the product flags:
+# 0 candidates) and tests/test_gpu_backward.py::test_backward_kernels_are_bit_stable_from_run_to_run checks the device.  (With the pass on,
+# this ROCm's clang currently crashes on csrc/mlp.hip, so the SLP-on schedule itself can no longer be inspected.)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wno-unused-value", "-fno-slp-vectorize"]
 

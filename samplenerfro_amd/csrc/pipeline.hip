@@ -199,19 +199,26 @@ __global__ void __launch_bounds__(256) adam_scalars_kernel(AdamSched c, int* __r
     mult = fminf((float)c.max_norm / (1e-7f + norm), 1.0f);             // train.py:174-180
   }
   scal[2] = mult;
+  scal[3] = 0.f;          // adam_apply counts the non-finite gradient entries of this update here
   *step = count + 1;
 }
 // optax.scale_by_adam + scale_by_schedule: mu, nu, theta updated in place
 __global__ void __launch_bounds__(256) adam_apply_kernel(float* __restrict__ theta, float* __restrict__ mu, float* __restrict__ nu,
                                                          const float* __restrict__ g, long long n, float b1, float b2, float eps,
-                                                         const float* __restrict__ scal) {
+                                                         float* __restrict__ scal) {
   const float a = scal[0], c2 = scal[1], mult = scal[2];
+  int bad = 0;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     const float gi = g[i] * mult;
+    bad += !(fabsf(gi) <= 3.402823466e38f);            // inf or NaN: e.g. a row whose f16 gradient chain overflowed
     const float m = mu[i] * b1 + gi * (1.0f - b1);
     const float v = nu[i] * b2 + (gi * gi) * (1.0f - b2);
     mu[i] = m; nu[i] = v;
     theta[i] = theta[i] + a * (m / (sqrtf(v * c2) + eps));
+  }
+  if (__builtin_amdgcn_ballot_w64(bad != 0) != 0) {    // (never taken on finite gradients)
+    for (int o = 32; o > 0; o >>= 1) bad += __shfl_down(bad, o);
+    if ((threadIdx.x & 63) == 0 && bad) atomicAdd(&scal[3], (float)bad);
   }
 }
 
@@ -530,7 +537,7 @@ extern "C" int rnerf_train_forward_backward(const rnerf_model* m, const rnerf_tr
   const double env_on = c->annealed_alpha > 0 ? 1.0 : 0.0;
   if (smooth) RNERF_TRY(rnerf_env_smooth_backward(rgb_env, ps, c->bg_smooth_weight * env_on, t.d_all + (size_t)3 * B, t.env_sum, stream));
   RNERF_TRY(rnerf_bkgd_backward(th_b, t.save_bk, t.d_all, (int64_t)B + M, m->rgb_padding, t.dy_bk, g_b, nullptr, stream));
-  RNERF_TRY(rnerf_train_stats(t.sums, B, Nf > 0, bg_on, smooth ? t.env_sum : nullptr, ps, env_on, theta, n_theta, c->frozen_sq, n_theta + c->frozen_count, stats8,
+  RNERF_TRY(rnerf_train_stats(t.sums, B, Nf > 0, c->bg_weight * bg_on, smooth ? t.env_sum : nullptr, ps, env_on, theta, n_theta, c->frozen_sq, n_theta + c->frozen_count, stats8,
                               stream));
   return RNERF_OK;
 }
@@ -560,7 +567,7 @@ extern "C" int rnerf_adam_update(const rnerf_adam_cfg* c, float* theta, float* m
   AdamSched s{c->lr_init, c->lr_final, c->lr_delay_mult, (double)c->max_steps, (double)c->lr_delay_steps, c->b1, c->b2, c->grad_max_norm, c->lr_override};
   hipLaunchKernelGGL(adam_scalars_kernel, dim3(1), dim3(256), 0, st, s, step_counter, (const float*)partial, n_partial, scal);
   hipLaunchKernelGGL(adam_apply_kernel, dim3(ADAM_BLOCKS), dim3(256), 0, st, theta, mu, nu, (const float*)grads, (long long)n_theta, (float)c->b1, (float)c->b2,
-                     (float)c->eps, (const float*)scal);
+                     (float)c->eps, scal);
   RNERF_CHECK_LAUNCH();
   return RNERF_OK;
 }

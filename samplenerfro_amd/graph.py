@@ -87,6 +87,17 @@ class GraphTrainStep:
         self.main.wait_stream(torch.cuda.current_stream())
         self._put(1 - self.slot, batch)
 
+    def next_buffers(self) -> Dict[str, torch.Tensor]:
+        """The static buffers of the step AFTER the next step() — {"origins", "viewdirs", "pixels"}, [B, 3] each — for a loader that
+        writes its batch in place (on a stream ordered before the next step(), e.g. the current one followed by order_after_loader())
+        instead of going through load_next()'s three copies."""
+        k = 1 - self.slot if self.prefetch else self.slot
+        return {"origins": self.origins[k], "viewdirs": self.viewdirs[k], "pixels": self.pixels[k]}
+
+    def order_after_loader(self) -> None:
+        """Order the next step() behind whatever the current stream has written into next_buffers()."""
+        self.main.wait_stream(torch.cuda.current_stream())
+
     # ---- the step ------------------------------------------------------------------------------------------------------------------
     def _march(self, slot: int, stream) -> None:
         k = slot if self.prefetch else 0
@@ -183,7 +194,7 @@ class GraphTrainStep:
         s8 = s.grads[n:]
         two = self.model.num_fine_samples > 0
         return Stats(loss=s8[0], psnr=s8[6], loss_c=s8[1], psnr_c=(s8[7] if two else 0.0), weight_l2=s8[4], loss_sp=0.0, loss_nrm=0.0,
-                     annealing_rate=self.annealed, coarse_alpha_target=0.0, fine_alpha_target=0.0, loss_bg=self.flags.bg_weight * s8[2],
+                     annealing_rate=self.annealed, coarse_alpha_target=0.0, fine_alpha_target=0.0, loss_bg=s8[2],
                      loss_bg_c=0.0, loss_bg_smooth=s8[3])
 
     def synchronize(self) -> None:

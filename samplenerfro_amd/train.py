@@ -64,6 +64,11 @@ class TrainState:
         self._step_dev_value = 0
         self.adam_scratch = torch.zeros(_lib.ADAM_SCRATCH_FLOATS, dtype=torch.float32, device=theta.device) if theta.is_cuda else None
 
+    def nonfinite_grads(self) -> int:
+        """Non-finite gradient entries met by the last rnerf_adam_update (reads a device scalar: synchronises).  Non-zero means a row's
+        f16 gradient chain left its 2^10 of headroom (backward modes "f32" / "tf32") or the loss itself went non-finite."""
+        return int(self.adam_scratch[3].item()) if self.adam_scratch is not None else 0
+
     def sync_step_counter(self) -> None:
         """Make the device-resident update count equal to self.step (they drift apart when the host sets step: restore, tests)."""
         if self.step_dev is not None and self._step_dev_value != self.step:
@@ -319,7 +324,7 @@ def _train_step_whole(model: NerfModel, rng, state: TrainState, batch, flags, ji
     s8 = G[n_theta:]
     two = model.num_fine_samples > 0
     stats = Stats(loss=s8[0], psnr=s8[6], loss_c=s8[1], psnr_c=(s8[7] if two else 0.0), weight_l2=s8[4], loss_sp=0.0, loss_nrm=0.0,
-                  annealing_rate=annealed, coarse_alpha_target=0.0, fine_alpha_target=0.0, loss_bg=flags.bg_weight * s8[2], loss_bg_c=0.0,
+                  annealing_rate=annealed, coarse_alpha_target=0.0, fine_alpha_target=0.0, loss_bg=s8[2], loss_bg_c=0.0,
                   loss_bg_smooth=s8[3])
     state.next_path = next_path
     return state, stats, rng
@@ -443,7 +448,7 @@ def train_step(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], 
     frozen_sq_of(state, variables)
     n_all = n_theta + state.frozen_sq[1]
     st = G[n_theta:]
-    ops.train_stats(sums, B, rgb_c is not None, bg_on, env_sum, ps, on, state.theta, state.frozen_sq[0], n_all, st)
+    ops.train_stats(sums, B, rgb_c is not None, flags.bg_weight * bg_on, env_sum, ps, on, state.theta, state.frozen_sq[0], n_all, st)
     distributed.allreduce_mean_([G[n_big:]])
     distributed.allreduce_end_mean_(pending, G[:n_big])
     grads = G[:n_theta]
@@ -467,6 +472,6 @@ def train_step(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], 
     state.apply_gradients(grads)
     stats = Stats(loss=st[0], psnr=st[6], loss_c=st[1], psnr_c=(st[7] if rgb_c is not None else 0.0),
                   weight_l2=st[4], loss_sp=0.0, loss_nrm=0.0, annealing_rate=annealed, coarse_alpha_target=0.0, fine_alpha_target=0.0,
-                  loss_bg=flags.bg_weight * st[2], loss_bg_c=0.0, loss_bg_smooth=st[3])
+                  loss_bg=st[2], loss_bg_c=0.0, loss_bg_smooth=st[3])
     state.next_path = next_path
     return state, stats, rng

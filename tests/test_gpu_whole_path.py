@@ -185,7 +185,7 @@ def test_adam_update_matches_the_optax_formulas():
         t = count + 1
         m2 = 0.9 * mu + 0.1 * G; v2 = 0.999 * nu + 0.001 * G * G
         th2 = theta - lr * (m2 / (1 - 0.9 ** t)) / (np.sqrt(v2 / (1 - 0.999 ** t)) + 1e-8)
-        assert int(step.item()) == count + 1
+        assert int(step.item()) == count + 1 and float(scratch[3]) == 0.0
         assert np.abs(t_mu.cpu().numpy() - m2).max() < 1e-8 and np.abs(t_nu.cpu().numpy() - v2).max() < 1e-9
         upd, want = t_th.cpu().numpy().astype(np.float64) - theta, th2 - theta
         assert np.abs(upd - want).max() < 2e-7 + 1e-4 * np.abs(want).max(), (wd, gv, gn, count)
@@ -227,3 +227,18 @@ def test_graph_replay_equals_the_eager_steps(Nf, prefetch):
     assert np.array_equal(g.rng(), rng) and state2.step == steps and int(state2.step_dev.item()) == steps
     assert (state2.theta - theta_e).abs().max().item() < 1e-7
     g.close()
+
+
+def test_adam_update_counts_nonfinite_gradients():
+    from samplenerfro_amd import _lib
+    lib = _lib.load()
+    n = 5000
+    a = _lib.AdamCfg()
+    a.lr_init, a.lr_final, a.lr_delay_mult, a.max_steps, a.lr_delay_steps = 5e-4, 5e-6, 0.01, 1000, 0
+    a.b1, a.b2, a.eps, a.n_all = 0.9, 0.999, 1e-8, n
+    g = torch.zeros(n, device=DEV); g[7] = float("inf"); g[4000] = float("nan"); g[4001] = -float("inf")
+    th, mu, nu = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    step = torch.zeros(1, dtype=torch.int32, device=DEV); scratch = torch.zeros(_lib.ADAM_SCRATCH_FLOATS, device=DEV)
+    _lib.check(lib.rnerf_adam_update(C.byref(a), th.data_ptr(), mu.data_ptr(), nu.data_ptr(), g.data_ptr(), n, None, 0, step.data_ptr(), scratch.data_ptr(),
+                                     _lib.current_stream()), "rnerf_adam_update")
+    assert float(scratch[3]) == 3.0
