@@ -20,6 +20,20 @@ import numpy as np
 F32 = np.float32
 HALF_PI_F32 = np.float32(0.5 * np.pi)
 
+# XLA may rewrite a division by a compile-time constant, x / c, into x * RN(1 / c) (its algebraic simplifier does so when the reciprocal
+# is "close enough"; whether jax 0.2.22's XLA did it for (p - nmin) / ndelta cannot be observed here: no JAX).  The two forms differ by
+# one ulp on a fraction of the inputs, which flips floor() for points within an ulp of a cell face.  With this switch on, the divisions
+# by launch constants in linear3 / build_table use the reciprocal form, so that the exposure of the "bit-exact index" claim to that
+# rewrite can be MEASURED (tools/xla_rcp_exposure.py, tests/test_oracle_exposure.py).  Default: the division as the reference writes it.
+CONST_DIV_AS_RECIPROCAL = False
+
+
+def _cdiv(x, c, dtype):
+    """x / c for a launch-constant c, in the form selected by CONST_DIV_AS_RECIPROCAL."""
+    if CONST_DIV_AS_RECIPROCAL:
+        return x * dtype(dtype(1) / dtype(c))
+    return x / dtype(c)
+
 
 # ----------------------------------------------------------------------------
 # G1: Gaussian prefilter of the IoR grid        (rnerf/ior_utils.py:327-363)
@@ -65,9 +79,9 @@ def build_table(grid, ndim, nmin, nmax, dtype=F32) -> np.ndarray:
     ndelta = compute_ndelta(ndim, nmin, nmax)
     g = np.asarray(grid).astype(dtype).reshape(ndim[0], ndim[1], ndim[2])
     p = np.pad(g, ((1, 1), (1, 1), (1, 1)), "edge")
-    dx = (p[2:, 1:-1, 1:-1] - p[:-2, 1:-1, 1:-1]) / dtype(2 * ndelta[0])
-    dy = (p[1:-1, 2:, 1:-1] - p[1:-1, :-2, 1:-1]) / dtype(2 * ndelta[1])
-    dz = (p[1:-1, 1:-1, 2:] - p[1:-1, 1:-1, :-2]) / dtype(2 * ndelta[2])
+    dx = _cdiv(p[2:, 1:-1, 1:-1] - p[:-2, 1:-1, 1:-1], 2 * ndelta[0], dtype)
+    dy = _cdiv(p[1:-1, 2:, 1:-1] - p[1:-1, :-2, 1:-1], 2 * ndelta[1], dtype)
+    dz = _cdiv(p[1:-1, 1:-1, 2:] - p[1:-1, 1:-1, :-2], 2 * ndelta[2], dtype)
     return np.stack([g, dx, dy, dz], axis=-1).reshape(-1, 4).astype(dtype)
 
 
@@ -78,9 +92,9 @@ def linear3(table, pts, ndim, nmin, nmax, dtype=F32, return_idx: bool = False):
     """ior_utils.py:188-223. pts [...,3] -> [...,4]; optional int32 idx [...,6] = x0,x1,y0,y1,z0,z1 (clamped)."""
     ndelta = compute_ndelta(ndim, nmin, nmax)
     pts = np.asarray(pts, dtype)
-    x = (pts[..., 0] - dtype(nmin[0])) / dtype(ndelta[0])
-    y = (pts[..., 1] - dtype(nmin[1])) / dtype(ndelta[1])
-    z = (pts[..., 2] - dtype(nmin[2])) / dtype(ndelta[2])
+    x = _cdiv(pts[..., 0] - dtype(nmin[0]), ndelta[0], dtype)
+    y = _cdiv(pts[..., 1] - dtype(nmin[1]), ndelta[1], dtype)
+    z = _cdiv(pts[..., 2] - dtype(nmin[2]), ndelta[2], dtype)
     x0 = np.floor(x).astype(np.int32); x1 = x0 + 1
     y0 = np.floor(y).astype(np.int32); y1 = y0 + 1
     z0 = np.floor(z).astype(np.int32); z1 = z0 + 1
