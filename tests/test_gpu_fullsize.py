@@ -295,3 +295,78 @@ def test_config4_dolphin_train_step_full_size(Bd):
         print(f"[B={Bd}] d {which} loss along its gradient: analytic {analytic:.6e}, finite difference {fd:.6e}")
         assert abs(fd - analytic) < 0.03 * abs(analytic) + 1e-5
     state.theta.copy_(theta0)
+
+
+def test_config3_ship_refractive_full_size_sample():
+    """BASELINE config 3 at its full size: 4096 rays x (128 + 256) samples, N = 1536, the 512^3 sphere grid AFTER the (9, 3.0) Gaussian
+    prefilter built on the device (G1 at scale: its time is recorded), the speculative march on rays that bend.  16 rays of the batch
+    against the oracle on the device-built table: path / directions / depths and the resample node indices bit for bit, RGB / depth /
+    opacity of both levels within 1e-4; the prefilter itself against the fp64 oracle on a 24^3 window cut out of the 512^3 grid."""
+    import time
+    from oracle import ref_np as R
+    from samplenerfro_amd import models, ops
+    from samplenerfro_amd.utils import Rays
+    dev = torch.device("cuda:0")
+    cfg = syn.CONFIGS["ship_refractive"]
+    ext, ksize, ksigma = cfg["extent"], cfg["ksize"], cfg["ksigma"]
+    a = torch.linspace(-ext, ext, G, dtype=torch.float64, device=dev)
+    r = torch.sqrt(a[:, None, None] ** 2 + a[None, :, None] ** 2 + a[None, None, :] ** 2)
+    raw = (((1.0 + 0.33 * torch.clamp((cfg["radius"] - r) / (2.0 * ext / (G - 1)) + 0.5, 0.0, 1.0)) - 1.0) * cfg["ri"] / 0.33 + 1.0).float()
+    del r
+    ops.grid_prefilter(raw[:64, :64, :64].contiguous(), ksize, ksigma)                   # (first call: module load)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    grid = ops.grid_prefilter(raw, ksize, ksigma)
+    torch.cuda.synchronize()
+    t_pref = time.perf_counter() - t0
+    print(f"rnerf_grid_prefilter (9, 3.0) at 512^3: {1e3 * t_pref:.1f} ms (3 separable passes, 0.54 GB in + out each)")
+    assert t_pref < 0.5
+    # G1 at scale: a window around the sphere's boundary (where the grid is not constant) against the dense fp64 kernel of the reference
+    lo = G // 2 + int(0.6 / (2 * ext / (G - 1))) - 12                                    # the boundary crosses the window along x
+    w0, w1 = lo - 4, lo + 24 + 4                                                         # + the kernel's halo
+    win = raw[w0:w1, G // 2 - 16:G // 2 + 16, G // 2 - 16:G // 2 + 16].double().cpu().numpy()
+    want = R.conv3d_normal(win.reshape(-1, 1), list(win.shape), ksize, ksigma, dtype=np.float64).reshape(win.shape)[4:-4, 4:-4, 4:-4]
+    got = grid[w0 + 4:w1 - 4, G // 2 - 12:G // 2 + 12, G // 2 - 12:G // 2 + 12].cpu().numpy()
+    assert float(np.abs(want).max()) > 1.2 and float(np.ptp(want)) > 0.2                 # the window really holds the boundary
+    assert float(np.abs(got - want).max()) < 2e-6
+    del raw
+    model = models.NerfModel(ndim=[G] * 3, nmin=[-ext] * 3, nmax=[ext] * 3, grid=grid, near=cfg["near"], far=cfg["far"], num_coarse_samples=S,
+                             num_fine_samples=256, num_path_samples=P, device=dev)
+    del grid
+    pf = syn.init_params_flat(0, fine=True, bias_scale=0.05)
+    variables = models.make_variables({k: torch.from_numpy(v).to(dev) for k, v in pf.items()})
+    o, d = syn.sphere_rays(B)
+    o, d = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
+    key = np.array([0, 3], np.uint32)
+    taps = {}
+    ret, _ = model.apply(variables, key, key, Rays(o, None, d, None), False, taps=taps)
+    n_path = taps["path_ior"][..., 0]
+    bent = (n_path.max(0).values > 1.4)
+    assert int(bent.sum()) > 500                                                         # a good part of the batch crosses the sphere
+    # 16 rays: 12 that cross the refractive sphere, 4 that miss it
+    idx_b = torch.nonzero(bent).reshape(-1)
+    idx_m = torch.nonzero(~bent).reshape(-1)
+    sel = torch.cat([idx_b[:: max(len(idx_b) // 12, 1)][:12], idx_m[:: max(len(idx_m) // 4, 1)][:4]])
+    oret, otaps = _oracle_sample(model, pf, o, d, taps["jitter"], sel, {})
+    pd = taps["path_pd"][:, sel].cpu().numpy()
+    assert np.array_equal(pd[..., :3].transpose(1, 0, 2), otaps["ray_pos"]) and np.array_equal(pd[..., 3].T, otaps["ray_dist"])
+    assert np.array_equal(taps["path_dr"][:, sel].cpu().numpy()[..., :3].transpose(1, 0, 2), otaps["ray_dir"])
+    # resample node indices: bit-exact GIVEN the same coarse weights (the oracle's sample_pdf fed the device's weights); end to end the
+    # weights differ by the MLP's ~1e-7, which may move a fine depth across a node depth for a few samples in ten thousand
+    gi = taps["idx_f"][:, sel].cpu().numpy().T
+    w_dev = taps["weights_c"][:, sel].cpu().numpy().T
+    jit = np.asarray(taps["jitter"], np.int64)
+    t_c = otaps["ray_dist"][:, jit]
+    mid = np.float32(0.5) * (t_c[..., 1:] + t_c[..., :-1])
+    _, _, _, _, idx_o = R.sample_pdf(R.linspace_u(256, len(sel), np.float32), mid, w_dev[..., 1:-1], otaps["ray_pos"], otaps["ray_dir"], otaps["ray_dist"],
+                                     otaps["idx_grad"], jit)
+    assert np.array_equal(gi, idx_o)
+    assert float((gi != otaps["idx_f"]).mean()) < 2e-3
+    for lvl in range(2):
+        for got_t, want_a in zip(ret[lvl][:3], oret[lvl][:3]):
+            assert float(np.abs(got_t[sel].cpu().numpy() - want_a).max()) < 1e-4
+    # whole-path call (rnerf_forward) on the full batch = the staged sequence with taps, bit for bit
+    ret_w, _ = model.apply(variables, key, key, Rays(o, None, d, None), False)
+    for la, lb in zip(ret_w, ret):
+        for x, y in zip(la, lb):
+            assert torch.equal(x, y)
