@@ -1525,6 +1525,9 @@ template <int KT, int NT> struct WgTrShape {
 template <int NP> constexpr int wgtr_nbuf() { return NP == 2 ? 4 : 8; }       // ring depth: what fits 160 KiB
 template <int NP> constexpr int wgtr_lds_bytes() { return wgtr_nbuf<NP>() * ((10 + 8) * NP + 1) * 1024; }       // largest job: 10 k-tiles + 8 n-tiles
 
+#if defined(RNERF_WGTR_ABL) && (RNERF_WGTR_ABL & 2)   /* profiling ablation: no LDS operand reads */
+__device__ __forceinline__ half8 tr_read8(const char* p) { const _Float16 v = (_Float16)(float)((size_t)p & 7); return half8{v, v, v, v, v, v, v, v}; }
+#else
 __device__ __forceinline__ half8 tr_read8(const char* p) {      // rows k .. k+3 at p, rows k+4 .. k+7 at p + 256 (4 rows x 64 B)
   typedef short short4v __attribute__((ext_vector_type(4)));
   typedef short short8v __attribute__((ext_vector_type(8)));
@@ -1533,7 +1536,12 @@ __device__ __forceinline__ half8 tr_read8(const char* p) {      // rows k .. k+3
   const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4*)(p + 256));
   return __builtin_bit_cast(half8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
+#endif
+#if defined(RNERF_WGTR_ABL) && (RNERF_WGTR_ABL & 1)   /* profiling ablation: the wgrad without its MFMAs (results are garbage) */
+__device__ __forceinline__ f32x16 mfma_h8(const half8 a, const half8 b, f32x16 c) { c[0] += (float)a[0] * (float)b[0]; return c; }
+#else
 __device__ __forceinline__ f32x16 mfma_h8(const half8 a, const half8 b, const f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+#endif
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
   __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
   asm volatile("" ::: "memory");
