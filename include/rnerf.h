@@ -190,6 +190,16 @@ int rnerf_march_all(const float* table, const rnerf_grid* g, const float* so3_pa
 int rnerf_generate_rays(const float* camtoworld, int32_t opencv, double fx, double fy, double cx, double cy, double pixel_center,
                         int32_t W, int32_t row0, int32_t rows, float* origins, float* directions, float* viewdirs, void* stream);
 
+/* ---- mip-style integrated positional encoding along the curved ray.  Replaces mip.cast_rays(t_vals, ray_pos_c, ray_dir_c,
+ * rays.radii, "cone", near) + mip.integrated_pos_enc(samples, min_deg, max_deg) (rnerf/mip.py:26-57,60-91,116-175) as the commented call sites
+ * of the reference use them (rnerf/models.py:249-254,386-391): the S samples of a ray (row addressing as rnerf_nerfmlp_forward; depths in
+ * pd.w) are the axes of conical frusta between consecutive depths (the last one 1e-3 long); each becomes a diagonal Gaussian whose mean is
+ * accumulated along the bent path.  radii: float[B] (Rays.radii).  Outputs (each nullable, sample-major): out_mean4 float4[S][B] =
+ * (mean xyz, t_mean), out_cov4 float4[S][B] = (diagonal covariance xyz, t_var), out_enc float[S][B][6 (max_deg - min_deg)] =
+ * exp(-var/2) sin(.) of [y, y + pi/2], y = mean * 2^deg degree-major (no identity features). */
+int rnerf_integrated_pos_enc(const float* rows_pd, const float* rows_dr, const int32_t* node_of_sample, int32_t S, int32_t B, const float* radii,
+                             double near, int32_t min_deg, int32_t max_deg, float* out_mean4, float* out_cov4, float* out_enc, void* stream);
+
 /* ---- T1 (loss): the reductions of train_step.loss_fn (train.py:89-92,105) for stage "radiance*".
  * rgb_c (nullable, N_f == 0), rgb_f: float[B][3]; trans_f: float[B]; trans_bkgd_f, pixels: float[B][3].
  * sums: float[4] (device) = { sum (rgb_f-pix)^2, sum (rgb_c-pix)^2, sum mask*|trans_bkgd_f-pix|, sum mask },

@@ -229,6 +229,71 @@ def pos_enc(x, min_deg: int, max_deg: int, dtype=F32):
     return np.concatenate([x, four], axis=-1)
 
 
+# ----------------------------------------------------------------------------
+# mip-style integrated positional encoding along the curved ray  (rnerf/mip.py:26-57,60-91,116-175)
+# (every call site in the reference is commented out, rnerf/models.py:249-254,386-391; restated as those comments would call it)
+# ----------------------------------------------------------------------------
+def _safe_trig(x, fn, dtype):
+    """math_utils.safe_trig_helper (rnerf/math_utils.py:28-39): fn(where(|x| < 100 pi, x, x % (100 pi)))."""
+    t = dtype(100 * np.pi)
+    return fn(np.where(np.abs(x) < t, x, np.mod(x, t))).astype(dtype)
+
+
+def conical_frustum_to_gaussian(d, t0, t1, base_radius, near, dtype=F32):
+    """mip.py:60-91 (stable form) + lift_gaussian :35-57 with diag=True.  d [B,S,3]; t0, t1 [B,S]; base_radius [B,1].
+    -> mean [B,S,3] (before the origin is added), cov_diag [B,S,3]."""
+    d = np.asarray(d, dtype); t0 = np.asarray(t0, dtype); t1 = np.asarray(t1, dtype); br = np.asarray(base_radius, dtype)
+    two, three = dtype(2), dtype(3)
+    mu = (t0 + t1) / two
+    hw = (t1 - t0) / two
+    mu2, hw2 = mu * mu, hw * hw                   # x**2 / x**4 as jax lowers them (lax.integer_pow: repeated squaring)
+    hw4 = hw2 * hw2
+    den = three * mu2 + hw2
+    t_mean = mu + (two * mu * hw2) / den
+    t_var = hw2 / three - dtype(4 / 15) * ((hw4 * (dtype(12) * mu2 - hw2)) / (den * den))
+    r_var = (br * br) * (mu2 / dtype(4) + dtype(5 / 12) * hw2 - dtype(4 / 15) * hw4 / den)
+    t = np.concatenate([t_mean[:, 0:1] - dtype(near), t_mean[:, 1:] - t_mean[:, :-1]], axis=-1)[..., None]      # :38
+    mean = np.zeros_like(d)
+    run = np.zeros((d.shape[0], 3), dtype)
+    for s in range(d.shape[1]):                                             # jnp.cumsum(d * t, axis=1), sequential order
+        run = run + d[:, s] * t[:, s]
+        mean[:, s] = run
+    d_mag_sq = np.maximum(dtype(1e-10), _seqsum(d * d, axis=-1, keepdims=True))
+    d_outer_diag = d * d
+    null_outer_diag = dtype(1) - d_outer_diag / d_mag_sq
+    cov_diag = t_var[..., None] * d_outer_diag + r_var[..., None] * null_outer_diag
+    return mean.astype(dtype), cov_diag.astype(dtype)
+
+
+def cast_rays_cone(t_vals, origins, directions, radii, near, dtype=F32):
+    """mip.cast_rays(t_vals, origins, directions, radii, "cone", near) (mip.py:116-140) as the commented call sites use it:
+    t_vals [B,S+1] = [ray_dist_c, last + 1e-3]; origins / directions = the coarse samples' positions / directions [B,S,3]."""
+    t_vals = np.asarray(t_vals, dtype)
+    means, covs = conical_frustum_to_gaussian(directions, t_vals[..., :-1], t_vals[..., 1:], radii, near, dtype)
+    return means + np.asarray(origins, dtype)[:, 0:1], covs
+
+
+def integrated_pos_enc(x, x_cov_diag, min_deg: int, max_deg: int, dtype=F32):
+    """mip.integrated_pos_enc, diag=True (mip.py:143-175) + expected_sin (:26-32): exp(-0.5 var) * safe_sin(x) for
+    [y, y + pi/2], y = x * 2^deg degree-major -> [..., 6 * (max_deg - min_deg)] (no identity features)."""
+    x = np.asarray(x, dtype); c = np.asarray(x_cov_diag, dtype)
+    scales = np.array([2 ** i for i in range(min_deg, max_deg)], dtype)
+    shape = list(x.shape[:-1]) + [-1]
+    y = (x[..., None, :] * scales[:, None]).reshape(shape)
+    y_var = (c[..., None, :] * scales[:, None] ** 2).reshape(shape)
+    xx = np.concatenate([y, y + dtype(0.5 * np.pi)], axis=-1)
+    vv = np.concatenate([y_var, y_var], axis=-1)
+    return (np.exp(dtype(-0.5) * vv) * _safe_trig(xx, np.sin, dtype)).astype(dtype)
+
+
+def integrated_pos_enc_of_path(ray_pos_c, ray_dir_c, ray_dist_c, radii, near, min_deg=0, max_deg=10, dtype=F32):
+    """The commented call sequence of rnerf/models.py:249-254 on the coarse samples of a marched path -> (means, covs, enc)."""
+    ray_dist_c = np.asarray(ray_dist_c, dtype)
+    t_vals = np.concatenate([ray_dist_c, ray_dist_c[..., -1:] + dtype(1e-3)], axis=-1)
+    means, covs = cast_rays_cone(t_vals, ray_pos_c, ray_dir_c, radii, near, dtype)
+    return means, covs, integrated_pos_enc(means, covs, min_deg, max_deg, dtype)
+
+
 def cosine_easing_window(min_freq_log2, max_freq_log2, num_bands, alpha, dtype=F32):
     """model_utils.py:218-233."""
     bands = np.linspace(min_freq_log2, max_freq_log2, num_bands).astype(dtype)

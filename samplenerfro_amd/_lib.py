@@ -119,6 +119,7 @@ SIGNATURES = {
     "rnerf_march_adjoint": (C.c_int, [_vp, _GP, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _dbl, _dbl, _i32, _vp, _vp]),
     "rnerf_nerfmlp_input_grad": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
     "rnerf_resample": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "rnerf_integrated_pos_enc": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _dbl, _i32, _i32, _vp, _vp, _vp, _vp]),
     # whole-path entry points (csrc/pipeline.hip)
     "rnerf_rng_split3": (C.c_int, [_vp, _vp, _vp]),
     "rnerf_rng_forward": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _vp]),

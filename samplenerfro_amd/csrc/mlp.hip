@@ -1772,6 +1772,9 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(RNERF_WGRA
 nerfmlp_wgrad_tr_kernel(const uint4* __restrict__ saved, const uint4* __restrict__ dy, long long R, float* __restrict__ workspace, const WgradTable tab,
                         long long* __restrict__ trace) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+#if defined(RNERF_WGTR_PRIO) && RNERF_WGTR_PRIO > 0
+  __builtin_amdgcn_s_setprio(RNERF_WGTR_PRIO);      // above the co-resident march wave in the SIMD's issue arbitration
+#endif
   if (trace && threadIdx.x == 0) trace[2 * blockIdx.x] = (long long)__builtin_amdgcn_s_memrealtime();
   int j = 0;
   while ((int)blockIdx.x >= tab.wg0[j + 1]) ++j;

@@ -586,6 +586,81 @@ __global__ void __launch_bounds__(256) generate_rays_kernel(RayCam c, int W, int
   }
 }
 
+// ---- mip-style integrated positional encoding along the CURVED ray (rnerf/mip.py:26-57,60-91,116-175), as the commented
+// call sites would use it (rnerf/models.py:249-254): the coarse samples of a marched path are the axes of conical frusta between
+// consecutive depths; each frustum becomes a diagonal Gaussian whose mean is accumulated ALONG the bent path (cumsum of d * dt), and the
+// encoding is exp(-var / 2) * sin(.) of the scaled mean.  One lane per ray (the cumulative mean is a serial sum per ray, in sample
+// order like the oracle); rows are sample-major, so every load and store of a wave is contiguous.
+__device__ __forceinline__ float safe_sin_f(float x) {      // math_utils.safe_sin: sin(where(|x| < 100 pi, x, x % (100 pi)))
+  const float t = 314.159271f;                              // f32(100 pi)
+  return sinf(fabsf(x) < t ? x : x - floorf(x / t) * t);
+}
+__global__ void __launch_bounds__(64) ipe_kernel(const float4* __restrict__ rows_pd, const float4* __restrict__ rows_dr,
+                                                 const int* __restrict__ node_of_sample, int S, int B, const float* __restrict__ radii,
+                                                 float near, int min_deg, int max_deg, float4* __restrict__ out_mean,
+                                                 float4* __restrict__ out_cov, float* __restrict__ enc) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float br = radii[b];
+  const int L = max_deg - min_deg;
+  auto rec = [&](int s) -> size_t { return (size_t)(node_of_sample ? node_of_sample[s] : s) * B + b; };
+  const float4 p0 = rows_pd[rec(0)];
+  float run[3] = {0.f, 0.f, 0.f};
+  float t_prev_mean = near;                                  // t = [t_mean_0 - near, t_mean_s - t_mean_(s-1)]  (mip.py:38)
+  float t0 = p0.w;
+  for (int s = 0; s < S; ++s) {
+    const float4 dr = rows_dr[rec(s)];
+    const float t1 = s + 1 < S ? rows_pd[rec(s + 1)].w : fadd(t0, 1e-3f);      // t_vals = [dist_c, last + 1e-3]
+    const float mu = fdiv(fadd(t0, t1), 2.f), hw = fdiv(fsub(t1, t0), 2.f);
+    const float mu2 = fmul(mu, mu), hw2 = fmul(hw, hw), hw4 = fmul(hw2, hw2);
+    const float den = fadd(fmul(3.f, mu2), hw2);
+    const float t_mean = fadd(mu, fdiv(fmul(fmul(2.f, mu), hw2), den));
+    const float t_var = fsub(fdiv(hw2, 3.f), fmul((float)(4.0 / 15.0), fdiv(fmul(hw4, fsub(fmul(12.f, mu2), hw2)), fmul(den, den))));
+    const float r_var = fmul(fmul(br, br), fsub(fadd(fdiv(mu2, 4.f), fmul((float)(5.0 / 12.0), hw2)), fdiv(fmul((float)(4.0 / 15.0), hw4), den)));
+    const float t = fsub(t_mean, t_prev_mean);
+    t_prev_mean = t_mean;
+    const float d[3] = {dr.x, dr.y, dr.z};
+    const float mag = fmaxf(1e-10f, fadd(fadd(fmul(d[0], d[0]), fmul(d[1], d[1])), fmul(d[2], d[2])));
+    float mean[3], cov[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      run[c] = fadd(run[c], fmul(d[c], t));
+      const float dd = fmul(d[c], d[c]);
+      mean[c] = fadd(run[c], c == 0 ? p0.x : (c == 1 ? p0.y : p0.z));            // + origins[:, 0:1]: the first coarse sample's position
+      cov[c] = fadd(fmul(t_var, dd), fmul(r_var, fsub(1.f, fdiv(dd, mag))));
+    }
+    const size_t o = (size_t)s * B + b;
+    if (out_mean) out_mean[o] = make_float4(mean[0], mean[1], mean[2], t_mean);
+    if (out_cov) out_cov[o] = make_float4(cov[0], cov[1], cov[2], t_var);
+    if (enc) {
+      float* e = enc + o * (size_t)(6 * L);
+      for (int k = 0; k < L; ++k) {
+        const float sc = (float)(1 << (min_deg + k));
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float y = fmul(mean[c], sc), yv = fmul(cov[c], fmul(sc, sc));
+          const float w = expf(fmul(-0.5f, yv));
+          e[3 * k + c] = fmul(w, safe_sin_f(y));
+          e[3 * L + 3 * k + c] = fmul(w, safe_sin_f(fadd(y, 1.5707963705062866f)));
+        }
+      }
+    }
+    t0 = t1;
+  }
+}
+
+extern "C" int rnerf_integrated_pos_enc(const float* rows_pd, const float* rows_dr, const int32_t* node_of_sample, int32_t S, int32_t B,
+                                        const float* radii, double near, int32_t min_deg, int32_t max_deg, float* out_mean4, float* out_cov4,
+                                        float* out_enc, void* stream) {
+  RNERF_CHECK_ARG(rows_pd && rows_dr && radii && (out_mean4 || out_cov4 || out_enc), "rnerf_integrated_pos_enc: null pointer");
+  RNERF_CHECK_ARG(S >= 1 && B >= 1 && min_deg >= 0 && max_deg > min_deg && max_deg <= 30, "rnerf_integrated_pos_enc: need S, B >= 1 and 0 <= min_deg < max_deg <= 30");
+  RNERF_CHECK_ARG((((uintptr_t)rows_pd | (uintptr_t)rows_dr | (uintptr_t)out_mean4 | (uintptr_t)out_cov4) & 15) == 0, "rnerf_integrated_pos_enc: float4 buffers must be 16-byte aligned");
+  hipLaunchKernelGGL(ipe_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const float4*)rows_pd, (const float4*)rows_dr, node_of_sample, S, B,
+                     radii, (float)near, min_deg, max_deg, (float4*)out_mean4, (float4*)out_cov4, out_enc);
+  RNERF_CHECK_LAUNCH();
+  return RNERF_OK;
+}
+
 extern "C" int rnerf_generate_rays(const float* camtoworld, int32_t opencv, double fx, double fy, double cx, double cy, double pixel_center,
                                    int32_t W, int32_t row0, int32_t rows, float* origins, float* directions, float* viewdirs, void* stream) {
   RNERF_CHECK_ARG(camtoworld && origins && viewdirs, "rnerf_generate_rays: null pointer");

@@ -478,3 +478,23 @@ def train_stats(sums, B: int, two_levels: bool, bg_on: float, env_loss_sum, ps: 
     check(lib.rnerf_train_stats(ptr(sums), int(B), int(bool(two_levels)), float(bg_on), ptr(env_loss_sum), int(ps), float(env_on),
                                 ptr(_chk(theta, "theta")), int(theta.numel()), float(frozen_sq), int(n_all), ptr(_chk(stats8, "stats8")),
                                 current_stream()), "rnerf_train_stats")
+
+
+def integrated_pos_enc(rows_pd: torch.Tensor, rows_dr: torch.Tensor, node_of_sample: Optional[torch.Tensor], S: int, B: int, radii: torch.Tensor,
+                       near: float, min_deg: int = 0, max_deg: int = 10, want_gaussians: bool = False):
+    """mip.cast_rays(..., "cone") + mip.integrated_pos_enc along the curved ray (rnerf/mip.py:26-175), as the reference's
+    commented call sites use them (rnerf/models.py:249-254).  -> enc [S,B,6L] (+ mean4 [S,B,4], cov4 [S,B,4] if want_gaussians)."""
+    lib = _lib.load()
+    dev = rows_pd.device
+    L = int(max_deg) - int(min_deg)
+    enc = torch.empty((S, B, 6 * L), dtype=torch.float32, device=dev)
+    mean = torch.empty((S, B, 4), dtype=torch.float32, device=dev) if want_gaussians else None
+    cov = torch.empty((S, B, 4), dtype=torch.float32, device=dev) if want_gaussians else None
+    r = _chk(radii.reshape(-1), "radii")
+    if r.numel() != B:
+        raise _lib.RnerfError(f"radii must hold one value per ray ({B}), got {r.numel()}")
+    if node_of_sample is not None:
+        node_of_sample = _chk(node_of_sample, "node_of_sample", torch.int32)
+    check(lib.rnerf_integrated_pos_enc(ptr(_chk(rows_pd, "rows_pd")), ptr(_chk(rows_dr, "rows_dr")), ptr(node_of_sample), int(S), int(B), ptr(r), float(near),
+                                       int(min_deg), int(max_deg), ptr(mean), ptr(cov), ptr(enc), current_stream()), "rnerf_integrated_pos_enc")
+    return (enc, mean, cov) if want_gaussians else enc

@@ -573,3 +573,33 @@ def test_normal_loss_and_smooth(scene):
     zero, smooth = model.apply(variables, T(x), T(g), 0.7, noise=T(noise), method=model.wrapper_compute_normal_loss_and_smooth)
     _, want = R.normal_loss_and_smooth(scene.table, tree, x, g, scene.ndim, scene.nmin, scene.nmax, 0.7, noise)
     assert zero == 0.0 and abs(float(smooth) - want) < 2e-5 * max(1.0, want)
+
+
+def test_integrated_pos_enc_along_a_bent_path():
+    """rnerf_integrated_pos_enc on the coarse samples of a refracted march (read through the jitter) against the oracle's
+    restatement of mip.cast_rays + mip.integrated_pos_enc (rnerf/mip.py:26-175): Gaussian means / covariances to float rounding, the 60
+    encoded features within the fp32 rounding of their 2^9-scaled arguments."""
+    from samplenerfro_amd import models, ops
+    dev = "cuda:0"
+    G, Nc, P, B = 24, 16, 4, 77
+    grid = R.conv3d_normal(syn.scale_ior(syn.sphere_grid(G, 1.5, 0.6), 0.5).reshape(-1, 1), [G] * 3, 3, 1.0).reshape(G, G, G).astype(np.float32)
+    table = R.build_table(grid, [G] * 3, [-1.5] * 3, [1.5] * 3)
+    o, d = syn.sphere_rays(B, seed=9)
+    pos, dirs, dist, _, _ = R.path_sampler(o, d, table, [G] * 3, [-1.5] * 3, [1.5] * 3, 2.0, 6.0, Nc * P, np.float32)
+    jit = (np.arange(0, Nc * P, P) + np.array([1, 3, 0, 2] * 4)).astype(np.int32)
+    radii = np.random.default_rng(1).uniform(5e-4, 2e-3, (B, 1)).astype(np.float32)
+    mean_o, cov_o, enc_o = R.integrated_pos_enc_of_path(pos[:, jit], dirs[:, jit], dist[:, jit], radii, 2.0, 0, 10, np.float32)
+    mean64, cov64, enc64 = R.integrated_pos_enc_of_path(pos[:, jit].astype(np.float64), dirs[:, jit].astype(np.float64), dist[:, jit].astype(np.float64),
+                                                       radii.astype(np.float64), 2.0, 0, 10, np.float64)
+    spec = _lib.Grid.make([G] * 3, [-1.5] * 3, [1.5] * 3)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    pd, dr, _, _ = ops.march(T(table), spec, T(o), T(d), 2.0, 6.0, Nc * P)
+    enc, mean, cov = ops.integrated_pos_enc(pd, dr, T(jit), Nc, B, T(radii), 2.0, 0, 10, want_gaussians=True)
+    mean, cov, enc = mean.cpu().numpy(), cov.cpu().numpy(), enc.cpu().numpy()
+    assert enc.shape == (Nc, B, 60)
+    assert np.abs(mean[..., :3].transpose(1, 0, 2) - mean_o).max() < 2e-6 and np.abs(mean[..., :3].transpose(1, 0, 2) - mean64).max() < 5e-6
+    assert np.abs(cov[..., :3].transpose(1, 0, 2) - cov_o).max() < 1e-9 + 1e-5 * np.abs(cov_o).max()
+    e = enc.transpose(1, 0, 2)
+    assert np.abs(e - enc64).max() < 1.5e-3           # 2^9 x at |x| ~ 4: fp32 argument rounding 1.2e-4 per ulp of the mean, a few ulps along the cumsum
+    assert np.abs(e - enc_o).max() < 1.5e-3
+    assert np.abs(e[..., :6] - enc64[..., :6]).max() < 2e-6                  # the low degrees are at float rounding

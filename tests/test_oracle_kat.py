@@ -176,3 +176,35 @@ def test_forward_shapes_and_f64_twin():
     assert all(x.dtype == np.float32 for x in ret[1])
     ret64, _ = R.nerf_forward(cfg, params, table.astype(np.float64), o.astype(np.float64), d.astype(np.float64), jit, dtype=np.float64)
     assert np.abs(ret64[0][0] - ret[0][0]).max() < 1e-4
+
+
+def test_integrated_pos_enc_kat():
+    """SURVEY 8f N4 (rnerf/mip.py:26-175).  On a STRAIGHT ray the mean accumulated along the path collapses to mip-NeRF's closed form
+    o + d * t_mean; the encoding has 6 L features without identity, equals plain sin for zero variance and is damped by exp(-var/2)."""
+    B, S = 5, 7
+    rng = np.random.default_rng(3)
+    o = rng.standard_normal((B, 3)); d = rng.standard_normal((B, 3)); d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    near = 2.0
+    t = near + np.cumsum(rng.uniform(0.1, 0.4, (B, S)), axis=1) - 0.1
+    pos = o[:, None] + t[..., None] * d[:, None]
+    dirs = np.broadcast_to(d[:, None], (B, S, 3)).copy()
+    radii = rng.uniform(1e-3, 3e-3, (B, 1))
+    means, covs, enc = R.integrated_pos_enc_of_path(pos, dirs, t, radii, near, 0, 10, np.float64)
+    t_vals = np.concatenate([t, t[:, -1:] + 1e-3], -1)
+    mu, hw = (t_vals[:, :-1] + t_vals[:, 1:]) / 2, (t_vals[:, 1:] - t_vals[:, :-1]) / 2
+    t_mean = mu + 2 * mu * hw ** 2 / (3 * mu ** 2 + hw ** 2)
+    # straight ray: first sample position + d * (t_mean - t_0) ... the reference adds origins[:, 0:1] = the FIRST sample's position to a
+    # cumsum that starts at t_mean_0 - near, so the closed form is pos_0 + d * (t_mean - near)
+    want = pos[:, 0:1] + d[:, None] * (t_mean - near)[..., None]
+    assert np.allclose(means, want, atol=1e-12)
+    assert enc.shape == (B, S, 60) and covs.shape == (B, S, 3) and np.all(covs > 0)
+    plain = R.integrated_pos_enc(means, np.zeros_like(covs), 0, 10, np.float64)
+    sc = 2.0 ** np.arange(10)
+    assert np.allclose(plain[..., :30], np.sin((means[..., None, :] * sc[:, None]).reshape(B, S, 30)), atol=1e-12)
+    assert np.all(np.abs(enc) <= np.abs(plain) + 1e-15)                       # the Gaussian only damps
+    k = 9                                                                     # highest degree: variance 4^9 times the base one
+    ratio = enc[..., 3 * k:3 * k + 3] / plain[..., 3 * k:3 * k + 3]
+    assert np.allclose(ratio, np.exp(-0.5 * covs * 4.0 ** k), rtol=1e-9)
+    f32 = R.integrated_pos_enc_of_path(pos, dirs, t, radii, near, 0, 10, np.float32)[2]
+    # fp32: the argument 2^9 x carries ~6e-5 of rounding at |x| ~ 4
+    assert f32.dtype == np.float32 and np.abs(f32 - enc).max() < 5e-4
