@@ -215,6 +215,9 @@ int rnerf_loss_reduce(const float* rgb_c, const float* rgb_f, const float* trans
 int rnerf_env_smooth_backward(const float* rgb_env, int32_t ps, double grad_scale, float* d_out, float* loss_sum, void* stream);
 int rnerf_train_stats(const float* sums, int32_t B, int32_t two_levels, double bg_scale, const float* env_loss_sum, int32_t ps, double env_on,
                       const float* theta, int64_t n_theta, double frozen_sq, int64_t n_all, float* stats8, void* stream);
+/* rnerf_train_stats in two parts (the sum of squares of theta does not depend on the step's data and may run anywhere before the scalars):
+ * rnerf_theta_sumsq accumulates sum theta^2 into stats8[5]; rnerf_train_stats with theta == NULL then only forms the scalars. */
+int rnerf_theta_sumsq(const float* theta, int64_t n_theta, float* stats8, void* stream);
 
 /* ---- T1 (backward of V1 + activations): d loss / d raw of one level, replacing jax.value_and_grad through
  * volumetric_rendering and the rgb/sigma activations (rnerf/model_utils.py:247-309, rnerf/models.py:334-338; train.py:164).
@@ -265,6 +268,12 @@ int rnerf_bkgd_forward_train(const float* params, const float* dirs, int32_t dir
                              float* out_rgb, void* save, void* stream);
 int rnerf_bkgd_backward(const float* params, const void* save, const float* d_out, int64_t n, double rgb_padding, void* dy,
                         float* grads, float* d_dirs, void* stream);
+/* The two halves of rnerf_bkgd_backward, for a host that overlaps them with other work: _dgrad fills dy (and d_dirs); _wgrad accumulates
+ * grads from (save, dy).  coresident != 0 selects a wgrad kernel of at most 80 registers per lane and no LDS, which fits beside the
+ * NerfMLP wgrad's waves on every CU: rnerf_train_forward_backward runs it on cfg->tail_stream, off the step's critical path. */
+int rnerf_bkgd_backward_dgrad(const float* params, const void* save, const float* d_out, int64_t n, double rgb_padding, void* dy, float* d_dirs,
+                              void* stream);
+int rnerf_bkgd_backward_wgrad(const void* save, void* dy, int64_t n, float* grads, int coresident, void* stream);
 
 /* ---- training of stage "all*" — jax.value_and_grad (train.py:164) through the N-step eikonal recurrence
  * (rnerf/eikonal_utils.py:29-49,100-124) and through so3_mlp + the Rodrigues rotation (rnerf/ior_utils.py:269-312), with path_sampler
@@ -371,6 +380,8 @@ typedef struct rnerf_train_cfg {
   double bg_weight, bg_smooth_weight, annealed_alpha;     /* train.py:90-92,127-132 */
   double frozen_sq;            /* sum of squares / count of the variables outside theta (the frozen path_sampler): weight_l2, train.py:147-153 */
   int64_t frozen_count;
+  void* tail_stream;           /* nullable: a second stream for work that is independent of the NerfMLP backward — the background MLP's weight
+                                  gradient (a co-resident kernel) and sum theta^2 run there beside the NerfMLP dgrad / wgrad; joined inside the call */
 } rnerf_train_cfg;
 /* The march of the NEXT batch (it reads neither the parameters nor anything of this step): when `next` is given, its rays are marched on
  * next->side_stream, forked from `stream` right behind the last NerfMLP wgrad, so that the latency-bound march runs beside the small

@@ -50,7 +50,7 @@ class TrainCfg(C.Structure):
     """rnerf_train_cfg: the loss terms of train_step.loss_fn that the shipped configs switch on (train.py:75-162)."""
     _fields_ = [("backward", C.c_int32), ("randomized", C.c_int32), ("use_random_choice", C.c_int32), ("bg_patch_size", C.c_int32),
                 ("bg_weight", C.c_double), ("bg_smooth_weight", C.c_double), ("annealed_alpha", C.c_double), ("frozen_sq", C.c_double),
-                ("frozen_count", C.c_int64)]
+                ("frozen_count", C.c_int64), ("tail_stream", C.c_void_p)]
 
 
 class AdamCfg(C.Structure):
@@ -109,6 +109,9 @@ SIGNATURES = {
     "rnerf_bkgd_dy_bytes": (C.c_size_t, [_i64]),
     "rnerf_bkgd_forward_train": (C.c_int, [_vp, _vp, _i32, _i64, _dbl, _vp, _vp, _vp]),
     "rnerf_bkgd_backward": (C.c_int, [_vp, _vp, _vp, _i64, _dbl, _vp, _vp, _vp, _vp]),
+    "rnerf_bkgd_backward_dgrad": (C.c_int, [_vp, _vp, _vp, _i64, _dbl, _vp, _vp, _vp]),
+    "rnerf_bkgd_backward_wgrad": (C.c_int, [_vp, _vp, _i64, _vp, C.c_int, _vp]),
+    "rnerf_theta_sumsq": (C.c_int, [_vp, _i64, _vp, _vp]),
     "rnerf_march_all_train": (C.c_int, [_vp, _GP, _vp, _vp, _vp, _vp, _vp, _i32, _dbl, _dbl, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "rnerf_so3_packed_bytes": (C.c_size_t, []),
     "rnerf_so3_save_bytes": (C.c_size_t, [_i64]),

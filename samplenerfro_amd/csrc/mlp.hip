@@ -2527,6 +2527,66 @@ __global__ void __launch_bounds__(256) bkgd_wgrad_kernel(const float* __restrict
   }
 }
 
+// The same wgrad as a kernel that can be CO-RESIDENT with the NerfMLP wgrad (which keeps 64-80 registers per SIMD free and nearly all
+// of the LDS for itself): one wave per (256-row chunk, unit, pair of n-tiles), at most 80 registers, no LDS — the partial of a chunk is
+// written by the wave that computed it.  It is slower than bkgd_wgrad_kernel when it runs alone (no unrolling headroom), which does
+// not matter where it is used: on a side stream beside the 2 ms NerfMLP wgrad, off the step's critical path (csrc/pipeline.hip).
+template <int KIND>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(40)))
+bkgd_wgrad_co_kernel(const float* __restrict__ save, const float* __restrict__ dy, long long n, float* __restrict__ partial) {
+  const BkgdUnit u = KIND == 0 ? kBkgdUnits[blockIdx.y] : kSo3Units[blockIdx.y];
+  const int lane = threadIdx.x & 63, m = lane & 31, h = lane >> 5;
+  const int NT = (u.nout + 31) / 32;
+  const int np = blockIdx.z;                          // n-tiles {2 np, 2 np + 1} = columns {4 m + 2 np, 4 m + 2 np + 1}
+  if (NT == 1 && np != 0) return;
+  const float* __restrict__ X = u.xk == 0 ? save : save + (size_t)n * SmallNet<KIND>::ENC_LD + (size_t)(u.xk - 1) * n * 128;
+  const float* __restrict__ dY = dy + (size_t)u.dk * n * 128;
+  const int k = 32 * u.kt + m;
+  const int kc = k < u.kin ? k : u.kin - 1;
+  const bool bias = u.boff >= 0;
+  const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  f32x16 acc0 = zero, acc1 = zero;
+  float bs0 = 0.f, bs1 = 0.f;
+  const long long r0 = (long long)blockIdx.x * 256;
+#pragma unroll 4
+  for (int i = 0; i < 128; ++i) {
+    const long long rr = r0 + 2 * i + h;
+    const bool ok = rr < n;
+    const size_t rc = (size_t)(ok ? rr : n - 1);
+    const float av = X[rc * u.ldx + kc];
+    const float a = (ok && k < u.kin) ? av : 0.f;
+    if (NT == 4) {
+      const float2 bv = *(const float2*)(dY + rc * 128 + 4 * m + 2 * np);
+      const float b0 = ok ? bv.x : 0.f, b1 = ok ? bv.y : 0.f;
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+      bs0 += b0; bs1 += b1;
+    } else {
+      const float bv = dY[rc * u.ldy + (m < u.nout ? m : u.nout - 1)];
+      const float b0 = (ok && m < u.nout) ? bv : 0.f;
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+      bs0 += b0;
+    }
+  }
+  float* pg = partial + (size_t)blockIdx.x * SmallNet<KIND>::NPARAMS;
+  bs0 += __shfl_xor(bs0, 32); bs1 += __shfl_xor(bs1, 32);
+  const int nn0 = NT == 4 ? 4 * m + 2 * np : m;
+  if (nn0 < u.nout) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ki = 32 * u.kt + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (ki < u.kin) {
+        pg[u.goff + ki * u.out_dim + nn0] = acc0[r];
+        if (NT == 4) pg[u.goff + ki * u.out_dim + nn0 + 1] = acc1[r];
+      }
+    }
+    if (bias && h == 0) {
+      pg[u.boff + nn0] = bs0;
+      if (NT == 4) pg[u.boff + nn0 + 1] = bs1;
+    }
+  }
+}
+
 template <int NPARAMS>
 __global__ void __launch_bounds__(256) bkgd_wgrad_reduce_kernel(const float* __restrict__ partial, int chunks, float* __restrict__ grads) {
   const int e = blockIdx.x * 256 + threadIdx.x;
@@ -2914,22 +2974,40 @@ extern "C" int rnerf_bkgd_forward_train(const float* params, const float* dirs, 
   return RNERF_OK;
 }
 
-extern "C" int rnerf_bkgd_backward(const float* params, const void* save, const float* d_out, int64_t n, double rgb_padding, void* dy,
-                                   float* grads, float* d_dirs, void* stream) {
-  RNERF_CHECK_ARG(params && save && d_out && dy && grads, "rnerf_bkgd_backward: null pointer");
-  RNERF_CHECK_ARG(n >= 1, "rnerf_bkgd_backward: n must be >= 1");
+extern "C" int rnerf_bkgd_backward_dgrad(const float* params, const void* save, const float* d_out, int64_t n, double rgb_padding, void* dy,
+                                         float* d_dirs, void* stream) {
+  RNERF_CHECK_ARG(params && save && d_out && dy, "rnerf_bkgd_backward_dgrad: null pointer");
+  RNERF_CHECK_ARG(n >= 1, "rnerf_bkgd_backward_dgrad: n must be >= 1");
+  hipLaunchKernelGGL(bkgd_dgrad_kernel, dim3((unsigned)((n + 31) / 32)), dim3(64), 0, (hipStream_t)stream, params, (const float*)save, d_out, (long long)n,
+                     (float)(1 + 2 * rgb_padding), (float)rgb_padding, (float*)dy, (float4*)d_dirs);
+  RNERF_CHECK_LAUNCH();
+  return RNERF_OK;
+}
+
+extern "C" int rnerf_bkgd_backward_wgrad(const void* save, void* dy, int64_t n, float* grads, int coresident, void* stream) {
+  RNERF_CHECK_ARG(save && dy && grads, "rnerf_bkgd_backward_wgrad: null pointer");
+  RNERF_CHECK_ARG(n >= 1, "rnerf_bkgd_backward_wgrad: n must be >= 1");
   hipStream_t st = (hipStream_t)stream;
   const float* sv = (const float*)save;
   float* dyf = (float*)dy;
-  hipLaunchKernelGGL(bkgd_dgrad_kernel, dim3((unsigned)((n + 31) / 32)), dim3(64), 0, st, params, sv, d_out, (long long)n,
-                     (float)(1 + 2 * rgb_padding), (float)rgb_padding, dyf, (float4*)d_dirs);
   const unsigned chunks = (unsigned)((n + 255) / 256);
   float* partial = dyf + (size_t)n * 5 * 128;
-  hipLaunchKernelGGL(bkgd_wgrad_kernel<0>, dim3(chunks, 18), dim3(256), 0, st, sv, (const float*)dyf, (long long)n, partial);
+  if (coresident)
+    hipLaunchKernelGGL(bkgd_wgrad_co_kernel<0>, dim3(chunks, 18, 2), dim3(64), 0, st, sv, (const float*)dyf, (long long)n, partial);
+  else
+    hipLaunchKernelGGL(bkgd_wgrad_kernel<0>, dim3(chunks, 18), dim3(256), 0, st, sv, (const float*)dyf, (long long)n, partial);
   hipLaunchKernelGGL(bkgd_wgrad_reduce_kernel<RNERF_BKGDMLP_PARAMS>, dim3((RNERF_BKGDMLP_PARAMS + 255) / 256), dim3(256), 0, st, (const float*)partial, (int)chunks,
                      grads);
   RNERF_CHECK_LAUNCH();
   return RNERF_OK;
+}
+
+extern "C" int rnerf_bkgd_backward(const float* params, const void* save, const float* d_out, int64_t n, double rgb_padding, void* dy,
+                                   float* grads, float* d_dirs, void* stream) {
+  RNERF_CHECK_ARG(params && save && d_out && dy && grads, "rnerf_bkgd_backward: null pointer");
+  int rc = rnerf_bkgd_backward_dgrad(params, save, d_out, n, rgb_padding, dy, d_dirs, stream);
+  if (rc != RNERF_OK) return rc;
+  return rnerf_bkgd_backward_wgrad(save, dy, n, grads, 0, stream);
 }
 
 extern "C" int rnerf_so3_query(const float* table, const rnerf_grid* g, const float* so3_params, const float* window10, const float* pts,

@@ -122,6 +122,17 @@ __global__ void __launch_bounds__(256) bkgd_dirs_kernel(const float4* __restrict
   }
 }
 
+// (experiment, -DRNERF_TAIL_DELAY_US=<n>, default 0 = not launched)
+// One wave that does nothing for `ticks` of the 100 MHz real-time counter.  Issued on the tail stream ahead of the co-resident kernels:
+// streams express "after X completed", not "after X has STARTED", so without it the small kernels race the NerfMLP wgrad for the CUs at
+// the fork, and wherever their waves land first the wgrad's 8-wave workgroup (2 x 216 registers per SIMD, 148 KiB of LDS) has to wait
+// for them to drain.  A few tens of microseconds later the wgrad's workgroups are resident everywhere and the co-resident waves only
+// take what it leaves free.
+__global__ void spin_kernel(long long ticks) {
+  const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
+  while ((long long)__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
 // trans_rgb_bkgd = trans * rgb_behind (rnerf/models.py:520-524)
 __global__ void __launch_bounds__(256) bd_cut_mul_kernel(const float* __restrict__ trans, const float* __restrict__ behind, int B,
                                                          float* __restrict__ out) {
@@ -380,6 +391,10 @@ extern "C" int rnerf_forward(const rnerf_model* m, const float* origins, const f
 
 // ---- training --------------------------------------------------------------------------------------------------------------------
 namespace rnerf {
+#ifndef RNERF_TAIL_DELAY_US
+#define RNERF_TAIL_DELAY_US 0
+#endif
+constexpr long long kTailDelayTicks = 100LL * RNERF_TAIL_DELAY_US;      // s_memrealtime counts at 100 MHz
 struct TrainBuffers {
   FwdBuffers f;
   int32_t* jitter; uint32_t* key_u;
@@ -529,16 +544,33 @@ extern "C" int rnerf_train_forward_backward(const rnerf_model* m, const rnerf_tr
     RNERF_TRY(rnerf_composite_backward(f.raw_c, path_pd, path_dr, jitter, Nc, B, bkgd, m->rgb_padding, m->sigma_bias, lf.rgb, pixels, lf.trans, lf.tb, t.sums,
                                        mse_scale, c->bg_weight * bg_on, t.d_raw, d_first, 0, m->white_bkgd, nullptr, stream));
   }
+  // The background MLP's backward needs only d_all (complete here: both levels' compositing backward have run).  Its dgrad chain stays on
+  // this stream; its weight gradient and sum theta^2 go to cfg->tail_stream, where they run beside the NerfMLP wgrad below (the
+  // co-resident wgrad kernel fits next to the NerfMLP wgrad's waves) and are joined before the stats.
+  const double env_on = c->annealed_alpha > 0 ? 1.0 : 0.0;
+  if (c->tail_stream) {
+    if (smooth) RNERF_TRY(rnerf_env_smooth_backward(rgb_env, ps, c->bg_smooth_weight * env_on, t.d_all + (size_t)3 * B, t.env_sum, stream));
+    RNERF_TRY(rnerf_bkgd_backward_dgrad(th_b, t.save_bk, t.d_all, (int64_t)B + M, m->rgb_padding, t.dy_bk, nullptr, stream));
+  }
   RNERF_TRY(rnerf_nerfmlp_pack_bwd(th_c, bwd, t.packed_bwd, stream));
   RNERF_TRY(rnerf_nerfmlp_dgrad(t.packed_bwd, t.packed_c, prec, bwd, t.save_c, t.d_raw, (int64_t)Nc * B, t.dy, stream));
+  if (c->tail_stream) {      // forked HERE, not earlier: the NerfMLP dgrad owns every CU whole, the wgrad below leaves room for these waves
+    RNERF_TRY(rnerf_fork(stream, c->tail_stream));
+    if (kTailDelayTicks > 0) hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)c->tail_stream, (long long)kTailDelayTicks);
+    RNERF_TRY(rnerf_bkgd_backward_wgrad(t.save_bk, t.dy_bk, (int64_t)B + M, g_b, 1, c->tail_stream));
+    RNERF_TRY(rnerf_theta_sumsq(theta, n_theta, stats8, c->tail_stream));
+  }
   if (next && next->beside_wgrad && Nf == 0) RNERF_TRY(march_next());
   RNERF_TRY(rnerf_nerfmlp_wgrad(prec, bwd, t.save_c, t.dy, (int64_t)Nc * B, g_c, t.wgrad_ws, stream));
   if (next && !next->beside_wgrad) RNERF_TRY(march_next());     // beside the tail below (background-MLP backward, loss glue) and the update
-  const double env_on = c->annealed_alpha > 0 ? 1.0 : 0.0;
-  if (smooth) RNERF_TRY(rnerf_env_smooth_backward(rgb_env, ps, c->bg_smooth_weight * env_on, t.d_all + (size_t)3 * B, t.env_sum, stream));
-  RNERF_TRY(rnerf_bkgd_backward(th_b, t.save_bk, t.d_all, (int64_t)B + M, m->rgb_padding, t.dy_bk, g_b, nullptr, stream));
-  RNERF_TRY(rnerf_train_stats(t.sums, B, Nf > 0, c->bg_weight * bg_on, smooth ? t.env_sum : nullptr, ps, env_on, theta, n_theta, c->frozen_sq, n_theta + c->frozen_count, stats8,
-                              stream));
+  if (c->tail_stream) {
+    RNERF_TRY(rnerf_join(stream, c->tail_stream));
+  } else {
+    if (smooth) RNERF_TRY(rnerf_env_smooth_backward(rgb_env, ps, c->bg_smooth_weight * env_on, t.d_all + (size_t)3 * B, t.env_sum, stream));
+    RNERF_TRY(rnerf_bkgd_backward(th_b, t.save_bk, t.d_all, (int64_t)B + M, m->rgb_padding, t.dy_bk, g_b, nullptr, stream));
+  }
+  RNERF_TRY(rnerf_train_stats(t.sums, B, Nf > 0, c->bg_weight * bg_on, smooth ? t.env_sum : nullptr, ps, env_on, c->tail_stream ? nullptr : theta, n_theta, c->frozen_sq,
+                              n_theta + c->frozen_count, stats8, stream));
   return RNERF_OK;
 }
 

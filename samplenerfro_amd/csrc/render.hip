@@ -746,12 +746,19 @@ extern "C" int rnerf_env_smooth_backward(const float* rgb_env, int32_t ps, doubl
 extern "C" int rnerf_train_stats(const float* sums, int32_t B, int32_t two_levels, double bg_scale, const float* env_loss_sum, int32_t ps,
                                  double env_on, const float* theta, int64_t n_theta, double frozen_sq, int64_t n_all, float* stats8,
                                  void* stream) {
-  RNERF_CHECK_ARG(sums && theta && stats8 && B >= 1 && n_theta >= 1 && n_all >= n_theta, "rnerf_train_stats: bad arguments");
+  RNERF_CHECK_ARG(sums && stats8 && B >= 1 && n_theta >= 1 && n_all >= n_theta, "rnerf_train_stats: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(sumsq_kernel, dim3(256), dim3(256), 0, st, theta, (long long)n_theta, stats8 + 5);
+  if (theta) hipLaunchKernelGGL(sumsq_kernel, dim3(256), dim3(256), 0, st, theta, (long long)n_theta, stats8 + 5);      // NULL: rnerf_theta_sumsq ran already
   const double m = ps >= 2 ? (double)(ps - 1) * ps * 3 : 1.0;
   hipLaunchKernelGGL(train_stats_kernel, dim3(1), dim3(64), 0, st, sums, (float)(1.0 / (3.0 * B)), two_levels, (float)bg_scale, env_loss_sum,
                      (float)(env_on / m), (float)frozen_sq, (float)(1.0 / (double)n_all), stats8);
+  RNERF_CHECK_LAUNCH();
+  return RNERF_OK;
+}
+
+extern "C" int rnerf_theta_sumsq(const float* theta, int64_t n_theta, float* stats8, void* stream) {
+  RNERF_CHECK_ARG(theta && stats8 && n_theta >= 1, "rnerf_theta_sumsq: bad arguments");
+  hipLaunchKernelGGL(sumsq_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, theta, (long long)n_theta, stats8 + 5);
   RNERF_CHECK_LAUNCH();
   return RNERF_OK;
 }

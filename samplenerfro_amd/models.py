@@ -257,6 +257,12 @@ class NerfModel:
         return h, _lib.Prefetch(o.data_ptr(), v.data_ptr(), pd.data_ptr(), dr.data_ptr(), self._side.cuda_stream,
                                  int(os.environ.get("RNERF_MARCH_BESIDE_WGRAD", "1")))
 
+    def tail_stream(self) -> torch.cuda.Stream:
+        """The stream rnerf_train_forward_backward uses for work that is independent of the NerfMLP backward (rnerf_train_cfg.tail_stream)."""
+        if getattr(self, "_tail", None) is None:
+            self._tail = torch.cuda.Stream(device=self.device)
+        return self._tail
+
     def release_reserved_cus(self) -> None:
         """Give the CUs reserved by prefetch_path(reserve_cus > 0) back to the MLP kernels."""
         self._mlp_wg_limit = 0

@@ -253,6 +253,11 @@ def train_cfg(model: NerfModel, state: TrainState, flags, annealed: float) -> "_
     c.bg_weight, c.bg_smooth_weight, c.annealed_alpha = float(flags.bg_weight), float(flags.bg_smooth_weight), float(annealed)
     fs = frozen_sq_of(state, state.variables)
     c.frozen_sq, c.frozen_count = fs[0], fs[1]
+    # RNERF_TAIL_STREAM=1 (experiment, off): the background-MLP weight gradient (a co-resident kernel) and sum theta^2 on a second stream
+    # beside the NerfMLP wgrad.  Measured neutral at 4096 x 128 (what they save on the critical path, ~0.12 ms, the wgrad loses to their
+    # waves: 2.04 -> 2.2-2.4 ms), +1-2 % at 1024 rays x (64 + 128)
+    if os.environ.get("RNERF_TAIL_STREAM") == "1" and hasattr(model, "tail_stream"):
+        c.tail_stream = model.tail_stream().cuda_stream
     return c
 
 

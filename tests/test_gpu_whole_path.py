@@ -122,11 +122,13 @@ def _train_setup(Nf, B, bd_cut=False, **flag_kw):
     return model, state, batch, flags
 
 
-@pytest.mark.parametrize("Nf,bd_cut,bwd", [(0, False, "f32"), (24, False, "f32"), (24, True, "tf32")])
-def test_whole_train_step_equals_the_staged_sequence(Nf, bd_cut, bwd):
+@pytest.mark.parametrize("Nf,bd_cut,bwd,tail", [(0, False, "f32", False), (24, False, "f32", False), (24, True, "tf32", False), (24, False, "f32", True)])
+def test_whole_train_step_equals_the_staged_sequence(Nf, bd_cut, bwd, tail, monkeypatch):
     """rnerf_train_forward_backward + rnerf_adam_update against the stage-by-stage train_step: identical gradient bits (same kernels,
     same order, same device-drawn jitter / stratified draws), parameters after three Adam steps within float rounding."""
     from samplenerfro_amd.train import train_step
+    if tail:                      # the opt-in second stream: background-MLP weight gradient by the co-resident kernel beside the NerfMLP wgrad
+        monkeypatch.setenv("RNERF_TAIL_STREAM", "1")
     out = {}
     for whole in (True, False):
         model, state, batch, flags = _train_setup(Nf, 160, bd_cut, backward_precision=bwd)
@@ -141,7 +143,13 @@ def test_whole_train_step_equals_the_staged_sequence(Nf, bd_cut, bwd):
                 theta1 = state.theta.clone()
             losses.append([float(stats.loss), float(stats.loss_c), float(stats.loss_bg), float(stats.loss_bg_smooth), float(stats.weight_l2), float(stats.psnr)])
         out[whole] = (gs, losses, state.theta.clone(), rng, state.step, theta1)
-    assert torch.equal(out[True][0][0], out[False][0][0])                       # first step: same parameters in, same gradient bits out
+    # first step: same parameters in -> the NerfMLP gradient bits are identical (same kernels, same order).  The background MLP's weight
+    # gradient comes from the co-resident wgrad kernel on the tail stream in the whole path (a different summation order over the rows):
+    # compared to float rounding
+    n_bk = 56963
+    ga, gb = out[True][0][0], out[False][0][0]
+    assert torch.equal(ga[:-n_bk], gb[:-n_bk])
+    assert (ga[-n_bk:] - gb[-n_bk:]).abs().max().item() <= 2e-6 * gb[-n_bk:].abs().max().item()
     assert np.allclose(out[True][1], out[False][1], rtol=2e-6, atol=1e-7)
     assert np.array_equal(out[True][3], out[False][3]) and out[True][4] == out[False][4] == 3
     # same gradient bits into the first update: the two Adam implementations (rnerf_adam_update / torch elementwise) differ by rounding only
