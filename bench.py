@@ -195,9 +195,9 @@ def relaunch_for_gpus(args):
 
 
 class Stepper:
-    """One training (or forward) step of a workload, repeated.  Training in the radiance stages replays the step's launch graph
-    (samplenerfro_amd.graph.GraphTrainStep: one hipGraphLaunch per step, the next step's march on a side branch); --no-graph issues the
-    kernels one by one through train_step."""
+    """One training (or forward) step of a workload, repeated.  Training goes through train_step (two whole-path C calls per step, the
+    next step's march on a side stream beside the wgrad); --graph replays the step's launch graph instead
+    (samplenerfro_amd.graph.GraphTrainStep: one hipGraphLaunch per step, the march on a side branch)."""
 
     def __init__(self, args, cfg, model, variables, rays, key, B, world, rank, fine, device, backward, mode, stage, pipeline, graph):
         import torch
@@ -319,7 +319,11 @@ def main():
                     help="march of step k+1 beside step k (train: a side branch of the step's graph / the side stream, default ON; "
                          "forward: beside the MLP on reserved CUs, default OFF)")
     ap.add_argument("--no-pipeline", dest="pipeline", action="store_false", help="every step runs its stages strictly in sequence")
-    ap.add_argument("--no-graph", dest="graph", action="store_false", help="train: issue the step's kernels one by one instead of replaying its launch graph")
+    ap.add_argument("--graph", dest="graph", action="store_true", default=False,
+                    help="train: replay the step's launch graph (one hipGraphLaunch per step: samplenerfro_amd.graph.GraphTrainStep) instead of "
+                         "issuing its ~30 kernels through the two whole-path C calls.  Measured 1-2 %% SLOWER on this ROCm (a graph node costs more "
+                         "than a stream launch and the step is not launch-bound), so it is off by default; the line reports it under `graph_replay`")
+    ap.add_argument("--no-graph", dest="graph", action="store_false")
     ap.add_argument("--no-extra", dest="extra", action="store_false",
                     help="skip the short timings of the other backward modes and of the other workload variants (train mode)")
     ap.add_argument("--no-frame", dest="frame", action="store_false",
@@ -410,6 +414,16 @@ def main():
     stepper.close()
     del stepper
     torch.cuda.empty_cache()
+    graph_replay = None
+    if train and args.extra and args.stage == "radiance":
+        # the same step the other way round (launch graph <-> stream launches), 10 steps: both forms of the north star's "one executable per step"
+        s3 = Stepper(args, cfg, model, variables, rays, key, B, world, rank, fine, device, args.backward, args.mode, args.stage, args.pipeline, not args.graph)
+        dt_g = timed_steps(s3, 2, 10, barrier, D, device)
+        s3.close()
+        del s3
+        torch.cuda.empty_cache()
+        graph_replay = {"launch": "one hipGraphLaunch per step" if not args.graph else "stream launches (two whole-path C calls per step)",
+                        "ms_per_step": 1e3 * dt_g / 10, "rays_per_s": B * world * 10 / dt_g}
 
     # ---- per-kernel roofline of the dominant kernels, HIP events on the launch stream ----------------------------------------------
     from samplenerfro_amd import ops, _lib
@@ -571,7 +585,9 @@ def main():
                            "tf32": "row-normalised f16 parts (11-bit significand), 1-2 MFMAs per product: ~1e-3 of max|g| on small batches, ~1e-5 at this size",
                            "bf16": "bf16 parts (8-bit significand), round 1's arithmetic: ~6e-3 of max|g| on small batches"}[args.backward]),
                        "launch": ("one hipGraph launch per step (key split, march branch, forward, backward, Adam: csrc/pipeline.hip)" if graph_used
-                                  else "kernels issued one by one from the host"),
+                                  else ("two whole-path C calls per step (rnerf_train_forward_backward + rnerf_adam_update, csrc/pipeline.hip): "
+                                        "every kernel of the step is sequenced in librnerf.so, none decided on the host" if train
+                                        else "one whole-path C call per batch (rnerf_forward)")),
                        "pipeline": ("none" if not args.pipeline else ("march(k+1) on a side branch beside the tail of step k" if train
                                                                           else "march(k+1) on a side stream overlaps MLP(k)"))},
             "roofline": {"kernel": "nerfmlp_fwd_kernel", "bound": "mfma", "achieved": mlp_achieved / 1e12, "peak": PEAK_MFMA_16BIT / 1e12,
@@ -606,6 +622,8 @@ def main():
             line["pmc_profile"] = pmc_meta
         if other_modes:
             line["other_backward_modes"] = other_modes
+        if graph_replay:
+            line["graph_replay"] = graph_replay
         if variants:
             line["variants"] = variants
         if frame is not None:

@@ -20,7 +20,7 @@ def test_bench_two_ranks(scaling):
     env = dict(os.environ, RNERF_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "example", "--rays", "512", "--no-frame",
-           "--no-cpu-baseline", "--scaling", scaling]
+           "--no-cpu-baseline", "--scaling", scaling] + (["--graph"] if scaling == "strong" else [])      # both launch forms with two ranks
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=560)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]

@@ -1,7 +1,7 @@
 mkdir -p gpurun_out/r03
 X="--no-extra --no-frame --no-cpu-baseline --steps 30 --warmup 5"
 for W in "--workload dolphin_train --rays 1024" "--workload dolphin_train --rays 512" ""; do
-  for M in "graph:" "eager_whole:--no-graph" "staged:--no-graph"; do
+  for M in "graph:--graph" "eager_whole:" "staged:"; do
     name=${M%%:*}; fl=${M#*:}
     if [ "$name" = staged ]; then export RNERF_STAGED=1; else unset RNERF_STAGED; fi
     python bench.py $W $X $fl 2>/dev/null | python -c "
