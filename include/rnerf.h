@@ -270,7 +270,7 @@ int rnerf_bkgd_backward(const float* params, const void* save, const float* d_ou
                         float* grads, float* d_dirs, void* stream);
 /* The two halves of rnerf_bkgd_backward, for a host that overlaps them with other work: _dgrad fills dy (and d_dirs); _wgrad accumulates
  * grads from (save, dy).  coresident != 0 selects a wgrad kernel of at most 80 registers per lane and no LDS, which fits beside the
- * NerfMLP wgrad's waves on every CU: rnerf_train_forward_backward runs it on cfg->tail_stream, off the step's critical path. */
+ * NerfMLP wgrad's waves on every CU (rnerf_train_cfg.coresident_bkgd_wgrad). */
 int rnerf_bkgd_backward_dgrad(const float* params, const void* save, const float* d_out, int64_t n, double rgb_padding, void* dy, float* d_dirs,
                               void* stream);
 int rnerf_bkgd_backward_wgrad(const void* save, void* dy, int64_t n, float* grads, int coresident, void* stream);
@@ -380,8 +380,10 @@ typedef struct rnerf_train_cfg {
   double bg_weight, bg_smooth_weight, annealed_alpha;     /* train.py:90-92,127-132 */
   double frozen_sq;            /* sum of squares / count of the variables outside theta (the frozen path_sampler): weight_l2, train.py:147-153 */
   int64_t frozen_count;
-  void* tail_stream;           /* nullable: a second stream for work that is independent of the NerfMLP backward — the background MLP's weight
-                                  gradient (a co-resident kernel) and sum theta^2 run there beside the NerfMLP dgrad / wgrad; joined inside the call */
+  void* aux_stream;            /* nullable: a second stream.  Everything of a step that depends on the parameters only — packing the operand streams of
+                                  both directions, zeroing the gradient buffer, sum theta^2 — runs there beside the key kernels, the march and the
+                                  background-MLP forward, and is joined inside the call before the first NerfMLP kernel */
+  int32_t coresident_bkgd_wgrad;  /* experiment (needs aux_stream): the background MLP's weight gradient as a co-resident kernel beside the NerfMLP wgrad */
 } rnerf_train_cfg;
 /* The march of the NEXT batch (it reads neither the parameters nor anything of this step): when `next` is given, its rays are marched on
  * next->side_stream, forked from `stream` right behind the last NerfMLP wgrad, so that the latency-bound march runs beside the small

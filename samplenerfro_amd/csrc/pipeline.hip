@@ -398,7 +398,7 @@ constexpr long long kTailDelayTicks = 100LL * RNERF_TAIL_DELAY_US;      // s_mem
 struct TrainBuffers {
   FwdBuffers f;
   int32_t* jitter; uint32_t* key_u;
-  void *packed_c, *packed_f, *packed_bwd, *save_c, *save_f, *save_bk, *dy, *dy_bk, *wgrad_ws;
+  void *packed_c, *packed_f, *packed_bwd, *packed_bwd_f, *save_c, *save_f, *save_bk, *dy, *dy_bk, *wgrad_ws;
   float *out_all, *level_c, *level_f, *sums, *d_all, *d_raw, *env_sum;
 };
 static size_t carve_train(const rnerf_model* m, const rnerf_train_cfg* c, int32_t B, bool own_path, void* ws, TrainBuffers* t) {
@@ -429,6 +429,7 @@ static size_t carve_train(const rnerf_model* m, const rnerf_train_cfg* c, int32_
   t->packed_c = k.bytes(rnerf_nerfmlp_packed_bytes(RNERF_PREC_F16X3));
   t->packed_f = Nf > 0 ? k.bytes(rnerf_nerfmlp_packed_bytes(RNERF_PREC_F16X3)) : nullptr;
   t->packed_bwd = k.bytes(rnerf_nerfmlp_bwd_packed_bytes());
+  t->packed_bwd_f = Nf > 0 ? k.bytes(rnerf_nerfmlp_bwd_packed_bytes()) : nullptr;
   t->save_c = k.bytes(rnerf_nerfmlp_save_bytes((int64_t)Nc * B, c->backward));
   t->save_f = Nf > 0 ? k.bytes(rnerf_nerfmlp_save_bytes((int64_t)S * B, c->backward)) : nullptr;
   t->save_bk = k.bytes(rnerf_bkgd_save_bytes((int64_t)(B + M)));
@@ -482,6 +483,19 @@ extern "C" int rnerf_train_forward_backward(const rnerf_model* m, const rnerf_tr
   float* g_b = grads + (size_t)RNERF_NERFMLP_PARAMS * (Nf > 0 ? 2 : 1);
   float* stats8 = grads + n_theta;
 
+  // ---- everything that depends on the parameters only — the operand streams of both directions, the zeroing of the gradient buffer,
+  //      sum theta^2 for weight_l2 — goes to cfg->aux_stream, beside the key kernels, the march and the background-MLP forward below
+  //      (~70 us of small launches off the critical path); joined before the first NerfMLP kernel
+  void* aux = c->aux_stream;
+  if (aux) {
+    RNERF_TRY(rnerf_fork(stream, aux));
+    RNERF_CHECK_HIP(hipMemsetAsync(grads, 0, (size_t)(n_theta + 8) * sizeof(float), (hipStream_t)aux));
+    RNERF_TRY(rnerf_nerfmlp_pack(th_c, prec, t.packed_c, aux));
+    if (Nf > 0) RNERF_TRY(rnerf_nerfmlp_pack(th_f, prec, t.packed_f, aux));
+    RNERF_TRY(rnerf_nerfmlp_pack_bwd(th_c, bwd, t.packed_bwd, aux));
+    if (Nf > 0) RNERF_TRY(rnerf_nerfmlp_pack_bwd(th_f, bwd, t.packed_bwd_f, aux));
+    RNERF_TRY(rnerf_theta_sumsq(theta, n_theta, stats8, aux));
+  }
   // ---- forward (models.forward with ctx) ----
   const int32_t* jitter = jitter_override;
   if (keys4) {
@@ -497,7 +511,7 @@ extern "C" int rnerf_train_forward_backward(const rnerf_model* m, const rnerf_tr
   RNERF_TRY(rnerf_bkgd_forward_train(th_b, f.bk_dirs, 4, (int64_t)B + M, m->rgb_padding, t.out_all, t.save_bk, stream));
   const float* bkgd = t.out_all;
   const float* rgb_env = t.out_all + (size_t)3 * B;
-  RNERF_TRY(rnerf_nerfmlp_pack(th_c, prec, t.packed_c, stream));
+  if (aux) RNERF_TRY(rnerf_join(stream, aux)); else RNERF_TRY(rnerf_nerfmlp_pack(th_c, prec, t.packed_c, stream));
   RNERF_TRY(rnerf_nerfmlp_forward_train(t.packed_c, prec, path_pd, path_dr, jitter, Nc, B, f.raw_c, t.save_c, bwd, max_workgroups, stream));
   Level lc = level_of(t.level_c, B);
   RNERF_TRY(rnerf_composite(f.raw_c, path_pd, path_dr, jitter, Nc, B, bkgd, m->white_bkgd, m->rgb_padding, m->sigma_bias, lc.rgb, lc.dist, lc.acc, lc.trans, lc.tb,
@@ -508,7 +522,7 @@ extern "C" int rnerf_train_forward_backward(const rnerf_model* m, const rnerf_tr
     int32_t per_ray = u_per_ray;
     if (!u) { RNERF_TRY(make_u(m, B, c->randomized, t.key_u, f.u, &per_ray, stream)); u = f.u; }
     RNERF_TRY(rnerf_resample(path_pd, path_dr, N, B, jitter, Nc, f.weights, u, per_ray, Nf, f.rows_pd, f.rows_dr, nullptr, f.scratch, stream));
-    RNERF_TRY(rnerf_nerfmlp_pack(th_f, prec, t.packed_f, stream));
+    if (!aux) RNERF_TRY(rnerf_nerfmlp_pack(th_f, prec, t.packed_f, stream));
     RNERF_TRY(rnerf_nerfmlp_forward_train(t.packed_f, prec, f.rows_pd, f.rows_dr, nullptr, S, B, f.raw_f, t.save_f, bwd, max_workgroups, stream));
     lf = level_of(t.level_f, B);
     RNERF_TRY(rnerf_composite(f.raw_f, f.rows_pd, f.rows_dr, nullptr, S, B, bkgd, m->white_bkgd, m->rgb_padding, m->sigma_bias, lf.rgb, lf.dist, lf.acc, lf.trans,
@@ -519,7 +533,7 @@ extern "C" int rnerf_train_forward_backward(const rnerf_model* m, const rnerf_tr
   RNERF_TRY(rnerf_loss_reduce(Nf > 0 ? lc.rgb : nullptr, lf.rgb, lf.trans, lf.tb, pixels, B, t.sums, stream));
   const double bg_on = (c->bg_weight > 0 && c->annealed_alpha > 0) ? 1.0 : 0.0;
   const double mse_scale = 2.0 / (3.0 * B);
-  RNERF_CHECK_HIP(hipMemsetAsync(grads, 0, (size_t)(n_theta + 8) * sizeof(float), st));
+  if (!aux) RNERF_CHECK_HIP(hipMemsetAsync(grads, 0, (size_t)(n_theta + 8) * sizeof(float), st));
   // The next batch's march on the side stream, forked from `stream` at the call.  With beside_wgrad it is issued right before the LARGEST
   // wgrad of the step (the fine level's when there is one): the wgrad keeps 64 registers free on every SIMD (RNERF_WGRAD_VGPRS), so the
   // march's waves are co-resident with it and the whole march hides behind that HBM-paced kernel.
@@ -534,8 +548,8 @@ extern "C" int rnerf_train_forward_backward(const rnerf_model* m, const rnerf_tr
   if (Nf > 0) {
     RNERF_TRY(rnerf_composite_backward(f.raw_f, f.rows_pd, f.rows_dr, nullptr, S, B, bkgd, m->rgb_padding, m->sigma_bias, lf.rgb, pixels, lf.trans, lf.tb, t.sums,
                                        mse_scale, c->bg_weight * bg_on, t.d_raw, d_first, 0, m->white_bkgd, m->bd_cut ? m->bd_cut_bbox : nullptr, stream));
-    RNERF_TRY(rnerf_nerfmlp_pack_bwd(th_f, bwd, t.packed_bwd, stream));
-    RNERF_TRY(rnerf_nerfmlp_dgrad(t.packed_bwd, t.packed_f, prec, bwd, t.save_f, t.d_raw, (int64_t)S * B, t.dy, stream));
+    if (!aux) RNERF_TRY(rnerf_nerfmlp_pack_bwd(th_f, bwd, t.packed_bwd_f, stream));
+    RNERF_TRY(rnerf_nerfmlp_dgrad(t.packed_bwd_f, t.packed_f, prec, bwd, t.save_f, t.d_raw, (int64_t)S * B, t.dy, stream));
     if (next && next->beside_wgrad) RNERF_TRY(march_next());
     RNERF_TRY(rnerf_nerfmlp_wgrad(prec, bwd, t.save_f, t.dy, (int64_t)S * B, g_f, t.wgrad_ws, stream));
     RNERF_TRY(rnerf_composite_backward(f.raw_c, path_pd, path_dr, jitter, Nc, B, bkgd, m->rgb_padding, m->sigma_bias, lc.rgb, pixels, nullptr, nullptr, nullptr,
@@ -544,32 +558,31 @@ extern "C" int rnerf_train_forward_backward(const rnerf_model* m, const rnerf_tr
     RNERF_TRY(rnerf_composite_backward(f.raw_c, path_pd, path_dr, jitter, Nc, B, bkgd, m->rgb_padding, m->sigma_bias, lf.rgb, pixels, lf.trans, lf.tb, t.sums,
                                        mse_scale, c->bg_weight * bg_on, t.d_raw, d_first, 0, m->white_bkgd, nullptr, stream));
   }
-  // The background MLP's backward needs only d_all (complete here: both levels' compositing backward have run).  Its dgrad chain stays on
-  // this stream; its weight gradient and sum theta^2 go to cfg->tail_stream, where they run beside the NerfMLP wgrad below (the
-  // co-resident wgrad kernel fits next to the NerfMLP wgrad's waves) and are joined before the stats.
+  // (experiment, cfg->coresident_bkgd_wgrad: the background MLP's weight gradient as a co-resident kernel on the aux stream beside the
+  //  NerfMLP wgrad — its dgrad chain then runs here, ahead of the NerfMLP dgrad; measured neutral at bench size)
   const double env_on = c->annealed_alpha > 0 ? 1.0 : 0.0;
-  if (c->tail_stream) {
+  const bool co = aux && c->coresident_bkgd_wgrad;
+  if (co) {
     if (smooth) RNERF_TRY(rnerf_env_smooth_backward(rgb_env, ps, c->bg_smooth_weight * env_on, t.d_all + (size_t)3 * B, t.env_sum, stream));
     RNERF_TRY(rnerf_bkgd_backward_dgrad(th_b, t.save_bk, t.d_all, (int64_t)B + M, m->rgb_padding, t.dy_bk, nullptr, stream));
   }
-  RNERF_TRY(rnerf_nerfmlp_pack_bwd(th_c, bwd, t.packed_bwd, stream));
+  if (!aux) RNERF_TRY(rnerf_nerfmlp_pack_bwd(th_c, bwd, t.packed_bwd, stream));
   RNERF_TRY(rnerf_nerfmlp_dgrad(t.packed_bwd, t.packed_c, prec, bwd, t.save_c, t.d_raw, (int64_t)Nc * B, t.dy, stream));
-  if (c->tail_stream) {      // forked HERE, not earlier: the NerfMLP dgrad owns every CU whole, the wgrad below leaves room for these waves
-    RNERF_TRY(rnerf_fork(stream, c->tail_stream));
-    if (kTailDelayTicks > 0) hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)c->tail_stream, (long long)kTailDelayTicks);
-    RNERF_TRY(rnerf_bkgd_backward_wgrad(t.save_bk, t.dy_bk, (int64_t)B + M, g_b, 1, c->tail_stream));
-    RNERF_TRY(rnerf_theta_sumsq(theta, n_theta, stats8, c->tail_stream));
+  if (co) {      // forked HERE, not earlier: the NerfMLP dgrad owns every CU whole, the wgrad below leaves room for these waves
+    RNERF_TRY(rnerf_fork(stream, aux));
+    if (kTailDelayTicks > 0) hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)aux, (long long)kTailDelayTicks);
+    RNERF_TRY(rnerf_bkgd_backward_wgrad(t.save_bk, t.dy_bk, (int64_t)B + M, g_b, 1, aux));
   }
   if (next && next->beside_wgrad && Nf == 0) RNERF_TRY(march_next());
   RNERF_TRY(rnerf_nerfmlp_wgrad(prec, bwd, t.save_c, t.dy, (int64_t)Nc * B, g_c, t.wgrad_ws, stream));
   if (next && !next->beside_wgrad) RNERF_TRY(march_next());     // beside the tail below (background-MLP backward, loss glue) and the update
-  if (c->tail_stream) {
-    RNERF_TRY(rnerf_join(stream, c->tail_stream));
+  if (co) {
+    RNERF_TRY(rnerf_join(stream, aux));
   } else {
     if (smooth) RNERF_TRY(rnerf_env_smooth_backward(rgb_env, ps, c->bg_smooth_weight * env_on, t.d_all + (size_t)3 * B, t.env_sum, stream));
     RNERF_TRY(rnerf_bkgd_backward(th_b, t.save_bk, t.d_all, (int64_t)B + M, m->rgb_padding, t.dy_bk, g_b, nullptr, stream));
   }
-  RNERF_TRY(rnerf_train_stats(t.sums, B, Nf > 0, c->bg_weight * bg_on, smooth ? t.env_sum : nullptr, ps, env_on, c->tail_stream ? nullptr : theta, n_theta, c->frozen_sq,
+  RNERF_TRY(rnerf_train_stats(t.sums, B, Nf > 0, c->bg_weight * bg_on, smooth ? t.env_sum : nullptr, ps, env_on, aux ? nullptr : theta, n_theta, c->frozen_sq,
                               n_theta + c->frozen_count, stats8, stream));
   return RNERF_OK;
 }

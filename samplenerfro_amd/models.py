@@ -258,7 +258,7 @@ class NerfModel:
                                  int(os.environ.get("RNERF_MARCH_BESIDE_WGRAD", "1")))
 
     def tail_stream(self) -> torch.cuda.Stream:
-        """The stream rnerf_train_forward_backward uses for work that is independent of the NerfMLP backward (rnerf_train_cfg.tail_stream)."""
+        """The stream rnerf_train_forward_backward uses for work that is independent of the NerfMLP backward (rnerf_train_cfg.aux_stream)."""
         if getattr(self, "_tail", None) is None:
             self._tail = torch.cuda.Stream(device=self.device)
         return self._tail

@@ -253,11 +253,14 @@ def train_cfg(model: NerfModel, state: TrainState, flags, annealed: float) -> "_
     c.bg_weight, c.bg_smooth_weight, c.annealed_alpha = float(flags.bg_weight), float(flags.bg_smooth_weight), float(annealed)
     fs = frozen_sq_of(state, state.variables)
     c.frozen_sq, c.frozen_count = fs[0], fs[1]
-    # RNERF_TAIL_STREAM=1 (experiment, off): the background-MLP weight gradient (a co-resident kernel) and sum theta^2 on a second stream
-    # beside the NerfMLP wgrad.  Measured neutral at 4096 x 128 (what they save on the critical path, ~0.12 ms, the wgrad loses to their
-    # waves: 2.04 -> 2.2-2.4 ms), +1-2 % at 1024 rays x (64 + 128)
-    if os.environ.get("RNERF_TAIL_STREAM") == "1" and hasattr(model, "tail_stream"):
-        c.tail_stream = model.tail_stream().cuda_stream
+    # the second stream of rnerf_train_cfg: what depends on the parameters only (operand packing, zeroing the gradient buffer, sum theta^2)
+    # runs there beside the head of the step (RNERF_NO_AUX_STREAM=1: everything on one stream)
+    if os.environ.get("RNERF_NO_AUX_STREAM") != "1" and hasattr(model, "tail_stream"):
+        c.aux_stream = model.tail_stream().cuda_stream
+        # RNERF_TAIL_STREAM=1 (experiment, off): the background-MLP weight gradient as a co-resident kernel beside the NerfMLP wgrad.  Measured
+        # neutral at 4096 x 128 (what it saves on the critical path, ~0.12 ms, the wgrad loses to the extra waves: 2.04 -> 2.2-2.4 ms),
+        # +1-2 % at 1024 rays x (64 + 128)
+        c.coresident_bkgd_wgrad = int(os.environ.get("RNERF_TAIL_STREAM") == "1")
     return c
 
 

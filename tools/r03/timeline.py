@@ -4,7 +4,7 @@
 import csv, sys
 rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(sys.argv[1]))]
 rows.sort()
-key = "rng_split3"
+key = "rng_forward"      # one per step in both launch forms (the key split runs on the host without the launch graph)
 starts = [i for i, r in enumerate(rows) if key in r[2]]
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 a, b = starts[-n - 1], starts[-n]
