@@ -166,6 +166,18 @@ int rnerf_voxelize(const double* verts, const int32_t* faces, const int32_t* bin
                    const double* bin_origin_size, const rnerf_grid* g, int32_t num_samples, double ior_inside, double ior_outside,
                    int32_t* count, float* out, int32_t* overflow, void* stream);
 
+/* Robust containment for meshes that are NOT watertight (pysdf casts one parity ray per point in a randomly rotated frame,
+ * sdf/src/sdf.cpp:156-168,270-322; a single ray through a hole misclassifies the point): three passes of the same column test along
+ * +z, +x, +y, then a per-sample majority.
+ *   rnerf_voxelize_samples : as rnerf_voxelize, but writes the inside flag of every sample: inside uint8[GK][GK][GK], GK = G * K, indexed
+ *                            [x sample][y sample][z sample] of the coordinates it was GIVEN.  The caller runs it three times with the mesh
+ *                            and the grid axes rotated: (x, y, z), (y, z, x), (z, x, y) (samplenerfro_amd/voxelize.py: robust=True).
+ *   rnerf_voxelize_majority: in_z / in_x / in_y = the outputs of those three passes; count int32[G^3] = samples with >= 2 of 3 votes. */
+int rnerf_voxelize_samples(const double* verts, const int32_t* faces, const int32_t* bin_start, const int32_t* bin_tris, int32_t num_bins,
+                           const double* bin_origin_size, const rnerf_grid* g, int32_t num_samples, uint8_t* inside, int32_t* overflow, void* stream);
+int rnerf_voxelize_majority(const uint8_t* in_z, const uint8_t* in_x, const uint8_t* in_y, int32_t num_voxels, int32_t num_samples,
+                            double ior_inside, double ior_outside, int32_t* count, float* out, void* stream);
+
 /* ---- G4 + P2: VoxMLP.__call__ (rnerf/ior_utils.py:269-312, shipped gin: annealed, use_residual, use_direct_output):
  * (n, grad n) by trilinear lookup and pred_grad = grad n rotated (Rodrigues) by the axis-angle so3_mlp(annealed_pos_enc(x)).
  * so3_params: device float[RNERF_SO3MLP_PARAMS] (flax order); window10: HOST float[10] = cosine_easing_window(0, 9, 10,

@@ -688,7 +688,7 @@ def voxelize(verts, faces, num_voxels, nmin, nmax, num_samples=4, ior_inside=1.3
     return out
 
 
-def voxelize_counts(verts, faces, num_voxels, nmin, nmax, num_samples=4):
+def voxelize_counts(verts, faces, num_voxels, nmin, nmax, num_samples=4, return_samples=False):
     """The same definition as voxelize() (crossing parity along +z at the K^3 sub-samples of voxelize_mesh.py:70-106), evaluated per
     (triangle, xy sample column) pair instead of per point so that a 128^3 x 4^3 grid over a 55 k-triangle mesh takes seconds.
     -> int32 [G,G,G]: number of sub-samples inside the mesh (voxelize() == (n*inside + (K^3-n)*outside) / K^3)."""
@@ -738,7 +738,22 @@ def voxelize_counts(verts, faces, num_voxels, nmin, nmax, num_samples=4):
     inside_sorted = (above & 1).astype(np.int8)
     inside = np.empty_like(inside_sorted)
     inside[:, zorder] = inside_sorted
+    if return_samples:
+        return inside.reshape(G * K, G * K, G * K)                 # [x sample][y sample][z sample]
     return inside.reshape(G, K, G, K, G, K).sum(axis=(1, 3, 5), dtype=np.int32)
+
+
+def voxelize_counts_robust(verts, faces, num_voxels, nmin, nmax, num_samples=4):
+    """Three-axis majority containment (not in the reference: pysdf casts ONE parity ray per point in a random frame,
+    sdf/src/sdf.cpp:156-168,270-322): the crossing-parity test along +z, +x and +y, a sample counts as inside when at least two agree.
+    Equal to voxelize_counts() on watertight meshes; well-defined where a hole lets one of the rays escape."""
+    G, K = int(num_voxels), int(num_samples)
+    v = np.asarray(verts, np.float64); lo = np.asarray(nmin, np.float64); hi = np.asarray(nmax, np.float64)
+    votes = np.zeros((G * K,) * 3, np.int8)
+    for perm, back in (((0, 1, 2), (0, 1, 2)), ((1, 2, 0), (2, 0, 1)), ((2, 0, 1), (1, 2, 0))):
+        ins = voxelize_counts(v[:, perm], faces, G, lo[list(perm)], hi[list(perm)], K, return_samples=True)    # indexed by the permuted axes
+        votes += ins.transpose(back)                                # back to [X][Y][Z]
+    return (votes >= 2).reshape(G, K, G, K, G, K).sum(axis=(1, 3, 5), dtype=np.int32)
 
 
 def counts_to_ior(counts, num_samples=4, ior_inside=1.33, ior_outside=1.0):

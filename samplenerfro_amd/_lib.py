@@ -101,6 +101,8 @@ SIGNATURES = {
     "rnerf_nerfmlp_dgrad": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _i64, _vp, _vp]),
     "rnerf_nerfmlp_wgrad": (C.c_int, [C.c_int, C.c_int, _vp, _vp, _i64, _vp, _vp, _vp]),
     "rnerf_voxelize": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _GP, _i32, _dbl, _dbl, _vp, _vp, _vp, _vp]),
+    "rnerf_voxelize_samples": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _GP, _i32, _vp, _vp, _vp]),
+    "rnerf_voxelize_majority": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _dbl, _dbl, _vp, _vp, _vp]),
     "rnerf_so3_query": (C.c_int, [_vp, _GP, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "rnerf_march_all": (C.c_int, [_vp, _GP, _vp, _vp, _vp, _vp, _vp, _i32, _dbl, _dbl, _i32, _vp, _vp, _vp, _vp]),
     "rnerf_generate_rays": (C.c_int, [_vp, _i32, _dbl, _dbl, _dbl, _dbl, _dbl, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),

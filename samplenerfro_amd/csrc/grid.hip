@@ -176,7 +176,9 @@ constexpr int VOX_MAXC = 96;      // crossings kept per column (a column with mo
 
 __global__ void __launch_bounds__(128) voxel_columns_kernel(const double* __restrict__ verts, const int* __restrict__ faces,
                                                             const int* __restrict__ bin_start, const int* __restrict__ bin_tris, VoxGrid vg,
-                                                            int* __restrict__ count, int* __restrict__ overflow) {
+                                                            int* __restrict__ count, int* __restrict__ overflow, unsigned char* __restrict__ bits) {
+  // bits != nullptr: instead of adding to the per-voxel counts, write the inside flag of every sample, [x sample][y sample][z sample]
+  // (the three-axis majority of rnerf_voxelize_majority combines three such arrays)
   const int GK = vg.G * vg.K;
   const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (id >= (long long)GK * GK) return;
@@ -212,17 +214,39 @@ __global__ void __launch_bounds__(128) voxel_columns_kernel(const double* __rest
     while (q >= 0 && zc[q] > v) { zc[q + 1] = zc[q]; --q; }
     zc[q + 1] = v;
   }
-  if (n == 0) return;
+  if (n == 0) return;                                             // (bits: zeroed by the launcher)
   for (int k = 0; k < vg.G; ++k) {
     int inside = 0;
     for (int c = 0; c < vg.K; ++c) {
       const double z = vox_coord(vg, 2, k, c);
       int lo = 0, hi = n;                                         // first crossing with zc > z
       while (lo < hi) { const int mid = (lo + hi) >> 1; if (zc[mid] > z) hi = mid; else lo = mid + 1; }
-      inside += (n - lo) & 1;                                     // odd number of crossings above -> inside
+      const int in = (n - lo) & 1;                                // odd number of crossings above -> inside
+      inside += in;
+      if (bits) bits[((size_t)xi * GK + yi) * GK + (size_t)k * vg.K + c] = (unsigned char)in;
     }
-    if (inside) atomicAdd(count + ((size_t)i * vg.G + j) * vg.G + k, inside);
+    if (!bits && inside) atomicAdd(count + ((size_t)i * vg.G + j) * vg.G + k, inside);
   }
+}
+
+// Three-axis majority (robust containment for meshes that are not watertight): a sample is inside when at least two of the three
+// axis-parallel parity rays (+z, +x, +y) say so.  in0 is indexed [X][Y][Z] (rays along z), in1 [Y][Z][X] (the pass that saw the mesh with
+// its axes rotated to (y, z, x): rays along x), in2 [Z][X][Y] (rays along y); X = i K + a etc.
+__global__ void __launch_bounds__(256) voxel_majority_kernel(const unsigned char* __restrict__ in0, const unsigned char* __restrict__ in1,
+                                                             const unsigned char* __restrict__ in2, int G, int K, int* __restrict__ count) {
+  const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= (long long)G * G * G) return;
+  const int k = (int)(id % G), j = (int)((id / G) % G), i = (int)(id / ((long long)G * G));
+  const size_t GK = (size_t)G * K;
+  int c = 0;
+  for (int a = 0; a < K; ++a)
+    for (int b = 0; b < K; ++b)
+      for (int d = 0; d < K; ++d) {
+        const size_t X = (size_t)i * K + a, Y = (size_t)j * K + b, Z = (size_t)k * K + d;
+        const int v = in0[(X * GK + Y) * GK + Z] + in1[(Y * GK + Z) * GK + X] + in2[(Z * GK + X) * GK + Y];
+        c += v >= 2;
+      }
+  count[id] = c;
 }
 
 __global__ void voxel_finalize_kernel(const int* __restrict__ count, long long n, int K3, double ior_in, double ior_out, float* __restrict__ out) {
@@ -234,10 +258,7 @@ __global__ void voxel_finalize_kernel(const int* __restrict__ count, long long n
 
 }  // namespace rnerf
 
-extern "C" int rnerf_voxelize(const double* verts, const int32_t* faces, const int32_t* bin_start, const int32_t* bin_tris, int32_t num_bins,
-                              const double* bin_origin_size, const rnerf_grid* g, int32_t num_samples, double ior_inside, double ior_outside,
-                              int32_t* count, float* out, int32_t* overflow, void* stream) {
-  RNERF_CHECK_ARG(verts && faces && bin_start && bin_tris && bin_origin_size && g && count && out && overflow, "rnerf_voxelize: null pointer");
+static int make_vox_grid(const rnerf_grid* g, int32_t num_samples, int32_t num_bins, const double* bin_origin_size, VoxGrid* out) {
   RNERF_CHECK_ARG(g->dims[0] == g->dims[1] && g->dims[1] == g->dims[2] && g->dims[0] >= 2, "rnerf_voxelize: cubic grids only (num_voxels^3)");
   RNERF_CHECK_ARG(num_samples >= 1 && num_samples <= 8 && num_bins >= 1, "rnerf_voxelize: need 1 <= num_samples <= 8, num_bins >= 1");
   VoxGrid vg;
@@ -251,15 +272,56 @@ extern "C" int rnerf_voxelize(const double* verts, const int32_t* faces, const i
   for (int a = 0; a < 8; ++a) vg.off[a] = a * ostep + -1.0;                                                  // np.linspace(-1, 1, K)
   if (num_samples > 1) vg.off[num_samples - 1] = 1.0;
   vg.bin0x = bin_origin_size[0]; vg.bin0y = bin_origin_size[1]; vg.inv_bx = 1.0 / bin_origin_size[2]; vg.inv_by = 1.0 / bin_origin_size[3];
+  *out = vg;
+  return RNERF_OK;
+}
+
+extern "C" int rnerf_voxelize(const double* verts, const int32_t* faces, const int32_t* bin_start, const int32_t* bin_tris, int32_t num_bins,
+                              const double* bin_origin_size, const rnerf_grid* g, int32_t num_samples, double ior_inside, double ior_outside,
+                              int32_t* count, float* out, int32_t* overflow, void* stream) {
+  RNERF_CHECK_ARG(verts && faces && bin_start && bin_tris && bin_origin_size && g && count && out && overflow, "rnerf_voxelize: null pointer");
+  VoxGrid vg;
+  int rc = make_vox_grid(g, num_samples, num_bins, bin_origin_size, &vg);
+  if (rc != RNERF_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
   const long long nvox = (long long)vg.G * vg.G * vg.G;
   RNERF_CHECK_HIP(hipMemsetAsync(count, 0, nvox * sizeof(int), st));
   RNERF_CHECK_HIP(hipMemsetAsync(overflow, 0, sizeof(int), st));
   const long long cols = (long long)vg.G * vg.K * vg.G * vg.K;
   hipLaunchKernelGGL(voxel_columns_kernel, dim3((unsigned)((cols + 127) / 128)), dim3(128), 0, st, verts, faces, bin_start, bin_tris, vg, count,
-                     overflow);
+                     overflow, (unsigned char*)nullptr);
   hipLaunchKernelGGL(voxel_finalize_kernel, dim3((unsigned)((nvox + 255) / 256)), dim3(256), 0, st, count, nvox, vg.K * vg.K * vg.K, ior_inside,
                      ior_outside, out);
+  RNERF_CHECK_LAUNCH();
+  return RNERF_OK;
+}
+
+extern "C" int rnerf_voxelize_samples(const double* verts, const int32_t* faces, const int32_t* bin_start, const int32_t* bin_tris, int32_t num_bins,
+                                      const double* bin_origin_size, const rnerf_grid* g, int32_t num_samples, uint8_t* inside, int32_t* overflow,
+                                      void* stream) {
+  RNERF_CHECK_ARG(verts && faces && bin_start && bin_tris && bin_origin_size && g && inside && overflow, "rnerf_voxelize_samples: null pointer");
+  VoxGrid vg;
+  int rc = make_vox_grid(g, num_samples, num_bins, bin_origin_size, &vg);
+  if (rc != RNERF_OK) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const long long GK = (long long)vg.G * vg.K;
+  RNERF_CHECK_HIP(hipMemsetAsync(inside, 0, (size_t)(GK * GK * GK), st));
+  RNERF_CHECK_HIP(hipMemsetAsync(overflow, 0, sizeof(int), st));
+  hipLaunchKernelGGL(voxel_columns_kernel, dim3((unsigned)((GK * GK + 127) / 128)), dim3(128), 0, st, verts, faces, bin_start, bin_tris, vg, (int*)nullptr,
+                     overflow, inside);
+  RNERF_CHECK_LAUNCH();
+  return RNERF_OK;
+}
+
+extern "C" int rnerf_voxelize_majority(const uint8_t* in_z, const uint8_t* in_x, const uint8_t* in_y, int32_t num_voxels, int32_t num_samples,
+                                       double ior_inside, double ior_outside, int32_t* count, float* out, void* stream) {
+  RNERF_CHECK_ARG(in_z && in_x && in_y && count && out, "rnerf_voxelize_majority: null pointer");
+  RNERF_CHECK_ARG(num_voxels >= 2 && num_samples >= 1 && num_samples <= 8, "rnerf_voxelize_majority: need num_voxels >= 2, 1 <= num_samples <= 8");
+  hipStream_t st = (hipStream_t)stream;
+  const long long nvox = (long long)num_voxels * num_voxels * num_voxels;
+  hipLaunchKernelGGL(voxel_majority_kernel, dim3((unsigned)((nvox + 255) / 256)), dim3(256), 0, st, in_z, in_x, in_y, num_voxels, num_samples, count);
+  hipLaunchKernelGGL(voxel_finalize_kernel, dim3((unsigned)((nvox + 255) / 256)), dim3(256), 0, st, count, nvox, num_samples * num_samples * num_samples,
+                     ior_inside, ior_outside, out);
   RNERF_CHECK_LAUNCH();
   return RNERF_OK;
 }

@@ -65,8 +65,13 @@ def build_xy_bins(verts: np.ndarray, faces: np.ndarray, lo: Sequence[float], hi:
 
 
 def voxelize(verts, faces, num_voxels: int, extent: float = 0.0, min_point=(-1, -1, -1), max_point=(1, 1, 1), num_samples: int = 4,
-             ior_inside: float = 1.33, ior_outside: float = 1.0, device=None, num_bins: Optional[int] = None):
-    """voxelize_mesh.py:54-106. -> (data float32 [G,G,G] on `device`, ndim, nmin, nmax)."""
+             ior_inside: float = 1.33, ior_outside: float = 1.0, device=None, num_bins: Optional[int] = None, robust: bool = False):
+    """voxelize_mesh.py:54-106. -> (data float32 [G,G,G] on `device`, ndim, nmin, nmax).
+    robust=True: three-axis majority containment (parity rays along +z, +x and +y, at least two must agree) for meshes that are not
+    watertight — a single parity ray through a hole misclassifies the sample (pysdf's one ray in a random frame has the same weakness);
+    identical to the default on closed meshes.  Costs three passes and (G * num_samples)^3 bytes x 3 of scratch."""
+    if robust:
+        return _voxelize_robust(verts, faces, num_voxels, extent, min_point, max_point, num_samples, ior_inside, ior_outside, device, num_bins)
     lib = _lib.load()
     device = torch.device(device if device is not None else ("cuda", torch.cuda.current_device()))
     if extent > 0:                                                   # voxelize_mesh.py:88-93
@@ -92,6 +97,47 @@ def voxelize(verts, faces, num_voxels: int, extent: float = 0.0, min_point=(-1, 
                              float(ior_inside), float(ior_outside), ptr(count), ptr(out), ptr(overflow), current_stream()), "rnerf_voxelize")
     if int(overflow.item()) != 0:
         raise _lib.RnerfError("rnerf_voxelize: a sample column crosses the surface more than 96 times")
+    return out, [G] * 3, nmin, nmax
+
+
+def _voxelize_robust(verts, faces, num_voxels, extent, min_point, max_point, num_samples, ior_inside, ior_outside, device, num_bins):
+    lib = _lib.load()
+    device = torch.device(device if device is not None else ("cuda", torch.cuda.current_device()))
+    if extent > 0:
+        nmin, nmax = [-float(extent)] * 3, [float(extent)] * 3
+    else:
+        nmin, nmax = [float(v) for v in min_point], [float(v) for v in max_point]
+    G, K = int(num_voxels), int(num_samples)
+    GK = G * K
+    if GK ** 3 * 3 > 48 * 2 ** 30:
+        raise _lib.RnerfError(f"voxelize(robust=True): 3 x {GK}^3 sample flags do not fit the scratch budget (48 GiB)")
+    verts = np.ascontiguousarray(verts, np.float64); faces = np.ascontiguousarray(faces, np.int32)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    f_d = d(faces)
+    overflow = torch.zeros(1, dtype=torch.int32, device=device)
+    flags = []
+    for perm in ((0, 1, 2), (1, 2, 0), (2, 0, 1)):                   # rays along z, x, y of the original frame
+        vp = np.ascontiguousarray(verts[:, perm])
+        lo_g = [nmin[a] for a in perm]; hi_g = [nmax[a] for a in perm]
+        spec = Grid.make([G] * 3, lo_g, hi_g)
+        pitch = (np.asarray(hi_g) - np.asarray(lo_g)) / (G - 1.0)
+        lo = np.asarray(lo_g) - pitch; hi = np.asarray(hi_g) + pitch
+        nb = int(num_bins or max(8, min(512, int(np.sqrt(max(len(faces), 1)) * 2))))
+        start, tris, size = build_xy_bins(vp, faces, lo, hi, nb)
+        if len(tris) == 0:
+            tris = np.zeros(1, np.int32)
+        inside = torch.empty(GK ** 3, dtype=torch.uint8, device=device)
+        org = (C.c_double * 4)(float(lo[0]), float(lo[1]), float(size[0]), float(size[1]))
+        v_d, s_d, t_d = d(vp), d(start), d(tris)                    # (named: a temporary would be freed — and its block reused — before the launch)
+        check(lib.rnerf_voxelize_samples(ptr(v_d), ptr(f_d), ptr(s_d), ptr(t_d), nb, C.cast(org, C.c_void_p), C.byref(spec), K, ptr(inside),
+                                         ptr(overflow), current_stream()), "rnerf_voxelize_samples")
+        if int(overflow.item()) != 0:
+            raise _lib.RnerfError("rnerf_voxelize_samples: a sample column crosses the surface more than 96 times")
+        flags.append(inside)
+    count = torch.empty(G * G * G, dtype=torch.int32, device=device)
+    out = torch.empty((G, G, G), dtype=torch.float32, device=device)
+    check(lib.rnerf_voxelize_majority(ptr(flags[0]), ptr(flags[1]), ptr(flags[2]), G, K, float(ior_inside), float(ior_outside), ptr(count), ptr(out),
+                                      current_stream()), "rnerf_voxelize_majority")
     return out, [G] * 3, nmin, nmax
 
 

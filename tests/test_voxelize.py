@@ -84,3 +84,53 @@ def test_device_voxeliser_sphere_volume_and_pkl_round_trip(tmp_path):
     V.save_mesh_pkl(str(tmp_path / "mesh.pkl"), out, extent=1.0, num_voxels=G)
     data, nd, mn, mx = Gd.load_mesh_pkl(str(tmp_path / "mesh.pkl"))
     assert nd == [G] * 3 and mn == [-1.0] * 3 and np.array_equal(data.reshape(G, G, G).astype(np.float32), out.cpu().numpy())
+
+
+# ---- three-axis majority containment (meshes that are not watertight) ----------------------------------------------------------------
+OPEN_TOP_F = np.array([t for t in CUBE_F.tolist() if not all(CUBE_V[i][2] > 0 for i in t)], np.int32)      # the cube without its +z face
+
+
+def test_oracle_majority_containment_survives_a_hole():
+    """A box with its +z face removed: a parity ray along +z escapes through the hole (every interior sample votes 'outside', and the
+    samples BELOW the box, whose ray crosses the bottom face once, vote 'inside'); the rays along +x and +y still cross a wall each — the
+    majority restores the closed box; on closed meshes it changes nothing.  (Half-width 0.55: no face coincides with a sample plane.)"""
+    G, K = 6, 3
+    lo, hi = [-1.0] * 3, [1.0] * 3
+    box = CUBE_V * 0.55
+    closed = R.voxelize_counts(box, CUBE_F, G, lo, hi, K)
+    assert closed.sum() > 0 and np.array_equal(R.voxelize_counts_robust(box, CUBE_F, G, lo, hi, K), closed)
+    assert len(OPEN_TOP_F) == 10
+    single = R.voxelize_counts(box, OPEN_TOP_F, G, lo, hi, K)
+    robust = R.voxelize_counts_robust(box, OPEN_TOP_F, G, lo, hi, K)
+    assert not np.array_equal(single, closed) and single[3, 3, 3] == 0 and closed[3, 3, 3] == 8     # the single ray misses the interior
+    assert np.array_equal(robust, closed)                                              # the majority sees the box
+    # a rotated box: still identical on the watertight mesh
+    v, f = _rotated_box()[:2]
+    assert np.array_equal(R.voxelize_counts_robust(v, f, G, lo, hi, K), R.voxelize_counts(v, f, G, lo, hi, K))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["open_box", "rotated_box", "anisotropic"])
+def test_device_majority_voxeliser_matches_the_oracle(case):
+    torch = pytest.importorskip("torch")
+    from samplenerfro_amd import voxelize as V
+    G, K = 9, 3
+    kw = dict(extent=1.0)
+    lo, hi = [-1.0] * 3, [1.0] * 3
+    if case == "open_box":
+        v, f = CUBE_V * 0.55, OPEN_TOP_F
+    elif case == "rotated_box":
+        v, f = _rotated_box()[:2]
+    else:                                           # different extents per axis: the axis rotation must carry nmin / nmax along
+        v, f = _rotated_box(seed=7, half=(0.5, 0.3, 0.2))[:2]
+        lo, hi = [-1.0, -0.8, -0.6], [1.2, 0.9, 0.7]
+        kw = dict(min_point=lo, max_point=hi)
+    out, ndim, nmin, nmax = V.voxelize(v, f, G, num_samples=K, device="cuda:0", num_bins=5, robust=True, **kw)
+    want = R.counts_to_ior(R.voxelize_counts_robust(v, f, G, lo, hi, K), K)
+    assert np.abs(out.cpu().numpy() - want).max() < 1e-6 and want.max() > 1.1
+    if case == "open_box":                          # and the default single-ray test gets the open box wrong
+        plain, _, _, _ = V.voxelize(v, f, G, num_samples=K, device="cuda:0", num_bins=5, **kw)
+        assert not torch.equal(plain, out) and float(plain[4, 4, 5]) == 1.0 and float(out[4, 4, 5]) > 1.0
+    else:
+        plain, _, _, _ = V.voxelize(v, f, G, num_samples=K, device="cuda:0", num_bins=5, **kw)
+        assert torch.equal(plain, out)
