@@ -370,3 +370,42 @@ def test_config3_ship_refractive_full_size_sample():
     for la, lb in zip(ret_w, ret):
         for x, y in zip(la, lb):
             assert torch.equal(x, y)
+
+
+def test_march_coresident_with_the_wgrad_changes_no_bit(world):
+    """The product train step at bench size (4096 x 128 flat, 512^3): the next batch's march is forked right before the NerfMLP wgrad and
+    runs co-resident with it on every CU (rnerf_prefetch.beside_wgrad; the wgrad is held to 224 registers for that).  Sharing SIMDs must
+    change nothing: the prefetched path record equals a stand-alone march of the same rays bit for bit, and the step's gradient equals the
+    gradient of the same step issued without any prefetch."""
+    from samplenerfro_amd import ops, utils
+    from samplenerfro_amd.train import TrainState, train_step
+    from samplenerfro_amd.utils import Rays
+    import copy
+    dev = torch.device("cuda:0")
+    m = copy.copy(world["sphere"])
+    m.num_fine_samples = 0
+    m._packed, m._jit_cache, m._ws, m._key_cache, m._u_lin, m._side, m._tail = {}, {}, {}, {}, None, None, None
+    pf = syn.init_params_flat(0, fine=False, bias_scale=0.05)
+    from samplenerfro_amd import models
+    flags = utils.default_flags(num_coarse_samples=S, num_fine_samples=0, num_path_samples=P, white_bkgd=False, bg_weight=0.025, bg_smooth_weight=1.0,
+                                bg_patch_size=128, use_online_sparsity=False, randomized=True, near=m.near, far=m.far)
+    rng = np.random.default_rng(11)
+    pix = torch.from_numpy(rng.uniform(0, 1, (B, 3)).astype(np.float32)).to(dev)
+    ev = rng.standard_normal((128, 128, 3)).astype(np.float32); ev /= np.linalg.norm(ev, axis=-1, keepdims=True)
+    o2, d2 = syn.sphere_rays(B, seed=99)
+    nxt = Rays(torch.from_numpy(o2).to(dev), None, torch.from_numpy(d2).to(dev), None)
+    batch = {"rays": world["rays"], "pixels": pix, "annealed_alpha": 0.5, "env_rays": Rays(None, None, torch.from_numpy(ev).to(dev), None)}
+    grads = []
+    for prefetch in (True, False):
+        variables = models.make_variables({k: torch.from_numpy(v).to(dev) for k, v in pf.items()})
+        state = TrainState.create(m, variables, flags)
+        state, stats, _ = train_step(m, np.array([5, 6], np.uint32), state, batch, flags, next_rays=nxt if prefetch else None)
+        torch.cuda.synchronize()
+        grads.append(state.grads[:state.theta.numel()].clone())
+        assert bool(torch.isfinite(stats.loss))
+        if prefetch:
+            h = state.next_path
+            h.event.synchronize()
+            pd, dr, _, _ = ops.march(m.table, m.spec, nxt.origins, nxt.viewdirs, m.near, m.far, N)
+            assert torch.equal(h.pd, pd) and torch.equal(h.dr, dr)
+    assert torch.equal(grads[0], grads[1])
