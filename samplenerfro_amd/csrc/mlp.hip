@@ -2135,85 +2135,112 @@ __device__ __forceinline__ So3Ops so3_split_ops(const float (&x)[8]) {
   So3Ops o; o.h = make_uint4(hh[0], hh[1], hh[2], hh[3]); o.l = make_uint4(ll[0], ll[1], ll[2], ll[3]);
   return o;
 }
-// acc[t] (+)= W-block(k-step) x operands, 4 n-tiles x 3 passes
-template <bool FIRST>
-__device__ __forceinline__ void so3_kstep16(f32x16 (&acc)[4], const uint4* __restrict__ blk, const So3Ops& b, int lane) {
-  const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const uint4 ah = blk[(size_t)t * 128 + lane], al = blk[(size_t)t * 128 + 64 + lane];
-    acc[t] = mfma16<true>(ah, b.h, FIRST ? zero : acc[t]);
-    acc[t] = mfma16<true>(ah, b.l, acc[t]);
-    acc[t] = mfma16<true>(al, b.h, acc[t]);
-  }
+// One so3_mlp evaluation by a WORKGROUP of four waves that all carry the same 32 rays: wave w owns n-tile w (outputs 32 w .. 32 w + 31) of every
+// layer and keeps its slice of the packed stream — 32 k-steps x (hi, lo) = 256 registers — for the whole march, so an evaluation reads
+// no weight from memory at all (round 2: one wave streamed all 262 KB from L2 per evaluation, 34 us each, latency-bound; the matrix work
+// of an evaluation is 96 MFMAs per wave here).  Between layers the waves exchange the converted operands through LDS: wave w converts
+// its 32 outputs (bias + ReLU + hi/lo split) = the k-steps 2 w and 2 w + 1 of the next layer, one barrier, every wave reads all 8.  The
+// encoding is split the same way (wave w computes k-step w: 8 of the 32 sines per lane).  Same arithmetic per product and per sum as
+// so3_pack16_kernel's layout implies (hi*hi + hi*lo + lo*hi per k-step, k-steps in order); only Dense_4 (128 -> 3, fp32 VALU) is summed
+// as four 32-feature partials.  Every exchange has its own LDS region, so one barrier per exchange is enough (a region is rewritten
+// only after the barriers of a whole evaluation have been passed by every wave).
+struct So3Shared {
+  uint4 enc[4][2][64];          // encoding operands: k-step, (hi, lo), lane
+  uint4 x[3][8][2][64];         // inputs of Dense_1, Dense_2, Dense_3: k-step, (hi, lo), lane
+  float4 out[4][32];            // Dense_4 partial sums per wave and ray
+  float bias[4][128];           // Dense_0 .. Dense_3
+  float k4[128][4];             // Dense_4 kernel rows (3 outputs, padded)
+  float tail[16];               // Dense_4 bias (3), the annealing window (10) at [4..13]
+};
+
+__device__ __forceinline__ f32x16 so3_mfma3(const uint4 ah, const uint4 al, const uint4 bh, const uint4 bl, const f32x16 c) {
+  f32x16 a = mfma16<true>(ah, bh, c);
+  a = mfma16<true>(ah, bl, a);
+  return mfma16<true>(al, bh, a);
 }
 
-// raw axis-angle of one point per lane pair, fp32-grade (f16 x 3); all 64 lanes must call it.  packed: so3_pack16_kernel's stream.
-__device__ __forceinline__ void so3_eval16(const uint4* __restrict__ packed, const float* __restrict__ params, float px, float py, float pz,
-                                           const So3Window& win, int lane, float (&raw)[3]) {
-  const int h = lane >> 5;
+__device__ __forceinline__ void so3_shared_init(So3Shared& sh, const float* __restrict__ params, const So3Window& win, int tid) {
+  for (int i = tid; i < 4 * 128; i += 256) { const int l = i >> 7, n = i & 127; sh.bias[l][n] = params[(l == 0 ? so3_boff(0) : (l == 1 ? so3_boff(1) : (l == 2 ? so3_boff(2) : so3_boff(3)))) + n]; }
+  for (int i = tid; i < 128 * 3; i += 256) sh.k4[i / 3][i % 3] = params[so3_koff(4) + i];
+  if (tid < 3) sh.tail[tid] = params[so3_boff(4) + tid];
+  if (tid < 10) sh.tail[4 + tid] = win.w[tid];
+}
+
+// raw axis-angle of the wave's 32 points (one per lane pair); all four waves of the workgroup must call it with the same points.
+// wh / wl: this wave's weight registers (block 4 ks + wave of so3_pack16_kernel's stream, ks = 0 .. 31 over the layers' k-steps).
+__device__ __forceinline__ void so3_eval_wg(So3Shared& sh, const uint4 (&wh)[32], const uint4 (&wl)[32], float px, float py, float pz, int wave, int lane,
+                                            float (&raw)[3]) {
+  const int m = lane & 31, h = lane >> 5;
   const float HALF_PI = 1.5707963705062866f;
-  const float pc[3] = {px, py, pz};
-  So3Ops enc[4];
-#pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    float v[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int f0 = 16 * s + 8 * (j >> 2) + (j & 3);                      // feature of half 0; half 1: + 4
-      const int f = f0 + 4 * h;
-      // f = 6 d + 3 is_cos + c: all four (f0, f0 + 4) cases are resolved from the lane's half at run time
-      const int d = f / 6, jj = f % 6, c = jj % 3;
-      const float x = c == 0 ? pc[0] : (c == 1 ? pc[1] : pc[2]);
-      const float xb = fmul(x, (float)(1 << (d < 10 ? d : 0)));
-      const float e = fmul(sinf(jj >= 3 ? fadd(xb, HALF_PI) : xb), win.w[d < 10 ? d : 0]);
-      v[j] = f < 60 ? e : 0.f;
-    }
-    enc[s] = so3_split_ops(v);
-  }
+  const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   constexpr float INV = 1.0f / SO3_WSCALE;
-  f32x16 acc[4];
-  // Dense_0
-#pragma unroll
-  for (int s = 0; s < 4; ++s) { if (s == 0) so3_kstep16<true>(acc, packed + (size_t)(so3_blocks_before(0) + 4 * s) * 128, enc[s], lane); else so3_kstep16<false>(acc, packed + (size_t)(so3_blocks_before(0) + 4 * s) * 128, enc[s], lane); }
-  auto hidden_ops = [&](int s, const float* __restrict__ bias) -> So3Ops {     // ReLU(acc / scale + bias) of the 8 features of k-step s
+  {   // annealed_pos_enc (model_utils.py:236-245), k-step `wave`: feature f = 6 d + 3 is_cos + c; the lane's half picks f0 or f0 + 4
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int n = 16 * s + 8 * (j >> 2) + 4 * h + (j & 3);
-      v[j] = fmaxf(fmaf(acc[s >> 1][8 * (s & 1) + j], INV, bias[n]), 0.f);
+      const int f = 16 * wave + 8 * (j >> 2) + (j & 3) + 4 * h;
+      const bool in = f < 60;
+      const int fc = in ? f : 0;
+      const int d = fc / 6, jj = fc - 6 * d, c = jj >= 3 ? jj - 3 : jj;
+      const float x = c == 0 ? px : (c == 1 ? py : pz);
+      const float xb = fmul(x, (float)(1 << d));
+      const float e = fmul(sinf(jj >= 3 ? fadd(xb, HALF_PI) : xb), sh.tail[4 + d]);
+      v[j] = in ? e : 0.f;
     }
-    return so3_split_ops(v);
-  };
-#pragma unroll 1
-  for (int l = 1; l <= 3; ++l) {
-    const float* __restrict__ bias = params + (l == 1 ? so3_boff(0) : (l == 2 ? so3_boff(1) : so3_boff(2)));
-    So3Ops x[8];
-#pragma unroll
-    for (int s = 0; s < 8; ++s) x[s] = hidden_ops(s, bias);
-    const uint4* __restrict__ base = packed + (size_t)(l == 1 ? so3_blocks_before(1) : (l == 2 ? so3_blocks_before(2) : so3_blocks_before(3))) * 128;
-    so3_kstep16<true>(acc, base, x[0], lane);
-#pragma unroll
-    for (int s = 1; s < 8; ++s) so3_kstep16<false>(acc, base + (size_t)(4 * s) * 128, x[s], lane);
-    if (l == 3) {                                                    // skip concat: the encoding again (rnerf/model_utils.py:131-132)
-#pragma unroll
-      for (int s = 0; s < 4; ++s) so3_kstep16<false>(acc, base + (size_t)(4 * (8 + s)) * 128, enc[s], lane);
-    }
+    const So3Ops e = so3_split_ops(v);
+    sh.enc[wave][0][lane] = e.h; sh.enc[wave][1][lane] = e.l;
   }
-  // Dense_4 (128 -> 3) on the VALU in fp32
-  const float* __restrict__ b3 = params + so3_boff(3);
-  const float* __restrict__ k4 = params + so3_koff(4);
+  __syncthreads();
+  f32x16 acc = zero;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) acc = so3_mfma3(wh[s], wl[s], sh.enc[s][0][lane], sh.enc[s][1][lane], acc);
+  // ReLU(acc / scale + bias) of this wave's 32 outputs = the operands of k-steps 2 w, 2 w + 1 of the next layer
+  auto hand_over = [&](int l) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const float4 b0 = *(const float4*)&sh.bias[l][32 * wave + 16 * half + 4 * h], b1 = *(const float4*)&sh.bias[l][32 * wave + 16 * half + 8 + 4 * h];
+      const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = fmaxf(fmaf(acc[8 * half + j], INV, bb[j]), 0.f);
+      const So3Ops o = so3_split_ops(v);
+      sh.x[l][2 * wave + half][0][lane] = o.h; sh.x[l][2 * wave + half][1][lane] = o.l;
+    }
+  };
+  hand_over(0);
+  __syncthreads();
+  acc = zero;
+#pragma unroll
+  for (int s = 0; s < 8; ++s) acc = so3_mfma3(wh[4 + s], wl[4 + s], sh.x[0][s][0][lane], sh.x[0][s][1][lane], acc);
+  hand_over(1);
+  __syncthreads();
+  acc = zero;
+#pragma unroll
+  for (int s = 0; s < 8; ++s) acc = so3_mfma3(wh[12 + s], wl[12 + s], sh.x[1][s][0][lane], sh.x[1][s][1][lane], acc);
+  hand_over(2);
+  __syncthreads();
+  acc = zero;
+#pragma unroll
+  for (int s = 0; s < 8; ++s) acc = so3_mfma3(wh[20 + s], wl[20 + s], sh.x[2][s][0][lane], sh.x[2][s][1][lane], acc);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) acc = so3_mfma3(wh[28 + s], wl[28 + s], sh.enc[s][0][lane], sh.enc[s][1][lane], acc);   // skip concat (model_utils.py:131-132)
+  // Dense_4 (128 -> 3) on the VALU in fp32: this wave's 32 features
   float o[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
+  for (int r = 0; r < 16; ++r) {
+    const int f = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;
+    const float v = fmaxf(fmaf(acc[r], INV, sh.bias[3][f]), 0.f);
+    const float4 k = *(const float4*)&sh.k4[f][0];
+    o[0] = fmaf(v, k.x, o[0]); o[1] = fmaf(v, k.y, o[1]); o[2] = fmaf(v, k.z, o[2]);
+  }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int f = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
-      const float v = fmaxf(fmaf(acc[t][r], INV, b3[f]), 0.f);
-      o[0] = fmaf(v, k4[f * 3 + 0], o[0]); o[1] = fmaf(v, k4[f * 3 + 1], o[1]); o[2] = fmaf(v, k4[f * 3 + 2], o[2]);
-    }
-#pragma unroll
-  for (int c = 0; c < 3; ++c) raw[c] = o[c] + __shfl_xor(o[c], 32) + params[so3_boff(4) + c];
+  for (int c = 0; c < 3; ++c) o[c] = o[c] + __shfl_xor(o[c], 32);
+  if (h == 0) sh.out[wave][m] = make_float4(o[0], o[1], o[2], 0.f);
+  __syncthreads();
+  const float4 q0 = sh.out[0][m], q1 = sh.out[1][m], q2 = sh.out[2][m], q3 = sh.out[3][m];
+  raw[0] = ((q0.x + q1.x) + (q2.x + q3.x)) + sh.tail[0];
+  raw[1] = ((q0.y + q1.y) + (q2.y + q3.y)) + sh.tail[1];
+  raw[2] = ((q0.z + q1.z) + (q2.z + q3.z)) + sh.tail[2];
 }
 
 // pred_grad = a (cos(t) v + sin(t) e x v + (1 - cos(t)) (e . v) e),  e = raw / |raw|, v = g / |g| with safe norms (ior_utils.py:305-312)
@@ -2248,18 +2275,29 @@ __global__ void __launch_bounds__(64) so3_query_kernel(const float4* __restrict_
   if (ok && h == 0) { out4[row] = c; pred_out[3 * row] = pred[0]; pred_out[3 * row + 1] = pred[1]; pred_out[3 * row + 2] = pred[2]; }
 }
 
-// E1/E2 with stage "all": one wave = 32 rays (both lane halves carry the ray state; the MLP needs the whole wave), the so3 MLP is
-// evaluated at every node.  Weights stream from L2 (262 KB per step per wave).
-__global__ void __launch_bounds__(64) march_all_kernel(const float4* __restrict__ table, GridParams gp, const float* __restrict__ params,
-                                                       const uint4* __restrict__ packed16, So3Window win, const float* __restrict__ origins, const float* __restrict__ viewdirs,
-                                                       int B, float near, float step, int num_nodes, float4* __restrict__ path_pd,
-                                                       float4* __restrict__ path_dr, float4* __restrict__ path_ior,
-                                                       // training record (nullable): raw direction + n per node, and the compacted list of
-                                                       // (ray, node) pairs at which pred_grad was selected (the object's boundary shell)
-                                                       float4* __restrict__ path_rdn, int* __restrict__ pair_count, int pair_cap,
-                                                       int2* __restrict__ pair_id, float4* __restrict__ pair_x, float4* __restrict__ pair_g,
-                                                       int* __restrict__ pair_of_node) {
+// E1/E2 with stage "all": one workgroup = 32 rays marched by four waves in lockstep (every wave carries the ray state in both lane
+// halves and repeats the cheap per-node arithmetic; the stores are dealt out by wave), so3_mlp is evaluated by the four waves together
+// (so3_eval_wg) at every node where any of the 32 rays is inside the boundary shell.  The branch is workgroup-uniform: all four waves
+// compute the same bits.
+__global__ void __launch_bounds__(256, 1) march_all_kernel(const float4* __restrict__ table, GridParams gp, const float* __restrict__ params,
+                                                          const uint4* __restrict__ packed16, So3Window win, const float* __restrict__ origins, const float* __restrict__ viewdirs,
+                                                          int B, float near, float step, int num_nodes, float4* __restrict__ path_pd,
+                                                          float4* __restrict__ path_dr, float4* __restrict__ path_ior,
+                                                          // training record (nullable): raw direction + n per node, and the compacted list of
+                                                          // (ray, node) pairs at which pred_grad was selected (the object's boundary shell)
+                                                          float4* __restrict__ path_rdn, int* __restrict__ pair_count, int pair_cap,
+                                                          int2* __restrict__ pair_id, float4* __restrict__ pair_x, float4* __restrict__ pair_g,
+                                                          int* __restrict__ pair_of_node) {
+  __shared__ So3Shared sh;
   const int lane = threadIdx.x & 63, m = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  so3_shared_init(sh, params, win, threadIdx.x);
+  uint4 wh[32], wl[32];
+#pragma unroll
+  for (int ks = 0; ks < 32; ++ks) {
+    const uint4* __restrict__ blk = packed16 + (size_t)(4 * ks + wave) * 128;
+    wh[ks] = blk[lane]; wl[ks] = blk[64 + lane];
+  }
   int r = blockIdx.x * 32 + m;
   const bool ok = r < B;
   if (!ok) r = B - 1;
@@ -2268,33 +2306,37 @@ __global__ void __launch_bounds__(64) march_all_kernel(const float4* __restrict_
 #pragma unroll
   for (int c = 0; c < 3; ++c) p[c] = fadd(origins[3 * r + c], fmul(near, d[c]));   // eikonal_utils.py:104-106
   float rt = near;
+  __syncthreads();
+  const bool writer = ok && h == 0;
   for (int k = 0; k < num_nodes; ++k) {
     const float4 c = trilinear(table, gp, p[0], p[1], p[2], nullptr);
-    if (ok && h == 0) {
-      const size_t o = (size_t)k * B + r;
-      const float nrm = fsqrt(fmaxf(fadd(fadd(fmul(d[0], d[0]), fmul(d[1], d[1])), fmul(d[2], d[2])), 1e-6f));
-      path_pd[o] = make_float4(p[0], p[1], p[2], rt);
-      path_dr[o] = make_float4(fdiv(d[0], nrm), fdiv(d[1], nrm), fdiv(d[2], nrm), 0.f);
-      if (path_ior) path_ior[o] = c;
+    const size_t o = (size_t)k * B + r;
+    if (writer) {
+      if (wave == 1) path_pd[o] = make_float4(p[0], p[1], p[2], rt);
+      if (wave == 2) {
+        const float nrm = fsqrt(fmaxf(fadd(fadd(fmul(d[0], d[0]), fmul(d[1], d[1])), fmul(d[2], d[2])), 1e-6f));
+        path_dr[o] = make_float4(fdiv(d[0], nrm), fdiv(d[1], nrm), fdiv(d[2], nrm), 0.f);
+      }
+      if (wave == 3 && path_ior) path_ior[o] = c;
     }
     const float g[3] = {c.y, c.z, c.w};
     const bool use = fsqrt(fadd(fadd(fmul(g[0], g[0]), fmul(g[1], g[1])), fmul(g[2], g[2]))) > 1e-3f;   // eikonal_utils.py:35
-    if (path_rdn && ok && h == 0) {
-      const size_t o = (size_t)k * B + r;
+    int idx = -1;
+    const bool record = path_rdn != nullptr && writer && wave == 0;
+    if (record) {
       path_rdn[o] = make_float4(d[0], d[1], d[2], c.x);
-      int idx = -1;
-      if (use) {
-        idx = atomicAdd(pair_count, 1);
-        if (idx < pair_cap) { pair_id[idx] = make_int2(r, k); pair_x[idx] = make_float4(p[0], p[1], p[2], 0.f); pair_g[idx] = make_float4(g[0], g[1], g[2], 0.f); }
-        else idx = -1;
-      }
-      pair_of_node[o] = idx;
+      if (use) idx = atomicAdd(pair_count, 1);      // consumed after the evaluation: its round trip hides behind the MLP
     }
     float pred[3] = {0.f, 0.f, 0.f};
     if (__builtin_amdgcn_ballot_w64(use) != 0) {     // pred_grad is only selected where |grad n| > 1e-3: outside the object's boundary
-      float raw[3];                                   // shell no ray of the wave needs the MLP (wave-uniform branch, same results)
-      so3_eval16(packed16, params, p[0], p[1], p[2], win, lane, raw);
+      float raw[3];                                   // shell no ray of the workgroup needs the MLP (workgroup-uniform branch, same results)
+      so3_eval_wg(sh, wh, wl, p[0], p[1], p[2], wave, lane, raw);
       so3_rotate(raw, g, pred);
+    }
+    if (record) {
+      if (idx >= pair_cap) idx = -1;
+      if (idx >= 0) { pair_id[idx] = make_int2(r, k); pair_x[idx] = make_float4(p[0], p[1], p[2], 0.f); pair_g[idx] = make_float4(g[0], g[1], g[2], 0.f); }
+      pair_of_node[o] = idx;
     }
     const float s = fdiv(step, c.x);
     float dl2 = 0.f;
@@ -3037,7 +3079,7 @@ extern "C" int rnerf_march_all(const float* table, const rnerf_grid* g, const fl
   for (int i = 0; i < 10; ++i) w.w[i] = window10[i];
   const float stepf = (float)((far - near) / (num_nodes - 1));  // models.py:122
   hipLaunchKernelGGL(so3_pack16_kernel, dim3((kSo3Blocks * 64 + 255) / 256), dim3(256), 0, (hipStream_t)stream, so3_params, (uint4*)so3_packed);
-  hipLaunchKernelGGL(march_all_kernel, dim3((unsigned)((B + 31) / 32)), dim3(64), 0, (hipStream_t)stream, (const float4*)table, gp, so3_params,
+  hipLaunchKernelGGL(march_all_kernel, dim3((unsigned)((B + 31) / 32)), dim3(256), 0, (hipStream_t)stream, (const float4*)table, gp, so3_params,
                      (const uint4*)so3_packed, w, origins, viewdirs, B, (float)near, stepf, num_nodes, (float4*)path_pd, (float4*)path_dr, (float4*)path_ior,
                      (float4*)nullptr, (int*)nullptr, 0, (int2*)nullptr, (float4*)nullptr, (float4*)nullptr, (int*)nullptr);
   RNERF_CHECK_LAUNCH();

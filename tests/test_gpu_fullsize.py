@@ -171,6 +171,40 @@ def _oracle_sample(model, pf, o, v, jitter, sel, cfg_kw, u=None):
     return ret, taps
 
 
+def test_stage_all_march_full_size(world):
+    """E1/E2 with stage "all*" at 4096 rays x 1536 nodes on the 512^3 sphere: so3_mlp is evaluated by four waves per 32-ray block that
+    exchange activations through LDS (one barrier per exchange) — a missed barrier would show up as run-to-run differences, so two
+    runs must agree bit for bit, in the given ray order and in the shell-coherent order (rays are independent: the order changes no
+    value); 8 rays against the oracle's stage-all path_sampler on the device-built table."""
+    from oracle import ref_np as R
+    from samplenerfro_amd import ops
+    shapes = [(60, 128), (128, 128), (128, 128), (188, 128), (128, 3)]
+    m, rays = world["sphere"], world["rays"]
+    rng = np.random.default_rng(21)
+    flat = syn.init_mlp_flat(rng, shapes, 0.05)
+    flat[-(128 * 3 + 3):-3] = (0.05 * rng.standard_normal(128 * 3)).astype(np.float32)      # a visible rotation (init is N(0, 1e-5))
+    so3 = torch.from_numpy(flat).to(rays.origins.device)
+    alpha = 0.8
+    runs = [ops.march_all(m.table, m.spec, so3, rays.origins, rays.viewdirs, m.near, m.far, N, alpha, False, coherent) for coherent in (False, False, True)]
+    for other in runs[1:]:
+        assert torch.equal(runs[0][0], other[0]) and torch.equal(runs[0][1], other[1])
+    pd, dr, _ = runs[0]
+    pd0, _, _, _ = ops.march(m.table, m.spec, rays.origins, rays.viewdirs, m.near, m.far, N)
+    moved = (pd[-1, :, :3] - pd0[-1, :, :3]).abs().amax(-1)
+    assert int((moved > 1e-3).sum()) > 500                               # so3_mlp really bends the rays that cross the sphere
+    idx_b = torch.nonzero(moved > 1e-3).reshape(-1)
+    idx_m = torch.nonzero(moved == 0).reshape(-1)
+    sel = torch.cat([idx_b[:: max(len(idx_b) // 6, 1)][:6], idx_m[:2]]).cpu().numpy()
+    table = m.table.cpu().numpy().reshape(-1, 4)
+    o, d = rays.origins.cpu().numpy()[sel], rays.viewdirs.cpu().numpy()[sel]
+    rp, rd, rt, _, _ = R.path_sampler(o, d, table, m.ndim, m.nmin, m.nmax, m.near, m.far, N, so3_params=syn.flat_to_np_tree(flat, shapes), annealed_alpha=alpha)
+    got_p = pd[:, sel, :3].cpu().numpy().transpose(1, 0, 2); got_t = pd[:, sel, 3].cpu().numpy().T; got_d = dr[:, sel, :3].cpu().numpy().transpose(1, 0, 2)
+    ep, et, ed = np.abs(got_p - rp).max(), np.abs(got_t - rt).max(), np.abs(got_d - rd).max()
+    print(f"stage-all march 4096 x 1536 vs the oracle on 8 rays: position {ep:.2e}, depth {et:.2e}, direction {ed:.2e}")
+    assert ep < 1e-4 and et < 1e-4 and ed < 1e-4
+    assert np.array_equal(got_p[6:], rp[6:])                             # rays outside the shell never see the MLP: bit-exact
+
+
 def test_config5_glass_full_size_chunk():
     """One render_image chunk of config 5: 8192 OpenCV rays, flat S = 256, P = 24 (N = 6144 eikonal steps), G = 384 anisotropic glass bbox,
     prefilter (5, 3.0).  24 rays of the chunk against the oracle (bit-exact path and voxel walk, RGB / depth 1e-4), the chunk's invariants."""

@@ -512,6 +512,8 @@ def test_march_all_stage(scene):
     pd = pd.cpu().numpy().transpose(1, 0, 2); dr = dr.cpu().numpy().transpose(1, 0, 2)
     assert np.abs(rp - rp0).max() > 1e-3                                               # the so3 term matters in this scene
     assert np.abs(pd[..., :3] - rp).max() < 2e-5 and np.abs(pd[..., 3] - rt).max() < 2e-5 and np.abs(dr[..., :3] - rd).max() < 2e-5
+    pd2, dr2, _ = ops.march_all(scene.table_d, scene.spec, T(flat), T(scene.o), T(scene.d), 2.0, 6.0, N, alpha)
+    assert np.array_equal(pd2.cpu().numpy().transpose(1, 0, 2), pd) and np.array_equal(dr2.cpu().numpy().transpose(1, 0, 2), dr)   # four waves per block, LDS exchange: no race
 
 
 def test_model_stage_all_end_to_end():

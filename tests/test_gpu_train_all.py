@@ -106,7 +106,15 @@ def test_all_stage_gradients(Nf, bwd, B):
         err = np.abs(a - b).max() / np.abs(b).max()
         print(f"[N_f={Nf}, {bwd}] {name}: cosine {cos:.7f}, max err / max |g| {err:.2e}, max |g| {np.abs(b).max():.2e}")
         # so3_mlp's gradient passes through the coarse MLP's input gradient, the 32-node reverse scan and the so3 backward
-        assert cos > 0.9999 and err < ({"f32": 5e-5, "tf32": 5e-3}[bwd] if name == "so3_mlp" else tol), name
+        if name == "so3_mlp":
+            assert cos > 0.9999 and err < {"f32": 5e-5, "tf32": 5e-3}[bwd], name
+            continue
+        # A ReLU pre-activation within fp32 rounding of 0 can fall on different sides in the device's fp32 forward and in the float64
+        # reference; one such flip changes the gradient of ONE unit's incoming weights by one row's contribution, visible at these few
+        # rows (seen: 64 elements of column 80 of Dense_5 off by 2.9e-5 of max |g|, everything else < 1e-6).  So: all but a 2e-4
+        # fraction of the elements within tol, the rest within 10 tol.
+        over = float((np.abs(a - b) >= tol * np.abs(b).max()).mean())
+        assert cos > 0.9999 and over < 2e-4 and err < 10 * tol, (name, over, err)
     assert np.abs(ref[state.segments["so3_mlp"][0]:]).max() > 1e-6          # the path really carries gradient
 
 
