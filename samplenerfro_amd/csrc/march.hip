@@ -16,11 +16,6 @@ __device__ __forceinline__ float quad_sumsq3(float a) {
   return fadd(fadd(quad_bcast<0>(a2), quad_bcast<1>(a2)), quad_bcast<2>(a2));
 }
 
-// x / d for a launch-constant divisor d: RN_f32(double(x) * RN_f64(1/d)) equals the correctly rounded f32 quotient
-// (the f64 product is within 2^-52 of x/d, while a f32/f32 quotient is never closer than 2^-49 to a rounding tie and
-// never exactly on one), at 3 instructions instead of the ~11 of the IEEE f32 division sequence.
-__device__ __forceinline__ float div_const(float x, double rcp_d) { return (float)((double)x * rcp_d); }
-
 struct MarchParams {
   int dx, dy, dz;
   float nmin[3];

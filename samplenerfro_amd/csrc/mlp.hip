@@ -2191,39 +2191,49 @@ __device__ __forceinline__ void so3_eval_wg(So3Shared& sh, const uint4 (&wh)[32]
     sh.enc[wave][0][lane] = e.h; sh.enc[wave][1][lane] = e.l;
   }
   __syncthreads();
+  // One layer: ALL operand reads first (distinct registers: left alone, hipcc reuses one register quad and issues each k-step's
+  // ds_read after the previous k-step's MFMAs, a full LDS round trip exposed per k-step), then the chain of MFMAs on one accumulator.
   f32x16 acc = zero;
+  uint4 eh[4], el[4];                // the encoding operands feed Dense_0 and, through the skip concat, Dense_3
 #pragma unroll
-  for (int s = 0; s < 4; ++s) acc = so3_mfma3(wh[s], wl[s], sh.enc[s][0][lane], sh.enc[s][1][lane], acc);
+  for (int s = 0; s < 4; ++s) { eh[s] = sh.enc[s][0][lane]; el[s] = sh.enc[s][1][lane]; }
+  RNERF_PIN();
+#pragma unroll
+  for (int s = 0; s < 4; ++s) acc = so3_mfma3(wh[s], wl[s], eh[s], el[s], acc);
   // ReLU(acc / scale + bias) of this wave's 32 outputs = the operands of k-steps 2 w, 2 w + 1 of the next layer
   auto hand_over = [&](int l) {
+    const float4 b0 = *(const float4*)&sh.bias[l][32 * wave + 4 * h], b1 = *(const float4*)&sh.bias[l][32 * wave + 8 + 4 * h];
+    const float4 b2 = *(const float4*)&sh.bias[l][32 * wave + 16 + 4 * h], b3 = *(const float4*)&sh.bias[l][32 * wave + 24 + 4 * h];
+    const float bb[16] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-      const float4 b0 = *(const float4*)&sh.bias[l][32 * wave + 16 * half + 4 * h], b1 = *(const float4*)&sh.bias[l][32 * wave + 16 * half + 8 + 4 * h];
-      const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
       float v[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = fmaxf(fmaf(acc[8 * half + j], INV, bb[j]), 0.f);
+      for (int j = 0; j < 8; ++j) v[j] = fmaxf(fmaf(acc[8 * half + j], INV, bb[8 * half + j]), 0.f);
       const So3Ops o = so3_split_ops(v);
       sh.x[l][2 * wave + half][0][lane] = o.h; sh.x[l][2 * wave + half][1][lane] = o.l;
     }
   };
+  auto layer = [&](int l, int ks0) {
+    uint4 bh[8], bl[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) { bh[s] = sh.x[l][s][0][lane]; bl[s] = sh.x[l][s][1][lane]; }
+    RNERF_PIN();
+    acc = zero;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) acc = so3_mfma3(wh[ks0 + s], wl[ks0 + s], bh[s], bl[s], acc);
+  };
   hand_over(0);
   __syncthreads();
-  acc = zero;
-#pragma unroll
-  for (int s = 0; s < 8; ++s) acc = so3_mfma3(wh[4 + s], wl[4 + s], sh.x[0][s][0][lane], sh.x[0][s][1][lane], acc);
+  layer(0, 4);
   hand_over(1);
   __syncthreads();
-  acc = zero;
-#pragma unroll
-  for (int s = 0; s < 8; ++s) acc = so3_mfma3(wh[12 + s], wl[12 + s], sh.x[1][s][0][lane], sh.x[1][s][1][lane], acc);
+  layer(1, 12);
   hand_over(2);
   __syncthreads();
-  acc = zero;
+  layer(2, 20);
 #pragma unroll
-  for (int s = 0; s < 8; ++s) acc = so3_mfma3(wh[20 + s], wl[20 + s], sh.x[2][s][0][lane], sh.x[2][s][1][lane], acc);
-#pragma unroll
-  for (int s = 0; s < 4; ++s) acc = so3_mfma3(wh[28 + s], wl[28 + s], sh.enc[s][0][lane], sh.enc[s][1][lane], acc);   // skip concat (model_utils.py:131-132)
+  for (int s = 0; s < 4; ++s) acc = so3_mfma3(wh[28 + s], wl[28 + s], eh[s], el[s], acc);   // skip concat (model_utils.py:131-132)
   // Dense_4 (128 -> 3) on the VALU in fp32: this wave's 32 features
   float o[3] = {0.f, 0.f, 0.f};
 #pragma unroll
@@ -2308,8 +2318,20 @@ __global__ void __launch_bounds__(256, 1) march_all_kernel(const float4* __restr
   float rt = near;
   __syncthreads();
   const bool writer = ok && h == 0;
+  // The chain of one step is position -> cell -> 8 gathers -> lerps -> n -> next position.  The next position needs only n and the
+  // CURRENT direction (not pred_grad), so the gathers of node k + 1 are issued as soon as n_k is known and everything else of node k
+  // — the record, the normalisation, the MLP — runs under their latency.
+  const GridRcp rcp = grid_rcp(gp);
+  TriCell cell;
+  trilinear_load<true>(table, gp, p[0], p[1], p[2], nullptr, cell, &rcp);
   for (int k = 0; k < num_nodes; ++k) {
-    const float4 c = trilinear(table, gp, p[0], p[1], p[2], nullptr);
+    const float4 c = trilinear_finish(cell);
+    const float s = fdiv(step, c.x);
+    float np[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) np[q] = fadd(p[q], fmul(s, d[q]));
+    trilinear_load<true>(table, gp, np[0], np[1], np[2], nullptr, cell, &rcp);      // (clamped indices: in bounds past the last node too)
+    RNERF_PIN();
     const size_t o = (size_t)k * B + r;
     if (writer) {
       if (wave == 1) path_pd[o] = make_float4(p[0], p[1], p[2], rt);
@@ -2338,15 +2360,13 @@ __global__ void __launch_bounds__(256, 1) march_all_kernel(const float4* __restr
       if (idx >= 0) { pair_id[idx] = make_int2(r, k); pair_x[idx] = make_float4(p[0], p[1], p[2], 0.f); pair_g[idx] = make_float4(g[0], g[1], g[2], 0.f); }
       pair_of_node[o] = idx;
     }
-    const float s = fdiv(step, c.x);
     float dl2 = 0.f;
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
-      const float np = fadd(p[q], fmul(s, d[q]));
       d[q] = fadd(d[q], fmul(step, use ? pred[q] : g[q]));
-      const float dl = fsub(p[q], np);
+      const float dl = fsub(p[q], np[q]);
       dl2 = q == 0 ? fmul(dl, dl) : fadd(dl2, fmul(dl, dl));
-      p[q] = np;
+      p[q] = np[q];
     }
     rt = fadd(rt, fsqrt(dl2));
   }
