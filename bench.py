@@ -515,10 +515,11 @@ def main():
     if train and args.extra and args.stage == "radiance" and args.workload == "ship_straight" and args.rays is None and args.fine is None:
         variants = {}
 
-        def run_variant(tag, vcfg, vmodel, vvars, vfine, vB, note):
+        def run_variant(tag, vcfg, vmodel, vvars, vfine, vB, note, vstage="radiance"):
             ov, dv = syn.sphere_rays(vB, seed=syn.SEED + rank)
             vrays = Rays(torch.from_numpy(ov).to(device), None, torch.from_numpy(dv).to(device), None)
-            sv = Stepper(args, vcfg, vmodel, vvars, vrays, key, vB, world, rank, vfine, device, args.backward, "train", "radiance", args.pipeline, args.graph)
+            sv = Stepper(args, vcfg, vmodel, vvars, vrays, key, vB, world, rank, vfine, device, args.backward, "train", vstage,
+                         args.pipeline and vstage == "radiance", args.graph and vstage == "radiance")
             dtv = timed_steps(sv, 2, 5, barrier, D, device)
             sv.close()
             torch.cuda.empty_cache()
@@ -540,6 +541,11 @@ def main():
         vm = models_with_fine(rmodel, rcfg, 256, device, args.precision)
         run_variant("ship_refractive_128+256", rcfg, vm[0], vm[1], 256, 4096, "BASELINE configs[2], hierarchical")
         del vm, rmodel, rvars
+        torch.cuda.empty_cache()
+        amodel, avars, _ = build_scene(rcfg, device, args.precision, 0, "all")
+        run_variant("ship_refractive_128_stage_all", rcfg, amodel, avars, 0, 4096, "stage all* (train.py:302-310): so3_mlp bends the gradient inside the march "
+                    "(evaluated by four waves per 32-ray block at every node of the boundary shell) and is trained through the march's adjoint", "all")
+        del amodel, avars
         torch.cuda.empty_cache()
         dcfg = dict(syn.CONFIGS["dolphin_train"])
         dmodel, dvars, _ = build_scene(dcfg, device, args.precision, dcfg["F"], "radiance")

@@ -1898,6 +1898,67 @@ static_assert(bkgd_koff(5) == RNERF_BKGDMLP_PARAMS, "bkgd MLP parameter count");
 // K=2 MFMA steps over the 27-d direction encoding: step q (0..13): half 0 / half 1 feature
 __host__ __device__ constexpr int dir_feature(int q, int h) { return q < 12 ? (h ? 15 + q : 3 + q) : (q == 12 ? (h ? 2 : 0) : (h ? -1 : 1)); }
 
+// acc[t] += W(step, t) * x(step) over NSTEP K=2 steps of v_mfma_f32_32x32x2_f32 for NT n-tiles, with the per-lane weight dwords fetched one
+// BATCH (4 steps) ahead of the MFMAs that consume them.  Left to itself hipcc emits load -> s_waitcnt vmcnt(0) -> MFMA for every single
+// product, re-using one register: a full L2 round trip (~650 cycles) per 64-cycle MFMA — the small-MLP kernels ran at a tenth of the
+// matrix rate (so3_fwd_train_kernel 1.77 ms for 208 k rows).  wload(step, t) must be a pure load of a lane-dependent address, x(step) a
+// register operand; both are called with constants after unrolling.  Same products in the same order: same bits.
+template <int NSTEP, int NT, typename WF, typename XF>
+__device__ __forceinline__ void mfma_f32_stream(f32x16* acc, WF wload, XF xop) {
+  constexpr int BS = 4, NB = (NSTEP + BS - 1) / BS;
+  float w[2][BS * NT];
+#pragma unroll
+  for (int i = 0; i < BS; ++i)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) w[0][i * NT + t] = i < NSTEP ? wload(i, t) : 0.f;
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    if (b + 1 < NB) {
+#pragma unroll
+      for (int i = 0; i < BS; ++i)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) w[(b + 1) & 1][i * NT + t] = (b + 1) * BS + i < NSTEP ? wload((b + 1) * BS + i, t) : 0.f;
+    }
+    RNERF_PIN();
+#pragma unroll
+    for (int i = 0; i < BS; ++i) {
+      if (b * BS + i < NSTEP) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[b & 1][i * NT + t], xop(b * BS + i), acc[t], 0, 0, 0);
+      }
+    }
+    RNERF_PIN();
+  }
+}
+
+// The same with the weights of a batch's 4 steps in ONE 16-byte load per n-tile (wload4(batch, t)): for the transposed products of the
+// dgrad chains a lane's 4 consecutive steps read 4 consecutive floats of one kernel row, while the lanes of a load are 512 bytes apart
+// (64 cache lines per instruction: the address unit, not the matrix pipe, paced these kernels with one dword per load).
+template <int NSTEP, int NT, typename WF4, typename XF>
+__device__ __forceinline__ void mfma_f32_stream4(f32x16* acc, WF4 wload4, XF xop) {
+  static_assert(NSTEP % 4 == 0, "whole batches");
+  constexpr int NB = NSTEP / 4;
+  float4 w[2][NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) w[0][t] = wload4(0, t);
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    if (b + 1 < NB) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) w[(b + 1) & 1][t] = wload4(b + 1, t);
+    }
+    RNERF_PIN();
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const float4 q = w[b & 1][t];
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(i == 0 ? q.x : (i == 1 ? q.y : (i == 2 ? q.z : q.w)), xop(4 * b + i), acc[t], 0, 0, 0);
+      }
+    RNERF_PIN();
+  }
+}
+
 __device__ __forceinline__ void small_init_bias(f32x16 (&acc)[4], const float* __restrict__ bias, int h) {
 #pragma unroll
   for (int t = 0; t < 4; ++t)
@@ -1907,27 +1968,17 @@ __device__ __forceinline__ void small_init_bias(f32x16 (&acc)[4], const float* _
 
 // acc += W[rows f(h)][:] x operand, for the 64 (t,r) steps of a 128-wide previous activation held in `x`
 __device__ __forceinline__ void small_prev_layer(f32x16 (&acc)[4], const f32x16 (&x)[4], const float* __restrict__ kern, int m, int h) {
-#pragma unroll
-  for (int ts = 0; ts < 4; ++ts)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int f = 32 * ts + (r & 3) + 8 * (r >> 2) + 4 * h;   // the feature this half holds in x[ts][r]
-#pragma unroll
-      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(kern[f * 128 + 32 * t + m], x[ts][r], acc[t], 0, 0, 0);
-    }
+  const float* __restrict__ kl = kern + 4 * h * 128 + m;           // step (ts, r): the feature this half holds in x[ts][r] = 32 ts + (r & 3) + 8 (r >> 2) + 4 h
+  mfma_f32_stream<64, 4>(acc, [&](int st, int t) { return kl[(32 * (st >> 4) + (st & 3) + 8 * ((st & 15) >> 2)) * 128 + 32 * t]; },
+                         [&](int st) { return x[st >> 4][st & 15]; });
 }
 
 __device__ __forceinline__ void small_dir_layer(f32x16 (&acc)[4], const float (&enc)[14], const float* __restrict__ kern, int m, int h) {
-#pragma unroll
-  for (int q = 0; q < 14; ++q) {
-    const int f0 = dir_feature(q, 0), f1 = dir_feature(q, 1);
-    const int f = h ? f1 : f0;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const float w = f < 0 ? 0.f : kern[f * 128 + 32 * t + m];
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, enc[q], acc[t], 0, 0, 0);
-    }
-  }
+  mfma_f32_stream<14, 4>(acc, [&](int q, int t) {
+    const int f = h ? dir_feature(q, 1) : dir_feature(q, 0);
+    const float w = kern[(f < 0 ? 0 : f) * 128 + 32 * t + m];
+    return f < 0 ? 0.f : w;
+  }, [&](int q) { return enc[q]; });
 }
 
 // save (training forward), fp32 row-major: [enc: n x 28][X1: n x 128][X2][X3][X4][out: n x 3]  (X_k = ReLU'd input of Dense_k)
@@ -2049,12 +2100,8 @@ struct So3Window { float w[10]; };   // cosine_easing_window(0, 9, 10, annealed_
 
 // K=2 steps over the 60 annealed features: step p, half h -> feature 2p + h = 6d + 3*is_cos + c with d = p / 3 for both halves
 __device__ __forceinline__ void so3_enc_layer(f32x16 (&acc)[4], const float (&enc)[30], const float* __restrict__ kern, int m, int h) {
-#pragma unroll
-  for (int p = 0; p < 30; ++p) {
-    const int f = 2 * p + h;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(kern[f * 128 + 32 * t + m], enc[p], acc[t], 0, 0, 0);
-  }
+  const float* __restrict__ kl = kern + h * 128 + m;
+  mfma_f32_stream<30, 4>(acc, [&](int p, int t) { return kl[2 * p * 128 + 32 * t]; }, [&](int p) { return enc[p]; });
 }
 
 // raw axis-angle of one point per lane pair (lanes m and m + 32 hold the same point); all 64 lanes must call it
@@ -2391,30 +2438,18 @@ __global__ void __launch_bounds__(256, 1) march_all_kernel(const float4* __restr
 // ---- backward of the background MLP (exact fp32 on v_mfma_f32_32x32x2_f32, as the forward) --------------------------------
 // dgrad chain: dX^T[k][row] = W[k][n] dY^T[n][row] with the accumulator registers as B operands; ReLU masks from the saved X_k.
 __device__ __forceinline__ void small_prev_layer_T(f32x16 (&acc)[4], const f32x16 (&x)[4], const float* __restrict__ kern, int m, int h) {
-#pragma unroll
-  for (int ts = 0; ts < 4; ++ts)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int f = 32 * ts + (r & 3) + 8 * (r >> 2) + 4 * h;   // output feature n this half holds in x[ts][r]
-#pragma unroll
-      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(kern[(32 * t + m) * 128 + f], x[ts][r], acc[t], 0, 0, 0);
-    }
+  const float* __restrict__ kl = kern + m * 128 + 4 * h;           // step (ts, r): output feature n = 32 ts + 8 (r >> 2) + 4 h + (r & 3) held in x[ts][r]
+  mfma_f32_stream4<64, 4>(acc, [&](int b, int t) { return *(const float4*)(kl + 32 * t * 128 + 32 * (b >> 2) + 8 * (b & 3)); },
+                          [&](int st) { return x[st >> 4][st & 15]; });
 }
 
 // acc2[t2] += W[f = 32 t2 + m][n(h)] * x (contraction over the 128 outputs n held in x): the input-gradient GEMM of a small MLP, f < fin
 __device__ __forceinline__ void small_input_T(f32x16 (&acc2)[2], const f32x16 (&x)[4], const float* __restrict__ kern, int fin, int m, int h) {
-#pragma unroll
-  for (int ts = 0; ts < 4; ++ts)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int nf = 32 * ts + (r & 3) + 8 * (r >> 2) + 4 * h;
-#pragma unroll
-      for (int t2 = 0; t2 < 2; ++t2) {
-        const int f = 32 * t2 + m;
-        const float w = kern[(f < fin ? f : fin - 1) * 128 + nf];
-        acc2[t2] = __builtin_amdgcn_mfma_f32_32x32x2f32(f < fin ? w : 0.f, x[ts][r], acc2[t2], 0, 0, 0);
-      }
-    }
+  mfma_f32_stream4<64, 2>(acc2, [&](int b, int t2) {
+    const int f = 32 * t2 + m;
+    const float4 w = *(const float4*)(kern + (f < fin ? f : fin - 1) * 128 + 32 * (b >> 2) + 8 * (b & 3) + 4 * h);
+    return f < fin ? w : make_float4(0.f, 0.f, 0.f, 0.f);
+  }, [&](int st) { return x[st >> 4][st & 15]; });
 }
 
 __global__ void __launch_bounds__(64) bkgd_dgrad_kernel(const float* __restrict__ params, const float* __restrict__ save,
