@@ -19,6 +19,10 @@ bash tools/r03/prof_step.sh final_step > $O/step_stats_and_timeline.txt 2>&1
 cp $R/gpurun_out/r03/final_step_kernel_stats.csv $O/train_step_kernel_stats.csv; cp $R/gpurun_out/r03/final_step_timeline.txt $O/train_step_timeline.txt
 bash tools/r03/prof_step.sh final_step_dolphin1024 --workload dolphin_train --rays 1024 > $O/step_dolphin1024.txt 2>&1
 cp $R/gpurun_out/r03/final_step_dolphin1024_timeline.txt $O/train_step_dolphin1024_timeline.txt
+# the stage-all* step: kernel stats of a no-extras run, and the march alone with its shell statistics
+bash tools/r03/prof_step.sh final_stage_all --workload ship_refractive --stage all > $O/step_stage_all.txt 2>&1
+cp $R/gpurun_out/r03/final_stage_all_kernel_stats.csv $O/kernel_stats_stage_all.csv
+python3 tools/march_all_time.py ship_refractive 4096 > $O/march_all_time.txt 2>&1
 # PMC passes (separate rocprofv3 runs per counter group)
 bash tools/r03/pmc_all.sh ship_straight_f0_train_f32 > $O/pmc_train.txt 2>&1
 bash tools/r03/pmc_all.sh ship_straight_f0_forward --mode forward > $O/pmc_forward.txt 2>&1
