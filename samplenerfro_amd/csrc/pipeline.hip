@@ -485,16 +485,14 @@ extern "C" int rnerf_train_forward_backward(const rnerf_model* m, const rnerf_tr
 
   // ---- everything that depends on the parameters only — the operand streams of both directions, the zeroing of the gradient buffer,
   //      sum theta^2 for weight_l2 — goes to cfg->aux_stream, beside the key kernels, the march and the background-MLP forward below
-  //      (~70 us of small launches off the critical path); joined before the first NerfMLP kernel
+  //      (~70 us of small launches off the critical path).  Two joins: the forward waits for the forward streams only; the backward's
+  //      streams and the sum are packed while the forward runs (its persistent grid leaves a few CUs free) and joined before the backward.
   void* aux = c->aux_stream;
   if (aux) {
     RNERF_TRY(rnerf_fork(stream, aux));
     RNERF_CHECK_HIP(hipMemsetAsync(grads, 0, (size_t)(n_theta + 8) * sizeof(float), (hipStream_t)aux));
     RNERF_TRY(rnerf_nerfmlp_pack(th_c, prec, t.packed_c, aux));
     if (Nf > 0) RNERF_TRY(rnerf_nerfmlp_pack(th_f, prec, t.packed_f, aux));
-    RNERF_TRY(rnerf_nerfmlp_pack_bwd(th_c, bwd, t.packed_bwd, aux));
-    if (Nf > 0) RNERF_TRY(rnerf_nerfmlp_pack_bwd(th_f, bwd, t.packed_bwd_f, aux));
-    RNERF_TRY(rnerf_theta_sumsq(theta, n_theta, stats8, aux));
   }
   // ---- forward (models.forward with ctx) ----
   const int32_t* jitter = jitter_override;
@@ -511,7 +509,14 @@ extern "C" int rnerf_train_forward_backward(const rnerf_model* m, const rnerf_tr
   RNERF_TRY(rnerf_bkgd_forward_train(th_b, f.bk_dirs, 4, (int64_t)B + M, m->rgb_padding, t.out_all, t.save_bk, stream));
   const float* bkgd = t.out_all;
   const float* rgb_env = t.out_all + (size_t)3 * B;
-  if (aux) RNERF_TRY(rnerf_join(stream, aux)); else RNERF_TRY(rnerf_nerfmlp_pack(th_c, prec, t.packed_c, stream));
+  if (aux) {
+    RNERF_TRY(rnerf_join(stream, aux));
+    RNERF_TRY(rnerf_nerfmlp_pack_bwd(th_c, bwd, t.packed_bwd, aux));
+    if (Nf > 0) RNERF_TRY(rnerf_nerfmlp_pack_bwd(th_f, bwd, t.packed_bwd_f, aux));
+    RNERF_TRY(rnerf_theta_sumsq(theta, n_theta, stats8, aux));
+  } else {
+    RNERF_TRY(rnerf_nerfmlp_pack(th_c, prec, t.packed_c, stream));
+  }
   RNERF_TRY(rnerf_nerfmlp_forward_train(t.packed_c, prec, path_pd, path_dr, jitter, Nc, B, f.raw_c, t.save_c, bwd, max_workgroups, stream));
   Level lc = level_of(t.level_c, B);
   RNERF_TRY(rnerf_composite(f.raw_c, path_pd, path_dr, jitter, Nc, B, bkgd, m->white_bkgd, m->rgb_padding, m->sigma_bias, lc.rgb, lc.dist, lc.acc, lc.trans, lc.tb,
@@ -544,6 +549,7 @@ extern "C" int rnerf_train_forward_backward(const rnerf_model* m, const rnerf_tr
                        next->side_stream);
   };
   // ---- backward, last level first ----
+  if (aux) RNERF_TRY(rnerf_join(stream, aux));
   float* d_first = t.d_all;                      // rows [0,B): d loss / d bkgd of the rays; rows [B,B+M): the env-map patch
   if (Nf > 0) {
     RNERF_TRY(rnerf_composite_backward(f.raw_f, f.rows_pd, f.rows_dr, nullptr, S, B, bkgd, m->rgb_padding, m->sigma_bias, lf.rgb, pixels, lf.trans, lf.tb, t.sums,
