@@ -205,6 +205,7 @@ class Stepper:
         from samplenerfro_amd import utils as U
         self.args, self.model, self.variables, self.rays, self.key, self.mode = args, model, variables, rays, key, mode
         self.train = mode == "train"
+        self.stage = stage
         self.pipeline, self.graph, self.h, self.rng, self.g = pipeline, graph and self.train and stage == "radiance", None, key, None
         if not self.train:
             return
@@ -238,6 +239,11 @@ class Stepper:
             return self.g.step().loss
         if self.train:
             from samplenerfro_amd.train import train_step
+            if self.stage == "all":
+                # a training batch is new every step, this bench's rays are not: forget the per-batch shell order (ops._shell_order: a
+                # plain pre-march + a sort) so that every timed step pays for it like a real one would
+                from samplenerfro_amd import ops as _ops
+                _ops._SHELL_CACHE.clear()
             # the march of step k+1 is issued on the side stream behind the backward of step k
             _, stats, self.rng = train_step(self.model, self.rng, self.tstate, self.batch, self.flags, path=self.h,
                                             next_rays=self.rays if (self.pipeline and not last) else None)

@@ -172,4 +172,10 @@ __device__ __forceinline__ float quad_prev(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0 | (0 << 2) | (1 << 4) | (2 << 6), 0xF, 0xF, true));
 }
 
+// (a0*a0 + a1*a1) + a2*a2 over the three coordinate lanes, in the reference's summation order
+__device__ __forceinline__ float quad_sumsq3(float a) {
+  const float a2 = fmul(a, a);
+  return fadd(fadd(quad_bcast<0>(a2), quad_bcast<1>(a2)), quad_bcast<2>(a2));
+}
+
 }  // namespace rnerf

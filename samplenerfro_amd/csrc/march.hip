@@ -10,12 +10,6 @@
 
 namespace rnerf {
 
-// (a0*a0 + a1*a1) + a2*a2 over the three coordinate lanes, in the reference's summation order
-__device__ __forceinline__ float quad_sumsq3(float a) {
-  const float a2 = fmul(a, a);
-  return fadd(fadd(quad_bcast<0>(a2), quad_bcast<1>(a2)), quad_bcast<2>(a2));
-}
-
 struct MarchParams {
   int dx, dy, dz;
   float nmin[3];

@@ -2150,34 +2150,39 @@ __device__ __forceinline__ void so3_eval(const float* __restrict__ params, float
   for (int c = 0; c < 3; ++c) raw[c] = o[c] + __shfl_xor(o[c], 32) + params[so3_boff(4) + c];
 }
 
-// ---- so3_mlp on the 16-bit matrix cores (f16 hi + lo split of both operands, 3 MFMAs per tile, fp32 accumulate: the arithmetic of the
-// NerfMLP engine) for the march of stage "all*", where it runs once per node: 384 v_mfma_f32_32x32x16_f16 per 32 rays instead of 1014
-// v_mfma_f32_32x32x2_f32, and the weights arrive as coalesced 1 KiB A-operand blocks instead of one dword per lane and MFMA.
-// Transposed chain as in nerfmlp_fwd_kernel: lane (ray m, half h) holds outputs n = 32 t + (r & 3) + 8 (r >> 2) + 4 h in acc[t][r] and feeds
-// k-step s, slot j of the next layer with feature 16 s + 8 (j >> 2) + 4 h + (j & 3) = acc[s >> 1][8 (s & 1) + j].
-// Packed stream: layers 0..3, k-steps (4, 8, 8, 12: Dense_3 = 8 previous + 4 encoding), 4 n-tiles; block = 64 lanes x uint4 hi, then lo.
-constexpr int SO3_KS[4] = {4, 8, 8, 12};
-__host__ __device__ constexpr int so3_blocks_before(int l) { int o = 0; for (int i = 0; i < l; ++i) o += SO3_KS[i] * 4; return o; }
-constexpr int kSo3Blocks = so3_blocks_before(4);                 // 128 blocks x 2 KiB
+// ---- so3_mlp on the 16-bit matrix cores (f16 hi + lo split of both operands, 3 MFMAs per product tile, fp32 accumulate: the arithmetic of
+// the NerfMLP engine) for the march of stage "all*", where it runs once per node of the boundary shell.  One WORKGROUP of four waves
+// evaluates it for 16 rays on v_mfma_f32_16x16x32_f16 (transposed chain: weights = A, rows = output features; activations = B, columns =
+// rays): lane (ray c = lane & 15, k-group g = lane >> 4) holds D rows 4 g + i of a 16-feature tile.  Wave w owns the output tiles 2 w and
+// 2 w + 1 (32 features) of every layer, so after a layer it holds, per lane, the 8 values
+//     slot j < 4: feature 32 w + 4 g + j (tile 2 w)       slot j >= 4: feature 32 w + 16 + 4 g + (j - 4) (tile 2 w + 1)
+// which is exactly what lane (c, g) must supply as B operand of k-step w (K = 32) of the next layer when the packed weights use the same
+// slot -> feature map.  Packed stream: 16 k-steps (Dense_0: 2 encoding; Dense_1, Dense_2: 4; Dense_3: 4 + 2 encoding) x 8 tiles; block
+// (ks, t) = 64 lanes x uint4 hi, then lo (2 KiB).  Encoding k-steps use feature 32 s + 8 g + j of annealed_pos_enc (zero past 59).
+constexpr int kSo3KSteps = 16;
+constexpr int kSo3Blocks = kSo3KSteps * 8;                       // 128 blocks x 2 KiB
 constexpr float SO3_WSCALE = 256.f;                              // keeps the lo parts of the f16 split normal (as Prec<F16X3>::WSCALE)
-// encoding feature fed by (k-step s, half h, slot j) of an encoding block: annealed_pos_enc index 6 d + 3 is_cos + c, or -1 (zero padding)
-__host__ __device__ constexpr int so3_enc_feature(int s, int h, int j) { const int f = 16 * s + 8 * (j >> 2) + 4 * h + (j & 3); return f < 60 ? f : -1; }
+// kernel row (input feature) of Dense_l fed by slot j of lane group g in k-step ks, or -1 (zero padding); l through *layer
+__host__ __device__ constexpr int so3s_row(int ks, int g, int j, int* layer) {
+  const int l = ks < 2 ? 0 : (ks < 6 ? 1 : (ks < 10 ? 2 : 3));
+  const int s = ks - (l == 0 ? 0 : (l == 1 ? 2 : (l == 2 ? 6 : 10)));
+  *layer = l;
+  const bool enc = l == 0 || (l == 3 && s >= 4);
+  if (enc) { const int f = 32 * (l == 0 ? s : s - 4) + 8 * g + j; return f < 60 ? (l == 0 ? f : 128 + f) : -1; }
+  return 32 * s + (j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4));
+}
 
 __global__ void so3_pack16_kernel(const float* __restrict__ params, uint4* __restrict__ packed) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= kSo3Blocks * 64) return;
   const int blk = gid >> 6, lane = gid & 63;
-  int l = 0;
-  while (l < 3 && blk >= so3_blocks_before(l + 1)) ++l;
-  const int rel = blk - so3_blocks_before(l), s = rel / 4, t = rel % 4;
-  const int n_out = 32 * t + (lane & 31), h = lane >> 5;
+  const int ks = blk >> 3, t = blk & 7;
+  const int n_out = 16 * t + (lane & 15), g = lane >> 4;
   float w[8];
   for (int j = 0; j < 8; ++j) {
-    int row;                                                      // input row of Dense_l's kernel
-    if (l == 0) row = so3_enc_feature(s, h, j);
-    else if (l == 3 && s >= 8) { const int f = so3_enc_feature(s - 8, h, j); row = f < 0 ? -1 : 128 + f; }
-    else row = 16 * s + 8 * (j >> 2) + 4 * h + (j & 3);
-    w[j] = row < 0 ? 0.f : params[so3_koff(l) + row * 128 + n_out] * SO3_WSCALE;
+    int l = 0;
+    const int row = so3s_row(ks, g, j, &l);
+    w[j] = row < 0 ? 0.f : params[(l == 0 ? so3_koff(0) : (l == 1 ? so3_koff(1) : (l == 2 ? so3_koff(2) : so3_koff(3)))) + row * 128 + n_out] * SO3_WSCALE;
   }
   uint32_t hi[4], lo[4];
   for (int p = 0; p < 4; ++p) split2<true>(w[2 * p], w[2 * p + 1], hi[p], lo[p]);
@@ -2193,28 +2198,24 @@ __device__ __forceinline__ So3Ops so3_split_ops(const float (&x)[8]) {
   So3Ops o; o.h = make_uint4(hh[0], hh[1], hh[2], hh[3]); o.l = make_uint4(ll[0], ll[1], ll[2], ll[3]);
   return o;
 }
-// One so3_mlp evaluation by a WORKGROUP of four waves that all carry the same 32 rays: wave w owns n-tile w (outputs 32 w .. 32 w + 31) of every
-// layer and keeps its slice of the packed stream — 32 k-steps x (hi, lo) = 256 registers — for the whole march, so an evaluation reads
-// no weight from memory at all (round 2: one wave streamed all 262 KB from L2 per evaluation, 34 us each, latency-bound; the matrix work
-// of an evaluation is 96 MFMAs per wave here).  Between layers the waves exchange the converted operands through LDS: wave w converts
-// its 32 outputs (bias + ReLU + hi/lo split) = the k-steps 2 w and 2 w + 1 of the next layer, one barrier, every wave reads all 8.  The
-// encoding is split the same way (wave w computes k-step w: 8 of the 32 sines per lane).  Same arithmetic per product and per sum as
-// so3_pack16_kernel's layout implies (hi*hi + hi*lo + lo*hi per k-step, k-steps in order); only Dense_4 (128 -> 3, fp32 VALU) is summed
-// as four 32-feature partials.  Every exchange has its own LDS region, so one barrier per exchange is enough (a region is rewritten
-// only after the barriers of a whole evaluation have been passed by every wave).
+
+// LDS of one 16-ray workgroup.  Every exchange has its own region, so one barrier per exchange is enough (a region is rewritten only after
+// the barriers of a whole evaluation have been passed by every wave).
 struct So3Shared {
-  uint4 enc[4][2][64];          // encoding operands: k-step, (hi, lo), lane
-  uint4 x[3][8][2][64];         // inputs of Dense_1, Dense_2, Dense_3: k-step, (hi, lo), lane
-  float4 out[4][32];            // Dense_4 partial sums per wave and ray
+  uint4 enc[2][2][64];          // encoding operands: k-step, (hi, lo), lane
+  uint4 x[3][4][2][64];         // inputs of Dense_1, Dense_2, Dense_3: k-step, (hi, lo), lane
+  float4 out[4][16];            // Dense_4 partial sums per wave and ray
+  float4 pos[16];               // the points to evaluate (written by the marching wave)
   float bias[4][128];           // Dense_0 .. Dense_3
   float k4[128][4];             // Dense_4 kernel rows (3 outputs, padded)
   float tail[16];               // Dense_4 bias (3), the annealing window (10) at [4..13]
+  int done;                     // set by the marching wave before its last barrier
 };
 
-__device__ __forceinline__ f32x16 so3_mfma3(const uint4 ah, const uint4 al, const uint4 bh, const uint4 bl, const f32x16 c) {
-  f32x16 a = mfma16<true>(ah, bh, c);
-  a = mfma16<true>(ah, bl, a);
-  return mfma16<true>(al, bh, a);
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 so3_mfma16(const uint4 a, const uint4 b, const f32x4 c) {
+  typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
 }
 
 __device__ __forceinline__ void so3_shared_init(So3Shared& sh, const float* __restrict__ params, const So3Window& win, int tid) {
@@ -2222,105 +2223,107 @@ __device__ __forceinline__ void so3_shared_init(So3Shared& sh, const float* __re
   for (int i = tid; i < 128 * 3; i += 256) sh.k4[i / 3][i % 3] = params[so3_koff(4) + i];
   if (tid < 3) sh.tail[tid] = params[so3_boff(4) + tid];
   if (tid < 10) sh.tail[4 + tid] = win.w[tid];
+  if (tid == 0) sh.done = 0;
 }
 
-// raw axis-angle of the wave's 32 points (one per lane pair); all four waves of the workgroup must call it with the same points.
-// wh / wl: this wave's weight registers (block 4 ks + wave of so3_pack16_kernel's stream, ks = 0 .. 31 over the layers' k-steps).
-__device__ __forceinline__ void so3_eval_wg(So3Shared& sh, const uint4 (&wh)[32], const uint4 (&wl)[32], float px, float py, float pz, int wave, int lane,
-                                            float (&raw)[3]) {
-  const int m = lane & 31, h = lane >> 5;
+// One evaluation of so3_mlp at the 16 points sh.pos[] by the four waves of the workgroup (all must call it; 5 barriers).  Wave w keeps
+// its slice of the packed stream — tiles 2 w, 2 w + 1 of the 16 k-steps, hi and lo = 256 registers — for the whole march: an evaluation
+// reads no weight from memory.  Between layers the waves exchange the converted operands through LDS: wave w converts its 32 outputs
+// (bias + ReLU + hi/lo split) = k-step w of the next layer; the encoding is split the same way (wave w: slots 4 (w & 1) .. + 3 of k-step
+// w >> 1, four sines per lane).  All operand reads of a layer are issued ahead of its MFMAs, which alternate between the wave's two
+// accumulators.  The result — Dense_4 (128 -> 3, fp32 VALU) as four 32-feature partials — is left in sh.out[wave][ray].
+__device__ __forceinline__ void so3_eval_wg(So3Shared& sh, const uint4 (&wh)[kSo3KSteps][2], const uint4 (&wl)[kSo3KSteps][2], int wave, int lane) {
+  const int c = lane & 15, g = lane >> 4;
   const float HALF_PI = 1.5707963705062866f;
-  const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const f32x4 zero = {0, 0, 0, 0};
   constexpr float INV = 1.0f / SO3_WSCALE;
-  {   // annealed_pos_enc (model_utils.py:236-245), k-step `wave`: feature f = 6 d + 3 is_cos + c; the lane's half picks f0 or f0 + 4
-    float v[8];
+  const float4 pt = sh.pos[c];
+  {   // annealed_pos_enc (model_utils.py:236-245): feature f = 6 d + 3 is_cos + c3, slots 4 (w & 1) .. + 3 of k-step w >> 1
+    const int s = wave >> 1, j0 = 4 * (wave & 1);
+    float v[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int f = 16 * wave + 8 * (j >> 2) + (j & 3) + 4 * h;
+    for (int j = 0; j < 4; ++j) {
+      const int f = 32 * s + 8 * g + j0 + j;
       const bool in = f < 60;
       const int fc = in ? f : 0;
-      const int d = fc / 6, jj = fc - 6 * d, c = jj >= 3 ? jj - 3 : jj;
-      const float x = c == 0 ? px : (c == 1 ? py : pz);
+      const int d = fc / 6, jj = fc - 6 * d, c3 = jj >= 3 ? jj - 3 : jj;
+      const float x = c3 == 0 ? pt.x : (c3 == 1 ? pt.y : pt.z);
       const float xb = fmul(x, (float)(1 << d));
-      const float e = fmul(pe_sin(jj >= 3 ? fadd(xb, HALF_PI) : xb), sh.tail[4 + d]);     // ~1 ulp, 20 VALU ops (ocml sinf: ~100, 8 per lane here)
+      const float e = fmul(pe_sin(jj >= 3 ? fadd(xb, HALF_PI) : xb), sh.tail[4 + d]);     // ~1 ulp, 20 VALU ops (ocml sinf: ~100)
       v[j] = in ? e : 0.f;
     }
-    const So3Ops e = so3_split_ops(v);
-    sh.enc[wave][0][lane] = e.h; sh.enc[wave][1][lane] = e.l;
+    uint32_t h0, l0, h1, l1;
+    split2<true>(v[0], v[1], h0, l0); split2<true>(v[2], v[3], h1, l1);
+    uint2* eh = (uint2*)&sh.enc[s][0][lane] + (wave & 1);
+    uint2* el = (uint2*)&sh.enc[s][1][lane] + (wave & 1);
+    *eh = make_uint2(h0, h1); *el = make_uint2(l0, l1);
   }
   __syncthreads();
-  // One layer: ALL operand reads first (distinct registers: left alone, hipcc reuses one register quad and issues each k-step's
-  // ds_read after the previous k-step's MFMAs, a full LDS round trip exposed per k-step), then the chain of MFMAs on one accumulator.
-  f32x16 acc = zero;
-  uint4 eh[4], el[4];                // the encoding operands feed Dense_0 and, through the skip concat, Dense_3
+  f32x4 a0 = zero, a1 = zero;
+  auto kstep = [&](int ks, const uint4 bh, const uint4 bl) {        // hi*hi + hi*lo + lo*hi, the two tiles interleaved
+    a0 = so3_mfma16(wh[ks][0], bh, a0); a1 = so3_mfma16(wh[ks][1], bh, a1);
+    a0 = so3_mfma16(wh[ks][0], bl, a0); a1 = so3_mfma16(wh[ks][1], bl, a1);
+    a0 = so3_mfma16(wl[ks][0], bh, a0); a1 = so3_mfma16(wl[ks][1], bh, a1);
+  };
+  auto enc_layer = [&](int ks0) {     // the encoding operands feed Dense_0 and, through the skip concat, Dense_3
+    uint4 eh[2], el[2];
 #pragma unroll
-  for (int s = 0; s < 4; ++s) { eh[s] = sh.enc[s][0][lane]; el[s] = sh.enc[s][1][lane]; }
-  RNERF_PIN();
+    for (int s = 0; s < 2; ++s) { eh[s] = sh.enc[s][0][lane]; el[s] = sh.enc[s][1][lane]; }
+    RNERF_PIN();
 #pragma unroll
-  for (int s = 0; s < 4; ++s) acc = so3_mfma3(wh[s], wl[s], eh[s], el[s], acc);
-  // ReLU(acc / scale + bias) of this wave's 32 outputs = the operands of k-steps 2 w, 2 w + 1 of the next layer
+    for (int s = 0; s < 2; ++s) kstep(ks0 + s, eh[s], el[s]);
+  };
+  // ReLU(acc / scale + bias) of this wave's 32 outputs = the operands of k-step w of the next layer
   auto hand_over = [&](int l) {
-    const float4 b0 = *(const float4*)&sh.bias[l][32 * wave + 4 * h], b1 = *(const float4*)&sh.bias[l][32 * wave + 8 + 4 * h];
-    const float4 b2 = *(const float4*)&sh.bias[l][32 * wave + 16 + 4 * h], b3 = *(const float4*)&sh.bias[l][32 * wave + 24 + 4 * h];
-    const float bb[16] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      float v[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = fmaxf(fmaf(acc[8 * half + j], INV, bb[8 * half + j]), 0.f);
-      const So3Ops o = so3_split_ops(v);
-      sh.x[l][2 * wave + half][0][lane] = o.h; sh.x[l][2 * wave + half][1][lane] = o.l;
-    }
+    const float4 b0 = *(const float4*)&sh.bias[l][32 * wave + 4 * g], b1 = *(const float4*)&sh.bias[l][32 * wave + 16 + 4 * g];
+    float v[8];
+    v[0] = fmaxf(fmaf(a0[0], INV, b0.x), 0.f); v[1] = fmaxf(fmaf(a0[1], INV, b0.y), 0.f); v[2] = fmaxf(fmaf(a0[2], INV, b0.z), 0.f); v[3] = fmaxf(fmaf(a0[3], INV, b0.w), 0.f);
+    v[4] = fmaxf(fmaf(a1[0], INV, b1.x), 0.f); v[5] = fmaxf(fmaf(a1[1], INV, b1.y), 0.f); v[6] = fmaxf(fmaf(a1[2], INV, b1.z), 0.f); v[7] = fmaxf(fmaf(a1[3], INV, b1.w), 0.f);
+    const So3Ops o = so3_split_ops(v);
+    sh.x[l][wave][0][lane] = o.h; sh.x[l][wave][1][lane] = o.l;
   };
   auto layer = [&](int l, int ks0) {
-    uint4 bh[8], bl[8];
+    uint4 bh[4], bl[4];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) { bh[s] = sh.x[l][s][0][lane]; bl[s] = sh.x[l][s][1][lane]; }
+    for (int s = 0; s < 4; ++s) { bh[s] = sh.x[l][s][0][lane]; bl[s] = sh.x[l][s][1][lane]; }
     RNERF_PIN();
-    acc = zero;
+    a0 = zero; a1 = zero;
 #pragma unroll
-    for (int s = 0; s < 8; ++s) acc = so3_mfma3(wh[ks0 + s], wl[ks0 + s], bh[s], bl[s], acc);
+    for (int s = 0; s < 4; ++s) kstep(ks0 + s, bh[s], bl[s]);
   };
+  enc_layer(0);
   hand_over(0);
   __syncthreads();
-  layer(0, 4);
+  layer(0, 2);
   hand_over(1);
   __syncthreads();
-  layer(1, 12);
+  layer(1, 6);
   hand_over(2);
   __syncthreads();
-  layer(2, 20);
-#pragma unroll
-  for (int s = 0; s < 4; ++s) acc = so3_mfma3(wh[28 + s], wl[28 + s], eh[s], el[s], acc);   // skip concat (model_utils.py:131-132)
-  // Dense_4 (128 -> 3) on the VALU in fp32: this wave's 32 features
+  layer(2, 10);
+  enc_layer(14);                     // skip concat (model_utils.py:131-132)
+  // Dense_4 (128 -> 3) on the VALU in fp32: this wave's 32 features, 8 per lane
   float o[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int f = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;
-    const float v = fmaxf(fmaf(acc[r], INV, sh.bias[3][f]), 0.f);
+  for (int j = 0; j < 8; ++j) {
+    const int f = 32 * wave + (j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4));
+    const float v = fmaxf(fmaf(j < 4 ? a0[j & 3] : a1[j & 3], INV, sh.bias[3][f]), 0.f);
     const float4 k = *(const float4*)&sh.k4[f][0];
     o[0] = fmaf(v, k.x, o[0]); o[1] = fmaf(v, k.y, o[1]); o[2] = fmaf(v, k.z, o[2]);
   }
 #pragma unroll
-  for (int c = 0; c < 3; ++c) o[c] = o[c] + __shfl_xor(o[c], 32);
-  if (h == 0) sh.out[wave][m] = make_float4(o[0], o[1], o[2], 0.f);
+  for (int q = 0; q < 3; ++q) { o[q] = o[q] + __shfl_xor(o[q], 16); o[q] = o[q] + __shfl_xor(o[q], 32); }
+  if (g == 0) sh.out[wave][c] = make_float4(o[0], o[1], o[2], 0.f);
   __syncthreads();
-  const float4 q0 = sh.out[0][m], q1 = sh.out[1][m], q2 = sh.out[2][m], q3 = sh.out[3][m];
-  raw[0] = ((q0.x + q1.x) + (q2.x + q3.x)) + sh.tail[0];
-  raw[1] = ((q0.y + q1.y) + (q2.y + q3.y)) + sh.tail[1];
-  raw[2] = ((q0.z + q1.z) + (q2.z + q3.z)) + sh.tail[2];
 }
 
 // pred_grad = a (cos(t) v + sin(t) e x v + (1 - cos(t)) (e . v) e),  e = raw / |raw|, v = g / |g| with safe norms (ior_utils.py:305-312)
-template <bool FAST = false>     // FAST (the march): sin / cos of the angle from pe_sincos (one reduction, ~1 ulp) instead of ocml's two
 __device__ __forceinline__ void so3_rotate(const float (&raw)[3], const float (&g)[3], float (&pred)[3]) {
   const float theta = fsqrt(fmaxf(fadd(fadd(fmul(raw[0], raw[0]), fmul(raw[1], raw[1])), fmul(raw[2], raw[2])), 1e-6f));
   const float e[3] = {fdiv(raw[0], theta), fdiv(raw[1], theta), fdiv(raw[2], theta)};
   const float a = fsqrt(fmaxf(fadd(fadd(fmul(g[0], g[0]), fmul(g[1], g[1])), fmul(g[2], g[2])), 1e-6f));
   const float v[3] = {fdiv(g[0], a), fdiv(g[1], a), fdiv(g[2], a)};
-  float ct, st;
-  if constexpr (FAST) pe_sincos(theta, st, ct);
-  else { ct = cosf(theta); st = sinf(theta); }
+  const float ct = cosf(theta), st = sinf(theta);
   const float cr[3] = {fsub(fmul(e[1], v[2]), fmul(e[2], v[1])), fsub(fmul(e[2], v[0]), fmul(e[0], v[2])), fsub(fmul(e[0], v[1]), fmul(e[1], v[0]))};
   const float dot = fadd(fadd(fmul(e[0], v[0]), fmul(e[1], v[1])), fmul(e[2], v[2]));
   const float k = fmul(fsub(1.0f, ct), dot);
@@ -2346,93 +2349,175 @@ __global__ void __launch_bounds__(64) so3_query_kernel(const float4* __restrict_
   if (ok && h == 0) { out4[row] = c; pred_out[3 * row] = pred[0]; pred_out[3 * row + 1] = pred[1]; pred_out[3 * row + 2] = pred[2]; }
 }
 
-// E1/E2 with stage "all": one workgroup = 32 rays marched by four waves in lockstep (every wave carries the ray state in both lane
-// halves and repeats the cheap per-node arithmetic; the stores are dealt out by wave), so3_mlp is evaluated by the four waves together
-// (so3_eval_wg) at every node where any of the 32 rays is inside the boundary shell.  The branch is workgroup-uniform: all four waves
-// compute the same bits.
-__global__ void __launch_bounds__(256, 1) march_all_kernel(const float4* __restrict__ table, GridParams gp, const float* __restrict__ params,
+// E1/E2 with stage "all": one workgroup = 16 rays.  Wave 0 marches them exactly like march_kernel does — four lanes per ray (lane q owns
+// coordinate q of the state and component (q + 1) & 3 of the table entries), the gathers of the next two nodes in flight from predicted
+// cells — and at every node where any of its rays is inside the boundary shell (|grad n| > 1e-3) hands the 16 positions to LDS; the other
+// three waves wait at that barrier, and all four evaluate so3_mlp together (so3_eval_wg).  Outside the shell a node costs what it costs in
+// the radiance-stage march; inside, the chain is one evaluation of 96 v_mfma_f32_16x16x32_f16 per wave.
+__global__ void __launch_bounds__(256, 1) march_all_kernel(const float4* __restrict__ table4, GridParams gp, const float* __restrict__ params,
                                                           const uint4* __restrict__ packed16, So3Window win, const float* __restrict__ origins, const float* __restrict__ viewdirs,
-                                                          int B, float near, float step, int num_nodes, float4* __restrict__ path_pd,
-                                                          float4* __restrict__ path_dr, float4* __restrict__ path_ior,
+                                                          int B, float near, float step, int num_nodes, float4* __restrict__ path_pd4,
+                                                          float4* __restrict__ path_dr4, float4* __restrict__ path_ior4,
                                                           // training record (nullable): raw direction + n per node, and the compacted list of
                                                           // (ray, node) pairs at which pred_grad was selected (the object's boundary shell)
-                                                          float4* __restrict__ path_rdn, int* __restrict__ pair_count, int pair_cap,
-                                                          int2* __restrict__ pair_id, float4* __restrict__ pair_x, float4* __restrict__ pair_g,
+                                                          float4* __restrict__ path_rdn4, int* __restrict__ pair_count, int pair_cap,
+                                                          int2* __restrict__ pair_id, float4* __restrict__ pair_x4, float4* __restrict__ pair_g4,
                                                           int* __restrict__ pair_of_node) {
   __shared__ So3Shared sh;
-  const int lane = threadIdx.x & 63, m = lane & 31, h = lane >> 5;
+  const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   so3_shared_init(sh, params, win, threadIdx.x);
-  uint4 wh[32], wl[32];
+  uint4 wh[kSo3KSteps][2], wl[kSo3KSteps][2];
 #pragma unroll
-  for (int ks = 0; ks < 32; ++ks) {
-    const uint4* __restrict__ blk = packed16 + (size_t)(4 * ks + wave) * 128;
-    wh[ks] = blk[lane]; wl[ks] = blk[64 + lane];
-  }
-  int r = blockIdx.x * 32 + m;
-  const bool ok = r < B;
-  if (!ok) r = B - 1;
-  float d[3] = {viewdirs[3 * r], viewdirs[3 * r + 1], viewdirs[3 * r + 2]};
-  float p[3];
+  for (int ks = 0; ks < kSo3KSteps; ++ks)
 #pragma unroll
-  for (int c = 0; c < 3; ++c) p[c] = fadd(origins[3 * r + c], fmul(near, d[c]));   // eikonal_utils.py:104-106
-  float rt = near;
+    for (int tt = 0; tt < 2; ++tt) {
+      const uint4* __restrict__ blk = packed16 + (size_t)(8 * ks + 2 * wave + tt) * 128;
+      wh[ks][tt] = blk[lane]; wl[ks][tt] = blk[64 + lane];
+    }
   __syncthreads();
-  const bool writer = ok && h == 0;
-  // The chain of one step is position -> cell -> 8 gathers -> lerps -> n -> next position.  The next position needs only n and the
-  // CURRENT direction (not pred_grad), so the gathers of node k + 1 are issued as soon as n_k is known and everything else of node k
-  // — the record, the normalisation, the MLP — runs under their latency.
-  const GridRcp rcp = grid_rcp(gp);
-  TriCell cell;
-  trilinear_load<true, true>(table, gp, p[0], p[1], p[2], nullptr, cell, &rcp);
-  for (int k = 0; k < num_nodes; ++k) {
-    const float4 c = trilinear_finish(cell);
-    const float s = fdiv(step, c.x);
-    float np[3];
-#pragma unroll
-    for (int q = 0; q < 3; ++q) np[q] = fadd(p[q], fmul(s, d[q]));
-    trilinear_load<true, true>(table, gp, np[0], np[1], np[2], nullptr, cell, &rcp);      // (clamped indices: in bounds past the last node too)
-    RNERF_PIN();
-    const size_t o = (size_t)k * B + r;
-    if (writer) {
-      if (wave == 1) path_pd[o] = make_float4(p[0], p[1], p[2], rt);
-      if (wave == 2) {
-        const float nrm = fsqrt(fmaxf(fadd(fadd(fmul(d[0], d[0]), fmul(d[1], d[1])), fmul(d[2], d[2])), 1e-6f));
-        path_dr[o] = make_float4(fdiv(d[0], nrm), fdiv(d[1], nrm), fdiv(d[2], nrm), 0.f);
-      }
-      if (wave == 3 && path_ior) path_ior[o] = c;
+  if (wave != 0) {                    // the evaluation waves: wait for the marcher's next request (or the end of the march)
+    for (;;) {
+      __syncthreads();
+      if (sh.done) return;
+      so3_eval_wg(sh, wh, wl, wave, lane);
     }
-    const float g[3] = {c.y, c.z, c.w};
-    // |grad n| > 1e-3 (eikonal_utils.py:35): sqrt_rn(s) > f32(1e-3) <=> s > 0x358637BE, the largest f32 whose correctly rounded root is
-    // still <= f32(1e-3) (sqrt is monotone) — the same decision for every s without the root on the per-node chain
-    const bool use = fadd(fadd(fmul(g[0], g[0]), fmul(g[1], g[1])), fmul(g[2], g[2])) > __uint_as_float(0x358637BEu);
-    int idx = -1;
-    const bool record = path_rdn != nullptr && writer && wave == 0;
-    if (record) {
-      path_rdn[o] = make_float4(d[0], d[1], d[2], c.x);
-      if (use) idx = atomicAdd(pair_count, 1);      // consumed after the evaluation: its round trip hides behind the MLP
-    }
-    float pred[3] = {0.f, 0.f, 0.f};
-    if (__builtin_amdgcn_ballot_w64(use) != 0) {     // pred_grad is only selected where |grad n| > 1e-3: outside the object's boundary
-      float raw[3];                                   // shell no ray of the workgroup needs the MLP (workgroup-uniform branch, same results)
-      so3_eval_wg(sh, wh, wl, p[0], p[1], p[2], wave, lane, raw);
-      so3_rotate<true>(raw, g, pred);
-    }
-    if (record) {
-      if (idx >= pair_cap) idx = -1;
-      if (idx >= 0) { pair_id[idx] = make_int2(r, k); pair_x[idx] = make_float4(p[0], p[1], p[2], 0.f); pair_g[idx] = make_float4(g[0], g[1], g[2], 0.f); }
-      pair_of_node[o] = idx;
-    }
-    float dl2 = 0.f;
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      d[q] = fadd(d[q], fmul(step, use ? pred[q] : g[q]));
-      const float dl = fsub(p[q], np[q]);
-      dl2 = q == 0 ? fmul(dl, dl) : fadd(dl2, fmul(dl, dl));
-      p[q] = np[q];
-    }
-    rt = fadd(rt, fsqrt(dl2));
   }
+  // ---- the marching wave: march_kernel's node (march.hip), plus the so3 term
+  const float* __restrict__ table = (const float*)table4;
+  float* __restrict__ path_pd = (float*)path_pd4; float* __restrict__ path_dr = (float*)path_dr4;
+  float* __restrict__ path_ior = (float*)path_ior4; float* __restrict__ path_rdn = (float*)path_rdn4;
+  float* __restrict__ pair_x = (float*)pair_x4; float* __restrict__ pair_g = (float*)pair_g4;
+  const int q = lane & 3, ray = lane >> 2;
+  int r = blockIdx.x * 16 + ray;
+  const bool live = r < B;
+  if (!live) r = B - 1;               // surplus quads replay the last ray (same values to the same addresses); their pair records are suppressed
+  const int qc = q < 3 ? q : 0;
+  const float nmin_q = qc == 0 ? gp.nminx : (qc == 1 ? gp.nminy : gp.nminz);
+  const double rcp_q = 1.0 / (double)(qc == 0 ? gp.ndx : (qc == 1 ? gp.ndy : gp.ndz));
+  const int dim_q = qc == 0 ? gp.dx : (qc == 1 ? gp.dy : gp.dz);
+  const unsigned comp = (q + 1) & 3;
+  const unsigned s1 = (unsigned)gp.dy * (unsigned)gp.dz * 16u, s2 = (unsigned)gp.dz * 16u;
+  const char* __restrict__ tabc = (const char*)table;
+  const unsigned cofs = comp * 4u;
+  float d = q < 3 ? viewdirs[3 * r + qc] : 0.f;
+  float p = q < 3 ? fadd(origins[3 * r + qc], fmul(near, d)) : 0.f;   // eikonal_utils.py:104-106
+  float rt = near;
+  struct Corners { float c[8]; int i0, i1; };     // 000 100 001 101 010 110 011 111 (xyz) + the indices they were gathered with
+  Corners ca, cb, cc;
+  auto gather = [&](int i0, int i1, Corners& o) {
+    o.i0 = i0; o.i1 = i1;
+    const unsigned x0 = quad_bcast_i<0>(i0), x1 = quad_bcast_i<0>(i1);
+    const unsigned y0 = quad_bcast_i<1>(i0), y1 = quad_bcast_i<1>(i1);
+    const unsigned z0 = quad_bcast_i<2>(i0) * 16u + cofs, z1 = quad_bcast_i<2>(i1) * 16u + cofs;
+    const unsigned bx0 = __umul24(x0, s1), bx1 = __umul24(x1, s1);
+    const unsigned b00 = bx0 + __umul24(y0, s2), b10 = bx1 + __umul24(y0, s2), b01 = bx0 + __umul24(y1, s2), b11 = bx1 + __umul24(y1, s2);
+    o.c[0] = *(const float*)(tabc + (b00 + z0)); o.c[1] = *(const float*)(tabc + (b10 + z0));
+    o.c[2] = *(const float*)(tabc + (b00 + z1)); o.c[3] = *(const float*)(tabc + (b10 + z1));
+    o.c[4] = *(const float*)(tabc + (b01 + z0)); o.c[5] = *(const float*)(tabc + (b11 + z0));
+    o.c[6] = *(const float*)(tabc + (b01 + z1)); o.c[7] = *(const float*)(tabc + (b11 + z1));
+  };
+  auto predict = [&](float xq, Corners& o) {
+    const int j = (int)floorf(xq);
+    gather(clampi(j, 0, dim_q - 1), clampi(j + 1, 0, dim_q - 1), o);
+  };
+  float x_prev;
+  {
+    const float x = div_const(fsub(p, nmin_q), rcp_q);
+    x_prev = div_const(fsub(fsub(p, fmul(step, d)), nmin_q), rcp_q);   // as if a vacuum step had led here
+    predict(x, ca);
+    predict(fadd(x, fsub(x, x_prev)), cb);
+  }
+  const size_t node_stride = 4 * (size_t)B;
+  size_t rec = 4 * (size_t)r;                                           // float offset of this ray's record of the current node
+  auto one_step = [&](int k, Corners& cn, Corners& nx) {
+    // ---- VoxMLP._linear3 addressing (ior_utils.py:188-211): one coordinate per lane
+    const float x = div_const(fsub(p, nmin_q), rcp_q);
+    const float fx = floorf(x);
+    const int i = (int)fx;
+    const float t = fsub(x, fx);
+    const int i0 = clampi(i, 0, dim_q - 1), i1 = clampi(i + 1, 0, dim_q - 1);
+    if (__builtin_amdgcn_ballot_w64(i0 != cn.i0 || i1 != cn.i1) != 0) gather(i0, i1, cn);     // mispredicted somewhere in the wave
+    const float dx = fsub(x, x_prev);
+    predict(fadd(x, fadd(dx, dx)), nx);
+    x_prev = x;
+    const float xd = quad_bcast<0>(t), yd = quad_bcast<1>(t), zd = quad_bcast<2>(t);
+    // ---- node record while the gathers are in flight (eikonal_utils.py:112-114), direction safe-normalised (math_utils.py:6-12)
+    const float nrm = fsqrt(fmaxf(quad_sumsq3(d), 1e-6f));
+    path_pd[rec + q] = q < 3 ? p : rt;
+    path_dr[rec + q] = q < 3 ? fdiv(d, nrm) : 0.f;
+    // ---- 7 lerps a*(1-t) + b*t (ior_utils.py:214-222)
+    const float oxd = fsub(1.0f, xd), oyd = fsub(1.0f, yd), ozd = fsub(1.0f, zd);
+    const float c00 = fadd(fmul(cn.c[0], oxd), fmul(cn.c[1], xd));
+    const float c01 = fadd(fmul(cn.c[2], oxd), fmul(cn.c[3], xd));
+    const float c10 = fadd(fmul(cn.c[4], oxd), fmul(cn.c[5], xd));
+    const float c11 = fadd(fmul(cn.c[6], oxd), fmul(cn.c[7], xd));
+    const float c0 = fadd(fmul(c00, oyd), fmul(c10, yd));
+    const float c1 = fadd(fmul(c01, oyd), fmul(c11, yd));
+    const float c = fadd(fmul(c0, ozd), fmul(c1, zd));   // lanes 0..2: grad component q, lane 3: n
+    if (path_ior) path_ior[rec + comp] = c;
+    const float n = quad_bcast<3>(c);
+    const float s = fdiv(step, n);
+    const float np = fadd(p, fmul(s, d));                // needs the current direction only
+    // |grad n| > 1e-3 (eikonal_utils.py:35): sqrt_rn(s) > f32(1e-3) <=> s > 0x358637BE, the largest f32 whose correctly rounded root is
+    // still <= f32(1e-3) (sqrt is monotone): the same decision for every s without a root on the chain
+    const float g2 = quad_sumsq3(c);
+    const bool use = g2 > __uint_as_float(0x358637BEu);
+    int idx = -1;
+    if (path_rdn) {
+      path_rdn[rec + q] = q < 3 ? d : n;
+      if (use && q == 0 && live) idx = atomicAdd(pair_count, 1);      // consumed after the evaluation: its round trip hides behind the MLP
+    }
+    float pred = 0.f;
+    if (__builtin_amdgcn_ballot_w64(use) != 0) {         // (a workgroup's rays are neighbours in the shell-coherent order)
+      if (q < 3) ((float*)&sh.pos[ray])[q] = p;
+      __syncthreads();
+      so3_eval_wg(sh, wh, wl, 0, lane);
+      const float4 r0 = sh.out[0][ray], r1 = sh.out[1][ray], r2 = sh.out[2][ray], r3 = sh.out[3][ray];
+      const float o0 = q == 0 ? r0.x : (q == 1 ? r0.y : r0.z), o1 = q == 0 ? r1.x : (q == 1 ? r1.y : r1.z);
+      const float o2 = q == 0 ? r2.x : (q == 1 ? r2.y : r2.z), o3 = q == 0 ? r3.x : (q == 1 ? r3.y : r3.z);
+      const float raw = q < 3 ? ((o0 + o1) + (o2 + o3)) + sh.tail[qc] : 0.f;
+      // pred_grad = a (cos(t) v + sin(t) e x v + (1 - cos(t)) (e . v) e),  e = raw / |raw|, v = g / |g| with safe norms (ior_utils.py:305-312)
+      const float theta = fsqrt(fmaxf(quad_sumsq3(raw), 1e-6f));
+      const float e = fdiv(raw, theta);
+      const float a = fsqrt(fmaxf(g2, 1e-6f));
+      const float v = q < 3 ? fdiv(c, a) : 0.f;
+      float ct, st;
+      pe_sincos(theta, st, ct);
+      const float e0 = quad_bcast<0>(e), e1 = quad_bcast<1>(e), e2 = quad_bcast<2>(e);
+      const float v0 = quad_bcast<0>(v), v1 = quad_bcast<1>(v), v2 = quad_bcast<2>(v);
+      const float ea = q == 0 ? e1 : (q == 1 ? e2 : e0), eb = q == 0 ? e2 : (q == 1 ? e0 : e1);
+      const float va = q == 0 ? v1 : (q == 1 ? v2 : v0), vb = q == 0 ? v2 : (q == 1 ? v0 : v1);
+      const float cr = fsub(fmul(ea, vb), fmul(eb, va));
+      const float dot = fadd(fadd(fmul(e0, v0), fmul(e1, v1)), fmul(e2, v2));
+      const float kk = fmul(fsub(1.0f, ct), dot);
+      pred = fmul(a, fadd(fadd(fmul(ct, v), fmul(st, cr)), fmul(kk, e)));
+    }
+    if (path_rdn) {
+      idx = quad_bcast_i<0>(idx);
+      if (idx >= pair_cap) idx = -1;
+      if (idx >= 0) {
+        if (q == 0) pair_id[idx] = make_int2(r, k);
+        pair_x[4 * (size_t)idx + q] = q < 3 ? p : 0.f;
+        pair_g[4 * (size_t)idx + q] = q < 3 ? c : 0.f;
+      }
+      if (q == 0 && live) pair_of_node[(size_t)k * B + r] = idx;
+    }
+    d = fadd(d, fmul(step, use ? pred : c));
+    rt = fadd(rt, fsqrt(quad_sumsq3(fsub(p, np))));
+    p = np;
+    rec += node_stride;
+  };
+  int k = 0;
+  for (; k + 2 < num_nodes; k += 3) {      // three nodes per trip: the corner register sets rotate instead of being copied
+    one_step(k, ca, cc);
+    one_step(k + 1, cb, ca);
+    one_step(k + 2, cc, cb);
+  }
+  if (k < num_nodes) { one_step(k, ca, cc); ++k; }
+  if (k < num_nodes) one_step(k, cb, ca);
+  sh.done = 1;
+  __syncthreads();
 }
 
 // ---- backward of the background MLP (exact fp32 on v_mfma_f32_32x32x2_f32, as the forward) --------------------------------
@@ -3148,10 +3233,11 @@ extern "C" int rnerf_march_all(const float* table, const rnerf_grid* g, const fl
   RNERF_CHECK_ARG(make_grid_params(g, &gp), "rnerf_march_all: bad grid");
   So3Window w;
   for (int i = 0; i < 10; ++i) w.w[i] = window10[i];
-  RNERF_CHECK_ARG((double)gp.dx * gp.dy * gp.dz * 16.0 < 4294967296.0, "rnerf_march_all: grid too large for 32-bit byte offsets (needs G^3 * 16 B < 4 GiB)");
+  RNERF_CHECK_ARG((double)gp.dx * gp.dy * gp.dz * 16.0 < 4294967296.0 && (double)gp.dy * gp.dz * 16.0 < 16777216.0 && gp.dx < 16777216,
+                  "rnerf_march_all: grid too large for 32-bit byte offsets (needs G^3 * 16 B < 4 GiB)");
   const float stepf = (float)((far - near) / (num_nodes - 1));  // models.py:122
   hipLaunchKernelGGL(so3_pack16_kernel, dim3((kSo3Blocks * 64 + 255) / 256), dim3(256), 0, (hipStream_t)stream, so3_params, (uint4*)so3_packed);
-  hipLaunchKernelGGL(march_all_kernel, dim3((unsigned)((B + 31) / 32)), dim3(256), 0, (hipStream_t)stream, (const float4*)table, gp, so3_params,
+  hipLaunchKernelGGL(march_all_kernel, dim3((unsigned)((B + 15) / 16)), dim3(256), 0, (hipStream_t)stream, (const float4*)table, gp, so3_params,
                      (const uint4*)so3_packed, w, origins, viewdirs, B, (float)near, stepf, num_nodes, (float4*)path_pd, (float4*)path_dr, (float4*)path_ior,
                      (float4*)nullptr, (int*)nullptr, 0, (int2*)nullptr, (float4*)nullptr, (float4*)nullptr, (int*)nullptr);
   RNERF_CHECK_LAUNCH();

@@ -6,6 +6,7 @@ Layouts: "sample-major" arrays are [S, B, ...] tensors (sample/node index first,
 from __future__ import annotations
 
 import ctypes as C
+import os
 import weakref
 from typing import Optional, Tuple
 
@@ -328,11 +329,16 @@ def so3_query(table: torch.Tensor, spec: Grid, so3_flat: torch.Tensor, pts: torc
 
 
 _SHELL_CACHE: dict = {}
+# Default of the `coherent` argument of march_all / march_all_train.  Off since the 16-ray-workgroup march (round 3): for a NEW batch the
+# order costs a plain pre-march + a sort + the permutation gathers (~0.9 ms at 4096 x 1536), which is what it saves (stage-all train step,
+# same box: 16.9 ms with it, 16.8 without; 15.8 only when the order is cached, i.e. the same rays again).  RNERF_SHELL_ORDER=1 turns it on
+# (repeated marches over the same incoherent rays).
+SHELL_ORDER = os.environ.get("RNERF_SHELL_ORDER", "0") == "1"
 
 
 def _shell_order(table: torch.Tensor, spec: Grid, o: torch.Tensor, v: torch.Tensor, near: float, far: float, num_nodes: int):
     """Permutation that groups rays whose paths meet the boundary shell (|grad n| > 1e-3, where so3_mlp is evaluated) over the same
-    node range.  The all* march evaluates the MLP for a 32-ray wave whenever ANY of its rays is in the shell, so coherent waves need
+    node range.  The all* march evaluates the MLP for a 16-ray workgroup whenever ANY of its rays is in the shell, so coherent groups need
     several times fewer evaluations.  The shell interval of a ray is read off a cheap pre-march without so3 (the paths differ only by
     the so3 rotation, irrelevant for grouping); rays are results-independent, so the order changes no value."""
     # cached per ray batch (tensor objects + versions): evaluating or training repeatedly on the same rays (render_image chunks of a
@@ -356,11 +362,13 @@ def _shell_order(table: torch.Tensor, spec: Grid, o: torch.Tensor, v: torch.Tens
 
 
 def march_all(table: torch.Tensor, spec: Grid, so3_flat: torch.Tensor, origins: torch.Tensor, viewdirs: torch.Tensor, near: float, far: float,
-              num_nodes: int, annealed_alpha: float = 1.0, want_ior: bool = False, coherent: bool = True):
+              num_nodes: int, annealed_alpha: float = 1.0, want_ior: bool = False, coherent: Optional[bool] = None):
     """E1/E2 with stage "all*" (rnerf/eikonal_utils.py:34-39). -> path_pd [N,B,4], path_dr [N,B,4], ior?"""
     lib = _lib.load()
     o = _chk(origins, "origins"); v = _chk(viewdirs, "viewdirs")
     B = o.shape[0]
+    if coherent is None:
+        coherent = SHELL_ORDER
     if coherent and B > 64:
         perm = _shell_order(table, spec, o, v, near, far, num_nodes)
         pd, dr, ior = march_all(table, spec, so3_flat, o[perm].contiguous(), v[perm].contiguous(), near, far, num_nodes, annealed_alpha, want_ior, False)
@@ -377,12 +385,14 @@ def march_all(table: torch.Tensor, spec: Grid, so3_flat: torch.Tensor, origins: 
 
 
 def march_all_train(table: torch.Tensor, spec: Grid, so3_flat: torch.Tensor, origins: torch.Tensor, viewdirs: torch.Tensor, near: float, far: float,
-                    num_nodes: int, annealed_alpha: float = 1.0, pair_cap: Optional[int] = None, coherent: bool = True):
+                    num_nodes: int, annealed_alpha: float = 1.0, pair_cap: Optional[int] = None, coherent: Optional[bool] = None):
     """rnerf_march_all_train: the stage "all*" march + the record its backward needs.  Returns a dict (pairs trimmed to their count:
     this reads the device counter, i.e. synchronises once per step)."""
     lib = _lib.load()
     o = _chk(origins, "origins"); v = _chk(viewdirs, "viewdirs")
     B, N, dev = o.shape[0], int(num_nodes), o.device
+    if coherent is None:
+        coherent = SHELL_ORDER
     if coherent and B > 64:
         perm = _shell_order(table, spec, o, v, near, far, N)
         rec = march_all_train(table, spec, so3_flat, o[perm].contiguous(), v[perm].contiguous(), near, far, N, annealed_alpha, pair_cap, False)
