@@ -298,6 +298,7 @@ int rnerf_bkgd_backward_wgrad(const void* save, void* dy, int64_t n, float* grad
  *   rnerf_so3_backward     : cotangents d_raw4 float4[nb] -> dx4 float4[nb] (nullable, d / d point) and, if grads != NULL (nb == n_save),
  *                            grads float[RNERF_SO3MLP_PARAMS] += ...; row i uses the saved activations of row i % n_save, so the three
  *                            unit cotangents of every point run as one batch of 3 n_save rows (the rows of J = d raw / d x);
+ *                            dy (rnerf_so3_dy_bytes(nb)) is scratch for the parameter gradient: written only when grads != NULL;
  *   rnerf_so3_pair_jacobian: per pair A = d grad / d position (P J + (d pred / d g) G, G = d g / d x of the trilinear interpolant) and
  *                            P = d pred / d raw, float[np][12] each (9 used, row-major);
  *   rnerf_march_adjoint    : the reverse scan; a_pos / a_dir float4[S][B] = d loss / d (position, normalised direction) of the coarse
