@@ -241,7 +241,7 @@ class Stepper:
             from samplenerfro_amd.train import train_step
             if self.stage == "all":
                 # a training batch is new every step, this bench's rays are not: forget the per-batch shell order (ops._shell_order: a
-                # plain pre-march + a sort) so that every timed step pays for it like a real one would
+                # coarse pre-march + a sort) so that every timed step pays for it like a real one would
                 from samplenerfro_amd import ops as _ops
                 _ops._SHELL_CACHE.clear()
             # the march of step k+1 is issued on the side stream behind the backward of step k

@@ -189,11 +189,14 @@ int rnerf_so3_query(const float* table, const rnerf_grid* g, const float* so3_pa
 
 /* ---- E1/E2 with stage "all*": the march with grad = where(|grad n| > 1e-3, pred_grad, grad n) (rnerf/eikonal_utils.py:34-39).
  * Outputs as rnerf_march (path_ior nullable).  so3_packed: device scratch of rnerf_so3_packed_bytes() bytes — the call packs the so3
- * parameters into the f16 hi + lo A-operand stream of the in-march MLP (3 x v_mfma_f32_32x32x16_f16 per tile, fp32 accumulate). */
+ * parameters into the f16 hi + lo A-operand stream of the in-march MLP (3 x v_mfma_f32_16x16x32_f16 per tile, fp32 accumulate).
+ * ray_order (nullable): int32[B], a permutation of the rays: workgroup i marches rays ray_order[16 i .. 16 i + 15] (a group of 16
+ * evaluates the MLP whenever ANY of its rays is inside the boundary shell, so rays with similar shell intervals should share a group).
+ * Every record is written at the ray's own index: the order changes no output. */
 size_t rnerf_so3_packed_bytes(void);
 int rnerf_march_all(const float* table, const rnerf_grid* g, const float* so3_params, void* so3_packed, const float* window10, const float* origins,
                     const float* viewdirs, int32_t B, double near, double far, int32_t num_nodes, float* path_pd, float* path_dr,
-                    float* path_ior, void* stream);
+                    float* path_ior, const int32_t* ray_order, void* stream);
 
 /* ---- pinhole ray generation on the device.  Replaces Dataset._generate_rays (rnerf/datasets.py:216-242, Blender
  * model: opencv = 0, fx = fy = focal, cx = W/2, cy = H/2) and the OpenCV variant (:486-518: opencv = 1, fx, fy, cx, cy from cam_mat),
@@ -308,7 +311,7 @@ int rnerf_bkgd_backward_wgrad(const void* save, void* dy, int64_t n, float* grad
 int rnerf_march_all_train(const float* table, const rnerf_grid* g, const float* so3_params, void* so3_packed, const float* window10, const float* origins,
                           const float* viewdirs, int32_t B, double near, double far, int32_t num_nodes, float* path_pd, float* path_dr,
                           float* path_rdn, int32_t* pair_count, int32_t pair_cap, int32_t* pair_id, float* pair_x, float* pair_g,
-                          int32_t* pair_of_node, void* stream);
+                          int32_t* pair_of_node, const int32_t* ray_order, void* stream);
 size_t rnerf_so3_save_bytes(int64_t n);
 size_t rnerf_so3_dy_bytes(int64_t nb);
 int rnerf_so3_forward_train(const float* so3_params, const float* window10, const float* pts4, int64_t n, void* save, void* stream);

@@ -104,7 +104,7 @@ SIGNATURES = {
     "rnerf_voxelize_samples": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _GP, _i32, _vp, _vp, _vp]),
     "rnerf_voxelize_majority": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _dbl, _dbl, _vp, _vp, _vp]),
     "rnerf_so3_query": (C.c_int, [_vp, _GP, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
-    "rnerf_march_all": (C.c_int, [_vp, _GP, _vp, _vp, _vp, _vp, _vp, _i32, _dbl, _dbl, _i32, _vp, _vp, _vp, _vp]),
+    "rnerf_march_all": (C.c_int, [_vp, _GP, _vp, _vp, _vp, _vp, _vp, _i32, _dbl, _dbl, _i32, _vp, _vp, _vp, _vp, _vp]),
     "rnerf_generate_rays": (C.c_int, [_vp, _i32, _dbl, _dbl, _dbl, _dbl, _dbl, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "rnerf_stratified_u": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
     "rnerf_bkgd_save_bytes": (C.c_size_t, [_i64]),
@@ -114,7 +114,7 @@ SIGNATURES = {
     "rnerf_bkgd_backward_dgrad": (C.c_int, [_vp, _vp, _vp, _i64, _dbl, _vp, _vp, _vp]),
     "rnerf_bkgd_backward_wgrad": (C.c_int, [_vp, _vp, _i64, _vp, C.c_int, _vp]),
     "rnerf_theta_sumsq": (C.c_int, [_vp, _i64, _vp, _vp]),
-    "rnerf_march_all_train": (C.c_int, [_vp, _GP, _vp, _vp, _vp, _vp, _vp, _i32, _dbl, _dbl, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "rnerf_march_all_train": (C.c_int, [_vp, _GP, _vp, _vp, _vp, _vp, _vp, _i32, _dbl, _dbl, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rnerf_so3_packed_bytes": (C.c_size_t, []),
     "rnerf_so3_save_bytes": (C.c_size_t, [_i64]),
     "rnerf_so3_dy_bytes": (C.c_size_t, [_i64]),

@@ -2362,7 +2362,7 @@ __global__ void __launch_bounds__(256, 1) march_all_kernel(const float4* __restr
                                                           // (ray, node) pairs at which pred_grad was selected (the object's boundary shell)
                                                           float4* __restrict__ path_rdn4, int* __restrict__ pair_count, int pair_cap,
                                                           int2* __restrict__ pair_id, float4* __restrict__ pair_x4, float4* __restrict__ pair_g4,
-                                                          int* __restrict__ pair_of_node) {
+                                                          int* __restrict__ pair_of_node, const int* __restrict__ ray_order) {
   __shared__ So3Shared sh;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -2392,6 +2392,7 @@ __global__ void __launch_bounds__(256, 1) march_all_kernel(const float4* __restr
   int r = blockIdx.x * 16 + ray;
   const bool live = r < B;
   if (!live) r = B - 1;               // surplus quads replay the last ray (same values to the same addresses); their pair records are suppressed
+  if (ray_order) r = ray_order[r];    // the rays of a workgroup in the caller's (shell-coherent) order; records go to the ray's own index
   const int qc = q < 3 ? q : 0;
   const float nmin_q = qc == 0 ? gp.nminx : (qc == 1 ? gp.nminy : gp.nminz);
   const double rcp_q = 1.0 / (double)(qc == 0 ? gp.ndx : (qc == 1 ? gp.ndy : gp.ndz));
@@ -3226,7 +3227,7 @@ extern "C" size_t rnerf_so3_packed_bytes(void) { return (size_t)kSo3Blocks * 128
 
 extern "C" int rnerf_march_all(const float* table, const rnerf_grid* g, const float* so3_params, void* so3_packed, const float* window10, const float* origins,
                                const float* viewdirs, int32_t B, double near, double far, int32_t num_nodes, float* path_pd, float* path_dr,
-                               float* path_ior, void* stream) {
+                               float* path_ior, const int32_t* ray_order, void* stream) {
   RNERF_CHECK_ARG(table && g && so3_params && so3_packed && window10 && origins && viewdirs && path_pd && path_dr, "rnerf_march_all: null pointer");
   RNERF_CHECK_ARG(B > 0 && num_nodes >= 2, "rnerf_march_all: need B > 0 and num_nodes >= 2");
   GridParams gp;
@@ -3239,7 +3240,7 @@ extern "C" int rnerf_march_all(const float* table, const rnerf_grid* g, const fl
   hipLaunchKernelGGL(so3_pack16_kernel, dim3((kSo3Blocks * 64 + 255) / 256), dim3(256), 0, (hipStream_t)stream, so3_params, (uint4*)so3_packed);
   hipLaunchKernelGGL(march_all_kernel, dim3((unsigned)((B + 15) / 16)), dim3(256), 0, (hipStream_t)stream, (const float4*)table, gp, so3_params,
                      (const uint4*)so3_packed, w, origins, viewdirs, B, (float)near, stepf, num_nodes, (float4*)path_pd, (float4*)path_dr, (float4*)path_ior,
-                     (float4*)nullptr, (int*)nullptr, 0, (int2*)nullptr, (float4*)nullptr, (float4*)nullptr, (int*)nullptr);
+                     (float4*)nullptr, (int*)nullptr, 0, (int2*)nullptr, (float4*)nullptr, (float4*)nullptr, (int*)nullptr, (const int*)ray_order);
   RNERF_CHECK_LAUNCH();
   return RNERF_OK;
 }

@@ -329,32 +329,31 @@ def so3_query(table: torch.Tensor, spec: Grid, so3_flat: torch.Tensor, pts: torc
 
 
 _SHELL_CACHE: dict = {}
-# Default of the `coherent` argument of march_all / march_all_train.  Off since the 16-ray-workgroup march (round 3): for a NEW batch the
-# order costs a plain pre-march + a sort + the permutation gathers (~0.9 ms at 4096 x 1536), which is what it saves (stage-all train step,
-# same box: 16.9 ms with it, 16.8 without; 15.8 only when the order is cached, i.e. the same rays again).  RNERF_SHELL_ORDER=1 turns it on
-# (repeated marches over the same incoherent rays).
-SHELL_ORDER = os.environ.get("RNERF_SHELL_ORDER", "0") == "1"
+# Default of the `coherent` argument of march_all / march_all_train: hand the kernel a ray order in which the 16 rays of a workgroup meet
+# the boundary shell over similar node ranges (a group evaluates so3_mlp whenever ANY of its rays is in the shell).  The order comes from a
+# COARSE plain pre-march (num_nodes / 8 nodes of 8 x the step: ~0.1 ms at 4096 rays) + one sort; the kernel writes every record at the
+# ray's own index, so nothing is permuted back.  RNERF_SHELL_ORDER=0 marches the rays in the given order.
+SHELL_ORDER = os.environ.get("RNERF_SHELL_ORDER", "1") == "1"
 
 
 def _shell_order(table: torch.Tensor, spec: Grid, o: torch.Tensor, v: torch.Tensor, near: float, far: float, num_nodes: int):
-    """Permutation that groups rays whose paths meet the boundary shell (|grad n| > 1e-3, where so3_mlp is evaluated) over the same
-    node range.  The all* march evaluates the MLP for a 16-ray workgroup whenever ANY of its rays is in the shell, so coherent groups need
-    several times fewer evaluations.  The shell interval of a ray is read off a cheap pre-march without so3 (the paths differ only by
-    the so3 rotation, irrelevant for grouping); rays are results-independent, so the order changes no value."""
-    # cached per ray batch (tensor objects + versions): evaluating or training repeatedly on the same rays (render_image chunks of a
-    # static camera, bench loops, several apply() calls per batch) pays the pre-march and the sort once
+    """int32 permutation that groups rays whose paths meet the boundary shell (|grad n| > 1e-3, where so3_mlp is evaluated) over the
+    same node range.  The shell interval of a ray is read off a coarse pre-march without so3 (the so3 rotation and the step length are
+    irrelevant for grouping); rays are results-independent, so the order changes no value."""
+    # cached per ray batch (tensor objects + versions): evaluating repeatedly on the same rays pays the pre-march and the sort once
     key = (id(o), o._version, id(v), v._version, o.shape[0], int(num_nodes), table.data_ptr(), float(near), float(far))
     ent = _SHELL_CACHE.get(key)
     if ent is not None and ent[0]() is o and ent[1]() is v:
         return ent[2]
-    _, _, ior, _ = march(table, spec, o, v, near, far, num_nodes, want_ior=True)
+    nc = max(int(num_nodes) // 8, 16)
+    _, _, ior, _ = march(table, spec, o, v, near, far, nc, want_ior=True)
     g = ior[..., 1:4]
-    m = (g * g).sum(-1) > 1e-6                                       # [N, B]
+    m = (g * g).sum(-1) > 1e-6                                       # [nc, B]
     hit = m.any(0)
     first = torch.argmax(m.to(torch.uint8), 0)
-    last = num_nodes - 1 - torch.argmax(torch.flip(m, [0]).to(torch.uint8), 0)
-    skey = torch.where(hit, (first // 16) * num_nodes + last, torch.full_like(first, 2 * num_nodes * num_nodes))
-    perm = torch.argsort(skey, stable=True)
+    last = nc - 1 - torch.argmax(torch.flip(m, [0]).to(torch.uint8), 0)
+    skey = torch.where(hit, (first // 2) * nc + last, torch.full_like(first, 2 * nc * nc))
+    perm = torch.argsort(skey, stable=True).to(torch.int32)
     if len(_SHELL_CACHE) >= 8:
         _SHELL_CACHE.clear()
     _SHELL_CACHE[key] = (weakref.ref(o), weakref.ref(v), perm)
@@ -369,18 +368,14 @@ def march_all(table: torch.Tensor, spec: Grid, so3_flat: torch.Tensor, origins: 
     B = o.shape[0]
     if coherent is None:
         coherent = SHELL_ORDER
-    if coherent and B > 64:
-        perm = _shell_order(table, spec, o, v, near, far, num_nodes)
-        pd, dr, ior = march_all(table, spec, so3_flat, o[perm].contiguous(), v[perm].contiguous(), near, far, num_nodes, annealed_alpha, want_ior, False)
-        inv = torch.empty_like(perm); inv[perm] = torch.arange(B, device=perm.device)
-        return pd[:, inv].contiguous(), dr[:, inv].contiguous(), (ior[:, inv].contiguous() if ior is not None else None)
+    order = _shell_order(table, spec, o, v, near, far, num_nodes) if (coherent and B > 16) else None
     pd = torch.empty((num_nodes, B, 4), dtype=torch.float32, device=o.device)
     dr = torch.empty_like(pd)
     ior = torch.empty_like(pd) if want_ior else None
     w = so3_window(annealed_alpha)
     packed = torch.empty(lib.rnerf_so3_packed_bytes(), dtype=torch.uint8, device=o.device)
     check(lib.rnerf_march_all(ptr(table), C.byref(spec), ptr(_chk(so3_flat, "so3_flat")), ptr(packed), w.ctypes.data_as(C.c_void_p), ptr(o), ptr(v), B,
-                              float(near), float(far), int(num_nodes), ptr(pd), ptr(dr), ptr(ior), current_stream()), "rnerf_march_all")
+                              float(near), float(far), int(num_nodes), ptr(pd), ptr(dr), ptr(ior), ptr(order), current_stream()), "rnerf_march_all")
     return pd, dr, ior
 
 
@@ -393,14 +388,7 @@ def march_all_train(table: torch.Tensor, spec: Grid, so3_flat: torch.Tensor, ori
     B, N, dev = o.shape[0], int(num_nodes), o.device
     if coherent is None:
         coherent = SHELL_ORDER
-    if coherent and B > 64:
-        perm = _shell_order(table, spec, o, v, near, far, N)
-        rec = march_all_train(table, spec, so3_flat, o[perm].contiguous(), v[perm].contiguous(), near, far, N, annealed_alpha, pair_cap, False)
-        inv = torch.empty_like(perm); inv[perm] = torch.arange(B, device=dev)
-        for k in ("path_pd", "path_dr", "path_rdn", "pair_of_node"):
-            rec[k] = rec[k][:, inv].contiguous()
-        rec["pair_id"][:, 0] = perm[rec["pair_id"][:, 0].long()].to(torch.int32)
-        return rec
+    order = _shell_order(table, spec, o, v, near, far, N) if (coherent and B > 16) else None
     cap = int(pair_cap) if pair_cap else N * B
     pd = torch.empty((N, B, 4), dtype=torch.float32, device=dev); dr = torch.empty_like(pd); rdn = torch.empty_like(pd)
     count = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -411,13 +399,12 @@ def march_all_train(table: torch.Tensor, spec: Grid, so3_flat: torch.Tensor, ori
     packed = torch.empty(lib.rnerf_so3_packed_bytes(), dtype=torch.uint8, device=dev)
     check(lib.rnerf_march_all_train(ptr(table), C.byref(spec), ptr(_chk(so3_flat, "so3_flat")), ptr(packed), w.ctypes.data_as(C.c_void_p), ptr(o), ptr(v), B,
                                     float(near), float(far), N, ptr(pd), ptr(dr), ptr(rdn), ptr(count), cap, ptr(pair_id), ptr(pair_x), ptr(pair_g),
-                                    ptr(pair_of_node), current_stream()), "rnerf_march_all_train")
+                                    ptr(pair_of_node), ptr(order), current_stream()), "rnerf_march_all_train")
     n = int(count.item())
     if n > cap:
         raise _lib.RnerfError(f"march_all_train: {n} boundary-shell pairs exceed pair_cap = {cap}")
     return dict(path_pd=pd, path_dr=dr, path_rdn=rdn, n_pairs=n, pair_id=pair_id[:n], pair_x=pair_x[:n].contiguous(), pair_g=pair_g[:n].contiguous(),
                 pair_of_node=pair_of_node, window=w)
-
 
 def so3_forward_train(so3_flat: torch.Tensor, window, pts4: torch.Tensor):
     """so3_mlp(annealed_pos_enc(x)) on pts4 [n,4] with saved activations -> (raw [n,4] view into save, save)."""

@@ -86,8 +86,8 @@ def _reference(model, state, batch, flags, taps, ev, grid, o, d, theta0):
 
 @pytest.mark.parametrize("Nf,bwd,B", [(0, "f32", 48), (12, "f32", 48), (0, "tf32", 48), (12, "f32", 160)])
 def test_all_stage_gradients(Nf, bwd, B, monkeypatch):
-    """B = 160 (> 64) with the shell-coherent ray permutation of ops.march_all_train switched on (RNERF_SHELL_ORDER=1; off by default): the
-    record is marched in sorted order and un-permuted (path, pair ids, pair_of_node) before the backward reads it."""
+    """B = 160 with the shell-coherent ray order handed to the march kernel (ops._shell_order; records are written at the rays' own
+    indices), the B = 48 cases in the given order."""
     from samplenerfro_amd.train import train_step
     from samplenerfro_amd import ops
     monkeypatch.setattr(ops, "SHELL_ORDER", B > 64)

@@ -40,16 +40,22 @@ g = ior[..., 1:4]
 m = (g * g).sum(-1) > 1e-6            # [N, B]
 pairs = int(m.sum())
 print(f"{wl}: {B} rays x {N} nodes, shell pairs {pairs} = {pairs / (B * N):.3%} of the nodes; rays touching the shell {int(m.any(0).sum())}")
-perm = ops._shell_order(model.table, model.spec, o, d, cfg["near"], cfg["far"], N)
+perm = ops._shell_order(model.table, model.spec, o, d, cfg["near"], cfg["far"], N).long()     # from the COARSE pre-march (N / 8 nodes)
 for name, mm in (("given order", m), ("shell order", m[:, perm])):
     for W in (64, 32, 16, 8):
         ev = int(mm.reshape(N, B // W, W).any(-1).sum())
-        print(f"  {name}: {W:2d}-ray waves: {ev} wave evaluations ({ev * W / max(pairs, 1):.2f} x the pairs), worst wave {int(mm.reshape(N, B // W, W).any(-1).sum(0).max())} of {N} nodes")
+        print(f"  {name}: {W:2d}-ray groups: {ev} group evaluations ({ev * W / max(pairs, 1):.2f} x the pairs), worst group {int(mm.reshape(N, B // W, W).any(-1).sum(0).max())} of {N} nodes")
 
 t_plain = timed(lambda: ops.march(model.table, model.spec, o, d, cfg["near"], cfg["far"], N))
-op = o[perm].contiguous(); dp = d[perm].contiguous()
-t_all_c = timed(lambda: ops.march_all(model.table, model.spec, so3, op, dp, cfg["near"], cfg["far"], N, 1.0, False, False))
-t_all_g = timed(lambda: ops.march_all(model.table, model.spec, so3, o, d, cfg["near"], cfg["far"], N, 1.0, False, False))
-t_all = timed(lambda: ops.march_all(model.table, model.spec, so3, o, d, cfg["near"], cfg["far"], N, 1.0, False, True))
-print(f"plain march {t_plain:.3f} ms; all* march: kernel on pre-sorted rays {t_all_c:.3f} ms, kernel on the given order {t_all_g:.3f} ms, "
-      f"ops.march_all (cached order + gathers) {t_all:.3f} ms")
+t_given = timed(lambda: ops.march_all(model.table, model.spec, so3, o, d, cfg["near"], cfg["far"], N, 1.0, False, False))
+t_cached = timed(lambda: ops.march_all(model.table, model.spec, so3, o, d, cfg["near"], cfg["far"], N, 1.0, False, True))
+
+
+def fresh():
+    ops._SHELL_CACHE.clear()
+    return ops.march_all(model.table, model.spec, so3, o, d, cfg["near"], cfg["far"], N, 1.0, False, True)
+
+
+t_fresh = timed(fresh)
+print(f"plain march {t_plain:.3f} ms; all* march: given ray order {t_given:.3f} ms, shell order handed to the kernel {t_cached:.3f} ms (order cached), "
+      f"{t_fresh:.3f} ms with the coarse pre-march + sort of a new batch")
