@@ -2656,7 +2656,15 @@ template <int KIND>
 __global__ void __launch_bounds__(256) bkgd_wgrad_kernel(const float* __restrict__ save, const float* __restrict__ dy, long long n,
                                                          float* __restrict__ partial) {
   __shared__ float red[4][4][1024 + 32];            // [wave][n-tile][acc reg * 64 + lane] (+ the bias row)
-  const BkgdUnit u = KIND == 0 ? kBkgdUnits[blockIdx.y] : kSo3Units[blockIdx.y];
+  // 1-D grid, XCD-aware: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so workgroup b = 8 slot + xcd takes
+  // unit slot % UNITS of chunk 8 (slot / UNITS) + xcd: the UNITS workgroups that read the same 256 rows of dY (each layer's dY by its
+  // 4-5 k-tiles) run back to back on ONE XCD and share them in its L2 (with (chunk, unit) as grid (x, y) they were `chunks` workgroups
+  // apart: every re-read went to memory).
+  constexpr int UNITS = SmallNet<KIND>::UNITS;
+  const int slot = blockIdx.x >> 3, xcd = blockIdx.x & 7;
+  const int chunk = 8 * (slot / UNITS) + xcd, unit = slot % UNITS;
+  if ((long long)chunk * 256 >= n) return;
+  const BkgdUnit u = KIND == 0 ? kBkgdUnits[unit] : kSo3Units[unit];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 31, h = lane >> 5;
   const float* __restrict__ X = u.xk == 0 ? save : save + (size_t)n * SmallNet<KIND>::ENC_LD + (size_t)(u.xk - 1) * n * 128;
   const float* __restrict__ dY = dy + (size_t)u.dk * n * 128;
@@ -2666,36 +2674,58 @@ __global__ void __launch_bounds__(256) bkgd_wgrad_kernel(const float* __restrict
   const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   f32x16 acc[4] = {zero, zero, zero, zero};
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};               // bias row: this lane's share of sum_rows dY[row][its column] (plain VALU adds)
-  const long long r0 = (long long)blockIdx.x * 256 + wave * 64;
-  // unconditional loads from clamped addresses + selects: with run-time predicates around the loads hipcc emits a branch and a
-  // vmcnt(0) per load, which serialises them; the n-tile count and the bias row are compile-time instances.
-  // With 4 n-tiles (a 128-wide dY) n-tile nt is the columns {4 m + nt}: one 16-byte load per lane and row feeds all four MFMAs
-  // (the kernel is bound by the latency of its operand loads, not by the matrix pipe).
+  const long long r0 = (long long)chunk * 256 + wave * 64;
+  // Operand loads: unconditional, from clamped addresses, a BATCH of 8 row pairs ahead of the MFMAs that consume them, and made opaque
+  // (empty asm on the loaded registers) before the row / column predicates are applied.  Without the last step hipcc turns
+  // `ok ? load : 0` back into a branch around the load followed by s_waitcnt vmcnt(0): two exposed round trips per 4 MFMAs
+  // (the so3 instance ran at a sixth of the matrix rate: 1.06 ms for 208 k rows).  The n-tile count and the bias row are compile-time
+  // instances.  With 4 n-tiles (a 128-wide dY) n-tile nt is the columns {4 m + nt}: one 16-byte load per lane and row feeds all four MFMAs.
   const int kc = k < u.kin ? k : u.kin - 1;
+  const bool kin_ok = k < u.kin;
   auto rows = [&](auto nt_c, auto bias_c) {
     constexpr int NTC = decltype(nt_c)::value;
     constexpr bool BIAS = decltype(bias_c)::value;
-#pragma unroll 16
-    for (int i = 0; i < 32; ++i) {
-      const long long rr = r0 + 2 * i + h;
-      const bool ok = rr < n;
-      const size_t rc = (size_t)(ok ? rr : n - 1);
-      const float av = X[rc * u.ldx + kc];
-      const float a = (ok && k < u.kin) ? av : 0.f;
-      if constexpr (NTC == 4) {
-        const float4 bv = *(const float4*)(dY + rc * 128 + 4 * m);
-        const float b[4] = {ok ? bv.x : 0.f, ok ? bv.y : 0.f, ok ? bv.z : 0.f, ok ? bv.w : 0.f};
+    constexpr int BS = 8, NB = 32 / BS;
+    float av[2][BS];
+    float4 bv[2][BS];
+    const int mc = m < u.nout ? m : u.nout - 1;
+    auto fetch = [&](int bi, int buf) {
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[nt], acc[nt], 0, 0, 0);
-          if constexpr (BIAS) bsum[nt] += b[nt];
-        }
-      } else {
-        const float bv = dY[rc * u.ldy + (m < u.nout ? m : u.nout - 1)];
-        const float b = (ok && m < u.nout) ? bv : 0.f;
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[0], 0, 0, 0);
-        if constexpr (BIAS) bsum[0] += b;
+      for (int j = 0; j < BS; ++j) {
+        const long long rr = r0 + 2 * (bi * BS + j) + h;
+        const size_t rc = (size_t)(rr < n ? rr : n - 1);
+        av[buf][j] = X[rc * u.ldx + kc];
+        if constexpr (NTC == 4) bv[buf][j] = *(const float4*)(dY + rc * 128 + 4 * m);
+        else bv[buf][j].x = dY[rc * u.ldy + mc];
       }
+    };
+    fetch(0, 0);
+#pragma unroll
+    for (int bi = 0; bi < NB; ++bi) {
+      if (bi + 1 < NB) fetch(bi + 1, (bi + 1) & 1);
+      RNERF_PIN();
+#pragma unroll
+      for (int j = 0; j < BS; ++j) {
+        const bool ok = r0 + 2 * (bi * BS + j) + h < n;
+        float a = av[bi & 1][j];
+        float4 q = bv[bi & 1][j];
+        if constexpr (NTC == 4) asm volatile("" : "+v"(a), "+v"(q.x), "+v"(q.y), "+v"(q.z), "+v"(q.w));
+        else asm volatile("" : "+v"(a), "+v"(q.x));
+        a = (ok && kin_ok) ? a : 0.f;
+        if constexpr (NTC == 4) {
+          const float b[4] = {ok ? q.x : 0.f, ok ? q.y : 0.f, ok ? q.z : 0.f, ok ? q.w : 0.f};
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) {
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[nt], acc[nt], 0, 0, 0);
+            if constexpr (BIAS) bsum[nt] += b[nt];
+          }
+        } else {
+          const float b = (ok && m < u.nout) ? q.x : 0.f;
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[0], 0, 0, 0);
+          if constexpr (BIAS) bsum[0] += b;
+        }
+      }
+      RNERF_PIN();
     }
   };
   using I1 = std::integral_constant<int, 1>; using I4 = std::integral_constant<int, 4>;
@@ -2712,7 +2742,7 @@ __global__ void __launch_bounds__(256) bkgd_wgrad_kernel(const float* __restrict
   __syncthreads();
   const int nt = wave;                                // wave w sums n-tile w over the 4 waves
   if (nt < NT) {
-    float* pg = partial + (size_t)blockIdx.x * SmallNet<KIND>::NPARAMS;
+    float* pg = partial + (size_t)chunk * SmallNet<KIND>::NPARAMS;
     const int nn = NT == 4 ? 4 * m + nt : m;          // the column this lane's accumulator entries belong to
     if (nn < u.nout) {
 #pragma unroll
@@ -3194,7 +3224,7 @@ extern "C" int rnerf_bkgd_backward_wgrad(const void* save, void* dy, int64_t n, 
   if (coresident)
     hipLaunchKernelGGL(bkgd_wgrad_co_kernel<0>, dim3(chunks, 18, 2), dim3(64), 0, st, sv, (const float*)dyf, (long long)n, partial);
   else
-    hipLaunchKernelGGL(bkgd_wgrad_kernel<0>, dim3(chunks, 18), dim3(256), 0, st, sv, (const float*)dyf, (long long)n, partial);
+    hipLaunchKernelGGL(bkgd_wgrad_kernel<0>, dim3(((chunks + 7) / 8) * 8 * SmallNet<0>::UNITS), dim3(256), 0, st, sv, (const float*)dyf, (long long)n, partial);
   hipLaunchKernelGGL(bkgd_wgrad_reduce_kernel<RNERF_BKGDMLP_PARAMS>, dim3((RNERF_BKGDMLP_PARAMS + 255) / 256), dim3(256), 0, st, (const float*)partial, (int)chunks,
                      grads);
   RNERF_CHECK_LAUNCH();
