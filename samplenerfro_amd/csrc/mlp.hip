@@ -208,6 +208,15 @@ __device__ __forceinline__ float pe_sin(float a) {
   p.s0(a); p.s1(); p.s2();
   return p.s3();
 }
+__device__ __forceinline__ float pe_cos(float a) {      // the cosine from the same reduction and polynomials (the next quadrant's sine)
+  PeSin p;
+  p.s0(a); p.s1(); p.s2();
+  const int q = (int)p.k;
+  const float z = p.z;
+  const float cp = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f), z * z, fmaf(-0.5f, z, 1.0f));
+  const float vc = (q & 1) ? p.sp : cp;
+  return ((q + 1) & 2) ? -vc : vc;
+}
 // sin and cos of one argument from one range reduction (cos a = the next quadrant's sine)
 __device__ __forceinline__ void pe_sincos(float a, float& sn, float& cs) {
   PeSin p;
