@@ -516,6 +516,35 @@ def test_march_all_stage(scene):
     assert np.array_equal(pd2.cpu().numpy().transpose(1, 0, 2), pd) and np.array_equal(dr2.cpu().numpy().transpose(1, 0, 2), dr)   # four waves per block, LDS exchange: no race
 
 
+@pytest.mark.parametrize("B", [37, 5])
+def test_march_all_ragged_batch(scene, B):
+    """A batch that does not fill its last 16-ray workgroup (surplus quads replay the last ray with their records suppressed), with and
+    without a ray order: rays are independent, so the first B rays of the 96-ray batch must come out bit for bit; the training record's
+    pair list must be a consistent index of exactly the nodes inside the shell."""
+    from samplenerfro_amd import ops
+    flat, _ = _so3(out_std=0.1)
+    N, alpha = 96, 0.8
+    o, d = T(scene.o), T(scene.d)
+    pd_all, dr_all, ior_all = ops.march_all(scene.table_d, scene.spec, T(flat), o, d, 2.0, 6.0, N, alpha, True, False)
+    ob, db = o[:B].contiguous(), d[:B].contiguous()
+    for coherent in (False, True):
+        pd, dr, ior = ops.march_all(scene.table_d, scene.spec, T(flat), ob, db, 2.0, 6.0, N, alpha, True, coherent)
+        assert torch.equal(pd, pd_all[:, :B]) and torch.equal(dr, dr_all[:, :B]) and torch.equal(ior, ior_all[:, :B])
+        rec = ops.march_all_train(scene.table_d, scene.spec, T(flat), ob, db, 2.0, 6.0, N, alpha, None, coherent)
+        assert torch.equal(rec["path_pd"], pd) and torch.equal(rec["path_dr"], dr)
+        g = ior[..., 1:4]
+        g2 = (g[..., 0] * g[..., 0] + g[..., 1] * g[..., 1]) + g[..., 2] * g[..., 2]                          # the kernel's association
+        inside = g2 > float(np.frombuffer(np.uint32(0x358637BE).tobytes(), np.float32)[0])                  # and its threshold (sqrt_rn(s) > 1e-3)
+        pon = rec["pair_of_node"]
+        assert torch.equal(pon >= 0, inside) and rec["n_pairs"] == int(inside.sum())
+        idx = pon[inside].long()
+        assert torch.equal(torch.sort(idx).values, torch.arange(rec["n_pairs"], device=idx.device))          # every pair exactly once
+        kk, rr = torch.nonzero(inside, as_tuple=True)
+        assert torch.equal(rec["pair_id"][idx].long(), torch.stack([rr, kk], 1))
+        assert torch.equal(rec["pair_x"][idx][:, :3], pd[kk, rr, :3]) and torch.equal(rec["pair_g"][idx][:, :3], g[kk, rr])
+        assert torch.equal(rec["path_rdn"][..., 3], ior[..., 0])
+
+
 def test_model_stage_all_end_to_end():
     """NerfModel with stage="all" (forward): RGB within 1e-4 of the oracle run with the same so3 parameters."""
     from samplenerfro_amd import models
