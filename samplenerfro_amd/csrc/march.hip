@@ -21,17 +21,75 @@ struct MarchParams {
 // divisions, the 7 four-component lerps and the state update of one step run in parallel across the quad and the
 // per-step dependent instruction chain is ~2.5x shorter than with one lane per ray.  Every value is produced by the same
 // individually rounded fp32 ops, in the same order, as rnerf/eikonal_utils.py:29-49 + rnerf/ior_utils.py:188-223.
+//
+// Two waves per 16 rays (round 3).  The kernel is bound by the instruction issue of ONE wave per step (~4 cycles per instruction), and
+// a third of a step's instructions produced the node RECORD — the safe-normalised direction (a correctly rounded sqrt + an IEEE
+// division), the travelled distance (another sqrt), the two stores and their addresses — none of which the recurrence needs.  Wave 0
+// (the marcher) now only advances the state and leaves (p, d) of every node in an LDS ring; wave 1 (the recorder), on another SIMD of
+// the CU, turns them into records a chunk of kMarchChunk nodes later.  One s_barrier per chunk and wave: the recorder reads chunk c
+// between barriers c and c + 1, the marcher overwrites that half of the ring only after barrier c + 1.  Same values, same bits.
+// With the record gone a step takes 0.26 us, and two steps of lead no longer cover an HBM round trip on a 512^3 table (2.1 GB): the
+// corners are gathered kMarchAhead steps ahead, into kMarchAhead + 1 register sets that rotate through an unrolled trip.
+#ifndef RNERF_MARCH_AHEAD
+#define RNERF_MARCH_AHEAD 2
+#endif
+constexpr int kMarchAhead = RNERF_MARCH_AHEAD;
+constexpr int kMarchSets = kMarchAhead + 1;
+constexpr int kMarchChunk = kMarchSets <= 4 ? 2 * kMarchSets : kMarchSets;      // nodes per ring half (a multiple of the register rotation); 2 x C x 512 B of LDS
+static_assert(2 * kMarchChunk * 512 <= 12 * 1024, "the ring must fit beside the weight-gradient kernel's LDS (148 KiB)");
+
+__device__ __forceinline__ void march_chunk_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <bool WANT_IOR, bool WANT_VOX>
-__global__ void __launch_bounds__(64) march_kernel(const float* __restrict__ table, MarchParams g,
-                                                   const float* __restrict__ origins, const float* __restrict__ viewdirs,
-                                                   int B, float near, float step, int num_nodes,
-                                                   float* __restrict__ path_pd, float* __restrict__ path_dr,
-                                                   float* __restrict__ path_ior, int* __restrict__ vox) {
-  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(128) march_kernel(const float* __restrict__ table, MarchParams g,
+                                                    const float* __restrict__ origins, const float* __restrict__ viewdirs,
+                                                    int B, float near, float step, int num_nodes,
+                                                    float* __restrict__ path_pd, float* __restrict__ path_dr,
+                                                    float* __restrict__ path_ior, int* __restrict__ vox) {
+  constexpr int C = kMarchChunk;
+  __shared__ float2 ring[2][C][64];               // (p, d) of the lane's coordinate, per node
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int gid = blockIdx.x * 64 + lane;
   const int q = gid & 3;
   int r = gid >> 2;
   if (r >= B) r = B - 1;   // surplus quads replay the last ray (same values to the same addresses, no divergence)
   const int qc = q < 3 ? q : 0;
+  const int nchunks = (num_nodes + C - 1) / C;    // the marcher always runs whole chunks (surplus nodes: clamped gathers, nothing stored)
+  const size_t node_stride = 4 * (size_t)B;
+
+  if (wave != 0) {
+    // ---- the recorder: node k = state before step k (eikonal_utils.py:112-114), direction safe-normalised (math_utils.py:6-12),
+    //      distance = near + the lengths of the steps so far (eikonal_utils.py:46)
+    float* __restrict__ out_pd = path_pd + 4 * (size_t)r + q;          // advanced by one node (B records) per node
+    float* __restrict__ out_dr = path_dr + 4 * (size_t)r + q;
+    float rt = near, p_prev = 0.f;
+    for (int c = 0; c < nchunks; ++c) {
+      march_chunk_barrier();                                           // chunk c is in the ring
+      const float2* __restrict__ src = &ring[c & 1][0][lane];
+#pragma unroll
+      for (int s = 0; s < C; ++s) {
+        const int k = c * C + s;
+        if (k >= num_nodes) break;
+        const float2 v = src[s * 64];
+        const float p = v.x, d = v.y;
+        if (k > 0) rt = fadd(rt, fsqrt(quad_sumsq3(fsub(p_prev, p))));
+        p_prev = p;
+        const float nrm = fsqrt(fmaxf(quad_sumsq3(d), 1e-6f));
+#ifdef RNERF_MARCH_NT
+        __builtin_nontemporal_store(q < 3 ? p : rt, out_pd);
+        __builtin_nontemporal_store(q < 3 ? fdiv(d, nrm) : 0.f, out_dr);
+#else
+        *out_pd = q < 3 ? p : rt;
+        *out_dr = q < 3 ? fdiv(d, nrm) : 0.f;
+#endif
+        out_pd += node_stride; out_dr += node_stride;
+      }
+    }
+    return;
+  }
+
+  // ---- the marcher
   const float nmin_q = g.nmin[qc];
   const double rcp_q = g.rcp_nd[qc];
   const int dim_q = qc == 0 ? g.dx : (qc == 1 ? g.dy : g.dz);
@@ -42,7 +100,6 @@ __global__ void __launch_bounds__(64) march_kernel(const float* __restrict__ tab
   const unsigned cofs = comp * 4u;
   float d = q < 3 ? viewdirs[3 * r + qc] : 0.f;
   float p = q < 3 ? fadd(origins[3 * r + qc], fmul(near, d)) : 0.f;   // eikonal_utils.py:104-106
-  float rt = near;
 
   // The gathers of steps k+1 and k+2 are issued EARLY, from predicted cells (grid coordinate extrapolated linearly from the
   // last two nodes), so that their latency overlaps the arithmetic of the steps before instead of adding to the per-step
@@ -50,7 +107,7 @@ __global__ void __launch_bounds__(64) march_kernel(const float* __restrict__ tab
   // the values in flight are exactly the ones the reference gathers; different (ray within ~1 ulp of a cell face, a few per
   // million steps) -> they are gathered again.  Results stay bit-identical to the un-speculated march.
   struct Corners { float c[8]; int i0, i1; };     // 000 100 001 101 010 110 011 111 (xyz) + the indices they were gathered with
-  Corners ca, cb, cc;
+  Corners cs[kMarchSets];
   auto gather = [&](int i0, int i1, Corners& o) {
     o.i0 = i0; o.i1 = i1;
     const unsigned x0 = quad_bcast_i<0>(i0), x1 = quad_bcast_i<0>(i1);
@@ -75,15 +132,14 @@ __global__ void __launch_bounds__(64) march_kernel(const float* __restrict__ tab
   {
     const float x = div_const(fsub(p, nmin_q), rcp_q);
     x_prev = div_const(fsub(fsub(p, fmul(step, d)), nmin_q), rcp_q);   // as if a vacuum step had led here
-    predict(x, ca);
-    predict(fadd(x, fsub(x, x_prev)), cb);
+    const float dx0 = fsub(x, x_prev);
+#pragma unroll
+    for (int j = 0; j < kMarchAhead; ++j) predict(fadd(x, fmul((float)j, dx0)), cs[j]);
   }
-  float* __restrict__ out_pd = path_pd + 4 * (size_t)r + q;          // advanced by one node (B records) per step
-  float* __restrict__ out_dr = path_dr + 4 * (size_t)r + q;
   float* __restrict__ out_ior = WANT_IOR ? path_ior + 4 * (size_t)r + comp : nullptr;
-  const size_t node_stride = 4 * (size_t)B;
-  // one step; cn = corners of this step, nx = where the corners of step k+2 are gathered to
-  auto one_step = [&](int k, Corners& cn, Corners& nx) {
+  // one step; cn = corners of this step, nx = where the corners of step k + kMarchAhead are gathered to, slot = this node's ring entry
+  auto one_step = [&](int k, Corners& cn, Corners& nx, float2* slot) {
+    *slot = make_float2(p, d);                     // the node record is the recorder's business
     // ---- VoxMLP._linear3 addressing (ior_utils.py:188-211): one coordinate per lane
 #if defined(RNERF_MARCH_ABL) && (RNERF_MARCH_ABL & 4)   /* profiling ablation: f32 multiply instead of the f64 product */
     const float x = fmul(fsub(p, nmin_q), (float)rcp_q);
@@ -97,23 +153,12 @@ __global__ void __launch_bounds__(64) march_kernel(const float* __restrict__ tab
 #if !(defined(RNERF_MARCH_ABL) && (RNERF_MARCH_ABL & 8))   /* profiling ablation: no misprediction check */
     if (__builtin_amdgcn_ballot_w64(i0 != cn.i0 || i1 != cn.i1) != 0) gather(i0, i1, cn);     // mispredicted somewhere in the wave
 #endif
-    // ---- speculative gather for step k+2
+    // ---- speculative gather for step k + kMarchAhead
     const float dx = fsub(x, x_prev);
-    predict(fadd(x, fadd(dx, dx)), nx);
+    predict(kMarchAhead == 2 ? fadd(x, fadd(dx, dx)) : fadd(x, fmul((float)kMarchAhead, dx)), nx);
     x_prev = x;
     const float xd = quad_bcast<0>(t), yd = quad_bcast<1>(t), zd = quad_bcast<2>(t);
-    // ---- node record while the gathers are in flight: node k = state before step k (eikonal_utils.py:112-114),
-    //      direction safe-normalised (math_utils.py:6-12)
-    const float nrm = fsqrt(fmaxf(quad_sumsq3(d), 1e-6f));
-#ifdef RNERF_MARCH_NT
-    __builtin_nontemporal_store(q < 3 ? p : rt, out_pd);
-    __builtin_nontemporal_store(q < 3 ? fdiv(d, nrm) : 0.f, out_dr);
-#else
-    *out_pd = q < 3 ? p : rt;
-    *out_dr = q < 3 ? fdiv(d, nrm) : 0.f;
-#endif
-    out_pd += node_stride; out_dr += node_stride;
-    if (WANT_VOX && q < 3) { const size_t o = (size_t)k * B + r; vox[6 * o + 2 * q] = i0; vox[6 * o + 2 * q + 1] = i1; }
+    if (WANT_VOX && q < 3 && k < num_nodes) { const size_t o = (size_t)k * B + r; vox[6 * o + 2 * q] = i0; vox[6 * o + 2 * q + 1] = i1; }
     // ---- 7 lerps a*(1-t) + b*t (ior_utils.py:214-222)
     const float oxd = fsub(1.0f, xd), oyd = fsub(1.0f, yd), ozd = fsub(1.0f, zd);
     const float c00 = fadd(fmul(cn.c[0], oxd), fmul(cn.c[1], xd));
@@ -123,7 +168,7 @@ __global__ void __launch_bounds__(64) march_kernel(const float* __restrict__ tab
     const float c0 = fadd(fmul(c00, oyd), fmul(c10, yd));
     const float c1 = fadd(fmul(c01, oyd), fmul(c11, yd));
     const float c = fadd(fmul(c0, ozd), fmul(c1, zd));   // lanes 0..2: grad component q, lane 3: n
-    if (WANT_IOR) { *out_ior = c; out_ior += node_stride; }
+    if (WANT_IOR && k < num_nodes) { *out_ior = c; out_ior += node_stride; }
     // ---- OneEikonalStep (eikonal_utils.py:41-45)
     const float n = quad_bcast<3>(c);
 #if defined(RNERF_MARCH_ABL) && (RNERF_MARCH_ABL & 2)   /* profiling ablation: no IEEE division on the chain */
@@ -131,19 +176,16 @@ __global__ void __launch_bounds__(64) march_kernel(const float* __restrict__ tab
 #else
     const float s = fdiv(step, n);
 #endif
-    const float np = fadd(p, fmul(s, d));
+    p = fadd(p, fmul(s, d));
     d = fadd(d, fmul(step, c));
-    rt = fadd(rt, fsqrt(quad_sumsq3(fsub(p, np))));
-    p = np;
   };
-  int k = 0;
-  for (; k + 2 < num_nodes; k += 3) {      // three steps per trip: the corner register sets rotate instead of being copied
-    one_step(k, ca, cc);
-    one_step(k + 1, cb, ca);
-    one_step(k + 2, cc, cb);
+  static_assert(C % kMarchSets == 0, "a chunk is a whole number of register rotations");
+  for (int c = 0, k = 0; c < nchunks; ++c, k += C) {      // the corner register sets rotate instead of being copied
+    float2* slot = &ring[c & 1][0][lane];
+#pragma unroll
+    for (int u = 0; u < C; ++u) one_step(k + u, cs[u % kMarchSets], cs[(u + kMarchAhead) % kMarchSets], slot + 64 * u);
+    march_chunk_barrier();
   }
-  if (k < num_nodes) { one_step(k, ca, cc); ++k; }
-  if (k < num_nodes) one_step(k, cb, ca);
 }
 
 }  // namespace rnerf
@@ -167,7 +209,7 @@ extern "C" int rnerf_march(const float* table, const rnerf_grid* g, const float*
   p.rcp_nd[0] = 1.0 / (double)gp.ndx; p.rcp_nd[1] = 1.0 / (double)gp.ndy; p.rcp_nd[2] = 1.0 / (double)gp.ndz;
   const float stepf = (float)((far - near) / (num_nodes - 1));  // models.py:122, Python double -> f32
   const float nearf = (float)near;
-  const dim3 block(64), grid((B + 15) / 16);   // 16 rays (quads) per wave: one wave per CU at B = 4096
+  const dim3 block(128), grid((B + 15) / 16);   // 16 rays (quads) per workgroup = marcher + recorder wave: one workgroup per CU at B = 4096
   hipStream_t st = (hipStream_t)stream;
 #define LAUNCH(I, V)                                                                                               \
   hipLaunchKernelGGL((march_kernel<I, V>), grid, block, 0, st, table, p, origins, viewdirs, B, nearf, stepf, num_nodes, \

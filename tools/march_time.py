@@ -23,3 +23,21 @@ for G in (64, 256, 512):
     ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(5)]
     print(f"G={G} march ms min/med = {min(ms):.3f}/{np.median(ms):.3f}  per-step us = {np.median(ms)*1e3/N:.3f}")
     del table
+# the refractive scene of BASELINE configs[2] (glass sphere after the (9, 3.0) prefilter): the rays bend, the speculative gathers mispredict
+for G in (256, 512):
+    spec = _lib.Grid.make([G] * 3, [-1.5] * 3, [1.5] * 3)
+    grid = torch.from_numpy(syn.scale_ior(syn.sphere_grid(G, 1.5, 0.6), 0.5).astype(np.float32)).to(dev)
+    grid = ops.grid_prefilter(grid, 9, 3.0)
+    table = ops.grid_build_table(grid, spec)
+    del grid
+    pd, dr, _, _ = ops.march(table, spec, o, d, 2.0, 6.0, N)
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+    ev[0].record()
+    for i in range(5):
+        ops.march(table, spec, o, d, 2.0, 6.0, N, out=(pd, dr))
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(5)]
+    print(f"refractive sphere G={G} march ms min/med = {min(ms):.3f}/{np.median(ms):.3f}")
+    del table
