@@ -91,6 +91,30 @@ def test_march_bit_exact(radius):
         assert np.all(ior[..., 0] == 1) and np.all(ior[..., 1:] == 0)
 
 
+@pytest.mark.parametrize("N,B", [(2, 1), (5, 17), (6, 16), (7, 50), (13, 33), (100, 3)])
+def test_march_ragged_chunks(N, B):
+    """The marcher / recorder pair works in chunks of 6 nodes and 16 rays: node counts and batches that end inside a chunk (surplus nodes are
+    marched but never stored, surplus quads replay the last ray), with and without the IoR / voxel-index outputs (four kernel variants)."""
+    from samplenerfro_amd import ops
+    sc = Scene(radius=0.6, ksize=3, B=B, seed=11)
+    pos, dirs, dist, n, g, vox = R.path_sampler(sc.o, sc.d, sc.table, sc.ndim, sc.nmin, sc.nmax, 2.0, 6.0, N, return_idx=True)
+    for want_ior, want_vox in ((False, False), (True, False), (False, True), (True, True)):
+        guard = torch.full((N + 2, B, 4), 7.0, device=dev())          # a node past the end would land in the guard rows
+        gdr = torch.full((N + 2, B, 4), 7.0, device=dev())
+        pd, dr, ior, vx = ops.march(sc.table_d, sc.spec, T(sc.o), T(sc.d), 2.0, 6.0, N, want_ior=want_ior, want_vox=want_vox,
+                                    out=(guard[:N], gdr[:N]))
+        assert bool((guard[N:] == 7.0).all()) and bool((gdr[N:] == 7.0).all())
+        pd, dr = pd.cpu().numpy(), dr.cpu().numpy()
+        np.testing.assert_array_equal(pd[..., :3].transpose(1, 0, 2), pos)
+        np.testing.assert_array_equal(pd[..., 3].T, dist)
+        np.testing.assert_array_equal(dr[..., :3].transpose(1, 0, 2), dirs)
+        if want_ior:
+            np.testing.assert_array_equal(ior.cpu().numpy()[..., :1].transpose(1, 0, 2), n)
+            np.testing.assert_array_equal(ior.cpu().numpy()[..., 1:].transpose(1, 0, 2), g)
+        if want_vox:
+            np.testing.assert_array_equal(vx.cpu().numpy().transpose(1, 0, 2), vox)
+
+
 def _rows(pos, dirs, dist):
     """[B,S,·] oracle arrays -> sample-major float4 records."""
     B, S = dist.shape
