@@ -40,6 +40,28 @@ static_assert(2 * kMarchChunk * 512 <= 12 * 1024, "the ring must fit beside the 
 
 __device__ __forceinline__ void march_chunk_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// The marcher is bound by instruction issue, so its integer glue is written as the instructions the ISA has for it (hipcc emits 3-4 for
+// each): clamp to [0, hi] = the median of (v, 0, hi); floor + convert in one; a*(1-t) + b*t with both products in one packed multiply
+// (v_pk_mul_f32 rounds each half like v_mul_f32: the same individually rounded ops in the same order).
+__device__ __forceinline__ int clamp0(int v, int hi) {
+  int r;
+  asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(v), "v"(hi));
+  return r;
+}
+__device__ __forceinline__ int floor_to_int(float x) {
+  int r;
+  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float lerp_pk(float a, float b, f32x2 w) {       // w = (1 - t, t)
+  const f32x2 v = {a, b};
+  const f32x2 m = v * w;
+  float r;      // as the instruction: left to itself hipcc pairs the sums of two lerps into v_pk_add_f32 and pays for it in register moves
+  asm("v_add_f32_e32 %0, %1, %2" : "=v"(r) : "v"(m.x), "v"(m.y));
+  return r;
+}
+
 template <bool WANT_IOR, bool WANT_VOX>
 __global__ void __launch_bounds__(128) march_kernel(const float* __restrict__ table, MarchParams g,
                                                     const float* __restrict__ origins, const float* __restrict__ viewdirs,
@@ -98,6 +120,8 @@ __global__ void __launch_bounds__(128) march_kernel(const float* __restrict__ ta
   const unsigned s1 = (unsigned)g.dy * (unsigned)g.dz * 16u, s2 = (unsigned)g.dz * 16u;
   const char* __restrict__ tabc = (const char*)table;   // uniform base; this lane's component goes into the 32-bit offset
   const unsigned cofs = comp * 4u;
+  const unsigned stride_q = q == 0 ? s1 : (q == 1 ? s2 : 16u);      // byte stride of this lane's axis
+  const int hi_q = dim_q - 1;
   float d = q < 3 ? viewdirs[3 * r + qc] : 0.f;
   float p = q < 3 ? fadd(origins[3 * r + qc], fmul(near, d)) : 0.f;   // eikonal_utils.py:104-106
 
@@ -110,11 +134,11 @@ __global__ void __launch_bounds__(128) march_kernel(const float* __restrict__ ta
   Corners cs[kMarchSets];
   auto gather = [&](int i0, int i1, Corners& o) {
     o.i0 = i0; o.i1 = i1;
-    const unsigned x0 = quad_bcast_i<0>(i0), x1 = quad_bcast_i<0>(i1);
-    const unsigned y0 = quad_bcast_i<1>(i0), y1 = quad_bcast_i<1>(i1);
-    const unsigned z0 = quad_bcast_i<2>(i0) * 16u + cofs, z1 = quad_bcast_i<2>(i1) * 16u + cofs;
-    const unsigned bx0 = __umul24(x0, s1), bx1 = __umul24(x1, s1);
-    const unsigned b00 = bx0 + __umul24(y0, s2), b10 = bx1 + __umul24(y0, s2), b01 = bx0 + __umul24(y1, s2), b11 = bx1 + __umul24(y1, s2);
+    // every lane scales its own axis, the quad exchanges byte offsets (the broadcasts fold into the adds as DPP operands)
+    const unsigned m0 = __umul24((unsigned)i0, stride_q), m1 = __umul24((unsigned)i1, stride_q);
+    const unsigned y0 = quad_bcast_i<1>(m0), y1 = quad_bcast_i<1>(m1);
+    const unsigned z0 = quad_bcast_i<2>(m0) + cofs, z1 = quad_bcast_i<2>(m1) + cofs;
+    const unsigned b00 = quad_bcast_i<0>(m0) + y0, b10 = quad_bcast_i<0>(m1) + y0, b01 = quad_bcast_i<0>(m0) + y1, b11 = quad_bcast_i<0>(m1) + y1;
 #if defined(RNERF_MARCH_ABL) && (RNERF_MARCH_ABL & 1)   /* profiling ablation: no gathers */
     for (int i_ = 0; i_ < 8; ++i_) o.c[i_] = __uint_as_float(0x3f800000u + ((b00 + z0 + b11 + z1) & 1u));
     return;
@@ -125,8 +149,8 @@ __global__ void __launch_bounds__(128) march_kernel(const float* __restrict__ ta
     o.c[6] = *(const float*)(tabc + (b01 + z1)); o.c[7] = *(const float*)(tabc + (b11 + z1));
   };
   auto predict = [&](float xp, Corners& o) {
-    const int j = (int)floorf(xp);
-    gather(clampi(j, 0, dim_q - 1), clampi(j + 1, 0, dim_q - 1), o);
+    const int j = floor_to_int(xp);
+    gather(clamp0(j, hi_q), clamp0(j + 1, hi_q), o);
   };
   float x_prev;
   {
@@ -149,7 +173,7 @@ __global__ void __launch_bounds__(128) march_kernel(const float* __restrict__ ta
     const float fx = floorf(x);
     const int i = (int)fx;
     const float t = fsub(x, fx);                   // (x - x0) / (x1 - x0), divisor exactly 1
-    const int i0 = clampi(i, 0, dim_q - 1), i1 = clampi(i + 1, 0, dim_q - 1);
+    const int i0 = clamp0(i, hi_q), i1 = clamp0(i + 1, hi_q);
 #if !(defined(RNERF_MARCH_ABL) && (RNERF_MARCH_ABL & 8))   /* profiling ablation: no misprediction check */
     if (__builtin_amdgcn_ballot_w64(i0 != cn.i0 || i1 != cn.i1) != 0) gather(i0, i1, cn);     // mispredicted somewhere in the wave
 #endif
@@ -160,14 +184,14 @@ __global__ void __launch_bounds__(128) march_kernel(const float* __restrict__ ta
     const float xd = quad_bcast<0>(t), yd = quad_bcast<1>(t), zd = quad_bcast<2>(t);
     if (WANT_VOX && q < 3 && k < num_nodes) { const size_t o = (size_t)k * B + r; vox[6 * o + 2 * q] = i0; vox[6 * o + 2 * q + 1] = i1; }
     // ---- 7 lerps a*(1-t) + b*t (ior_utils.py:214-222)
-    const float oxd = fsub(1.0f, xd), oyd = fsub(1.0f, yd), ozd = fsub(1.0f, zd);
-    const float c00 = fadd(fmul(cn.c[0], oxd), fmul(cn.c[1], xd));
-    const float c01 = fadd(fmul(cn.c[2], oxd), fmul(cn.c[3], xd));
-    const float c10 = fadd(fmul(cn.c[4], oxd), fmul(cn.c[5], xd));
-    const float c11 = fadd(fmul(cn.c[6], oxd), fmul(cn.c[7], xd));
-    const float c0 = fadd(fmul(c00, oyd), fmul(c10, yd));
-    const float c1 = fadd(fmul(c01, oyd), fmul(c11, yd));
-    const float c = fadd(fmul(c0, ozd), fmul(c1, zd));   // lanes 0..2: grad component q, lane 3: n
+    const f32x2 wx = {fsub(1.0f, xd), xd}, wy = {fsub(1.0f, yd), yd}, wz = {fsub(1.0f, zd), zd};
+    const float c00 = lerp_pk(cn.c[0], cn.c[1], wx);
+    const float c01 = lerp_pk(cn.c[2], cn.c[3], wx);
+    const float c10 = lerp_pk(cn.c[4], cn.c[5], wx);
+    const float c11 = lerp_pk(cn.c[6], cn.c[7], wx);
+    const float c0 = lerp_pk(c00, c10, wy);
+    const float c1 = lerp_pk(c01, c11, wy);
+    const float c = lerp_pk(c0, c1, wz);   // lanes 0..2: grad component q, lane 3: n
     if (WANT_IOR && k < num_nodes) { *out_ior = c; out_ior += node_stride; }
     // ---- OneEikonalStep (eikonal_utils.py:41-45)
     const float n = quad_bcast<3>(c);
