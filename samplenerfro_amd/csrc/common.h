@@ -178,4 +178,26 @@ __device__ __forceinline__ float quad_sumsq3(float a) {
   return fadd(fadd(quad_bcast<0>(a2), quad_bcast<1>(a2)), quad_bcast<2>(a2));
 }
 
+// The marching waves (march.hip, march_all_kernel in mlp.hip) are bound by instruction issue, so its integer glue is written as the instructions the ISA has for it (hipcc emits 3-4 for
+// each): clamp to [0, hi] = the median of (v, 0, hi); floor + convert in one; a*(1-t) + b*t with both products in one packed multiply
+// (v_pk_mul_f32 rounds each half like v_mul_f32: the same individually rounded ops in the same order).
+__device__ __forceinline__ int clamp0(int v, int hi) {
+  int r;
+  asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(v), "v"(hi));
+  return r;
+}
+__device__ __forceinline__ int floor_to_int(float x) {
+  int r;
+  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float lerp_pk(float a, float b, f32x2_t w) {       // w = (1 - t, t)
+  const f32x2_t v = {a, b};
+  const f32x2_t m = v * w;
+  float r;      // as the instruction: left to itself hipcc pairs the sums of two lerps into v_pk_add_f32 and pays for it in register moves
+  asm("v_add_f32_e32 %0, %1, %2" : "=v"(r) : "v"(m.x), "v"(m.y));
+  return r;
+}
+
 }  // namespace rnerf

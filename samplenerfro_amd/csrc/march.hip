@@ -40,28 +40,6 @@ static_assert(2 * kMarchChunk * 512 <= 12 * 1024, "the ring must fit beside the 
 
 __device__ __forceinline__ void march_chunk_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// The marcher is bound by instruction issue, so its integer glue is written as the instructions the ISA has for it (hipcc emits 3-4 for
-// each): clamp to [0, hi] = the median of (v, 0, hi); floor + convert in one; a*(1-t) + b*t with both products in one packed multiply
-// (v_pk_mul_f32 rounds each half like v_mul_f32: the same individually rounded ops in the same order).
-__device__ __forceinline__ int clamp0(int v, int hi) {
-  int r;
-  asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(v), "v"(hi));
-  return r;
-}
-__device__ __forceinline__ int floor_to_int(float x) {
-  int r;
-  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));
-  return r;
-}
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float lerp_pk(float a, float b, f32x2 w) {       // w = (1 - t, t)
-  const f32x2 v = {a, b};
-  const f32x2 m = v * w;
-  float r;      // as the instruction: left to itself hipcc pairs the sums of two lerps into v_pk_add_f32 and pays for it in register moves
-  asm("v_add_f32_e32 %0, %1, %2" : "=v"(r) : "v"(m.x), "v"(m.y));
-  return r;
-}
-
 template <bool WANT_IOR, bool WANT_VOX>
 __global__ void __launch_bounds__(128) march_kernel(const float* __restrict__ table, MarchParams g,
                                                     const float* __restrict__ origins, const float* __restrict__ viewdirs,
@@ -184,7 +162,7 @@ __global__ void __launch_bounds__(128) march_kernel(const float* __restrict__ ta
     const float xd = quad_bcast<0>(t), yd = quad_bcast<1>(t), zd = quad_bcast<2>(t);
     if (WANT_VOX && q < 3 && k < num_nodes) { const size_t o = (size_t)k * B + r; vox[6 * o + 2 * q] = i0; vox[6 * o + 2 * q + 1] = i1; }
     // ---- 7 lerps a*(1-t) + b*t (ior_utils.py:214-222)
-    const f32x2 wx = {fsub(1.0f, xd), xd}, wy = {fsub(1.0f, yd), yd}, wz = {fsub(1.0f, zd), zd};
+    const f32x2_t wx = {fsub(1.0f, xd), xd}, wy = {fsub(1.0f, yd), yd}, wz = {fsub(1.0f, zd), zd};
     const float c00 = lerp_pk(cn.c[0], cn.c[1], wx);
     const float c01 = lerp_pk(cn.c[2], cn.c[3], wx);
     const float c10 = lerp_pk(cn.c[4], cn.c[5], wx);

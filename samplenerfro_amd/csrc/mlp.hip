@@ -2410,26 +2410,27 @@ __global__ void __launch_bounds__(256, 1) march_all_kernel(const float4* __restr
   const unsigned s1 = (unsigned)gp.dy * (unsigned)gp.dz * 16u, s2 = (unsigned)gp.dz * 16u;
   const char* __restrict__ tabc = (const char*)table;
   const unsigned cofs = comp * 4u;
+  const unsigned stride_q = q == 0 ? s1 : (q == 1 ? s2 : 16u);      // byte stride of this lane's axis
+  const int hi_q = dim_q - 1;
   float d = q < 3 ? viewdirs[3 * r + qc] : 0.f;
   float p = q < 3 ? fadd(origins[3 * r + qc], fmul(near, d)) : 0.f;   // eikonal_utils.py:104-106
   float rt = near;
   struct Corners { float c[8]; int i0, i1; };     // 000 100 001 101 010 110 011 111 (xyz) + the indices they were gathered with
   Corners ca, cb, cc;
-  auto gather = [&](int i0, int i1, Corners& o) {
+  auto gather = [&](int i0, int i1, Corners& o) {       // (the integer glue as in march.hip: clamp0 / floor_to_int / lerp_pk, common.h)
     o.i0 = i0; o.i1 = i1;
-    const unsigned x0 = quad_bcast_i<0>(i0), x1 = quad_bcast_i<0>(i1);
-    const unsigned y0 = quad_bcast_i<1>(i0), y1 = quad_bcast_i<1>(i1);
-    const unsigned z0 = quad_bcast_i<2>(i0) * 16u + cofs, z1 = quad_bcast_i<2>(i1) * 16u + cofs;
-    const unsigned bx0 = __umul24(x0, s1), bx1 = __umul24(x1, s1);
-    const unsigned b00 = bx0 + __umul24(y0, s2), b10 = bx1 + __umul24(y0, s2), b01 = bx0 + __umul24(y1, s2), b11 = bx1 + __umul24(y1, s2);
+    const unsigned m0 = __umul24((unsigned)i0, stride_q), m1 = __umul24((unsigned)i1, stride_q);
+    const unsigned y0 = quad_bcast_i<1>(m0), y1 = quad_bcast_i<1>(m1);
+    const unsigned z0 = quad_bcast_i<2>(m0) + cofs, z1 = quad_bcast_i<2>(m1) + cofs;
+    const unsigned b00 = quad_bcast_i<0>(m0) + y0, b10 = quad_bcast_i<0>(m1) + y0, b01 = quad_bcast_i<0>(m0) + y1, b11 = quad_bcast_i<0>(m1) + y1;
     o.c[0] = *(const float*)(tabc + (b00 + z0)); o.c[1] = *(const float*)(tabc + (b10 + z0));
     o.c[2] = *(const float*)(tabc + (b00 + z1)); o.c[3] = *(const float*)(tabc + (b10 + z1));
     o.c[4] = *(const float*)(tabc + (b01 + z0)); o.c[5] = *(const float*)(tabc + (b11 + z0));
     o.c[6] = *(const float*)(tabc + (b01 + z1)); o.c[7] = *(const float*)(tabc + (b11 + z1));
   };
   auto predict = [&](float xq, Corners& o) {
-    const int j = (int)floorf(xq);
-    gather(clampi(j, 0, dim_q - 1), clampi(j + 1, 0, dim_q - 1), o);
+    const int j = floor_to_int(xq);
+    gather(clamp0(j, hi_q), clamp0(j + 1, hi_q), o);
   };
   float x_prev;
   {
@@ -2446,7 +2447,7 @@ __global__ void __launch_bounds__(256, 1) march_all_kernel(const float4* __restr
     const float fx = floorf(x);
     const int i = (int)fx;
     const float t = fsub(x, fx);
-    const int i0 = clampi(i, 0, dim_q - 1), i1 = clampi(i + 1, 0, dim_q - 1);
+    const int i0 = clamp0(i, hi_q), i1 = clamp0(i + 1, hi_q);
     if (__builtin_amdgcn_ballot_w64(i0 != cn.i0 || i1 != cn.i1) != 0) gather(i0, i1, cn);     // mispredicted somewhere in the wave
     const float dx = fsub(x, x_prev);
     predict(fadd(x, fadd(dx, dx)), nx);
@@ -2457,14 +2458,14 @@ __global__ void __launch_bounds__(256, 1) march_all_kernel(const float4* __restr
     path_pd[rec + q] = q < 3 ? p : rt;
     path_dr[rec + q] = q < 3 ? fdiv(d, nrm) : 0.f;
     // ---- 7 lerps a*(1-t) + b*t (ior_utils.py:214-222)
-    const float oxd = fsub(1.0f, xd), oyd = fsub(1.0f, yd), ozd = fsub(1.0f, zd);
-    const float c00 = fadd(fmul(cn.c[0], oxd), fmul(cn.c[1], xd));
-    const float c01 = fadd(fmul(cn.c[2], oxd), fmul(cn.c[3], xd));
-    const float c10 = fadd(fmul(cn.c[4], oxd), fmul(cn.c[5], xd));
-    const float c11 = fadd(fmul(cn.c[6], oxd), fmul(cn.c[7], xd));
-    const float c0 = fadd(fmul(c00, oyd), fmul(c10, yd));
-    const float c1 = fadd(fmul(c01, oyd), fmul(c11, yd));
-    const float c = fadd(fmul(c0, ozd), fmul(c1, zd));   // lanes 0..2: grad component q, lane 3: n
+    const f32x2_t wx = {fsub(1.0f, xd), xd}, wy = {fsub(1.0f, yd), yd}, wz = {fsub(1.0f, zd), zd};
+    const float c00 = lerp_pk(cn.c[0], cn.c[1], wx);
+    const float c01 = lerp_pk(cn.c[2], cn.c[3], wx);
+    const float c10 = lerp_pk(cn.c[4], cn.c[5], wx);
+    const float c11 = lerp_pk(cn.c[6], cn.c[7], wx);
+    const float c0 = lerp_pk(c00, c10, wy);
+    const float c1 = lerp_pk(c01, c11, wy);
+    const float c = lerp_pk(c0, c1, wz);   // lanes 0..2: grad component q, lane 3: n
     if (path_ior) path_ior[rec + comp] = c;
     const float n = quad_bcast<3>(c);
     const float s = fdiv(step, n);
