@@ -48,7 +48,8 @@ enum rnerf_precision {
   RNERF_PREC_BF16X3 = 2,
   RNERF_PREC_F16 = 3,
   RNERF_PREC_BF16 = 4,
-  RNERF_PREC_F16X2 = 5
+  RNERF_PREC_F16X2 = 5,
+  RNERF_PREC_F16F8 = 6   /* inference only: f16 main term + the two cross terms of the hi/lo split on the fp8 (e4m3) MFMA; |W| < 3.99 */
 };
 
 /* Arithmetic of the NerfMLP backward (dgrad + wgrad).  The reference differentiates in fp32 (train.py:164).

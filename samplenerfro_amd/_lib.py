@@ -11,8 +11,8 @@ from typing import Optional
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "librnerf.so")
 
-PREC_F32, PREC_F16X3, PREC_BF16X3, PREC_F16, PREC_BF16, PREC_F16X2 = 0, 1, 2, 3, 4, 5
-PRECISIONS = {"f16x3": PREC_F16X3, "bf16x3": PREC_BF16X3, "f16": PREC_F16, "bf16": PREC_BF16, "f16x2": PREC_F16X2}
+PREC_F32, PREC_F16X3, PREC_BF16X3, PREC_F16, PREC_BF16, PREC_F16X2, PREC_F16F8 = 0, 1, 2, 3, 4, 5, 6
+PRECISIONS = {"f16x3": PREC_F16X3, "bf16x3": PREC_BF16X3, "f16": PREC_F16, "bf16": PREC_BF16, "f16x2": PREC_F16X2, "f16f8": PREC_F16F8}
 # enum rnerf_backward (include/rnerf.h): arithmetic of the NerfMLP dgrad + wgrad.  "f32" = hi + lo f16 parts (fp32-grade, the reference
 # differentiates in fp32, train.py:164); "tf32" = single f16 parts (11-bit significand); "bf16" = 8-bit significand.
 BWD_BF16, BWD_F16, BWD_F16X2 = 0, 1, 2

@@ -80,13 +80,20 @@ constexpr int AUX_FLOATS = 3464;
 
 template <int PREC>
 struct Prec {
-  static constexpr bool F16 = (PREC == RNERF_PREC_F16X3 || PREC == RNERF_PREC_F16 || PREC == RNERF_PREC_F16X2);
-  static constexpr int NP = (PREC == RNERF_PREC_F16X3 || PREC == RNERF_PREC_BF16X3 || PREC == RNERF_PREC_F16X2) ? 2 : 1;   // parts of a WEIGHT
+  static constexpr bool F16 = (PREC == RNERF_PREC_F16X3 || PREC == RNERF_PREC_F16 || PREC == RNERF_PREC_F16X2 || PREC == RNERF_PREC_F16F8);
+  // F8X: f16 main term + the two cross terms of the hi/lo split on v_mfma_f32_32x32x16_fp8_fp8 (e4m3).  The cross terms carry 2^-11 of the
+  // product and need 4 bits, not 11: same instruction count and operand bytes as f16x3, but the fp8 MFMA draws less power, and with every CU
+  // busy the engine is power-limited (tools/ubench/mfma_fp8.hip: 16.8 instead of 19.4 ns per MFMA for a 1 f16 + 2 fp8 mix).  Second block of a
+  // weight tile = [fp8(W_lo) x 8 | fp8(W 2^-10) x 8] per lane, second operand part = [fp8(x) x 8 | fp8(x_lo 2^10) x 8]: with the weights
+  // scaled by 2^14 both factors of both terms sit in the middle of e4m3's range without any block scale (W_lo ~ 4 W, x_lo 2^10 ~ x / 4).
+  static constexpr bool F8X = PREC == RNERF_PREC_F16F8;
+  static constexpr int NP = (PREC == RNERF_PREC_F16X3 || PREC == RNERF_PREC_BF16X3 || PREC == RNERF_PREC_F16X2 || F8X) ? 2 : 1;   // parts of a WEIGHT
   // MFMA passes per tile of a two-part stream: 3 = W_hi x_hi + W_lo x_hi + W_hi x_lo (fp32-grade);
   // 22 = (W_hi + W_lo) x_hi (f16x2: exact weights, activations rounded to f16 — 2/3 of the matrix work)
-  static constexpr int PASSES = PREC == RNERF_PREC_F16X2 ? 22 : 3;
-  // power-of-two weight scale: keeps the lo part of an f16 split out of the f16 subnormal range
-  static constexpr float WSCALE = F16 ? 256.f : 1.f;
+  // 38 = W_hi x_hi (f16) + W_lo x (fp8) + W x_lo (fp8)
+  static constexpr int PASSES = PREC == RNERF_PREC_F16X2 ? 22 : (F8X ? 38 : 3);
+  // power-of-two weight scale: keeps the lo part of an f16 split out of the f16 subnormal range (f16f8: |W| must stay below 3.99)
+  static constexpr float WSCALE = F8X ? 16384.f : (F16 ? 256.f : 1.f);
   static constexpr size_t STREAM_BYTES = (size_t)kTotalBlocks * NP * 1024;
   static constexpr int SLAB = 8 * NP * 1024;        // one slab = 1 k-step of an N=256 layer = 2 k-steps of the N=128 view layer
   static constexpr size_t PACKED_BYTES = STREAM_BYTES + (size_t)AUX_FLOATS * 4;
@@ -115,6 +122,45 @@ __device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t&
   float ha, hb;
   unpack2<F16>(hi, ha, hb);
   lo = pack2<F16>(a - ha, b - hb);
+}
+
+// ---- fp8 (e4m3) cross-term operands of the f16f8 precision ------------------------------------------------------------------
+constexpr float F8X_LO_SCALE = 1024.f;       // x_lo is multiplied, the W image of the second cross term divided by it
+// two values -> two fp8 bytes in half `HI` of `old` (the other half is kept).  Written as the instruction: the LOW half is a plain output
+// (the builtin takes the old value as an input, and an "old" that does not exist yet is an undefined register the allocator spills and
+// reloads); SCALED = v_cvt_scalef32_pk_fp8_f32, which divides by its scale operand (the power of two 1 / F8X_LO_SCALE).  Overflow: with
+// MODE.FP16_OVFL set (f8x_mode()) the conversion clamps to +-448, without it a value above ~464 becomes NaN (probed: fp8_cvt_probe.hip).
+template <bool HI, bool SCALED = false>
+__device__ __forceinline__ uint32_t f8_pair(uint32_t old, float a, float b) {
+  uint32_t r = old;
+  const float inv = 1.0f / F8X_LO_SCALE;
+  if constexpr (!SCALED) {
+    if constexpr (HI) asm("v_cvt_pk_fp8_f32 %0, %1, %2 op_sel:[0,0,1]" : "+v"(r) : "v"(a), "v"(b));
+    else asm("v_cvt_pk_fp8_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  } else {
+    if constexpr (HI) asm("v_cvt_scalef32_pk_fp8_f32 %0, %1, %2, %3 op_sel:[0,0,0,1]" : "+v"(r) : "v"(a), "v"(b), "v"(inv));
+    else asm("v_cvt_scalef32_pk_fp8_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(inv));
+  }
+  return r;
+}
+// fp8 conversions clamp instead of producing NaN: MODE.FP16_OVFL (bit 23); set once at the head of an f16f8 kernel
+__device__ __forceinline__ void f8x_mode() { asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1"); }
+__device__ __forceinline__ f32x16 mfma_f8(uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1, const f32x16 c) {
+  const long A = (long)(((unsigned long long)a1 << 32) | a0), B = (long)(((unsigned long long)b1 << 32) | b0);
+  return __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(A, B, c, 0, 0, 0);
+}
+// lo part of an operand in the f16f8 layout from 8 values and their f16 hi parts: [fp8(x) x 8 | fp8((x - hi) 2^10) x 8]
+__device__ __forceinline__ uint4 f8x_lo_part(const float (&x)[8], const uint32_t (&h)[4]) {
+  uint32_t o[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    float ha, hb;
+    unpack2<true>(h[p], ha, hb);
+    const float r0 = x[2 * p] - ha, r1 = x[2 * p + 1] - hb;
+    if (p & 1) { o[p >> 1] = f8_pair<true>(o[p >> 1], x[2 * p], x[2 * p + 1]); o[2 + (p >> 1)] = f8_pair<true, true>(o[2 + (p >> 1)], r0, r1); }
+    else { o[p >> 1] = f8_pair<false>(o[p >> 1], x[2 * p], x[2 * p + 1]); o[2 + (p >> 1)] = f8_pair<false, true>(o[2 + (p >> 1)], r0, r1); }
+  }
+  return make_uint4(o[0], o[1], o[2], o[3]);
 }
 
 template <bool F16>
@@ -163,9 +209,22 @@ __global__ void nerfmlp_pack_kernel(const float* __restrict__ params, char* __re
     }
     uint32_t hi[4], lo[4];
     for (int p = 0; p < 4; ++p) split2<F16>(w[2 * p], w[2 * p + 1], hi[p], lo[p]);
+    if constexpr (PP::F8X) {      // [fp8(W_lo) x 8 | fp8(W / 2^10) x 8]
+      f8x_mode();
+      float wl[8], ws[8];
+      for (int p = 0; p < 4; ++p) {
+        float ha, hb;
+        unpack2<true>(hi[p], ha, hb);
+        wl[2 * p] = w[2 * p] - ha; wl[2 * p + 1] = w[2 * p + 1] - hb;
+        ws[2 * p] = w[2 * p] * (1.0f / F8X_LO_SCALE); ws[2 * p + 1] = w[2 * p + 1] * (1.0f / F8X_LO_SCALE);
+      }
+      lo[0] = f8_pair<true>(f8_pair<false>(0u, wl[0], wl[1]), wl[2], wl[3]); lo[1] = f8_pair<true>(f8_pair<false>(0u, wl[4], wl[5]), wl[6], wl[7]);
+      lo[2] = f8_pair<true>(f8_pair<false>(0u, ws[0], ws[1]), ws[2], ws[3]); lo[3] = f8_pair<true>(f8_pair<false>(0u, ws[4], ws[5]), ws[6], ws[7]);
+    }
     uint4* dst = (uint4*)(packed + (size_t)blk * PP::NP * 1024);
     dst[lane] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-    if (PP::NP == 2) dst[64 + lane] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    if constexpr (PP::F8X) { uint2* d2 = (uint2*)(dst + 64); d2[lane] = make_uint2(lo[0], lo[1]); d2[64 + lane] = make_uint2(lo[2], lo[3]); }
+    else if (PP::NP == 2) dst[64 + lane] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
   }
   float* aux = (float*)(packed + PP::STREAM_BYTES);
   if (gid < AUX_FLOATS) {
@@ -312,11 +371,12 @@ __device__ __forceinline__ void split8(const float (&x)[8], uint4& hi, uint4& lo
   uint32_t h[4], l[4];
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
-    if constexpr (PP::NP == 2) split2<PP::F16>(x[2 * p], x[2 * p + 1], h[p], l[p]);
+    if constexpr (PP::NP == 2 && !PP::F8X) split2<PP::F16>(x[2 * p], x[2 * p + 1], h[p], l[p]);
     else { h[p] = pack2<PP::F16>(x[2 * p], x[2 * p + 1]); l[p] = 0; }
   }
   hi = make_uint4(h[0], h[1], h[2], h[3]);
-  lo = make_uint4(l[0], l[1], l[2], l[3]);
+  if constexpr (PP::F8X) lo = f8x_lo_part(x, h);
+  else lo = make_uint4(l[0], l[1], l[2], l[3]);
 }
 
 // Conversion of the previous layer's outputs into the B operands of the NEXT k-step, cut into small chunks that are issued
@@ -366,6 +426,7 @@ struct PrevConv {
       }
     } else if constexpr (C == 2) {
       hi[mt][p] = pack2<PP::F16>(x0, x1);
+      if constexpr (PP::F8X) lo[mt][p >> 1] = f8_pair<(p & 1) != 0>(lo[mt][p >> 1], x0, x1);       // fp8(x): the operand of the W_lo term
     } else if constexpr (C == 3) {
       if constexpr (PP::NP == 2) {
         if constexpr (PP::F16) {   // x - (float)hi as one v_fma_mix_f32 per value (exact: the residual is representable)
@@ -380,7 +441,8 @@ struct PrevConv {
         }
       }
     } else {
-      if constexpr (PP::NP == 2) lo[mt][p] = pack2<PP::F16>(x0, x1);
+      if constexpr (PP::F8X) lo[mt][2 + (p >> 1)] = f8_pair<(p & 1) != 0, true>(lo[mt][2 + (p >> 1)], x0, x1);   // fp8(x_lo 2^10)
+      else if constexpr (PP::NP == 2) lo[mt][p] = pack2<PP::F16>(x0, x1);
       else lo[mt][p] = 0;
 #ifndef RNERF_FWD_NOMASK
       if constexpr (MASK) nz[mt] |= pk_min1(hi[mt][p]) << p;   // post-ReLU values are non-negative: min(u16, 1) = non-zero flag of each half
@@ -450,7 +512,13 @@ struct EncWork {
       if constexpr (q0 < NSIN) f0 = e0.s3(); else f0 = plain<mt, q0>();
       if constexpr (q1 < NSIN) f1 = e1.s3(); else f1 = plain<mt, q1>();
     } else {
-      if constexpr (PP::NP == 2) split2<PP::F16>(f0, f1, hi[mt][p], lo[mt][p]);
+      if constexpr (PP::F8X) {
+        hi[mt][p] = pack2<true>(f0, f1);
+        float ha, hb;
+        unpack2<true>(hi[mt][p], ha, hb);
+        lo[mt][p >> 1] = f8_pair<(p & 1) != 0>(lo[mt][p >> 1], f0, f1);
+        lo[mt][2 + (p >> 1)] = f8_pair<(p & 1) != 0, true>(lo[mt][2 + (p >> 1)], f0 - ha, f1 - hb);
+      } else if constexpr (PP::NP == 2) split2<PP::F16>(f0, f1, hi[mt][p], lo[mt][p]);
       else { hi[mt][p] = pack2<PP::F16>(f0, f1); lo[mt][p] = 0; }
     }
   }
@@ -528,6 +596,17 @@ __device__ __forceinline__ void tile_mfma(f32x16& a0, f32x16& a1, const uint4 ah
     work.template chunk<4, PI>();
     RNERF_PIN();
     a1 = mfma16<PP::F16>(al, b.h1, a1);
+  } else if constexpr (PP::NP == 2 && PASSES == 38) {      // f16 main term + the two cross terms on the fp8 MFMA
+    a0 = mfma_f8(al.x, al.y, b.l0.x, b.l0.y, a0);            // fp8(W_lo) * fp8(x)
+    work.template chunk<2, PI>();
+    RNERF_PIN();
+    a1 = mfma_f8(al.x, al.y, b.l1.x, b.l1.y, a1);
+    work.template chunk<3, PI>();
+    RNERF_PIN();
+    a0 = mfma_f8(al.z, al.w, b.l0.z, b.l0.w, a0);            // fp8(W 2^-10) * fp8(x_lo 2^10)
+    work.template chunk<4, PI>();
+    RNERF_PIN();
+    a1 = mfma_f8(al.z, al.w, b.l1.z, b.l1.w, a1);
   } else if constexpr (PP::NP == 2 && PASSES == 2) {
     a0 = mfma16<PP::F16>(ah, b.l0, a0);
     work.template chunk<2, PI>();
@@ -565,11 +644,21 @@ __device__ __forceinline__ void kstep_mfma(f32x16 (&acc0)[8], f32x16 (&acc1)[8],
   using PP = Prec<PREC>;
   const uint4* a = (const uint4*)slab + lane + (size_t)KOFF * NT * PP::NP * 64;
   uint4 fh[FRAG_DEPTH], fl[FRAG_DEPTH];
+  // second block of a tile: 16 bytes per lane; f16f8: two 8-byte planes [fp8(W_lo): 64 lanes][fp8(W 2^-10): 64 lanes], read as two
+  // conflict-free 8-byte loads (read as one 16-byte value whose halves are used at different times, hipcc re-reads the first half later
+  // with a second, narrower load right in front of its MFMA)
+  auto load_lo = [&](int tile) -> uint4 {
+    if constexpr (PP::F8X) {
+      const uint2* a2 = (const uint2*)((const uint4*)slab + ((size_t)KOFF * NT + tile) * PP::NP * 64 + 64) + lane;
+      const uint2 u = a2[0], v = a2[64];
+      return make_uint4(u.x, u.y, v.x, v.y);
+    } else return a[(tile * PP::NP + PP::NP - 1) * 64];
+  };
 #pragma unroll
   for (int t = 0; t < FRAG_DEPTH; ++t) {
     const int tt = t < NT ? t : NT - 1;
     fh[t] = a[(tt * PP::NP) * 64];
-    fl[t] = a[(tt * PP::NP + PP::NP - 1) * 64];
+    fl[t] = load_lo(tt);
   }
 #define RNERF_TILE(T)                                                                                     \
   if constexpr (T < NT) {                                                                                 \
@@ -578,7 +667,7 @@ __device__ __forceinline__ void kstep_mfma(f32x16 (&acc0)[8], f32x16 (&acc1)[8],
     tile_mfma<PREC, FIRST, (T & 7), W, PASSES>(acc0[T], acc1[T], ah, al, b, work);                        \
     if constexpr (T + FRAG_DEPTH < NT && !NOREAD) {                                                       \
       fh[T % FRAG_DEPTH] = a[((T + FRAG_DEPTH) * PP::NP) * 64];                                           \
-      fl[T % FRAG_DEPTH] = a[((T + FRAG_DEPTH) * PP::NP + PP::NP - 1) * 64];                              \
+      fl[T % FRAG_DEPTH] = load_lo(T + FRAG_DEPTH);                                                       \
     }                                                                                                     \
   }
   RNERF_TILE(0) RNERF_TILE(1)
@@ -632,6 +721,7 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
   using PP = Prec<PREC>;
   constexpr int SLAB = PP::SLAB;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if constexpr (PP::F8X) f8x_mode();
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = lane & 31, h = lane >> 5;
@@ -864,6 +954,9 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
 #undef RNERF_KSTEP
       PH(3);
       if (l == 5) {   // skip concat: [x, inputs] (rnerf/model_utils.py:68-69)
+        // the encoding is recomputed here on purpose (in the MFMA shadow); with the position opaque the compiler cannot keep layer 0's
+        // encoded values alive across five layers instead (f16f8: it kept all 64, through scratch — 8 k clocks per skip slab instead of 4)
+        asm volatile("" : "+v"(pd[0].x), "+v"(pd[0].y), "+v"(pd[0].z), "+v"(pd[1].x), "+v"(pd[1].y), "+v"(pd[1].z));
         cur = enc_ops(pd, 0, 30);
         RNERF_PE_KSTEP(0, false, false) RNERF_PE_KSTEP(1, false, false) RNERF_PE_KSTEP(2, false, false) RNERF_PE_KSTEP(3, false, false)
         PH(5);
@@ -2847,13 +2940,14 @@ __global__ void __launch_bounds__(256) bkgd_wgrad_reduce_kernel(const float* __r
 using namespace rnerf;
 
 static bool prec_ok(int p) {
-  return p == RNERF_PREC_F16X3 || p == RNERF_PREC_BF16X3 || p == RNERF_PREC_F16 || p == RNERF_PREC_BF16 || p == RNERF_PREC_F16X2;
+  return p == RNERF_PREC_F16X3 || p == RNERF_PREC_BF16X3 || p == RNERF_PREC_F16 || p == RNERF_PREC_BF16 || p == RNERF_PREC_F16X2 || p == RNERF_PREC_F16F8;
 }
 
 extern "C" size_t rnerf_nerfmlp_packed_bytes(int precision) {
   switch (precision) {
     case RNERF_PREC_F16X3:
     case RNERF_PREC_F16X2: return Prec<RNERF_PREC_F16X3>::PACKED_BYTES;       // f16x2 reads the f16x3 stream
+    case RNERF_PREC_F16F8: return Prec<RNERF_PREC_F16F8>::PACKED_BYTES;
     case RNERF_PREC_BF16X3: return Prec<RNERF_PREC_BF16X3>::PACKED_BYTES;
     case RNERF_PREC_F16: return Prec<RNERF_PREC_F16>::PACKED_BYTES;
     case RNERF_PREC_BF16: return Prec<RNERF_PREC_BF16>::PACKED_BYTES;
@@ -2870,6 +2964,7 @@ extern "C" int rnerf_nerfmlp_pack(const float* params, int precision, void* pack
   switch (precision) {
     case RNERF_PREC_F16X3:
     case RNERF_PREC_F16X2: hipLaunchKernelGGL(nerfmlp_pack_kernel<RNERF_PREC_F16X3>, dim3(grid), dim3(block), 0, st, params, (char*)packed); break;
+    case RNERF_PREC_F16F8: hipLaunchKernelGGL(nerfmlp_pack_kernel<RNERF_PREC_F16F8>, dim3(grid), dim3(block), 0, st, params, (char*)packed); break;
     case RNERF_PREC_BF16X3: hipLaunchKernelGGL(nerfmlp_pack_kernel<RNERF_PREC_BF16X3>, dim3(grid), dim3(block), 0, st, params, (char*)packed); break;
     case RNERF_PREC_F16: hipLaunchKernelGGL(nerfmlp_pack_kernel<RNERF_PREC_F16>, dim3(grid), dim3(block), 0, st, params, (char*)packed); break;
     default: hipLaunchKernelGGL(nerfmlp_pack_kernel<RNERF_PREC_BF16>, dim3(grid), dim3(block), 0, st, params, (char*)packed); break;
@@ -2961,6 +3056,7 @@ extern "C" int rnerf_nerfmlp_forward(const void* packed, int precision, const fl
   switch (precision) {
     case RNERF_PREC_F16X3: return launch_fwd<RNERF_PREC_F16X3>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, max_workgroups);
     case RNERF_PREC_F16X2: return launch_fwd<RNERF_PREC_F16X2>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, max_workgroups);
+    case RNERF_PREC_F16F8: return launch_fwd<RNERF_PREC_F16F8>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, max_workgroups);
     case RNERF_PREC_BF16X3: return launch_fwd<RNERF_PREC_BF16X3>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, max_workgroups);
     case RNERF_PREC_F16: return launch_fwd<RNERF_PREC_F16>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, max_workgroups);
     default: return launch_fwd<RNERF_PREC_BF16>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, max_workgroups);

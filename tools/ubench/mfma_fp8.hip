@@ -18,17 +18,32 @@ __global__ void __launch_bounds__(256, 1) k(float* out, unsigned long long* cyc,
   unsigned long long t0 = __builtin_amdgcn_s_memtime();
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
-    for (int r = 0; r < 6; ++r)
+    for (int r = 0; r < (KIND >= 4 ? 0 : 6); ++r)
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         if constexpr (KIND == 0) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[i], 0, 0, 0);
         else if constexpr (KIND == 1) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a8, b8, acc[i], 0, 0, 0);
         else if constexpr (KIND == 2) acc[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, Bv, acc[i], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
-        else {
+        else if constexpr (KIND == 3) {
           if (r % 3 == 0) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[i], 0, 0, 0);
           else acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a8, b8, acc[i], 0, 0, 0);
         }
       }
+    // dependent orders of the f16f8 engine (48 MFMAs per trip as above): G accumulators take their f16 term, then their two fp8 terms
+    if constexpr (KIND >= 4) {
+      constexpr int G = KIND == 4 ? 2 : (KIND == 5 ? 4 : 8);
+#pragma unroll
+      for (int rep = 0; rep < 2; ++rep)
+#pragma unroll
+        for (int g0 = 0; g0 < 8; g0 += G) {
+#pragma unroll
+          for (int i = 0; i < G; ++i) acc[g0 + i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[g0 + i], 0, 0, 0);
+#pragma unroll
+          for (int i = 0; i < G; ++i) acc[g0 + i] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a8, b8, acc[g0 + i], 0, 0, 0);
+#pragma unroll
+          for (int i = 0; i < G; ++i) acc[g0 + i] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a8 + 1, b8, acc[g0 + i], 0, 0, 0);
+        }
+    }
   }
   unsigned long long t1 = __builtin_amdgcn_s_memtime();
   float s = 0;
@@ -58,6 +73,9 @@ int main() {
     run<1>("fp8 32x32x16", blocks, 32768);
     run<2>("f8f6f4 32x32x64 (fp8 x fp8)", blocks, 131072);
     run<3>("1 f16 + 2 fp8 32x32x16 per product", blocks, 32768);
+    run<4>("f16, then 2 fp8 ONTO it: 2 accumulators at a time", blocks, 32768);
+    run<5>("f16, then 2 fp8 ONTO it: 4 accumulators at a time", blocks, 32768);
+    run<6>("f16, then 2 fp8 ONTO it: 8 accumulators at a time", blocks, 32768);
   }
   return 0;
 }
