@@ -76,7 +76,8 @@ constexpr int AUX_BSIG = 2816;         // Dense_8 bias (+3 pad)
 constexpr int AUX_WRGB = 2820;         // Dense_11 kernel transposed [3][128]
 constexpr int AUX_BRGB = 3204;         // Dense_11 bias (+1 pad)
 constexpr int AUX_ZERO = 3208;         // 256 zeros: the sigma weights of every layer but the trunk output (PrevConv SIG)
-constexpr int AUX_FLOATS = 3464;
+constexpr int AUX_FLAG = 3464;         // f16f8: non-zero = a weight left the f16 range of the 2^14-scaled stream (the forward then returns NaN)
+constexpr int AUX_FLOATS = 3468;
 
 template <int PREC>
 struct Prec {
@@ -206,6 +207,7 @@ __global__ void nerfmlp_pack_kernel(const float* __restrict__ params, char* __re
     for (int j = 0; j < 8; ++j) {
       const int f = in_feature(l, s, h, j);
       w[j] = f < 0 ? 0.f : params[nerf_koff(d) + f * out_dim + n_out] * PP::WSCALE;
+      if constexpr (PP::F8X) { if (!(fabsf(w[j]) <= 65504.f)) ((float*)(packed + PP::STREAM_BYTES))[AUX_FLAG] = 1.0f; }   // zeroed by the launcher
     }
     uint32_t hi[4], lo[4];
     for (int p = 0; p < 4; ++p) split2<F16>(w[2 * p], w[2 * p + 1], hi[p], lo[p]);
@@ -227,7 +229,7 @@ __global__ void nerfmlp_pack_kernel(const float* __restrict__ params, char* __re
     else if (PP::NP == 2) dst[64 + lane] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
   }
   float* aux = (float*)(packed + PP::STREAM_BYTES);
-  if (gid < AUX_FLOATS) {
+  if (gid < AUX_FLAG) {
     float v = 0.f;
     if (gid < AUX_WSIG) {
       const int l = gid >> 8, n = gid & 255, d = mfma_layer(l).dense;
@@ -1086,6 +1088,9 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
       }
       sig0 = sig0 + __shfl_xor(sig0, 32) + bsig;
       sig1 = sig1 + __shfl_xor(sig1, 32) + bsig;
+      if constexpr (PP::F8X) {      // a weight outside the range of this precision's operand stream: fail loudly, not plausibly
+        if (auxt[AUX_FLAG] != 0.f) { const float qn = __builtin_nanf(""); p0[0] = p0[1] = p0[2] = qn; p1[0] = p1[1] = p1[2] = qn; sig0 = qn; sig1 = qn; }
+      }
       if (h == 0) {
         if (row_ok[0]) out_raw[row[0]] = make_float4(p0[0], p0[1], p0[2], sig0);
         if (row_ok[1]) out_raw[row[1]] = make_float4(p1[0], p1[1], p1[2], sig1);
@@ -2964,7 +2969,10 @@ extern "C" int rnerf_nerfmlp_pack(const float* params, int precision, void* pack
   switch (precision) {
     case RNERF_PREC_F16X3:
     case RNERF_PREC_F16X2: hipLaunchKernelGGL(nerfmlp_pack_kernel<RNERF_PREC_F16X3>, dim3(grid), dim3(block), 0, st, params, (char*)packed); break;
-    case RNERF_PREC_F16F8: hipLaunchKernelGGL(nerfmlp_pack_kernel<RNERF_PREC_F16F8>, dim3(grid), dim3(block), 0, st, params, (char*)packed); break;
+    case RNERF_PREC_F16F8:
+      RNERF_CHECK_HIP(hipMemsetAsync((char*)packed + Prec<RNERF_PREC_F16F8>::STREAM_BYTES + AUX_FLAG * sizeof(float), 0, 4 * sizeof(float), st));
+      hipLaunchKernelGGL(nerfmlp_pack_kernel<RNERF_PREC_F16F8>, dim3(grid), dim3(block), 0, st, params, (char*)packed);
+      break;
     case RNERF_PREC_BF16X3: hipLaunchKernelGGL(nerfmlp_pack_kernel<RNERF_PREC_BF16X3>, dim3(grid), dim3(block), 0, st, params, (char*)packed); break;
     case RNERF_PREC_F16: hipLaunchKernelGGL(nerfmlp_pack_kernel<RNERF_PREC_F16>, dim3(grid), dim3(block), 0, st, params, (char*)packed); break;
     default: hipLaunchKernelGGL(nerfmlp_pack_kernel<RNERF_PREC_BF16>, dim3(grid), dim3(block), 0, st, params, (char*)packed); break;

@@ -26,8 +26,8 @@ def test_binding_covers_header(lib_path):
     assert sorted(_lib.SIGNATURES) == declared_symbols()
     lib = _lib.load()
     assert lib.rnerf_version() == 1
-    assert lib.rnerf_nerfmlp_packed_bytes(_lib.PREC_F16X3) == 1160 * 2 * 1024 + 3464 * 4      # operand stream + aux floats (biases, heads, the zero block)
-    assert lib.rnerf_nerfmlp_packed_bytes(_lib.PREC_BF16) == 1160 * 1024 + 3464 * 4
+    assert lib.rnerf_nerfmlp_packed_bytes(_lib.PREC_F16X3) == 1160 * 2 * 1024 + 3468 * 4      # operand stream + aux floats (biases, heads, the zero block, the f16f8 range flag)
+    assert lib.rnerf_nerfmlp_packed_bytes(_lib.PREC_BF16) == 1160 * 1024 + 3468 * 4
     assert lib.rnerf_nerfmlp_packed_bytes(99) == 0
     assert b"precision" in lib.rnerf_last_error()
 

@@ -230,6 +230,28 @@ def test_nerf_mlp(scene, prec):
     assert err < MLP_TOL[prec]
 
 
+def test_nerf_mlp_f16f8_weight_range(scene):
+    """f16f8 scales the weights by 2^14 into f16: a weight of magnitude >= 4 cannot be represented, and the forward then returns NaN instead of
+    a plausible wrong colour; in-range weights give the f16x3 outputs within this precision's error."""
+    from samplenerfro_amd import ops
+    pf = syn.init_params_flat(7, bias_scale=0.1)
+    rng = np.random.default_rng(5)
+    B, S = 37, 11
+    pos = rng.uniform(-3, 3, (B, S, 3)).astype(F32)
+    dirs = R.safe_l2_normalize(rng.standard_normal((B, S, 3)).astype(F32))
+    t = np.sort(rng.uniform(2, 6, (B, S)).astype(F32), -1)
+    pd, dr = _rows(pos, dirs, t)
+    flat = pf["coarse_mlp"].copy()
+    big = flat.copy()
+    big[100] = 4.5                                   # one kernel entry of Dense_0 outside the range
+    out = ops.nerfmlp_forward(ops.nerfmlp_pack(T(big), _lib.PREC_F16F8), _lib.PREC_F16F8, T(pd), T(dr), None, S, B).cpu().numpy()
+    assert np.isnan(out).all()
+    out = ops.nerfmlp_forward(ops.nerfmlp_pack(T(flat), _lib.PREC_F16F8), _lib.PREC_F16F8, T(pd), T(dr), None, S, B).cpu().numpy()
+    assert np.isfinite(out).all()                    # and a re-pack of in-range weights clears the flag
+    ref = ops.nerfmlp_forward(ops.nerfmlp_pack(T(flat), _lib.PREC_F16X3), _lib.PREC_F16X3, T(pd), T(dr), None, S, B).cpu().numpy()
+    assert np.abs(out - ref).max() < 2e-4
+
+
 def test_nerf_mlp_node_indirection(scene):
     """Coarse pass addressing: rows read through node_of_sample (the jitter) from the path record."""
     from samplenerfro_amd import ops

@@ -7,6 +7,7 @@ python3 bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "default 
 python3 bench.py --mode forward > $O/bench_forward.json 2> $O/bench_forward.err; echo "forward rc=$?"
 python3 bench.py --backward tf32 --no-extra --no-frame --no-cpu-baseline > $O/bench_train_tf32.json 2>/dev/null
 python3 bench.py --mode forward --precision f16x2 --no-cpu-baseline > $O/bench_forward_f16x2.json 2>/dev/null
+python3 bench.py --mode forward --precision f16f8 --no-cpu-baseline > $O/bench_forward_f16f8.json 2>/dev/null
 python3 bench.py --workload ship_refractive --no-extra --no-frame > $O/bench_ship_refractive.json 2>/dev/null
 python3 bench.py --workload dolphin_train --no-extra --no-frame --no-cpu-baseline > $O/bench_dolphin_train.json 2>/dev/null
 python3 bench.py --workload ship_refractive --stage all --no-extra --no-frame --no-cpu-baseline > $O/bench_stage_all.json 2>/dev/null
