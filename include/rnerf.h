@@ -41,7 +41,11 @@ enum rnerf_status {
  * both operands, 3 MFMAs per tile (error ~2^-21 / ~2^-16 per product); F16 / BF16 = single MFMA;
  * F16X2 (forward / inference only) = exact hi+lo f16 weights x activations rounded to f16, 2 MFMAs per tile: the f16x3 operand stream,
  * 2/3 of its matrix work; measured end-to-end |dRGB| vs f16x3 3e-5 .. 5e-5 on the bench workload — inside the 1e-4
- * contract for weights of ordinary size but without the 2x margin f16x3 keeps everywhere, hence opt-in. */
+ * contract for weights of ordinary size but without the 2x margin f16x3 keeps everywhere, hence opt-in.
+ * F16F8 (forward / inference only) = f16 main term + the two cross terms of the hi/lo split on v_mfma_f32_32x32x16_fp8_fp8 (e4m3): the
+ * instruction count and operand bytes of F16X3 at lower power (the engine is power-limited: ~8 % faster); measured end-to-end |dRGB| vs the
+ * oracle 2e-6.  Its operand stream scales the weights by 2^14: a NerfMLP weight of magnitude >= 3.99 makes rnerf_nerfmlp_forward return NaN
+ * (flag raised by rnerf_nerfmlp_pack), never a plausible wrong colour.  Own packed stream: pack with the precision you run. */
 enum rnerf_precision {
   RNERF_PREC_F32 = 0,
   RNERF_PREC_F16X3 = 1,
@@ -49,7 +53,7 @@ enum rnerf_precision {
   RNERF_PREC_F16 = 3,
   RNERF_PREC_BF16 = 4,
   RNERF_PREC_F16X2 = 5,
-  RNERF_PREC_F16F8 = 6   /* inference only: f16 main term + the two cross terms of the hi/lo split on the fp8 (e4m3) MFMA; |W| < 3.99 */
+  RNERF_PREC_F16F8 = 6
 };
 
 /* Arithmetic of the NerfMLP backward (dgrad + wgrad).  The reference differentiates in fp32 (train.py:164).
