@@ -584,7 +584,21 @@ def main():
         rgb_img, _, _ = U.render_image(fn, fr, key, False, chunk=chunk)
         barrier()
         frame = {"ms_per_frame": 1e3 * D.max_over_ranks(time.perf_counter() - t1, device), "height": H, "width": W, "samples": cfg["S"] + fine,
-                 "chunk": chunk, "finite": bool(torch.isfinite(rgb_img).all())}
+                 "chunk": chunk, "finite": bool(torch.isfinite(rgb_img).all()), "precision": args.precision}
+        if args.extra and args.precision == "f16x3" and args.stage == "radiance":
+            # the same frame with the opt-in inference precision f16f8 (the two cross terms of the hi/lo split on the fp8 MFMA):
+            # its time and its largest colour difference from the f16x3 frame above (same weights: build_scene is seeded)
+            m8, v8, _ = build_scene(cfg, device, "f16f8", fine, args.stage)
+            fn8 = lambda k0, k1, r, path=None: m8.apply(v8, k0, k1, r, False, path=path)
+            U.render_image(fn8, fr, key, False, chunk=chunk)
+            barrier()
+            t1 = time.perf_counter()
+            rgb8, _, _ = U.render_image(fn8, fr, key, False, chunk=chunk)
+            barrier()
+            frame["f16f8"] = {"ms_per_frame": 1e3 * D.max_over_ranks(time.perf_counter() - t1, device),
+                              "max_abs_rgb_vs_f16x3_frame": float((rgb8 - rgb_img).abs().max()), "finite": bool(torch.isfinite(rgb8).all())}
+            del m8, v8, rgb8
+            torch.cuda.empty_cache()
     if rank == 0:
         total_rays = B * args.steps * world
         rows_per_ray = S + (S + fine if fine > 0 else 0)
