@@ -28,6 +28,11 @@ def test_binding_covers_header(lib_path):
     assert lib.rnerf_version() == 1
     assert lib.rnerf_nerfmlp_packed_bytes(_lib.PREC_F16X3) == 1160 * 2 * 1024 + 3468 * 4      # operand stream + aux floats (biases, heads, the zero block, the f16f8 range flag)
     assert lib.rnerf_nerfmlp_packed_bytes(_lib.PREC_BF16) == 1160 * 1024 + 3468 * 4
+    assert lib.rnerf_nerfmlp_packed_bytes(_lib.PREC_F16F8) == lib.rnerf_nerfmlp_packed_bytes(_lib.PREC_F16X3)      # same blocks, other contents
+    # the Python names follow enum rnerf_precision of the header
+    hdr = open(os.path.join(ROOT, "include", "rnerf.h")).read()
+    for name, val in _lib.PRECISIONS.items():
+        assert re.search(r"RNERF_PREC_%s\s*=\s*%d\b" % (name.upper(), val), hdr), name
     assert lib.rnerf_nerfmlp_packed_bytes(99) == 0
     assert b"precision" in lib.rnerf_last_error()
 
