@@ -174,6 +174,15 @@ def cpu_train_step(R, mc, pf, params, table, o, d, jitter, cfg, fine, seed):
     return B / dt, dt
 
 
+def dtype_label(precision, backward, train):
+    """The arithmetic the path computes in, not a precision claim: operand format of the MFMAs / accumulator."""
+    fwd = {"f16x3": "f16x3", "bf16x3": "bf16x3", "f16x2": "f16x2", "f16f8": "f16+fp8x2", "f16": "f16", "bf16": "bf16", "f32": "f32"}.get(precision, precision)
+    if not train:
+        return fwd + "/fp32-acc"
+    bwd = {"f32": "f16x3", "tf32": "f16", "bf16": "bf16"}[backward]
+    return (fwd if bwd == fwd else fwd + " fwd, " + bwd + " bwd") + "/fp32-acc"
+
+
 def relaunch_for_gpus(args):
     """`--gpus N` is the contract, not a label: one process per GPU.  Started bare (`python bench.py --gpus N`, no launcher in the
     environment) with N > 1, this process becomes the launcher: it starts `python -m torch.distributed.run --nproc-per-node N bench.py
@@ -411,7 +420,34 @@ def main():
     stepper = Stepper(args, cfg, model, variables, rays, key, B, world, rank, fine, device, args.backward, args.mode, args.stage, args.pipeline, args.graph)
     dt = timed_steps(stepper, args.warmup, args.steps, barrier, D, device)
     graph_used = stepper.g is not None
+    # dispersion of the same measurement: five more windows of K steps each on the same stepper, outside the headline
+    stability = None
+    if args.extra:
+        wins = [1e3 * timed_steps(stepper, 0, args.steps, barrier, D, device) / args.steps for _ in range(5)]
+        stability = {"windows": 5, "steps_per_window": args.steps, "ms_per_step": [round(w, 4) for w in wins], "median_ms": float(np.median(wins)),
+                     "min_ms": float(min(wins)), "max_ms": float(max(wins)), "spread_frac": float((max(wins) - min(wins)) / np.median(wins)),
+                     "note": "boxes of the pool differ by +-3 %; A/B deltas are only meaningful as same-box pairs (DESIGN.md §4)"}
 
+    coll = None
+    if train and D.active():
+        # the step's one exchange, timed with events on the launch stream: the all-reduce alone (back to back, nothing else queued), and what
+        # of it a step cannot hide = (step with the collective) - (step with it skipped; the replicas' parameters diverge there, timing only)
+        G = stepper.tstate.grads
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(11)]
+        D.allreduce_mean_([G]); torch.cuda.synchronize()
+        ev[0].record()
+        for i in range(10):
+            D.allreduce_mean_([G]); ev[i + 1].record()
+        torch.cuda.synchronize()
+        ar_us = float(np.median([1e3 * ev[i].elapsed_time(ev[i + 1]) for i in range(10)]))
+        os.environ["RNERF_SKIP_ALLREDUCE"] = "1"
+        dt_skip = timed_steps(stepper, 1, 10, barrier, D, device) / 10
+        del os.environ["RNERF_SKIP_ALLREDUCE"]
+        dt_with = timed_steps(stepper, 1, 10, barrier, D, device) / 10
+        coll = {"allreduce_us": ar_us, "allreduce_bytes": int(G.numel() * 4), "exposed_us": 1e6 * (dt_with - dt_skip),
+                "step_ms_with": 1e3 * dt_with, "step_ms_without": 1e3 * dt_skip,
+                "note": "allreduce_us: the flat gradient + stats buffer, median of 10 back-to-back all-reduces (events on the launch stream); exposed_us: "
+                        "step time with minus without the collective (10 steps each, same stepper)"}
     other_modes = None
     if train and args.extra:
         # the same step with the other backward arithmetics (5 steps each, after 2 warm-up steps), for the record in the same line
@@ -558,8 +594,15 @@ def main():
         dcfg = dict(syn.CONFIGS["dolphin_train"])
         dmodel, dvars, _ = build_scene(dcfg, device, args.precision, dcfg["F"], "radiance")
         for vB, note in ((4096, "BASELINE configs[3] on one GPU: 64 + 128 samples, 256^3 grid, global batch 4096"),
-                         (1024, "the reference's default batch (configs/example.yaml:20)"), (512, "one GPU's shard of 4096 rays over 8 GPUs")):
+                         (1024, "the reference's default batch (configs/example.yaml:20)"), (512, "one GPU's shard of 4096 rays over 8 GPUs"),
+                         (128, "one GPU's shard of the reference's default batch (1024 rays) over 8 GPUs")):
             run_variant("dolphin_train_%d" % vB, dcfg, dmodel, dvars, dcfg["F"], vB, note)
+        if world > 1:
+            # BASELINE configs[3] as written — STRONG scaling: the global batch split over the ranks that ran (train.py:196)
+            for gB in (4096, 1024):
+                if gB % world == 0:
+                    run_variant("dolphin_train_global%d_strong" % gB, dcfg, dmodel, dvars, dcfg["F"], gB // world,
+                                "global batch %d = %d rays per GPU on %d GPUs, gradient all-reduce included (rays_per_s is the whole job's)" % (gB, gB // world, world))
         del dmodel, dvars
         torch.cuda.empty_cache()
         variants["scene_build_s"] = {"ship_straight (table only)": t_scene, "ship_refractive (sphere + (9, 3.0) prefilter + table, 512^3)": t_refr}
@@ -584,7 +627,48 @@ def main():
         rgb_img, _, _ = U.render_image(fn, fr, key, False, chunk=chunk)
         barrier()
         frame = {"ms_per_frame": 1e3 * D.max_over_ranks(time.perf_counter() - t1, device), "height": H, "width": W, "samples": cfg["S"] + fine,
-                 "chunk": chunk, "finite": bool(torch.isfinite(rgb_img).all()), "precision": args.precision}
+                 "chunk": chunk, "finite": bool(torch.isfinite(rgb_img).all()), "precision": args.precision,
+                 "what": "every rank renders the WHOLE frame (one GPU's time)"}
+
+        def sharded_frame(mdl, vrs, rays_hw, ck):
+            """BASELINE configs[4]'s form: the image rows sharded over the ranks (eval.py:95-105, rnerf/utils.py:353-370), no collective;
+            the frame is done when the slowest rank is."""
+            f2 = lambda k0, k1, r, path=None: mdl.apply(vrs, k0, k1, r, False, path=path)
+            D.render_image_sharded(f2, rays_hw, key, False, chunk=ck, gather=False)
+            barrier()
+            t2 = time.perf_counter()
+            blk = D.render_image_sharded(f2, rays_hw, key, False, chunk=ck, gather=False)[0]
+            barrier()
+            return 1e3 * D.max_over_ranks(time.perf_counter() - t2, device), blk
+
+        if world > 1:
+            ms_sh, blk = sharded_frame(model, variables, fr, chunk)
+            lo, hi = D.shard_bounds(H, world, rank)
+            frame["ms_per_frame_sharded"] = ms_sh
+            frame["sharded"] = {"ranks": world, "rows_per_rank": hi - lo, "block_equals_full_frame_rows": bool(torch.equal(blk, rgb_img[lo:hi])),
+                                "what": "contiguous row blocks per rank, no collective (distributed.render_image_sharded)"}
+        if args.extra and args.stage == "radiance" and args.workload == "ship_straight" and args.rays is None and args.fine is None:
+            # BASELINE configs[4]: glass, 800 x 800, 256 samples per ray, P = 24 -> N = 6144 eikonal steps, 384^3 grid after (5, 3.0)
+            gcfg = dict(syn.CONFIGS["glass_frame"])
+            del rgb_img
+            gm, gv, _ = build_scene(gcfg, device, args.precision, 0, "radiance")
+            gfn = lambda k0, k1, r, path=None: gm.apply(gv, k0, k1, r, False, path=path)
+            gchunk = 16384
+            if world > 1:
+                ms_g, _blk = sharded_frame(gm, gv, fr, gchunk)
+            else:
+                U.render_image(gfn, fr, key, False, chunk=gchunk)
+                barrier()
+                t1 = time.perf_counter()
+                g_img, _, _ = U.render_image(gfn, fr, key, False, chunk=gchunk)
+                barrier()
+                ms_g = 1e3 * (time.perf_counter() - t1)
+            frame["glass_frame"] = {("ms_per_frame_sharded" if world > 1 else "ms_per_frame"): ms_g, "ranks": world, "samples": gcfg["S"],
+                                    "eikonal_steps": gcfg["S"] * gcfg["P"], "grid": gcfg["G"], "chunk": gchunk,
+                                    "what": "BASELINE configs[4]: 800 x 800 x 256 samples, N = 6144, rows sharded over the ranks that ran"}
+            del gm, gv
+            torch.cuda.empty_cache()
+            rgb_img = U.render_image(fn, fr, key, False, chunk=chunk)[0] if (args.precision == "f16x3") else None
         if args.extra and args.precision == "f16x3" and args.stage == "radiance":
             # the same frame with the opt-in inference precision f16f8 (the two cross terms of the hi/lo split on the fp8 MFMA, DESIGN.md 3.2):
             # its time and its largest colour difference from the f16x3 frame above (same weights: build_scene is seeded)
@@ -606,7 +690,7 @@ def main():
         line = {
             "metric": "rays/sec (train step)" if train else "rays/sec (forward render pass)", "value": total_rays / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": args.scaling,
-            "vs_baseline": None, "dtype": ("f32" if (not train or args.backward == "f32") else ("f16" if args.backward == "tf32" else "bf16")), "data": "synthetic",
+            "vs_baseline": None, "dtype": dtype_label(args.precision, args.backward, train), "data": "synthetic",
             "config": {"workload": f"{args.workload}: {'train step (forward + backward + grad all-reduce + Adam)' if train else 'forward render pass'}, "
                                    f"{B} rays/GPU x {S} coarse + {fine} fine samples, "
                                    f"P={cfg['P']} (N={N} eikonal steps), grid {cfg['G']}^3", "rays_per_gpu": B,
@@ -650,7 +734,12 @@ def main():
                                              "so MFMA issue is ~3 x this fraction (DESIGN.md §4: the 3-pass floor)"}
         line["collectives"] = {"backend": (dist.get_backend() if dist.is_initialized() else None), "ranks": world,
                                "per_step": ("none" if not (train and D.active()) else
-                                            "one all-reduce(mean) of the flat gradient + stats buffer between the backward graph and the update graph")}
+                                            "all-reduce(mean) of the flat gradient + stats buffer between the backward and the update; the NerfMLP "
+                                            "segments (95 % of the bytes) start on a side stream right behind the last wgrad, beside the step's tail")}
+        if coll:
+            line["collectives"].update(coll)
+        if stability:
+            line["stability"] = stability
         if pmc_meta is not None:
             line["pmc_profile"] = pmc_meta
         if other_modes:

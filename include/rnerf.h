@@ -37,7 +37,9 @@ enum rnerf_status {
   RNERF_ERR_UNSUPPORTED = -3
 };
 
-/* MLP arithmetic. F32 = v_mfma_f32_32x32x2_f32 (exact fp32 fma chain); F16X3 / BF16X3 = hi/lo split of
+/* MLP arithmetic. F32 (rnerf_nerfmlp_pack / rnerf_nerfmlp_forward only) = every Dense as ONE sequential chain of v_fma_f32 per output, then + bias: exact
+ * fp32 semantics with a defined summation order — the on-device arbiter of the MFMA precisions (csrc/mlp_f32.hip; ~100 x slower, for
+ * parity tests: it separates split-f16 error, the oracle's summation order and real bugs on the device); F16X3 / BF16X3 = hi/lo split of
  * both operands, 3 MFMAs per tile (error ~2^-21 / ~2^-16 per product); F16 / BF16 = single MFMA;
  * F16X2 (forward / inference only) = exact hi+lo f16 weights x activations rounded to f16, 2 MFMAs per tile: the f16x3 operand stream,
  * 2/3 of its matrix work; measured end-to-end |dRGB| vs f16x3 3e-5 .. 5e-5 on the bench workload — inside the 1e-4
@@ -197,7 +199,10 @@ int rnerf_so3_query(const float* table, const rnerf_grid* g, const float* so3_pa
  * parameters into the f16 hi + lo A-operand stream of the in-march MLP (3 x v_mfma_f32_16x16x32_f16 per tile, fp32 accumulate).
  * ray_order (nullable): int32[B], a permutation of the rays: workgroup i marches rays ray_order[16 i .. 16 i + 15] (a group of 16
  * evaluates the MLP whenever ANY of its rays is inside the boundary shell, so rays with similar shell intervals should share a group).
- * Every record is written at the ray's own index: the order changes no output. */
+ * Every record is written at the ray's own index: the order changes no output.
+ * Grid size limit (rnerf_march_all and rnerf_march_all_train; rnerf_march has none): the table is addressed with 32-bit byte offsets and
+ * 24-bit row strides — dims[0] * dims[1] * dims[2] * 16 B < 4 GiB and dims[1] * dims[2] * 16 < 2^24, i.e. cubic grids up to 645^3
+ * (every shipped config: 128^3 .. 512^3); larger grids are rejected with RNERF_ERR_ARG, never mis-addressed. */
 size_t rnerf_so3_packed_bytes(void);
 int rnerf_march_all(const float* table, const rnerf_grid* g, const float* so3_params, void* so3_packed, const float* window10, const float* origins,
                     const float* viewdirs, int32_t B, double near, double far, int32_t num_nodes, float* path_pd, float* path_dr,
@@ -405,6 +410,10 @@ typedef struct rnerf_train_cfg {
                                   both directions, zeroing the gradient buffer, sum theta^2 — runs there beside the key kernels, the march and the
                                   background-MLP forward, and is joined inside the call before the first NerfMLP kernel */
   int32_t coresident_bkgd_wgrad;  /* experiment (needs aux_stream): the background MLP's weight gradient as a co-resident kernel beside the NerfMLP wgrad */
+  void* grads_stream;          /* nullable: a stream the call orders behind the LAST NerfMLP wgrad (rnerf_fork at that point).  grads[0 .. NerfMLP
+                                  segments) are final there: a caller with more than one rank starts their all-reduce (jax.lax.pmean, train.py:166 —
+                                  95 % of the bytes) on this stream as soon as the call returns, beside the background-MLP backward and the loss tail
+                                  still queued on `stream`, and joins before rnerf_adam_update */
 } rnerf_train_cfg;
 /* The march of the NEXT batch (it reads neither the parameters nor anything of this step): when `next` is given, its rays are marched on
  * next->side_stream, forked from `stream` right behind the last NerfMLP wgrad, so that the latency-bound march runs beside the small
@@ -437,7 +446,8 @@ typedef struct rnerf_adam_cfg {
   double b1, b2, eps;
   double weight_decay_mult, grad_max_val, grad_max_norm;
   int64_t n_all;               /* number of variables weight_l2 averages over (theta + frozen) */
-  double lr_override;          /* > 0: constant learning rate (tests) */
+  double lr_override;          /* the learning rate of this update when use_lr_override != 0 (a replaced schedule, tests); 0.0 is honoured */
+  int32_t use_lr_override;     /* 0: the reference's schedule (rnerf/utils.py:490-528) from the device-resident step counter */
 } rnerf_adam_cfg;
 int rnerf_adam_update(const rnerf_adam_cfg* c, float* theta, float* mu, float* nu, float* grads, int64_t n_theta, const float* frozen_params,
                       int64_t n_frozen, int32_t* step_counter, float* scratch, void* stream);

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "librnerf.so")
 
 PREC_F32, PREC_F16X3, PREC_BF16X3, PREC_F16, PREC_BF16, PREC_F16X2, PREC_F16F8 = 0, 1, 2, 3, 4, 5, 6
-PRECISIONS = {"f16x3": PREC_F16X3, "bf16x3": PREC_BF16X3, "f16": PREC_F16, "bf16": PREC_BF16, "f16x2": PREC_F16X2, "f16f8": PREC_F16F8}
+PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3, "bf16x3": PREC_BF16X3, "f16": PREC_F16, "bf16": PREC_BF16, "f16x2": PREC_F16X2, "f16f8": PREC_F16F8}
 # enum rnerf_backward (include/rnerf.h): arithmetic of the NerfMLP dgrad + wgrad.  "f32" = hi + lo f16 parts (fp32-grade, the reference
 # differentiates in fp32, train.py:164); "tf32" = single f16 parts (11-bit significand); "bf16" = 8-bit significand.
 BWD_BF16, BWD_F16, BWD_F16X2 = 0, 1, 2
@@ -50,14 +50,15 @@ class TrainCfg(C.Structure):
     """rnerf_train_cfg: the loss terms of train_step.loss_fn that the shipped configs switch on (train.py:75-162)."""
     _fields_ = [("backward", C.c_int32), ("randomized", C.c_int32), ("use_random_choice", C.c_int32), ("bg_patch_size", C.c_int32),
                 ("bg_weight", C.c_double), ("bg_smooth_weight", C.c_double), ("annealed_alpha", C.c_double), ("frozen_sq", C.c_double),
-                ("frozen_count", C.c_int64), ("aux_stream", C.c_void_p), ("coresident_bkgd_wgrad", C.c_int32)]
+                ("frozen_count", C.c_int64), ("aux_stream", C.c_void_p), ("coresident_bkgd_wgrad", C.c_int32), ("grads_stream", C.c_void_p)]
 
 
 class AdamCfg(C.Structure):
     """rnerf_adam_cfg: optax.adam + the reference's learning-rate schedule and gradient clipping (train.py:169-183,312-317)."""
     _fields_ = [("lr_init", C.c_double), ("lr_final", C.c_double), ("lr_delay_mult", C.c_double), ("max_steps", C.c_int64),
                 ("lr_delay_steps", C.c_int64), ("b1", C.c_double), ("b2", C.c_double), ("eps", C.c_double), ("weight_decay_mult", C.c_double),
-                ("grad_max_val", C.c_double), ("grad_max_norm", C.c_double), ("n_all", C.c_int64), ("lr_override", C.c_double)]
+                ("grad_max_val", C.c_double), ("grad_max_norm", C.c_double), ("n_all", C.c_int64), ("lr_override", C.c_double),
+                ("use_lr_override", C.c_int32)]
 
 
 class Prefetch(C.Structure):

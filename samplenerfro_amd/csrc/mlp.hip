@@ -18,6 +18,7 @@
 //     of one layer, shared by the 4 waves: 1 KB of L2->LDS traffic per row and layer.
 //   * Persistent grid: each workgroup walks row tiles with stride gridDim.x and prefetches across layer and tile seams.
 #include "common.h"
+#include "nerfmlp_layout.h"
 
 #include <stdlib.h>
 #include <type_traits>
@@ -35,23 +36,6 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 #define GLOBAL_AS __attribute__((address_space(1)))
 #define LDS_AS __attribute__((address_space(3)))
-
-// ------------------------------------------------------------------------------------------------------------------
-// Parameter layout of the flat fp32 NerfMLP buffer (flax creation order, rnerf/model_utils.py:58-89).
-// ------------------------------------------------------------------------------------------------------------------
-struct DenseShape { int in, out; };
-__host__ __device__ constexpr DenseShape nerf_dense(int d) {
-  constexpr DenseShape t[12] = {{63, 256},  {256, 256}, {256, 256}, {256, 256}, {256, 256}, {319, 256},
-                                {256, 256}, {256, 256}, {256, 1},   {256, 256}, {283, 128}, {128, 3}};
-  return t[d];
-}
-__host__ __device__ constexpr int nerf_koff(int d) {
-  int o = 0;
-  for (int i = 0; i < d; ++i) o += nerf_dense(i).in * nerf_dense(i).out + nerf_dense(i).out;
-  return o;
-}
-__host__ __device__ constexpr int nerf_boff(int d) { return nerf_koff(d) + nerf_dense(d).in * nerf_dense(d).out; }
-static_assert(nerf_koff(12) == RNERF_NERFMLP_PARAMS, "NerfMLP parameter count");
 
 // The 10 MFMA layers: Dense_0..Dense_7 (trunk), Dense_9 (bottleneck), Dense_10 (view layer).
 // kind: 0 = input is the 63-d positional encoding; 1 = previous activations; 2 = previous + PE (skip concat,
@@ -131,6 +115,9 @@ constexpr float F8X_LO_SCALE = 1024.f;       // x_lo is multiplied, the W image 
 // (the builtin takes the old value as an input, and an "old" that does not exist yet is an undefined register the allocator spills and
 // reloads); SCALED = v_cvt_scalef32_pk_fp8_f32, which divides by its scale operand (the power of two 1 / F8X_LO_SCALE).  Overflow: with
 // MODE.FP16_OVFL set (f8x_mode()) the conversion clamps to +-448, without it a value above ~464 becomes NaN (probed: fp8_cvt_probe.hip).
+// ORDER CONTRACT: the LOW half of a word must be converted BEFORE its HIGH half (the LOW form starts a fresh register and would drop a high
+// half written earlier).  Every caller walks the value pairs p = 0, 1, 2, 3 upwards (f8x_lo_part, PrevConv / EncWork chunks, the pack
+// kernel); f8_word() below builds a whole word in the right order for new callers.
 template <bool HI, bool SCALED = false>
 __device__ __forceinline__ uint32_t f8_pair(uint32_t old, float a, float b) {
   uint32_t r = old;
@@ -143,6 +130,11 @@ __device__ __forceinline__ uint32_t f8_pair(uint32_t old, float a, float b) {
     else asm("v_cvt_scalef32_pk_fp8_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(inv));
   }
   return r;
+}
+// one whole fp8 word from four values, low half first (the order contract of f8_pair in one place)
+template <bool SCALED = false>
+__device__ __forceinline__ uint32_t f8_word(float a, float b, float c, float d) {
+  return f8_pair<true, SCALED>(f8_pair<false, SCALED>(0u, a, b), c, d);
 }
 // fp8 conversions clamp instead of producing NaN: MODE.FP16_OVFL (bit 23); set once at the head of an f16f8 kernel
 __device__ __forceinline__ void f8x_mode() { asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1"); }
@@ -243,53 +235,6 @@ __global__ void nerfmlp_pack_kernel(const float* __restrict__ params, char* __re
 }
 
 // ---- forward kernel -----------------------------------------------------------------------------------------------------
-// sin for the positional encoding: 3-constant Cody-Waite reduction by pi/2 (exact products through fma; |a| < ~2^15) and the
-// Cephes sinf/cosf minimax polynomials on [-pi/4, pi/4] (~1 ulp).  ~20 VALU ops instead of the ~100 of the generic ocml
-// sinf with its Payne-Hanek path.  The argument itself is formed exactly like the reference: fl(fl(x * 2^d) + fl(pi/2)).
-// (cut into four dependent stages so that EncWork can issue them one per MFMA slot; pe_sin runs the same stages back to back)
-struct PeSin {
-  float a, k, r, z, sp;
-  __device__ __forceinline__ void s0(float arg) { a = arg; k = rintf(a * 0.63661977236758134f); }
-  __device__ __forceinline__ void s1() {
-    r = fmaf(-k, 1.5707963705062866f, a);
-    r = fmaf(-k, -4.3711388286737929e-08f, r);
-    r = fmaf(-k, -1.7151245100059311e-15f, r);
-    z = r * r;
-  }
-  __device__ __forceinline__ void s2() { sp = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, r, r); }
-  __device__ __forceinline__ float s3() const {
-    const int q = (int)k;
-    const float cp = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f), z * z, fmaf(-0.5f, z, 1.0f));
-    const float v = (q & 1) ? cp : sp;
-    return (q & 2) ? -v : v;
-  }
-};
-__device__ __forceinline__ float pe_sin(float a) {
-  PeSin p;
-  p.s0(a); p.s1(); p.s2();
-  return p.s3();
-}
-__device__ __forceinline__ float pe_cos(float a) {      // the cosine from the same reduction and polynomials (the next quadrant's sine)
-  PeSin p;
-  p.s0(a); p.s1(); p.s2();
-  const int q = (int)p.k;
-  const float z = p.z;
-  const float cp = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f), z * z, fmaf(-0.5f, z, 1.0f));
-  const float vc = (q & 1) ? p.sp : cp;
-  return ((q + 1) & 2) ? -vc : vc;
-}
-// sin and cos of one argument from one range reduction (cos a = the next quadrant's sine)
-__device__ __forceinline__ void pe_sincos(float a, float& sn, float& cs) {
-  PeSin p;
-  p.s0(a); p.s1(); p.s2();
-  const int q = (int)p.k;
-  const float z = p.z;
-  const float cp = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f), z * z, fmaf(-0.5f, z, 1.0f));
-  const float vs = (q & 1) ? cp : p.sp, vc = (q & 1) ? p.sp : cp;
-  sn = (q & 2) ? -vs : vs;
-  cs = ((q + 1) & 2) ? -vc : vc;
-}
-
 // Weight-stream DMA (global -> LDS, 16 B per lane, 1 KiB per wave-instruction).  Written as inline asm on purpose: for the
 // __builtin_amdgcn_global_load_lds form hipcc orders every later ds_read behind the DMA (it cannot prove the reads hit the
 // OTHER ring slot) and emits s_waitcnt vmcnt(0) right after the issue, which serialises the prefetch with the compute.
@@ -2942,14 +2887,21 @@ __global__ void __launch_bounds__(256) bkgd_wgrad_reduce_kernel(const float* __r
 
 }  // namespace rnerf
 
+namespace rnerf {
+// csrc/mlp_f32.hip: the exact-fp32 arbiter (RNERF_PREC_F32)
+int launch_fwd_f32(const void* packed, const float* rows_pd, const float* rows_dr, const int32_t* node_of_sample, int32_t B, long long total_rows,
+                   float* out_raw, hipStream_t st);
+}
+
 using namespace rnerf;
 
 static bool prec_ok(int p) {
-  return p == RNERF_PREC_F16X3 || p == RNERF_PREC_BF16X3 || p == RNERF_PREC_F16 || p == RNERF_PREC_BF16 || p == RNERF_PREC_F16X2 || p == RNERF_PREC_F16F8;
+  return p == RNERF_PREC_F32 || p == RNERF_PREC_F16X3 || p == RNERF_PREC_BF16X3 || p == RNERF_PREC_F16 || p == RNERF_PREC_BF16 || p == RNERF_PREC_F16X2 || p == RNERF_PREC_F16F8;
 }
 
 extern "C" size_t rnerf_nerfmlp_packed_bytes(int precision) {
   switch (precision) {
+    case RNERF_PREC_F32: return (size_t)RNERF_NERFMLP_PARAMS * sizeof(float);  // the flat fp32 buffer itself
     case RNERF_PREC_F16X3:
     case RNERF_PREC_F16X2: return Prec<RNERF_PREC_F16X3>::PACKED_BYTES;       // f16x2 reads the f16x3 stream
     case RNERF_PREC_F16F8: return Prec<RNERF_PREC_F16F8>::PACKED_BYTES;
@@ -2967,6 +2919,9 @@ extern "C" int rnerf_nerfmlp_pack(const float* params, int precision, void* pack
   const int threads = kTotalBlocks * 64, block = 256, grid = (threads + block - 1) / block;
   hipStream_t st = (hipStream_t)stream;
   switch (precision) {
+    case RNERF_PREC_F32:
+      RNERF_CHECK_HIP(hipMemcpyAsync(packed, params, (size_t)RNERF_NERFMLP_PARAMS * sizeof(float), hipMemcpyDeviceToDevice, st));
+      return RNERF_OK;
     case RNERF_PREC_F16X3:
     case RNERF_PREC_F16X2: hipLaunchKernelGGL(nerfmlp_pack_kernel<RNERF_PREC_F16X3>, dim3(grid), dim3(block), 0, st, params, (char*)packed); break;
     case RNERF_PREC_F16F8:
@@ -3062,6 +3017,7 @@ extern "C" int rnerf_nerfmlp_forward(const void* packed, int precision, const fl
   const long long total = (long long)S * B;
   hipStream_t st = (hipStream_t)stream;
   switch (precision) {
+    case RNERF_PREC_F32: return launch_fwd_f32(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st);
     case RNERF_PREC_F16X3: return launch_fwd<RNERF_PREC_F16X3>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, max_workgroups);
     case RNERF_PREC_F16X2: return launch_fwd<RNERF_PREC_F16X2>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, max_workgroups);
     case RNERF_PREC_F16F8: return launch_fwd<RNERF_PREC_F16F8>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, max_workgroups);

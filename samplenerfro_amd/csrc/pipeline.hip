@@ -8,6 +8,7 @@
 
 #include <math.h>
 #include <mutex>
+#include <utility>
 #include <vector>
 
 namespace rnerf {
@@ -175,7 +176,7 @@ __global__ void __launch_bounds__(256) adam_frozen_sq_kernel(const float* __rest
   __syncthreads();
   if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
-struct AdamSched { double lr_init, lr_final, lr_delay_mult, max_steps, lr_delay_steps, b1, b2, max_norm, lr_override; };
+struct AdamSched { double lr_init, lr_final, lr_delay_mult, max_steps, lr_delay_steps, b1, b2, max_norm, lr_override; int use_override; };
 // scal[0] = -lr / (1 - b1^t), scal[1] = 1 / (1 - b2^t), scal[2] = norm-clip multiplier; the step counter is incremented.
 // learning_rate_decay: rnerf/utils.py:490-528 in float64 like the host version.
 __global__ void __launch_bounds__(256) adam_scalars_kernel(AdamSched c, int* __restrict__ step, const float* __restrict__ partial, int n_partial,
@@ -190,7 +191,7 @@ __global__ void __launch_bounds__(256) adam_scalars_kernel(AdamSched c, int* __r
   const int count = *step;
   const double t = (double)count + 1.0;
   double lr;
-  if (c.lr_override > 0) {
+  if (c.use_override) {          // an explicit flag, not "lr > 0": a schedule that returns exactly 0.0 (warm-up, count 0) is a zero step
     lr = c.lr_override;
   } else {
     double delay = 1.0;
@@ -581,6 +582,7 @@ extern "C" int rnerf_train_forward_backward(const rnerf_model* m, const rnerf_tr
   }
   if (next && next->beside_wgrad && Nf == 0) RNERF_TRY(march_next());
   RNERF_TRY(rnerf_nerfmlp_wgrad(prec, bwd, t.save_c, t.dy, (int64_t)Nc * B, g_c, t.wgrad_ws, stream));
+  if (c->grads_stream) RNERF_TRY(rnerf_fork(stream, c->grads_stream));      // the NerfMLP gradient segments are final: the caller's collective may start
   if (next && !next->beside_wgrad) RNERF_TRY(march_next());     // beside the tail below (background-MLP backward, loss glue) and the update
   if (co) {
     RNERF_TRY(rnerf_join(stream, aux));
@@ -615,7 +617,7 @@ extern "C" int rnerf_adam_update(const rnerf_adam_cfg* c, float* theta, float* m
       }
     }
   }
-  AdamSched s{c->lr_init, c->lr_final, c->lr_delay_mult, (double)c->max_steps, (double)c->lr_delay_steps, c->b1, c->b2, c->grad_max_norm, c->lr_override};
+  AdamSched s{c->lr_init, c->lr_final, c->lr_delay_mult, (double)c->max_steps, (double)c->lr_delay_steps, c->b1, c->b2, c->grad_max_norm, c->lr_override, c->use_lr_override != 0};
   hipLaunchKernelGGL(adam_scalars_kernel, dim3(1), dim3(256), 0, st, s, step_counter, (const float*)partial, n_partial, scal);
   hipLaunchKernelGGL(adam_apply_kernel, dim3(ADAM_BLOCKS), dim3(256), 0, st, theta, mu, nu, (const float*)grads, (long long)n_theta, (float)c->b1, (float)c->b2,
                      (float)c->eps, scal);
@@ -624,7 +626,21 @@ extern "C" int rnerf_adam_update(const rnerf_adam_cfg* c, float* theta, float* m
 }
 
 // ---- hipGraph --------------------------------------------------------------------------------------------------------------------
+namespace {
+// Events recorded inside a stream capture become graph edges.  They are collected per capturing thread (capture mode is thread local) and
+// handed to the executable graph at rnerf_graph_end; rnerf_graph_destroy releases them with it.  Outside capture the event is released as
+// soon as the wait is enqueued (HIP defers the destruction until the event has completed).
+std::mutex g_ev_mu;
+thread_local std::vector<hipEvent_t> tl_capture_events;
+std::vector<std::pair<void*, std::vector<hipEvent_t>>> g_graph_events;
+void drop_events(std::vector<hipEvent_t>& v) {
+  for (hipEvent_t e : v) (void)hipEventDestroy(e);
+  v.clear();
+}
+}  // namespace
+
 extern "C" int rnerf_graph_begin(void* stream) {
+  drop_events(tl_capture_events);      // leftovers of a capture that failed before rnerf_graph_end
   RNERF_CHECK_HIP(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));
   return RNERF_OK;
 }
@@ -632,11 +648,17 @@ extern "C" int rnerf_graph_begin(void* stream) {
 extern "C" int rnerf_graph_end(void* stream, void** graph_exec) {
   RNERF_CHECK_ARG(graph_exec, "rnerf_graph_end: null pointer");
   hipGraph_t g = nullptr;
-  RNERF_CHECK_HIP(hipStreamEndCapture((hipStream_t)stream, &g));
+  hipError_t err = hipStreamEndCapture((hipStream_t)stream, &g);
+  if (err != hipSuccess) { drop_events(tl_capture_events); set_error("hipStreamEndCapture failed: %s", hipGetErrorString(err)); return RNERF_ERR_HIP; }
   hipGraphExec_t e = nullptr;
-  hipError_t err = hipGraphInstantiate(&e, g, nullptr, nullptr, 0);
+  err = hipGraphInstantiate(&e, g, nullptr, nullptr, 0);
   hipGraphDestroy(g);
-  if (err != hipSuccess) { set_error("hipGraphInstantiate failed: %s", hipGetErrorString(err)); return RNERF_ERR_HIP; }
+  if (err != hipSuccess) { drop_events(tl_capture_events); set_error("hipGraphInstantiate failed: %s", hipGetErrorString(err)); return RNERF_ERR_HIP; }
+  {
+    std::lock_guard<std::mutex> l(g_ev_mu);
+    g_graph_events.emplace_back((void*)e, std::move(tl_capture_events));
+  }
+  tl_capture_events.clear();
   *graph_exec = (void*)e;
   return RNERF_OK;
 }
@@ -648,30 +670,32 @@ extern "C" int rnerf_graph_launch(void* graph_exec, void* stream) {
 }
 
 extern "C" int rnerf_graph_destroy(void* graph_exec) {
-  if (graph_exec) RNERF_CHECK_HIP(hipGraphExecDestroy((hipGraphExec_t)graph_exec));
+  if (!graph_exec) return RNERF_OK;
+  std::vector<hipEvent_t> ev;
+  {
+    std::lock_guard<std::mutex> l(g_ev_mu);
+    for (size_t i = 0; i < g_graph_events.size(); ++i)
+      if (g_graph_events[i].first == graph_exec) { ev = std::move(g_graph_events[i].second); g_graph_events.erase(g_graph_events.begin() + i); break; }
+  }
+  RNERF_CHECK_HIP(hipGraphExecDestroy((hipGraphExec_t)graph_exec));
+  drop_events(ev);
   return RNERF_OK;
 }
-
-namespace {
-// events recorded inside a stream capture become graph edges; they are kept until the library unloads (a handful per captured graph).
-// Outside capture the event is released as soon as the wait is enqueued (HIP defers the destruction until the event has completed).
-std::mutex g_ev_mu;
-std::vector<hipEvent_t> g_capture_events;
-}  // namespace
 
 static int order_after(hipStream_t first, hipStream_t then) {
   hipEvent_t e = nullptr;
   RNERF_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  RNERF_CHECK_HIP(hipStreamIsCapturing(first, &cs));
-  RNERF_CHECK_HIP(hipEventRecord(e, first));
-  RNERF_CHECK_HIP(hipStreamWaitEvent(then, e, 0));
-  if (cs == hipStreamCaptureStatusNone) {
-    RNERF_CHECK_HIP(hipEventDestroy(e));
-  } else {
-    std::lock_guard<std::mutex> l(g_ev_mu);
-    g_capture_events.push_back(e);
+  hipError_t err = hipStreamIsCapturing(first, &cs);
+  if (err == hipSuccess) err = hipEventRecord(e, first);
+  if (err == hipSuccess) err = hipStreamWaitEvent(then, e, 0);
+  if (err != hipSuccess) {      // no leak on the error path
+    (void)hipEventDestroy(e);
+    set_error("stream ordering failed: %s", hipGetErrorString(err));
+    return RNERF_ERR_HIP;
   }
+  if (cs == hipStreamCaptureStatusNone) RNERF_CHECK_HIP(hipEventDestroy(e));
+  else tl_capture_events.push_back(e);
   return RNERF_OK;
 }
 

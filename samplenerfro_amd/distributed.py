@@ -42,6 +42,12 @@ def _force() -> bool:
     return os.environ.get("RNERF_FORCE_DIST") == "1"
 
 
+def _skip() -> bool:
+    """RNERF_SKIP_ALLREDUCE=1 (bench.py's `collectives.exposed_us` only): the gradient exchange is left out, so that the step can be timed
+    with and without it.  The replicas' parameters diverge: never set outside a timing loop."""
+    return os.environ.get("RNERF_SKIP_ALLREDUCE") == "1"
+
+
 def active() -> bool:
     """True when the collectives of the path are to be issued: more than one rank, or a forced one-rank group."""
     return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _force())
@@ -72,7 +78,7 @@ def allreduce_mean_(buffers: Sequence[torch.Tensor], extra: Optional[torch.Tenso
     All buffers are flattened into ONE contiguous tensor so a step costs a single all-reduce (5.26 MB for the reference
     network: latency-bound over xGMI, so fewer, larger messages win)."""
     rank, w = world()
-    if not active():
+    if not active() or _skip():
         return
     parts = [b.reshape(-1) for b in buffers] + ([extra.reshape(-1)] if extra is not None else [])
     if len(parts) == 1 and parts[0].is_contiguous():             # the train step keeps gradients + stats in one buffer already
@@ -93,7 +99,7 @@ def allreduce_begin(buf: torch.Tensor, force: bool = False):
     The train step starts the NerfMLP gradients (95 % of the bytes) right behind the last wgrad, so the collective runs beside
     the background-MLP backward and the loss tail instead of after them.  force: issue the collective even in a one-rank group
     (tests/test_gpu_rccl.py drives RCCL itself that way on a one-GPU box)."""
-    if not (active() or (force and dist.is_available() and dist.is_initialized())):
+    if not (active() or (force and dist.is_available() and dist.is_initialized())) or _skip():
         return None
     return dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
 

@@ -57,8 +57,13 @@ class GraphTrainStep:
         self.rng_state = torch.from_numpy(np.asarray(rng, np.uint32).reshape(2).view(np.int32).copy()).to(dev)
         self.keys4 = torch.zeros(4, dtype=torch.int32, device=dev)
         self.m = model.c_model()
-        self.c = train_cfg(model, state, flags, self.annealed)
-        self.a = adam_cfg(state, flags, 0.0)
+        # annealed_alpha of the batch in each static slot (train.py:350-351 ramps it every step; loss_bg / loss_bg_smooth are gated on
+        # annealed_alpha > 0, train.py:92,130).  In the radiance stages only that gate reaches the kernels, as launch arguments frozen into a
+        # captured graph: one cfg + one graph per (slot, gate, frozen-variables key), chosen per step from the batch's value.
+        self.alpha = [self.annealed, self.annealed]
+        self.cfgs: Dict[Any, Any] = {}
+        self.c = self._cfg(self.annealed)
+        self.a = adam_cfg(state, flags, None)
         self.ws = torch.empty(self.lib.rnerf_train_workspace_bytes(C.byref(self.m), C.byref(self.c), B), dtype=torch.uint8, device=dev)
         self.main = torch.cuda.Stream(device=dev)
         self.side = torch.cuda.Stream(device=dev)
@@ -67,9 +72,23 @@ class GraphTrainStep:
         self._marched = False
         self.split = distributed.active()       # two graphs around the all-reduce when the collective is live
 
+    def _cfg(self, annealed: float):
+        """rnerf_train_cfg for this gate and the current frozen variables (kept alive: captured graphs were issued from it)."""
+        fkey = frozen_sq_of(self.state, self.state.variables)[2]
+        key = (annealed > 0, fkey)
+        if key not in self.cfgs:
+            self.cfgs[key] = train_cfg(self.model, self.state, self.flags, annealed)
+        return self.cfgs[key]
+
+    def set_annealed(self, annealed_alpha: float) -> None:
+        """annealed_alpha of the batch the next step() trains on (batches given to load / load_next carry their own "annealed_alpha")."""
+        self.alpha[self.slot] = float(annealed_alpha)
+
     # ---- data ----------------------------------------------------------------------------------------------------------------------
     def _put(self, slot: int, batch) -> None:
         rays: Rays = batch["rays"]
+        if batch.get("annealed_alpha") is not None:
+            self.alpha[slot] = float(np.asarray(batch["annealed_alpha"]).reshape(-1)[0])
         with torch.cuda.stream(self.main):
             self.origins[slot].copy_(rays.origins, non_blocking=True)
             self.viewdirs[slot].copy_(rays.viewdirs, non_blocking=True)
@@ -164,13 +183,21 @@ class GraphTrainStep:
                 distributed.allreduce_mean_([self.state.grads])
         self._issue_back()
 
-    def step(self) -> Stats:
+    def step(self, annealed_alpha: Optional[float] = None) -> Stats:
         s, slot = self.state, self.slot
-        s.sync_step_counter()
+        if annealed_alpha is not None:
+            self.alpha[slot] = float(annealed_alpha)
+        self.annealed = self.alpha[slot]
+        # everything the caller's stream did to the parameters, the step counter or the static buffers since the last step (restore, an
+        # eval render, logging copies) is ordered before this step's in-place update
+        self.main.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.main):
+            s.sync_step_counter()
+        self.c = self._cfg(self.annealed)
         if not self._marched and self.prefetch:
             self._march(slot, self.main.cuda_stream)            # first step (or after load()): nothing prefetched this slot's path
             self._marched = True
-        key = (slot, self.annealed > 0)
+        key = (slot, self.annealed > 0, frozen_sq_of(s, s.variables)[2])
         if not self.graphs:
             self._warm(slot)                                    # the very first step runs eagerly (and warms every launcher)
             self.graphs["warm"] = True

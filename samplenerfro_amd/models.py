@@ -263,6 +263,12 @@ class NerfModel:
             self._tail = torch.cuda.Stream(device=self.device)
         return self._tail
 
+    def comm_stream(self) -> torch.cuda.Stream:
+        """The stream the train step's NerfMLP-gradient all-reduce is issued from (rnerf_train_cfg.grads_stream: ordered behind the last wgrad)."""
+        if getattr(self, "_comm", None) is None:
+            self._comm = torch.cuda.Stream(device=self.device)
+        return self._comm
+
     def release_reserved_cus(self) -> None:
         """Give the CUs reserved by prefetch_path(reserve_cus > 0) back to the MLP kernels."""
         self._mlp_wg_limit = 0

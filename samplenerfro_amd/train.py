@@ -264,14 +264,15 @@ def train_cfg(model: NerfModel, state: TrainState, flags, annealed: float) -> "_
     return c
 
 
-def adam_cfg(state: TrainState, flags, lr_override: float = 0.0) -> "_lib.AdamCfg":
+def adam_cfg(state: TrainState, flags, lr_override: Optional[float] = None) -> "_lib.AdamCfg":
     a = _lib.AdamCfg()
     a.lr_init, a.lr_final, a.lr_delay_mult = float(flags.lr_init), float(flags.lr_final), float(flags.lr_delay_mult)
     a.max_steps, a.lr_delay_steps = int(flags.max_steps), int(flags.lr_delay_steps)
     a.b1, a.b2, a.eps = 0.9, 0.999, 1e-8
     a.weight_decay_mult, a.grad_max_val, a.grad_max_norm = float(flags.weight_decay_mult), float(flags.grad_max_val), float(flags.grad_max_norm)
     a.n_all = state.theta.numel() + frozen_sq_of(state, state.variables)[1]
-    a.lr_override = float(lr_override)
+    a.use_lr_override = int(lr_override is not None)      # an explicit switch: a replaced schedule may return exactly 0.0
+    a.lr_override = float(lr_override) if lr_override is not None else 0.0
     return a
 
 
@@ -313,14 +314,28 @@ def _train_step_whole(model: NerfModel, rng, state: TrainState, batch, flags, ji
     nxt, next_path = None, None
     if next_rays is not None:
         next_path, nxt = model.prefetch_slot(next_rays)
+    # jax.lax.pmean of gradients and stats (train.py:166-167).  With more than one rank the NerfMLP segments (95 % of the bytes) start their
+    # all-reduce on a side stream the call orders behind the last wgrad, beside the background-MLP backward and the loss tail still queued
+    # on the main stream; the background-MLP gradients and the stats follow in a small second one.
+    comm = model.comm_stream() if (distributed.active() and hasattr(model, "comm_stream")) else None
+    if comm is not None:
+        c = _lib.TrainCfg.from_buffer_copy(c)          # (train_cfg results may be shared: the stream is this call's)
+        c.grads_stream = comm.cuda_stream
     _lib.check(lib.rnerf_train_forward_backward(C.byref(m), C.byref(c), state.theta.data_ptr(), o.data_ptr(), v.data_ptr(), pixels.data_ptr(), _lib.ptr(env), B,
                                                 keys.data_ptr(), _lib.ptr(jit), _lib.ptr(u), per_ray, _lib.ptr(pd), _lib.ptr(dr), G.data_ptr(), ws.data_ptr(),
                                                 int(model._mlp_wg_limit), C.byref(nxt) if nxt is not None else None, st), "rnerf_train_forward_backward")
     if next_path is not None:
         next_path.event.record(model._side)
-    distributed.allreduce_mean_([G])                   # jax.lax.pmean of gradients and stats (train.py:166-167): one flat buffer
+    if comm is not None:
+        n_big = state.segments["bkgd_mlp"][0]
+        with torch.cuda.stream(comm):
+            pending = distributed.allreduce_begin(G[:n_big])
+        distributed.allreduce_mean_([G[n_big:]])
+        distributed.allreduce_end_mean_(pending, G[:n_big])
+    else:
+        distributed.allreduce_mean_([G])
     default_lr = state._lr_fn_default is state.lr_fn
-    a = adam_cfg(state, flags, 0.0 if default_lr else float(state.lr_fn(state.step)))
+    a = adam_cfg(state, flags, None if default_lr else float(state.lr_fn(state.step)))
     state.sync_step_counter()
     fs = frozen_sq_of(state, state.variables)
     frozen = state.variables["flat"].get("so3_mlp") if fs[1] > 0 else None

@@ -31,6 +31,27 @@ def test_bench_two_ranks(scaling):
     assert d["metric"] == "rays/sec (train step)" and d["unit"] == "rays/s" and d["value"] > 0
     assert abs(d["value"] - 2 * per * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]      # whole-job rays / max-over-ranks time
     assert d["roofline"]["frac"] > 0 and d["config"]["backward_precision"] == "f32"
+    c = d["collectives"]                       # the step's one exchange, timed
+    assert c["ranks"] == 2 and c["allreduce_us"] > 0 and c["allreduce_bytes"] > 4 * 1_000_000 and "exposed_us" in c
+    assert d["stability"]["windows"] == 5 and d["stability"]["min_ms"] <= d["stability"]["median_ms"] <= d["stability"]["max_ms"]
+    assert d["dtype"] == "f16x3/fp32-acc"
+
+
+@pytest.mark.timeout(600)
+def test_bench_frame_leg_is_sharded_over_the_ranks():
+    """BASELINE configs[4]'s form with two ranks: every rank renders its contiguous block of image rows (eval.py:95-105,
+    rnerf/utils.py:353-370; no collective) and the blocks equal the rows of the single-rank frame bit for bit."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, RNERF_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "example", "--rays", "512", "--mode", "forward",
+           "--no-cpu-baseline", "--no-extra"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=560)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    f = d["frame"]
+    assert f["ms_per_frame_sharded"] > 0 and f["sharded"]["ranks"] == 2 and f["sharded"]["rows_per_rank"] == 400
+    assert f["sharded"]["block_equals_full_frame_rows"] is True and f["finite"]
 
 
 @pytest.mark.timeout(600)

@@ -44,7 +44,35 @@ def e4m3_block(x, axis, block=32):
     return np.moveaxis(q, -1, axis)
 
 
-MODES = ("f16x3", "f16x2", "f16+fp8x2")
+def mx_block(x, axis, ebits, mbits, emax_val, block=32):
+    """Round to a small MX float (1 sign, `ebits` exponent, `mbits` mantissa bits, largest finite value `emax_val`, subnormals, no inf / nan:
+    e2m3 = fp6 (max 7.5), e2m1 = fp4 (max 6)) with one E8M0 scale per `block` consecutive elements along `axis`."""
+    x = np.moveaxis(np.asarray(x, np.float64), axis, -1)
+    K = x.shape[-1]
+    pad = (-K) % block
+    xp = np.pad(x, [(0, 0)] * (x.ndim - 1) + [(0, pad)])
+    xb = xp.reshape(xp.shape[:-1] + (-1, block))
+    amax = np.abs(xb).max(-1, keepdims=True)
+    scale = 2.0 ** np.ceil(np.log2(np.maximum(amax, 1e-300) / emax_val))
+    y = xb / scale
+    bias = 2 ** (ebits - 1) - 1
+    emin = 1 - bias                                                            # exponent of the smallest normal
+    e = np.maximum(np.floor(np.log2(np.maximum(np.abs(y), 2.0 ** (emin - mbits - 2)))), emin)
+    q = np.round(y / 2.0 ** (e - mbits)) * 2.0 ** (e - mbits)
+    q = np.clip(q, -emax_val, emax_val) * scale
+    q = q.reshape(xp.shape)[..., :K]
+    return np.moveaxis(q, -1, axis)
+
+
+def e2m3_block(x, axis):
+    return mx_block(x, axis, 2, 3, 7.5)
+
+
+def e2m1_block(x, axis):
+    return mx_block(x, axis, 2, 1, 6.0)
+
+
+MODES = ("f16x3", "f16x2", "f16+fp8x2", "f16+fp6x2", "f16+fp4x2")
 
 
 def make_dense(mode):
@@ -57,8 +85,12 @@ def make_dense(mode):
             y = xh @ kh + xh @ kl + xl @ kh
         elif mode == "f16x2":                     # exact weights (hi + lo) x activations rounded to f16: the shipped opt-in precision
             y = xh @ kh + xh @ kl
-        else:                                     # f16 main term + both cross terms on block-scaled fp8 operands
+        elif mode == "f16+fp8x2":                 # f16 main term + both cross terms on block-scaled fp8 operands
             y = xh @ kh + e4m3_block(xh, -1) @ e4m3_block(kl, 0) + e4m3_block(xl, -1) @ e4m3_block(kh, 0)
+        elif mode == "f16+fp6x2":                 # the same with fp6 e2m3 operands (the f8f6f4 MFMA issues fp6 / fp4 at twice the fp8 rate)
+            y = xh @ kh + e2m3_block(xh, -1) @ e2m3_block(kl, 0) + e2m3_block(xl, -1) @ e2m3_block(kh, 0)
+        else:
+            y = xh @ kh + e2m1_block(xh, -1) @ e2m1_block(kl, 0) + e2m1_block(xl, -1) @ e2m1_block(kh, 0)
         return y + b
     return dense
 
@@ -94,7 +126,7 @@ def main():
         results.append(row)
         print(row)
     out = {"what": "max |dRGB| against float64 over 192 rays x 128 samples (refractive sphere grid 64^3), NerfMLP products emulated per mode",
-           "mfma_ticks_per_K64_product": {"f16x3": 384, "f16x2": 256, "f16+fp8x2": 256}, "results": results}
+           "mfma_ticks_per_K64_product": {"f16x3": 384, "f16x2": 256, "f16+fp8x2": 256, "f16+fp6x2": 192, "f16+fp4x2": 192}, "results": results}
     if len(sys.argv) > 1:
         json.dump(out, open(sys.argv[1], "w"), indent=1)
 
