@@ -60,7 +60,8 @@ constexpr int AUX_BSIG = 2816;         // Dense_8 bias (+3 pad)
 constexpr int AUX_WRGB = 2820;         // Dense_11 kernel transposed [3][128]
 constexpr int AUX_BRGB = 3204;         // Dense_11 bias (+1 pad)
 constexpr int AUX_ZERO = 3208;         // 256 zeros: the sigma weights of every layer but the trunk output (PrevConv SIG)
-constexpr int AUX_FLAG = 3464;         // f16f8: non-zero = a weight left the f16 range of the 2^14-scaled stream (the forward then returns NaN)
+constexpr int AUX_FLAG = 3464;         // f16 modes: non-zero = a weight left the f16 range of the scaled stream (|W| >= 256 for the 2^8-scaled streams: the
+                                       // forward returns NaN, never a plausible wrong colour; |W| >= 3.99 for f16f8's 2^14: the launch falls back to f16x3)
 constexpr int AUX_FLOATS = 3468;
 
 template <int PREC>
@@ -199,7 +200,7 @@ __global__ void nerfmlp_pack_kernel(const float* __restrict__ params, char* __re
     for (int j = 0; j < 8; ++j) {
       const int f = in_feature(l, s, h, j);
       w[j] = f < 0 ? 0.f : params[nerf_koff(d) + f * out_dim + n_out] * PP::WSCALE;
-      if constexpr (PP::F8X) { if (!(fabsf(w[j]) <= 65504.f)) ((float*)(packed + PP::STREAM_BYTES))[AUX_FLAG] = 1.0f; }   // zeroed by the launcher
+      if constexpr (PP::F16) { if (!(fabsf(w[j]) <= 65504.f)) ((float*)(packed + PP::STREAM_BYTES))[AUX_FLAG] = 1.0f; }   // zeroed by the launcher
     }
     uint32_t hi[4], lo[4];
     for (int p = 0; p < 4; ++p) split2<F16>(w[2 * p], w[2 * p + 1], hi[p], lo[p]);
@@ -657,7 +658,11 @@ template <int PREC, int dbg, int TRAIN>
 __global__ void __launch_bounds__(256, 1)
 nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ rows_pd, const float4* __restrict__ rows_dr,
                    const int* __restrict__ node_of_sample, int B, long long total_rows, int n_tiles, float4* __restrict__ out_raw,
-                   uint4* __restrict__ save, long long save_rows, int* __restrict__ tileq) {
+                   uint4* __restrict__ save, long long save_rows, int* __restrict__ tileq, const float* __restrict__ gate, int gate_skip_if) {
+  // gate (nullable): a range flag raised by a pack kernel.  The launch does nothing when (flag set) == gate_skip_if: the f16f8 forward steps
+  // aside when one of ITS weights left the range of its 2^14-scaled stream, and the f16x3 launch queued right behind it (same outputs,
+  // gate_skip_if = 0) does the work instead — a per-launch fallback decided on the device, no host round trip (rnerf_nerfmlp_forward).
+  if (gate != nullptr && ((gate[0] != 0.f) == (gate_skip_if != 0))) return;
   // tileq != nullptr (training forward on a capped grid): tiles beyond the first round are handed out by an atomic counter (tileq[0],
   // zeroed by the launcher; tileq[1 + workgroup] passes the draw from thread 0 to the other waves) — with fewer workgroups than CUs the
   // static stride would leave most of the chip idle in a last partial round (2048 tiles over 248 workgroups: 9 rounds instead of 8.26).
@@ -1033,7 +1038,7 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
       }
       sig0 = sig0 + __shfl_xor(sig0, 32) + bsig;
       sig1 = sig1 + __shfl_xor(sig1, 32) + bsig;
-      if constexpr (PP::F8X) {      // a weight outside the range of this precision's operand stream: fail loudly, not plausibly
+      if constexpr (PP::F16 && !PP::F8X) {      // a weight outside the range of this precision's operand stream (|W| >= 256): fail loudly, not plausibly
         if (auxt[AUX_FLAG] != 0.f) { const float qn = __builtin_nanf(""); p0[0] = p0[1] = p0[2] = qn; p1[0] = p1[1] = p1[2] = qn; sig0 = qn; sig1 = qn; }
       }
       if (h == 0) {
@@ -2895,6 +2900,11 @@ int launch_fwd_f32(const void* packed, const float* rows_pd, const float* rows_d
 
 using namespace rnerf;
 
+// f16f8 packs TWO streams: its own, and behind it (256-byte aligned) the f16x3 stream a launch falls back to when a weight is out of its range
+constexpr size_t kF8Fallback = (Prec<RNERF_PREC_F16F8>::PACKED_BYTES + 255) & ~(size_t)255;
+
+#define RNERF_TRY_(expr) do { int rc_ = (expr); if (rc_ != RNERF_OK) return rc_; } while (0)
+
 static bool prec_ok(int p) {
   return p == RNERF_PREC_F32 || p == RNERF_PREC_F16X3 || p == RNERF_PREC_BF16X3 || p == RNERF_PREC_F16 || p == RNERF_PREC_BF16 || p == RNERF_PREC_F16X2 || p == RNERF_PREC_F16F8;
 }
@@ -2904,7 +2914,7 @@ extern "C" size_t rnerf_nerfmlp_packed_bytes(int precision) {
     case RNERF_PREC_F32: return (size_t)RNERF_NERFMLP_PARAMS * sizeof(float);  // the flat fp32 buffer itself
     case RNERF_PREC_F16X3:
     case RNERF_PREC_F16X2: return Prec<RNERF_PREC_F16X3>::PACKED_BYTES;       // f16x2 reads the f16x3 stream
-    case RNERF_PREC_F16F8: return Prec<RNERF_PREC_F16F8>::PACKED_BYTES;
+    case RNERF_PREC_F16F8: return kF8Fallback + Prec<RNERF_PREC_F16X3>::PACKED_BYTES;   // its own stream, then the f16x3 stream it falls back to
     case RNERF_PREC_BF16X3: return Prec<RNERF_PREC_BF16X3>::PACKED_BYTES;
     case RNERF_PREC_F16: return Prec<RNERF_PREC_F16>::PACKED_BYTES;
     case RNERF_PREC_BF16: return Prec<RNERF_PREC_BF16>::PACKED_BYTES;
@@ -2923,13 +2933,19 @@ extern "C" int rnerf_nerfmlp_pack(const float* params, int precision, void* pack
       RNERF_CHECK_HIP(hipMemcpyAsync(packed, params, (size_t)RNERF_NERFMLP_PARAMS * sizeof(float), hipMemcpyDeviceToDevice, st));
       return RNERF_OK;
     case RNERF_PREC_F16X3:
-    case RNERF_PREC_F16X2: hipLaunchKernelGGL(nerfmlp_pack_kernel<RNERF_PREC_F16X3>, dim3(grid), dim3(block), 0, st, params, (char*)packed); break;
+    case RNERF_PREC_F16X2:
+      RNERF_CHECK_HIP(hipMemsetAsync((char*)packed + Prec<RNERF_PREC_F16X3>::STREAM_BYTES + AUX_FLAG * sizeof(float), 0, 4 * sizeof(float), st));
+      hipLaunchKernelGGL(nerfmlp_pack_kernel<RNERF_PREC_F16X3>, dim3(grid), dim3(block), 0, st, params, (char*)packed); break;
     case RNERF_PREC_F16F8:
       RNERF_CHECK_HIP(hipMemsetAsync((char*)packed + Prec<RNERF_PREC_F16F8>::STREAM_BYTES + AUX_FLAG * sizeof(float), 0, 4 * sizeof(float), st));
       hipLaunchKernelGGL(nerfmlp_pack_kernel<RNERF_PREC_F16F8>, dim3(grid), dim3(block), 0, st, params, (char*)packed);
+      RNERF_CHECK_HIP(hipMemsetAsync((char*)packed + kF8Fallback + Prec<RNERF_PREC_F16X3>::STREAM_BYTES + AUX_FLAG * sizeof(float), 0, 4 * sizeof(float), st));
+      hipLaunchKernelGGL(nerfmlp_pack_kernel<RNERF_PREC_F16X3>, dim3(grid), dim3(block), 0, st, params, (char*)packed + kF8Fallback);
       break;
+    case RNERF_PREC_F16:
+      RNERF_CHECK_HIP(hipMemsetAsync((char*)packed + Prec<RNERF_PREC_F16>::STREAM_BYTES + AUX_FLAG * sizeof(float), 0, 4 * sizeof(float), st));
+      hipLaunchKernelGGL(nerfmlp_pack_kernel<RNERF_PREC_F16>, dim3(grid), dim3(block), 0, st, params, (char*)packed); break;
     case RNERF_PREC_BF16X3: hipLaunchKernelGGL(nerfmlp_pack_kernel<RNERF_PREC_BF16X3>, dim3(grid), dim3(block), 0, st, params, (char*)packed); break;
-    case RNERF_PREC_F16: hipLaunchKernelGGL(nerfmlp_pack_kernel<RNERF_PREC_F16>, dim3(grid), dim3(block), 0, st, params, (char*)packed); break;
     default: hipLaunchKernelGGL(nerfmlp_pack_kernel<RNERF_PREC_BF16>, dim3(grid), dim3(block), 0, st, params, (char*)packed); break;
   }
   RNERF_CHECK_LAUNCH();
@@ -2950,11 +2966,12 @@ static int mlp_debug_flags() {
 
 template <int PREC, int DBG, int TRAIN = 0>
 static int launch_fwd_dbg(const void* packed, const float* rows_pd, const float* rows_dr, const int32_t* node_of_sample, int32_t B,
-                          long long total_rows, float* out_raw, hipStream_t st, void* save = nullptr, int max_wg = 0);
+                          long long total_rows, float* out_raw, hipStream_t st, void* save = nullptr, int max_wg = 0, const float* gate = nullptr,
+                          int gate_skip_if = 0);
 
 template <int PREC>
 static int launch_fwd(const void* packed, const float* rows_pd, const float* rows_dr, const int32_t* node_of_sample, int32_t B,
-                      long long total_rows, float* out_raw, hipStream_t st, int max_wg) {
+                      long long total_rows, float* out_raw, hipStream_t st, int max_wg, const float* gate = nullptr, int gate_skip_if = 0) {
 #ifdef RNERF_MLP_ABLATE
   switch (mlp_debug_flags()) {
     case 1: return launch_fwd_dbg<PREC, 1>(packed, rows_pd, rows_dr, node_of_sample, B, total_rows, out_raw, st, nullptr, max_wg);
@@ -2974,12 +2991,12 @@ static int launch_fwd(const void* packed, const float* rows_pd, const float* row
     default: break;
   }
 #endif
-  return launch_fwd_dbg<PREC, 0>(packed, rows_pd, rows_dr, node_of_sample, B, total_rows, out_raw, st, nullptr, max_wg);
+  return launch_fwd_dbg<PREC, 0>(packed, rows_pd, rows_dr, node_of_sample, B, total_rows, out_raw, st, nullptr, max_wg, gate, gate_skip_if);
 }
 
 template <int PREC, int DBG, int TRAIN>
 static int launch_fwd_dbg(const void* packed, const float* rows_pd, const float* rows_dr, const int32_t* node_of_sample, int32_t B,
-                      long long total_rows, float* out_raw, hipStream_t st, void* save, int max_wg) {
+                      long long total_rows, float* out_raw, hipStream_t st, void* save, int max_wg, const float* gate, int gate_skip_if) {
   using PP = Prec<PREC>;
   const int n_tiles = (int)((total_rows + 255) / 256);
   int dev = 0, cus = 0;
@@ -3000,7 +3017,7 @@ static int launch_fwd_dbg(const void* packed, const float* rows_pd, const float*
   }
   hipLaunchKernelGGL((nerfmlp_fwd_kernel<PREC, DBG, TRAIN>), dim3(grid), dim3(256), lds, st, (const char*)packed, (const float4*)rows_pd,
                      (const float4*)rows_dr, node_of_sample, B, total_rows, n_tiles, (float4*)out_raw, (uint4*)save,
-                     (long long)n_tiles * 256, tileq);
+                     (long long)n_tiles * 256, tileq, gate, gate_skip_if);
   RNERF_CHECK_LAUNCH();
   return RNERF_OK;
 }
@@ -3020,7 +3037,13 @@ extern "C" int rnerf_nerfmlp_forward(const void* packed, int precision, const fl
     case RNERF_PREC_F32: return launch_fwd_f32(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st);
     case RNERF_PREC_F16X3: return launch_fwd<RNERF_PREC_F16X3>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, max_workgroups);
     case RNERF_PREC_F16X2: return launch_fwd<RNERF_PREC_F16X2>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, max_workgroups);
-    case RNERF_PREC_F16F8: return launch_fwd<RNERF_PREC_F16F8>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, max_workgroups);
+    case RNERF_PREC_F16F8: {
+      // the f16f8 launch steps aside when its pack kernel flagged a weight outside the range of the 2^14-scaled stream (|W| >= 3.99); the f16x3
+      // launch behind it (its stream sits in the same packed buffer) runs only then: a fallback per launch, decided on the device
+      const float* flag = (const float*)((const char*)packed + Prec<RNERF_PREC_F16F8>::STREAM_BYTES) + AUX_FLAG;
+      RNERF_TRY_(launch_fwd<RNERF_PREC_F16F8>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, max_workgroups, flag, 1));
+      return launch_fwd<RNERF_PREC_F16X3>((const char*)packed + kF8Fallback, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, max_workgroups, flag, 0);
+    }
     case RNERF_PREC_BF16X3: return launch_fwd<RNERF_PREC_BF16X3>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, max_workgroups);
     case RNERF_PREC_F16: return launch_fwd<RNERF_PREC_F16>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, max_workgroups);
     default: return launch_fwd<RNERF_PREC_BF16>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, max_workgroups);

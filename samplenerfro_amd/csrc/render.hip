@@ -124,11 +124,13 @@ __global__ void __launch_bounds__(64) composite_kernel(const float4* __restrict_
 // train.py:89-92,105: loss = mean((rgb_f - pix)^2) + mean((rgb_c - pix)^2)
 //                            + bg_weight * 1[alpha>0] * sum(mask * |trans_rgb_bkgd_f - pix|) / (sum(mask) + 1),  mask = trans_f > 0.5
 // sums[0] = sum (rgb_f-pix)^2, sums[1] = sum (rgb_c-pix)^2, sums[2] = sum mask*|tb_f-pix|, sums[3] = sum mask (rays)
-__global__ void __launch_bounds__(256) loss_reduce_kernel(const float* __restrict__ rgb_c, const float* __restrict__ rgb_f,
-                                                          const float* __restrict__ trans_f, const float* __restrict__ tb_f,
-                                                          const float* __restrict__ pix, int B, float* __restrict__ sums) {
+// ONE workgroup, fixed reduction tree: the four sums are the same bits on every run (they used to be float atomics over 16 workgroups), and
+// the kernel writes them outright — no memset launch ahead of it.
+__global__ void __launch_bounds__(1024) loss_reduce_kernel(const float* __restrict__ rgb_c, const float* __restrict__ rgb_f,
+                                                           const float* __restrict__ trans_f, const float* __restrict__ tb_f,
+                                                           const float* __restrict__ pix, int B, float* __restrict__ sums) {
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < B; r += gridDim.x * blockDim.x) {
+  for (int r = threadIdx.x; r < B; r += blockDim.x) {
     const float m = trans_f[r] > 0.5f ? 1.f : 0.f;
     a3 += m;
     for (int c = 0; c < 3; ++c) {
@@ -140,7 +142,14 @@ __global__ void __launch_bounds__(256) loss_reduce_kernel(const float* __restric
     }
   }
   for (int o = 32; o > 0; o >>= 1) { a0 += __shfl_down(a0, o); a1 += __shfl_down(a1, o); a2 += __shfl_down(a2, o); a3 += __shfl_down(a3, o); }
-  if ((threadIdx.x & 63) == 0) { atomicAdd(sums + 0, a0); atomicAdd(sums + 1, a1); atomicAdd(sums + 2, a2); atomicAdd(sums + 3, a3); }
+  __shared__ float red[16][4];
+  if ((threadIdx.x & 63) == 0) { float* q = red[threadIdx.x >> 6]; q[0] = a0; q[1] = a1; q[2] = a2; q[3] = a3; }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    float s = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[w][threadIdx.x];
+    sums[threadIdx.x] = s;
+  }
 }
 
 // Backward of one level: d loss / d raw (rgb, sigma) per sample and d loss / d bkgd per ray.
@@ -680,9 +689,7 @@ extern "C" int rnerf_loss_reduce(const float* rgb_c, const float* rgb_f, const f
   RNERF_CHECK_ARG(rgb_f && trans_f && trans_bkgd_f && pixels && sums, "rnerf_loss_reduce: null pointer");
   RNERF_CHECK_ARG(B >= 1, "rnerf_loss_reduce: B must be >= 1");
   hipStream_t st = (hipStream_t)stream;
-  RNERF_CHECK_HIP(hipMemsetAsync(sums, 0, 4 * sizeof(float), st));
-  const int blocks = (B + 255) / 256 < 256 ? (B + 255) / 256 : 256;
-  hipLaunchKernelGGL(loss_reduce_kernel, dim3(blocks), dim3(256), 0, st, rgb_c, rgb_f, trans_f, trans_bkgd_f, pixels, B, sums);
+  hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(1024), 0, st, rgb_c, rgb_f, trans_f, trans_bkgd_f, pixels, B, sums);
   RNERF_CHECK_LAUNCH();
   return RNERF_OK;
 }

@@ -379,6 +379,11 @@ def march_all(table: torch.Tensor, spec: Grid, so3_flat: torch.Tensor, origins: 
     return pd, dr, ior
 
 
+# order of the compacted (ray, node) pair list of the stage-all* march: "sorted" (default) = by (node, ray), deterministic from run to run;
+# "atomic" = the kernel's arrival order (RNERF_PAIR_ORDER=atomic: saves a sort of n_pairs keys and a gather over [N, B] per step)
+PAIR_ORDER = os.environ.get("RNERF_PAIR_ORDER", "sorted")
+
+
 def march_all_train(table: torch.Tensor, spec: Grid, so3_flat: torch.Tensor, origins: torch.Tensor, viewdirs: torch.Tensor, near: float, far: float,
                     num_nodes: int, annealed_alpha: float = 1.0, pair_cap: Optional[int] = None, coherent: Optional[bool] = None):
     """rnerf_march_all_train: the stage "all*" march + the record its backward needs.  Returns a dict (pairs trimmed to their count:
@@ -403,7 +408,19 @@ def march_all_train(table: torch.Tensor, spec: Grid, so3_flat: torch.Tensor, ori
     n = int(count.item())
     if n > cap:
         raise _lib.RnerfError(f"march_all_train: {n} boundary-shell pairs exceed pair_cap = {cap}")
-    return dict(path_pd=pd, path_dr=dr, path_rdn=rdn, n_pairs=n, pair_id=pair_id[:n], pair_x=pair_x[:n].contiguous(), pair_g=pair_g[:n].contiguous(),
+    pid, px, pg = pair_id[:n], pair_x[:n], pair_g[:n]
+    if n > 1 and PAIR_ORDER == "sorted":
+        # The kernel hands out pair slots with one atomicAdd per pair, i.e. in arrival order: run-to-run different, and with it the summation
+        # order of so3_mlp's weight gradient.  Re-order the compacted list by its (node, ray) key — unique, so the order is a function of the
+        # batch alone — and re-point pair_of_node: every kernel downstream sees the same pairs in the same slots on every run.
+        key = pid[:, 1].to(torch.int64) * B + pid[:, 0].to(torch.int64)
+        perm = torch.argsort(key)
+        inv = torch.empty(n, dtype=torch.int32, device=dev)
+        inv[perm] = torch.arange(n, dtype=torch.int32, device=dev)
+        pid, px, pg = pid[perm], px[perm], pg[perm]
+        flat = pair_of_node.view(-1)
+        pair_of_node = torch.where(flat >= 0, inv[flat.clamp(min=0).to(torch.int64)], flat).view(N, B)
+    return dict(path_pd=pd, path_dr=dr, path_rdn=rdn, n_pairs=n, pair_id=pid, pair_x=px.contiguous(), pair_g=pg.contiguous(),
                 pair_of_node=pair_of_node, window=w)
 
 def so3_forward_train(so3_flat: torch.Tensor, window, pts4: torch.Tensor):
