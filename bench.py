@@ -36,11 +36,12 @@ PRECISION_NOTES = {
     "f16x2": "exact hi + lo f16 weights x activations rounded to f16, 2 MFMAs per product (opt-in inference mode: |dRGB| 3e-5..7e-5, "
              "inside the 1e-4 contract without the margin f16x3 keeps)",
     "f16f8": "f16 main term + the two cross terms of the hi/lo split on the fp8 (e4m3) MFMA: 3 MFMAs per product like f16x3, less power "
-             "(opt-in inference mode: |dRGB| ~2e-6 vs the oracle; weights must stay below 3.99 in magnitude)",
+             "(the default arithmetic of the render pass: |dRGB| ~2e-6 vs the oracle; a weight of magnitude >= 3.99 makes the launch fall back to "
+             "f16x3 on the device)",
 }
 
 
-def build_scene(cfg, device, precision, fine, stage="radiance"):
+def build_scene(cfg, device, precision, fine, stage="radiance", eval_precision=None):
     import torch
     from samplenerfro_amd import models, ops, synthetic as syn
     G, ext = cfg["G"], cfg["extent"]
@@ -58,7 +59,7 @@ def build_scene(cfg, device, precision, fine, stage="radiance"):
         grid = torch.ones((G, G, G), dtype=torch.float32, device=device)
     model = models.NerfModel(ndim=ndim, nmin=nmin, nmax=nmax, grid=grid, near=cfg["near"], far=cfg["far"],
                              num_coarse_samples=cfg["S"], num_fine_samples=fine, num_path_samples=cfg["P"],
-                             precision=precision, device=device, stage=stage)
+                             precision=precision, eval_precision=eval_precision, device=device, stage=stage)
     del grid
     pf = syn.init_params_flat(0, fine=fine > 0)
     flat = {k: torch.from_numpy(v).to(device) for k, v in pf.items()}
@@ -334,7 +335,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="ship_straight")
     ap.add_argument("--fine", type=int, default=None, help="num_fine_samples (default: the workload's flat variant, 0)")
-    ap.add_argument("--precision", default="f16x3")
+    ap.add_argument("--precision", default="f16x3", help="arithmetic of training and of every tapped path")
+    ap.add_argument("--eval-precision", default=None,
+                    help="arithmetic of the pure render pass (forward mode, the frame): default = construct_nerf's default, f16f8 (f16 main term + fp8 "
+                         "cross terms, device-side fallback to f16x3 when a weight is out of its range), when --precision is f16x3; else --precision")
     ap.add_argument("--rays", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pipeline", dest="pipeline", action="store_true", default=None,
@@ -369,6 +373,8 @@ def main():
         args.pipeline = args.mode == "train"
     if args.cpu_rays is None:
         args.cpu_rays = 4096 if args.mode == "forward" else 512
+    if args.eval_precision is None:
+        args.eval_precision = "f16f8" if args.precision == "f16x3" else args.precision
 
     import torch
     import torch.distributed as dist
@@ -398,7 +404,7 @@ def main():
             raise SystemExit("--scaling strong: the global batch must be divisible by the number of ranks (train.py:196)")
         B //= world
     t_scene = time.perf_counter()
-    model, variables, pf = build_scene(cfg, device, args.precision, fine, args.stage)
+    model, variables, pf = build_scene(cfg, device, args.precision, fine, args.stage, args.eval_precision)
     torch.cuda.synchronize()
     t_scene = time.perf_counter() - t_scene
     if args.stage == "all":
@@ -481,7 +487,9 @@ def main():
     N = S * cfg["P"]
     path_pd, path_dr, _, _ = ops.march(model.table, model.spec, rays.origins, rays.viewdirs, cfg["near"], cfg["far"], N)
     jit = model._jitter_dev(model.make_jitter(key))
-    packed = model._packed_weights(variables, "coarse_mlp")
+    prec_fwd = model.precision if train else model.eval_precision       # the arithmetic the measured pass runs its NerfMLP in
+    prec_fwd_name = args.precision if train else args.eval_precision
+    packed = model._packed_weights(variables, "coarse_mlp", prec_fwd)
     reps = max(5, min(args.steps, 20))
 
     def timed(fn):
@@ -494,7 +502,7 @@ def main():
         return float(np.mean([e[i].elapsed_time(e[i + 1]) for i in range(reps)]))
 
     out_raw = torch.empty((S, B, 4), dtype=torch.float32, device=device)
-    mlp_ms = timed(lambda: ops.nerfmlp_forward(packed, model.precision, path_pd, path_dr, jit, S, B, out=out_raw))
+    mlp_ms = timed(lambda: ops.nerfmlp_forward(packed, prec_fwd, path_pd, path_dr, jit, S, B, out=out_raw))
     mlp_flops = MLP_FLOP_PER_ROW * S * B
     mlp_achieved = mlp_flops / (mlp_ms * 1e-3)
     # march kernel (HBM-bound by its algorithmic gather bytes: 8 corners x 16 B per step)
@@ -509,6 +517,7 @@ def main():
         rows = S * B
         BW = _lib.BACKWARDS[args.backward]
         pbwd = ops.nerfmlp_pack_bwd(variables["flat"]["coarse_mlp"], None, BW)
+        packed = model._packed_weights(variables, "coarse_mlp")
         raw_t, save_t = ops.nerfmlp_forward_train(packed, model.precision, path_pd, path_dr, jit, S, B, BW)
         d_raw = torch.randn((S, B, 4), device=device) * 1e-3
         dy_t = torch.empty(lib.rnerf_nerfmlp_dy_bytes(rows, BW), dtype=torch.uint8, device=device)
@@ -606,7 +615,7 @@ def main():
         del dmodel, dvars
         torch.cuda.empty_cache()
         variants["scene_build_s"] = {"ship_straight (table only)": t_scene, "ship_refractive (sphere + (9, 3.0) prefilter + table, 512^3)": t_refr}
-        model, variables, pf = build_scene(cfg, device, args.precision, fine, args.stage)
+        model, variables, pf = build_scene(cfg, device, args.precision, fine, args.stage, args.eval_precision)
 
     frame = None
     if args.frame:
@@ -627,7 +636,7 @@ def main():
         rgb_img, _, _ = U.render_image(fn, fr, key, False, chunk=chunk)
         barrier()
         frame = {"ms_per_frame": 1e3 * D.max_over_ranks(time.perf_counter() - t1, device), "height": H, "width": W, "samples": cfg["S"] + fine,
-                 "chunk": chunk, "finite": bool(torch.isfinite(rgb_img).all()), "precision": args.precision,
+                 "chunk": chunk, "finite": bool(torch.isfinite(rgb_img).all()), "precision": args.eval_precision,
                  "what": "every rank renders the WHOLE frame (one GPU's time)"}
 
         def sharded_frame(mdl, vrs, rays_hw, ck):
@@ -651,7 +660,7 @@ def main():
             # BASELINE configs[4]: glass, 800 x 800, 256 samples per ray, P = 24 -> N = 6144 eikonal steps, 384^3 grid after (5, 3.0)
             gcfg = dict(syn.CONFIGS["glass_frame"])
             del rgb_img
-            gm, gv, _ = build_scene(gcfg, device, args.precision, 0, "radiance")
+            gm, gv, _ = build_scene(gcfg, device, args.precision, 0, "radiance", args.eval_precision)
             gfn = lambda k0, k1, r, path=None: gm.apply(gv, k0, k1, r, False, path=path)
             gchunk = 16384
             if world > 1:
@@ -668,19 +677,20 @@ def main():
                                     "what": "BASELINE configs[4]: 800 x 800 x 256 samples, N = 6144, rows sharded over the ranks that ran"}
             del gm, gv
             torch.cuda.empty_cache()
-            rgb_img = U.render_image(fn, fr, key, False, chunk=chunk)[0] if (args.precision == "f16x3") else None
-        if args.extra and args.precision == "f16x3" and args.stage == "radiance":
-            # the same frame with the opt-in inference precision f16f8 (the two cross terms of the hi/lo split on the fp8 MFMA):
-            # its time and its largest colour difference from the f16x3 frame above (same weights: build_scene is seeded)
-            m8, v8, _ = build_scene(cfg, device, "f16f8", fine, args.stage)
+            frame["glass_frame"]["precision"] = args.eval_precision
+            rgb_img = U.render_image(fn, fr, key, False, chunk=chunk)[0] if (args.eval_precision != args.precision) else None
+        if args.extra and args.eval_precision != args.precision and args.stage == "radiance":
+            # the same frame in the TRAINING arithmetic (f16x3, fp32-grade): its time and the largest colour difference between the two frames
+            # (same weights: build_scene is seeded)
+            m8, v8, _ = build_scene(cfg, device, args.precision, fine, args.stage)
             fn8 = lambda k0, k1, r, path=None: m8.apply(v8, k0, k1, r, False, path=path)
             U.render_image(fn8, fr, key, False, chunk=chunk)
             barrier()
             t1 = time.perf_counter()
             rgb8, _, _ = U.render_image(fn8, fr, key, False, chunk=chunk)
             barrier()
-            frame["f16f8"] = {"ms_per_frame": 1e3 * D.max_over_ranks(time.perf_counter() - t1, device),
-                              "max_abs_rgb_vs_f16x3_frame": float((rgb8 - rgb_img).abs().max()), "finite": bool(torch.isfinite(rgb8).all())}
+            frame[args.precision] = {"ms_per_frame": 1e3 * D.max_over_ranks(time.perf_counter() - t1, device),
+                                     "max_abs_rgb_vs_the_frame_above": float((rgb8 - rgb_img).abs().max()), "finite": bool(torch.isfinite(rgb8).all())}
             del m8, v8, rgb8
             torch.cuda.empty_cache()
     if rank == 0:
@@ -690,12 +700,13 @@ def main():
         line = {
             "metric": "rays/sec (train step)" if train else "rays/sec (forward render pass)", "value": total_rays / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": args.scaling,
-            "vs_baseline": None, "dtype": dtype_label(args.precision, args.backward, train), "data": "synthetic",
+            "vs_baseline": None, "dtype": dtype_label(args.precision if train else args.eval_precision, args.backward, train), "data": "synthetic",
             "config": {"workload": f"{args.workload}: {'train step (forward + backward + grad all-reduce + Adam)' if train else 'forward render pass'}, "
                                    f"{B} rays/GPU x {S} coarse + {fine} fine samples, "
                                    f"P={cfg['P']} (N={N} eikonal steps), grid {cfg['G']}^3", "rays_per_gpu": B,
                        "mlp_rows_per_ray": rows_per_ray, "pass": args.mode, "stage": args.stage,
-                       "precision": args.precision + ": forward — " + PRECISION_NOTES.get(args.precision, "single 16-bit MFMA per product, fp32 accumulate"),
+                       "precision": prec_fwd_name + ": forward — " + PRECISION_NOTES.get(prec_fwd_name, "single 16-bit MFMA per product, fp32 accumulate"),
+                       "eval_precision": args.eval_precision,
                        "backward_precision": (None if not train else args.backward),
                        "backward_precision_note": (None if not train else {
                            "f32": "row-normalised f16 hi + lo parts of every saved activation and gradient (22 bits), 3 MFMAs per product: within 1e-5 of max|g| vs float64",
@@ -708,11 +719,12 @@ def main():
                        "pipeline": ("none" if not args.pipeline else ("march(k+1) on a side branch beside the tail of step k" if train
                                                                           else "march(k+1) on a side stream overlaps MLP(k)"))},
             "roofline": {"kernel": "nerfmlp_fwd_kernel", "bound": "mfma", "achieved": mlp_achieved / 1e12, "peak": PEAK_MFMA_16BIT / 1e12,
-                         "unit": "TFLOP/s", "frac": mlp_achieved / PEAK_MFMA_16BIT, "traffic": traffic_of("nerfmlp_fwd_kernel<1, 0, 0>"),
+                         "unit": "TFLOP/s", "frac": mlp_achieved / PEAK_MFMA_16BIT, "traffic": traffic_of("nerfmlp_fwd_kernel<%d, 0, 0>" % prec_fwd),
                          "avg_launch_ms": mlp_ms, "algorithmic_flop_per_launch": mlp_flops,
                          # computed, not a counter: MFMA flops issued (3 passes in the x3 modes) / (launch time x 2.5 PF)
-                         "mfma_issue_frac_computed": {"f16x3": 3, "bf16x3": 3, "f16x2": 2, "f16f8": 3}.get(args.precision, 1) * mlp_achieved / PEAK_MFMA_16BIT,
-                         "counters": counters_of("nerfmlp_fwd_kernel<1, 0, 0>")},
+                         "precision": prec_fwd_name,
+                         "mfma_issue_frac_computed": {"f16x3": 3, "bf16x3": 3, "f16x2": 2, "f16f8": 3}.get(prec_fwd_name, 1) * mlp_achieved / PEAK_MFMA_16BIT,
+                         "counters": counters_of("nerfmlp_fwd_kernel<%d, 0, 0>" % prec_fwd)},
             "roofline_march": {"kernel": "march_kernel", "bound": "hbm", "achieved": march_achieved / 1e9, "peak": PEAK_HBM / 1e9,
                                "unit": "GB/s", "frac": march_achieved / PEAK_HBM, "traffic": traffic_of("march_kernel"), "avg_launch_ms": march_ms,
                                "algorithmic_bytes_per_launch": march_bytes},

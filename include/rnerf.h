@@ -46,8 +46,11 @@ enum rnerf_status {
  * contract for weights of ordinary size but without the 2x margin f16x3 keeps everywhere, hence opt-in.
  * F16F8 (forward / inference only) = f16 main term + the two cross terms of the hi/lo split on v_mfma_f32_32x32x16_fp8_fp8 (e4m3): the
  * instruction count and operand bytes of F16X3 at lower power (the engine is power-limited: ~8 % faster); measured end-to-end |dRGB| vs the
- * oracle 2e-6.  Its operand stream scales the weights by 2^14: a NerfMLP weight of magnitude >= 3.99 makes rnerf_nerfmlp_forward return NaN
- * (flag raised by rnerf_nerfmlp_pack), never a plausible wrong colour.  Own packed stream: pack with the precision you run. */
+ * oracle 2e-6.  Its operand stream scales the weights by 2^14: a NerfMLP weight of magnitude >= 3.99 raises a flag in rnerf_nerfmlp_pack, and
+ * every rnerf_nerfmlp_forward launch then steps aside for the F16X3 launch queued behind it (the F16F8 packed buffer carries both streams):
+ * a per-launch fallback decided on the device, F16X3's bits, no host round trip.  Own packed stream: pack with the precision you run.
+ * Range of every f16 mode (never silent): a weight of magnitude >= 256 (2^8-scaled streams) or a hidden activation above f16's 65504 yields
+ * NaN outputs for the rows concerned — the forward watches the largest f16 operand it forms per row — never a plausible wrong colour. */
 enum rnerf_precision {
   RNERF_PREC_F32 = 0,
   RNERF_PREC_F16X3 = 1,

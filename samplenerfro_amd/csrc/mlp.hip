@@ -281,6 +281,11 @@ __device__ __forceinline__ void issue_slab(const char* __restrict__ gsrc, unsign
 // B operands of one k-step for the wave's two 32-row m-tiles
 // min(u16, 1) of both halves of a dword = the non-zero flags of two non-negative 16-bit floats.  Written as the instruction:
 // hipcc expands __builtin_elementwise_min(u16x2, {1,1}) into ~20 SDWA compares / scalar mask ops per dword.
+__device__ __forceinline__ uint32_t pk_maxu(uint32_t a, uint32_t b) {
+  uint32_t r;
+  asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 __device__ __forceinline__ uint32_t pk_min1(uint32_t w) {
   uint32_t r;
   asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(w), "v"(0x00010001u));
@@ -296,6 +301,17 @@ __device__ __forceinline__ float4 gload4(const float* p) {
 }
 
 struct KOps { uint4 h0, l0, h1, l1; };
+
+// ReLU as an INTEGER max on the bit pattern: max_i32(bits(x), 0) is x for x >= +0, +0 for every negative x (and -0), and — unlike
+// v_max_f32, which returns the non-NaN operand — it keeps +inf and NaN.  That matters because the activations travel as f16 parts: a hidden
+// activation above 65504 becomes hi = inf, lo = x - inf = -inf, the next layer's sums inf - inf = NaN, and with fmaxf(NaN, 0) = 0 every unit
+// of that layer silently read 0 — finite, plausible, wrong outputs (found in round 4; tools/r04/dbg_hot.py).  With the integer max the NaN
+// reaches the outputs: out of range means non-finite, never plausible.  NO_FLOOR (= INT_MIN) turns the max into the identity (bottleneck).
+constexpr int RELU_FLOOR = 0, NO_FLOOR = (int)0x80000000u;
+__device__ __forceinline__ float relu_keep(float x, int floor_bits) {
+  const int b = __builtin_bit_cast(int, x);
+  return __builtin_bit_cast(float, b > floor_bits ? b : floor_bits);
+}
 
 // streaming accesses of the training tensors (written once, read once by a later kernel): keep them out of the L2 working set
 #ifdef RNERF_NO_NT
@@ -344,7 +360,7 @@ struct PrevConv {
   float v1[8];        // m-tile 1: raw accumulator values of the 8 features of k-step S (from LDS)
   float b[8];         // fp32 bias of the producing layer
   __device__ __forceinline__ PrevConv(const f32x16& p) : p0(p) {}
-  float floor_v;   // 0 (ReLU) or -inf (bottleneck: no activation)
+  int floor_v;     // RELU_FLOOR (ReLU) or NO_FLOOR (bottleneck: no activation) — see relu_keep()
   uint32_t hi[2][4], lo[2][4];
   // the pair in flight, per m-tile (a 4-tile k-step runs one pair of each m-tile at a time: PairOfPairs).  Four scalars, not arrays:
   // the inline asm below takes them by "+v", and an array member whose element goes into an asm operand stays in memory (scratch)
@@ -363,8 +379,8 @@ struct PrevConv {
       x0 = fmaf(r0, INV_SCALE, b[2 * p]);
       x1 = fmaf(r1, INV_SCALE, b[2 * p + 1]);
     } else if constexpr (C == 1) {
-      x0 = fmaxf(x0, floor_v);
-      x1 = fmaxf(x1, floor_v);
+      x0 = relu_keep(x0, floor_v);
+      x1 = relu_keep(x1, floor_v);
       if constexpr (SIG) {
         // volatile asm: as plain fmaf() the two FMAs are sunk below the residual stage (which overwrites x0 / x1 in place), and the
         // copies of x0 / x1 that keeps alive are spilled — 16 scratch stores per k-step
@@ -680,7 +696,6 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
   const float* __restrict__ aux = (const float*)(packed + PP::STREAM_BYTES);
   float4* __restrict__ st1 = (float4*)(smem + 2 * SLAB + wave * 32768) + lane;   // + (t*4 + rq)*64
   constexpr float INV_SCALE = 1.0f / PP::WSCALE;
-  const float NEG_INF = -__builtin_inff();
   int buf = 0;
   size_t off = 0;   // stream offset of the next slab to prefetch
   float prof_dma = 0.f, prof_bar = 0.f, prof_tot = 0.f, prof_n = 0.f;
@@ -739,6 +754,21 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
       }
     };
 
+    // Range watch of the f16 operand parts (RNERF_FWD_NORANGE: ablation).  A hidden activation above f16's 65504 becomes hi = inf; the next
+    // layer's sums are inf - inf = NaN (sign bit set on this hardware), which the ReLU turns into 0 — every unit of that layer would read 0
+    // and the outputs would be finite, plausible and wrong (found in round 4, tools/r04/dbg_hot.py).  So the largest |hi| bit pattern per lane
+    // is kept (one v_pk_max_u16 per operand dword: positive f16 order like their bits, inf = 0x7C00) and a row that met inf / NaN returns NaN.
+    uint32_t ovf0 = 0, ovf1 = 0;
+    auto watch = [&](const KOps& o, bool is_signed) {
+#ifndef RNERF_FWD_NORANGE
+      if constexpr (PP::F16) {
+        const uint32_t am = is_signed ? 0x7FFF7FFFu : 0xFFFFFFFFu;      // the bottleneck has no ReLU: drop the sign bits
+        ovf0 = pk_maxu(pk_maxu(ovf0, o.h0.x & am), pk_maxu(pk_maxu(o.h0.y & am, o.h0.z & am), o.h0.w & am));
+        ovf1 = pk_maxu(pk_maxu(ovf1, o.h1.x & am), pk_maxu(pk_maxu(o.h1.y & am, o.h1.z & am), o.h1.w & am));
+      }
+#endif
+    };
+
     uint32_t mw0 = 0, mw1 = 0;                                                // mask bytes of up to 4 k-steps, then one dword store
     auto save_mask = [&](int set, int s, uint32_t nib0, uint32_t nib1) {      // nib: nz_nibbles() of the hi operands of k-step s
 #ifdef RNERF_FWD_NOMASK       /* profiling ablation */
@@ -779,7 +809,7 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
     };
 
     // operands of k-step s from the previous layer's outputs: x = max(acc * inv_scale + bias, floor), hi/lo split.
-    auto prev_ops = [&](int s, const float* __restrict__ bias, float floor_v) -> KOps {
+    auto prev_ops = [&](int s, const float* __restrict__ bias, int floor_v) -> KOps {
       const float4 b0 = *(const float4*)(bias + 16 * s + 4 * h), b1 = *(const float4*)(bias + 16 * s + 8 + 4 * h);
       const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
       const float4 u0 = st1[((s >> 1) * 4 + 2 * (s & 1)) * 64], u1 = st1[((s >> 1) * 4 + 2 * (s & 1) + 1) * 64];
@@ -787,8 +817,8 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
       float x0[8], x1[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        x0[j] = fmaxf(fmaf(prev0[s >> 1][8 * (s & 1) + j], INV_SCALE, bb[j]), floor_v);
-        x1[j] = fmaxf(fmaf(r1[j], INV_SCALE, bb[j]), floor_v);
+        x0[j] = relu_keep(fmaf(prev0[s >> 1][8 * (s & 1) + j], INV_SCALE, bb[j]), floor_v);
+        x1[j] = relu_keep(fmaf(r1[j], INV_SCALE, bb[j]), floor_v);
       }
       KOps o;
       split8<PREC>(x0, o.h0, o.l0);
@@ -833,7 +863,7 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
     {
       cur = enc_ops(pd, 0, 30);
       SeamWork<PREC, TRAIN != 0> seam(acc0, acc1, prev0, st1);
-      seam.cv.floor_v = 0.f;
+      seam.cv.floor_v = RELU_FLOOR;
       load_bias8(0, auxt + AUX_BIAS, seam.cv.b);
       load_bias8(0, auxt + AUX_ZERO, seam.cv.ws);
       // k-steps 0..2 convert the position-encoding operands of the next k-step in their own MFMA shadows (EncWork), k-step 3 carries the seam
@@ -869,7 +899,7 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
       // the seam of this layer: hand-over of the outputs + conversion of the next layer's k-step 0 (bias of THIS layer; the bottleneck
       // Dense_9 = layer 8 has no activation), run by the layer's last k-step
       SeamWork<PREC, TRAIN != 0> seam(acc0, acc1, prev0, st1);
-      seam.cv.floor_v = l == 8 ? NEG_INF : 0.f;
+      seam.cv.floor_v = l == 8 ? NO_FLOOR : RELU_FLOOR;
       // sigma head (Dense_8, rnerf/model_utils.py:70) = sum over the trunk output x7 = the inputs of layer 8: k-step 0 in layer 7's seam,
       // k-steps 1..15 in layer 8's conversions.  (The seam's bias / sigma weights are fetched at k-step 13: 16 registers less in the steady state.)
       const float* __restrict__ wseam = auxt + (l == 7 ? AUX_WSIG : AUX_ZERO);
@@ -877,6 +907,7 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
 #define RNERF_KSTEP(S)                                                                                              \
       {                                                                                                              \
         save_ops(SAVE_L1 + 16 * (l - 1) + S, cur);                                                                   \
+        watch(cur, false);                                                                                           \
         if constexpr (TRAIN != 0 && S == 0) save_mask(l - 1, 0, nz_nibbles(cur.h0), nz_nibbles(cur.h1));                  \
         if constexpr (S == 13) { load_bias8(0, bias + 256, seam.cv.b); load_bias8(0, wseam, seam.cv.ws); }           \
         float bnn[8], wnn[8];                                                                                        \
@@ -885,7 +916,7 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
         auto dma = [&]() { SLAB_PREFETCH(true); };                                                                   \
         if constexpr (S + 1 < 16) {                                                                                  \
           PrevConv<PREC, S + 1, TRAIN != 0, true> cv(prev0[(S + 1) >> 1]);                                           \
-          cv.floor_v = 0.f;                                                                                          \
+          cv.floor_v = RELU_FLOOR;                                                                                        \
           _Pragma("unroll") for (int j = 0; j < 8; ++j) { cv.b[j] = bnext[j]; cv.ws[j] = wnext[j]; }                 \
           load_state8(S + 1, cv.v1);                                                                                 \
           if (dbg & 8) { kstep_mfma<PREC, 8, 0, S == 0, NoWork, (dbg & 16) != 0>(acc0, acc1, cur, smem + buf * SLAB, lane, nowork, dma); } \
@@ -923,7 +954,7 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
     {
       const float* __restrict__ bias = auxt + AUX_BIAS + 256 * 8;
       KOps c0 = cur;                             // converted by layer 8's seam
-      KOps c1 = prev_ops(1, bias, NEG_INF);
+      KOps c1 = prev_ops(1, bias, NO_FLOOR);
       float bA[8], bB[8];                        // biases of the two k-steps converted in the shadow of the current slab
       load_bias8(2, bias, bA);
       load_bias8(3, bias, bB);
@@ -931,13 +962,14 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
       {                                                                                                              \
         save_ops(SAVE_L1 + 16 * 8 + 2 * SL, c0);                                                                     \
         save_ops(SAVE_L1 + 16 * 8 + 2 * SL + 1, c1);                                                                 \
+        watch(c0, true); watch(c1, true);                                                                            \
         SLAB_PREFETCH(true);                                                                                         \
         if constexpr (SL + 1 < 8) {                                                                                  \
           float bA2[8], bB2[8];                                                                                      \
           if constexpr (SL + 2 < 8) { load_bias8(2 * SL + 4, bias, bA2); load_bias8(2 * SL + 5, bias, bB2); }        \
           PrevConv<PREC, 2 * SL + 2, false> cvA(prev0[SL + 1]);                                                      \
           PrevConv<PREC, 2 * SL + 3, false> cvB(prev0[SL + 1]);                                                      \
-          cvA.floor_v = NEG_INF; cvB.floor_v = NEG_INF;                                                              \
+          cvA.floor_v = NO_FLOOR; cvB.floor_v = NO_FLOOR;                                                                \
           _Pragma("unroll") for (int j = 0; j < 8; ++j) { cvA.b[j] = bA[j]; cvB.b[j] = bB[j]; }                      \
           load_state8(2 * SL + 2, cvA.v1);                                                                           \
           load_state8(2 * SL + 3, cvB.v1);                                                                           \
@@ -1002,8 +1034,8 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
           const float bv[4] = {bb.x, bb.y, bb.z, bb.w}, wrv[4] = {wr.x, wr.y, wr.z, wr.w}, wgv[4] = {wg.x, wg.y, wg.z, wg.w}, wbv[4] = {wb.x, wb.y, wb.z, wb.w};
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            const float v0 = fmaxf(fmaf(acc0[t][4 * g + i], INV_SCALE, bv[i]), 0.f);
-            const float v1 = fmaxf(fmaf(acc1[t][4 * g + i], INV_SCALE, bv[i]), 0.f);
+            const float v0 = relu_keep(fmaf(acc0[t][4 * g + i], INV_SCALE, bv[i]), RELU_FLOOR);
+            const float v1 = relu_keep(fmaf(acc1[t][4 * g + i], INV_SCALE, bv[i]), RELU_FLOOR);
             p0[0] = fmaf(v0, wrv[i], p0[0]); p0[1] = fmaf(v0, wgv[i], p0[1]); p0[2] = fmaf(v0, wbv[i], p0[2]);
             p1[0] = fmaf(v1, wrv[i], p1[0]); p1[1] = fmaf(v1, wgv[i], p1[1]); p1[2] = fmaf(v1, wbv[i], p1[2]);
             rv0[4 * g + i] = v0; rv1[4 * g + i] = v1;
@@ -1038,6 +1070,15 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
       }
       sig0 = sig0 + __shfl_xor(sig0, 32) + bsig;
       sig1 = sig1 + __shfl_xor(sig1, 32) + bsig;
+#ifndef RNERF_FWD_NORANGE
+      if constexpr (PP::F16) {      // an activation outside f16's range somewhere along this row's chain (either half of its features)
+        ovf0 = pk_maxu(ovf0, (uint32_t)__shfl_xor((int)ovf0, 32));
+        ovf1 = pk_maxu(ovf1, (uint32_t)__shfl_xor((int)ovf1, 32));
+        const float qn = __builtin_nanf("");
+        if ((ovf0 & 0xFFFFu) >= 0x7C00u || (ovf0 >> 16) >= 0x7C00u) { p0[0] = p0[1] = p0[2] = qn; sig0 = qn; }
+        if ((ovf1 & 0xFFFFu) >= 0x7C00u || (ovf1 >> 16) >= 0x7C00u) { p1[0] = p1[1] = p1[2] = qn; sig1 = qn; }
+      }
+#endif
       if constexpr (PP::F16 && !PP::F8X) {      // a weight outside the range of this precision's operand stream (|W| >= 256): fail loudly, not plausibly
         if (auxt[AUX_FLAG] != 0.f) { const float qn = __builtin_nanf(""); p0[0] = p0[1] = p0[2] = qn; p1[0] = p1[1] = p1[2] = qn; sig0 = qn; sig1 = qn; }
       }

@@ -78,7 +78,7 @@ class NerfModel:
                  use_mask_bbox=False, bd_cut_dist=None, cfg_name=None, use_random_choice=True, use_online_sparsity=False,
                  use_fine_sparsity=False, net_depth=8, net_width=256, net_depth_condition=1, net_width_condition=128,
                  skip_layer=4, num_rgb_channels=3, num_sigma_channels=1, legacy_posenc_order=False, lindisp=False,
-                 precision="f16x3", device=None, **unused):
+                 precision="f16x3", eval_precision=None, device=None, **unused):
         if not (stage.startswith("radiance") or stage.startswith("all") or stage.startswith("ior")):
             raise NotImplementedError(f"stage={stage!r}: expected radiance*, ior* or all* (rnerf/eikonal_utils.py:34-39, train.py:286-310)")
         if (net_depth, net_width, net_depth_condition, net_width_condition, skip_layer) != (8, 256, 1, 128, 4):
@@ -101,6 +101,13 @@ class NerfModel:
         self.use_random_choice = bool(use_random_choice)
         self.use_online_sparsity, self.use_fine_sparsity = bool(use_online_sparsity), bool(use_fine_sparsity)
         self.precision = PRECISIONS[precision]
+        # eval_precision: the arithmetic of the pure render pass (apply() without taps / ctx -> ONE rnerf_forward call: eval.py, render_image).
+        # None = `precision`.  construct_nerf defaults it to "f16f8": the f16 main term + fp8 cross terms, ~8 % faster, |dRGB| ~2e-6 of the
+        # oracle, and since round 4 safe to default — a weight outside its range makes the launch fall back to f16x3 on the device.
+        # Training (train_step) and every tapped / staged path always run `precision`.
+        if eval_precision is not None and eval_precision not in PRECISIONS:
+            raise ValueError(f"eval_precision must be one of {sorted(PRECISIONS)}")
+        self.eval_precision = PRECISIONS[eval_precision] if eval_precision is not None else self.precision
         self.coarse_step_size = (self.far - self.near) / self.num_coarse_samples         # rnerf/models.py:133-134
         self.fine_step_size = (self.far - self.near) / (self.num_coarse_samples + self.num_fine_samples)
         self.num_samples = self.num_coarse_samples * self.num_path_samples               # rnerf/models.py:121
@@ -142,14 +149,16 @@ class NerfModel:
             variables.setdefault("flat", {})[name] = f
         return f
 
-    def _packed_weights(self, variables, name: str) -> torch.Tensor:
+    def _packed_weights(self, variables, name: str, precision: Optional[int] = None) -> torch.Tensor:
         flat = self._flat(variables, name, NERF_MLP_SHAPES)
-        ent = self._packed.get(name)
+        prec = self.precision if precision is None else int(precision)
+        slot = name if prec == self.precision else (name, prec)          # one cached operand stream per (network, arithmetic)
+        ent = self._packed.get(slot)
         # keyed on the tensor OBJECT (weakly) + its version: a data_ptr key would go stale when a freed buffer's address is reused
         if ent is None or ent[0]() is not flat or ent[1] != flat._version:
-            buf = ops.nerfmlp_pack(flat.detach(), self.precision, ent[2] if ent is not None else None)
-            self._packed[name] = (weakref.ref(flat), flat._version, buf)
-        return self._packed[name][2]
+            buf = ops.nerfmlp_pack(flat.detach(), prec, ent[2] if ent is not None else None)
+            self._packed[slot] = (weakref.ref(flat), flat._version, buf)
+        return self._packed[slot][2]
 
     # ---- randomness -------------------------------------------------------------------------------------------------------
     def make_jitter(self, key) -> np.ndarray:
@@ -274,23 +283,24 @@ class NerfModel:
         self._mlp_wg_limit = 0
 
     # ---- the whole path in one call (csrc/pipeline.hip) ------------------------------------------------------------------------
-    def c_model(self, variables=None) -> "_lib.Model":
-        """The rnerf_model descriptor of this model (+ the packed weights of `variables`, when given)."""
+    def c_model(self, variables=None, precision: Optional[int] = None) -> "_lib.Model":
+        """The rnerf_model descriptor of this model (+ the packed weights of `variables`, when given); precision: override (eval_precision)."""
+        prec = self.precision if precision is None else int(precision)
         m = _lib.Model()
         m.table = self.table.data_ptr()
         m.grid = self.spec
         m.near, m.far = self.near, self.far
         m.num_coarse, m.num_fine, m.num_path = self.num_coarse_samples, self.num_fine_samples, self.num_path_samples
-        m.precision, m.white_bkgd = int(self.precision), int(self.white_bkgd)
+        m.precision, m.white_bkgd = int(prec), int(self.white_bkgd)
         m.rgb_padding, m.sigma_bias = self.rgb_padding, self.sigma_bias
         m.bd_cut = int(self.bd_cut_dist is not None and self.num_fine_samples > 0)
         if m.bd_cut:
             for i, v in enumerate(self._bd_cut_bbox()):
                 m.bd_cut_bbox[i] = float(v)
         if variables is not None:
-            m.packed_coarse = self._packed_weights(variables, "coarse_mlp").data_ptr()
+            m.packed_coarse = self._packed_weights(variables, "coarse_mlp", prec).data_ptr()
             if self.num_fine_samples > 0:
-                m.packed_fine = self._packed_weights(variables, "fine_mlp").data_ptr()
+                m.packed_fine = self._packed_weights(variables, "fine_mlp", prec).data_ptr()
             m.bkgd_params = self._flat(variables, "bkgd_mlp", BKGD_MLP_SHAPES).detach().data_ptr()
         return m
 
@@ -321,7 +331,7 @@ class NerfModel:
         o, v = ops._chk(rays.origins, "origins"), ops._chk(rays.viewdirs, "viewdirs")
         B, Nc, Nf = o.shape[0], self.num_coarse_samples, self.num_fine_samples
         st = _lib.current_stream()
-        m = self.c_model(variables)
+        m = self.c_model(variables, self.eval_precision)
         keys = None
         if jitter is None:
             keys = self._keys_dev(rng_0, rng_1)
@@ -574,8 +584,10 @@ def make_variables(flat: Dict[str, torch.Tensor]) -> Dict[str, Any]:
     return {"params": params, "flat": dict(flat)}
 
 
-def construct_nerf(key, example_batch, args, ndim, nmin, nmax, grid, precision: str = "f16x3", device=None):
-    """rnerf/models.py:538-618: build the model and initial variables.  `args` is a flags namespace (utils.default_flags)."""
+def construct_nerf(key, example_batch, args, ndim, nmin, nmax, grid, precision: str = "f16x3", device=None, eval_precision: Optional[str] = "f16f8"):
+    """rnerf/models.py:538-618: build the model and initial variables.  `args` is a flags namespace (utils.default_flags).
+    precision: the arithmetic of training and of every tapped path (fp32-grade f16x3); eval_precision: the arithmetic of the pure render pass
+    (model.apply as eval.py / render_image call it) — "f16f8" by default (NerfModel.__init__), None = the same as `precision`."""
     if args.rgb_activation != "sigmoid" or args.sigma_activation != "softplus" or args.net_activation != "relu":
         raise NotImplementedError("the HIP kernels implement relu / sigmoid / softplus (the reference defaults, rnerf/utils.py:168-175)")
     if args.sh_deg >= 0 and args.use_viewdirs:
@@ -589,7 +601,7 @@ def construct_nerf(key, example_batch, args, ndim, nmin, nmax, grid, precision: 
         num_sigma_channels=args.num_sigma_channels, lindisp=args.lindisp, legacy_posenc_order=args.legacy_posenc_order,
         ndim=ndim, nmin=nmin, nmax=nmax, grid=grid, stage=args.stage, num_path_samples=args.num_path_samples,
         use_fine_sparsity=args.use_fine_sparsity, use_online_sparsity=args.use_online_sparsity,
-        sh_direnc_deg=args.sh_direnc_deg, cfg_name=args.config, precision=precision, device=device,
+        sh_direnc_deg=args.sh_direnc_deg, cfg_name=args.config, precision=precision, eval_precision=eval_precision, device=device,
         bd_cut_dist=getattr(args, "bd_cut_dist", None))
     key1, _key2, _key3 = prng.split(np.asarray(key, np.uint32), 3)
     return model, model.init(key1)

@@ -28,7 +28,9 @@ def test_binding_covers_header(lib_path):
     assert lib.rnerf_version() == 1
     assert lib.rnerf_nerfmlp_packed_bytes(_lib.PREC_F16X3) == 1160 * 2 * 1024 + 3468 * 4      # operand stream + aux floats (biases, heads, the zero block, the f16f8 range flag)
     assert lib.rnerf_nerfmlp_packed_bytes(_lib.PREC_BF16) == 1160 * 1024 + 3468 * 4
-    assert lib.rnerf_nerfmlp_packed_bytes(_lib.PREC_F16F8) == lib.rnerf_nerfmlp_packed_bytes(_lib.PREC_F16X3)      # same blocks, other contents
+    x3 = lib.rnerf_nerfmlp_packed_bytes(_lib.PREC_F16X3)
+    assert lib.rnerf_nerfmlp_packed_bytes(_lib.PREC_F16F8) == (x3 + 255) // 256 * 256 + x3      # its own stream (same blocks, other contents) + the f16x3 stream it falls back to
+    assert lib.rnerf_nerfmlp_packed_bytes(_lib.PREC_F32) == 595844 * 4                            # the exact-fp32 arbiter reads the flat buffer itself
     # the Python names follow enum rnerf_precision of the header
     hdr = open(os.path.join(ROOT, "include", "rnerf.h")).read()
     for name, val in _lib.PRECISIONS.items():
