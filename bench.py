@@ -113,7 +113,7 @@ def parity_vs_oracle(model, pf, cfg, fine, device, n_rays=4096):
     from samplenerfro_amd.utils import Rays
     G, ext = cfg["G"], cfg["extent"]
     ndim, nmin, nmax = [G] * 3, [-ext] * 3, [ext] * 3
-    table = model.table.cpu().numpy().reshape(-1, 4)
+    table = model.table_reference().cpu().numpy().reshape(-1, 4)
     o, d = syn.sphere_rays(n_rays, seed=syn.SEED + 7)
     mc = R.ModelConfig(ndim, nmin, nmax, near=cfg["near"], far=cfg["far"], num_coarse_samples=cfg["S"], num_fine_samples=fine,
                        num_path_samples=cfg["P"])

@@ -80,7 +80,21 @@ typedef struct rnerf_grid {
   int32_t dims[3];
   double nmin[3];
   double nmax[3];
+  int32_t layout;   /* enum rnerf_table_layout: the memory order of the float4 table built for / read with this grid */
 } rnerf_grid;
+
+/* Memory order of the (n, grad n) table.  REFERENCE = flat index x*Gy*Gz + y*Gz + z, x slowest (rnerf/ior_utils.py:161,214 — the order the
+ * reference indexes with).  BRICKS = 2x2x2 bricks of 128 bytes, bricks x-major: entry (x, y, z) lives at
+ *   (((x>>1)*By + (y>>1))*Bz + (z>>1))*8 + (x&1)*4 + (y&1)*2 + (z&1),   B* = ceil(G* / 2)
+ * so the 8 corners of a trilinear lookup in an even-aligned cell are ONE 128-byte line and a bent ray meets ~40 % fewer new lines per step
+ * (SURVEY 8f N2 "Morton / brick relayout"; measured in profiles/r04/march_time.txt).  Values and indices are the reference's either way:
+ * only addresses differ.  Every entry point that takes (table, grid) reads the table in grid->layout; rnerf_grid_build_table writes it so. */
+enum rnerf_table_layout {
+  RNERF_TABLE_REFERENCE = 0,
+  RNERF_TABLE_BRICKS = 1
+};
+/* floats a table of this grid / layout occupies (REFERENCE: 4 G^3; BRICKS: 32 per brick, odd dimensions padded to whole bricks) */
+size_t rnerf_grid_table_floats(const rnerf_grid* g);
 
 /* Sizes of the flat fp32 parameter buffers (flax creation order Dense_0.. ; per layer kernel[in][out]
  * row-major followed by bias[out]).  NerfMLP: rnerf/model_utils.py:30-90, MLP: :93-140. */

@@ -26,15 +26,20 @@ class RnerfError(RuntimeError):
     pass
 
 
+TABLE_LAYOUTS = {"reference": 0, "bricks": 1}      # enum rnerf_table_layout
+
+
 class Grid(C.Structure):
     """rnerf_grid (include/rnerf.h): reference VoxMLP.ndim/nmin/nmax (rnerf/ior_utils.py:124-144)."""
-    _fields_ = [("dims", C.c_int32 * 3), ("nmin", C.c_double * 3), ("nmax", C.c_double * 3)]
+    _fields_ = [("dims", C.c_int32 * 3), ("nmin", C.c_double * 3), ("nmax", C.c_double * 3), ("layout", C.c_int32)]
 
     @classmethod
-    def make(cls, ndim, nmin, nmax) -> "Grid":
+    def make(cls, ndim, nmin, nmax, layout="reference") -> "Grid":
+        """layout: enum rnerf_table_layout — "reference" (flat index x*Gy*Gz + y*Gz + z, rnerf/ior_utils.py:214) or "bricks" (2x2x2 bricks)."""
         g = cls()
         for i in range(3):
             g.dims[i] = int(ndim[i]); g.nmin[i] = float(nmin[i]); g.nmax[i] = float(nmax[i])
+        g.layout = TABLE_LAYOUTS[layout] if isinstance(layout, str) else int(layout)
         return g
 
 
@@ -79,6 +84,7 @@ SIGNATURES = {
     "rnerf_version": (C.c_int, []),
     "rnerf_device_cus": (C.c_int, []),
     "rnerf_grid_prefilter": (C.c_int, [_vp, _vp, _vp, C.POINTER(_i32 * 3), C.c_int, _dbl, _vp]),
+    "rnerf_grid_table_floats": (C.c_size_t, [_GP]),
     "rnerf_grid_build_table": (C.c_int, [_vp, _vp, _GP, _vp]),
     "rnerf_grid_query": (C.c_int, [_vp, _GP, _vp, _i64, _vp, _vp, _vp]),
     "rnerf_march": (C.c_int, [_vp, _GP, _vp, _vp, _i32, _dbl, _dbl, _i32, _vp, _vp, _vp, _vp, _vp]),

@@ -37,7 +37,17 @@ struct GridParams {
   float nminx, nminy, nminz;
   float ndx, ndy, ndz;        // f32(ndelta)
   float tdx, tdy, tdz;        // f32(2*ndelta)
+  // table addressing, both layouts (enum rnerf_table_layout) in one form: the BYTE offset of entry (x, y, z) is the sum over the axes of
+  // (i >> 1) * sa[axis] + (i & 1) * sb[axis].  REFERENCE order: sb = the axis stride, sa = 2 sb; BRICKS: sa = the brick stride along
+  // the axis, sb = 64 / 32 / 16 (the entry's place inside its 2x2x2 brick).
+  int layout;
+  unsigned sa[3], sb[3];
+  unsigned long long table_bytes;
 };
+__host__ __device__ __forceinline__ size_t table_offset(const GridParams& g, int x, int y, int z) {      // in bytes
+  return (size_t)(x >> 1) * g.sa[0] + (size_t)(x & 1) * g.sb[0] + (size_t)(y >> 1) * g.sa[1] + (size_t)(y & 1) * g.sb[1] +
+         (size_t)(z >> 1) * g.sa[2] + (size_t)(z & 1) * g.sb[2];
+}
 
 inline bool make_grid_params(const rnerf_grid* g, GridParams* p) {
   if (!g) return false;
@@ -49,7 +59,27 @@ inline bool make_grid_params(const rnerf_grid* g, GridParams* p) {
   p->nminx = (float)g->nmin[0]; p->nminy = (float)g->nmin[1]; p->nminz = (float)g->nmin[2];
   p->ndx = (float)nd[0]; p->ndy = (float)nd[1]; p->ndz = (float)nd[2];
   p->tdx = (float)(2 * nd[0]); p->tdy = (float)(2 * nd[1]); p->tdz = (float)(2 * nd[2]);
+  p->layout = g->layout;
+  if (g->layout == RNERF_TABLE_REFERENCE) {
+    const unsigned long long sy = (unsigned long long)g->dims[2] * 16ull, sx = sy * (unsigned long long)g->dims[1];
+    if (2 * sx > 0xFFFFFFFFull) return false;
+    p->sb[0] = (unsigned)sx; p->sb[1] = (unsigned)sy; p->sb[2] = 16u;
+    for (int i = 0; i < 3; ++i) p->sa[i] = 2u * p->sb[i];
+    p->table_bytes = sx * (unsigned long long)g->dims[0];
+  } else if (g->layout == RNERF_TABLE_BRICKS) {
+    const unsigned long long by = (g->dims[1] + 1) / 2, bz = (g->dims[2] + 1) / 2, bx = (g->dims[0] + 1) / 2;
+    if (by * bz * 128ull > 0xFFFFFFFFull) return false;
+    p->sa[0] = (unsigned)(by * bz * 128ull); p->sa[1] = (unsigned)(bz * 128ull); p->sa[2] = 128u;
+    p->sb[0] = 64u; p->sb[1] = 32u; p->sb[2] = 16u;
+    p->table_bytes = bx * by * bz * 128ull;
+  } else {
+    return false;
+  }
   return true;
+}
+// the marching kernels address the table with 32-bit byte offsets formed by 24-bit multiplies: table < 4 GiB, every factor < 2^24
+inline bool grid_fits_u32(const GridParams& p) {
+  return p.table_bytes < 4294967296ull && p.sa[0] < 16777216u && p.sa[1] < 16777216u && p.dx < 16777216 && p.dy < 16777216 && p.dz < 16777216;
 }
 
 // Individually rounded fp32 ops: the march / lookup / resample kernels must not contract a*b+c
@@ -108,21 +138,20 @@ __device__ __forceinline__ void trilinear_load(const float4* __restrict__ tab, c
   y0 = clampi(y0, 0, g.dy - 1); y1 = clampi(y1, 0, g.dy - 1);
   z0 = clampi(z0, 0, g.dz - 1); z1 = clampi(z1, 0, g.dz - 1);
   if (idx6) { idx6[0] = x0; idx6[1] = x1; idx6[2] = y0; idx6[3] = y1; idx6[4] = z0; idx6[5] = z1; }
-  const size_t s1 = (size_t)g.dy * g.dz, s2 = (size_t)g.dz;
-  const size_t bx0 = s1 * x0, bx1 = s1 * x1, by0 = s2 * y0, by1 = s2 * y1;
-#ifdef RNERF_TRILINEAR_NOLOAD      /* profiling ablation: the address arithmetic without the 8 gathers */
-  {
-    const float f = __uint_as_float(0x3f800000u + (unsigned)((bx0 + by0 + z0 + bx1 + by1 + z1) & 1));
-    const float4 v = make_float4(f, 0.f, 0.f, 0.f);
-    c.d000 = v; c.d100 = v; c.d001 = v; c.d101 = v; c.d010 = v; c.d110 = v; c.d011 = v; c.d111 = v;
-    return;
-  }
-#endif
+  // byte offsets per axis (both table layouts: GridParams::sa / sb)
   if constexpr (OFF32) {
     const char* __restrict__ tb = (const char*)tab;
-    const unsigned t1 = (unsigned)g.dy * (unsigned)g.dz * 16u, t2 = (unsigned)g.dz * 16u;
-    const unsigned ax0 = t1 * (unsigned)x0, ax1 = t1 * (unsigned)x1, ay0 = t2 * (unsigned)y0, ay1 = t2 * (unsigned)y1;
-    const unsigned az0 = 16u * (unsigned)z0, az1 = 16u * (unsigned)z1;
+    const unsigned ax0 = (unsigned)(x0 >> 1) * g.sa[0] + (unsigned)(x0 & 1) * g.sb[0], ax1 = (unsigned)(x1 >> 1) * g.sa[0] + (unsigned)(x1 & 1) * g.sb[0];
+    const unsigned ay0 = (unsigned)(y0 >> 1) * g.sa[1] + (unsigned)(y0 & 1) * g.sb[1], ay1 = (unsigned)(y1 >> 1) * g.sa[1] + (unsigned)(y1 & 1) * g.sb[1];
+    const unsigned az0 = (unsigned)(z0 >> 1) * g.sa[2] + (unsigned)(z0 & 1) * g.sb[2], az1 = (unsigned)(z1 >> 1) * g.sa[2] + (unsigned)(z1 & 1) * g.sb[2];
+#ifdef RNERF_TRILINEAR_NOLOAD      /* profiling ablation: the address arithmetic without the 8 gathers */
+    {
+      const float f = __uint_as_float(0x3f800000u + ((ax0 + ay0 + az0 + ax1 + ay1 + az1) & 16u) / 16u);
+      const float4 v = make_float4(f, 0.f, 0.f, 0.f);
+      c.d000 = v; c.d100 = v; c.d001 = v; c.d101 = v; c.d010 = v; c.d110 = v; c.d011 = v; c.d111 = v;
+      return;
+    }
+#endif
     const unsigned b00 = ax0 + ay0, b10 = ax1 + ay0, b01 = ax0 + ay1, b11 = ax1 + ay1;
     c.d000 = *(const float4*)(tb + (b00 + az0)); c.d100 = *(const float4*)(tb + (b10 + az0));
     c.d001 = *(const float4*)(tb + (b00 + az1)); c.d101 = *(const float4*)(tb + (b10 + az1));
@@ -130,10 +159,14 @@ __device__ __forceinline__ void trilinear_load(const float4* __restrict__ tab, c
     c.d011 = *(const float4*)(tb + (b01 + az1)); c.d111 = *(const float4*)(tb + (b11 + az1));
     return;
   }
-  c.d000 = tab[bx0 + by0 + z0]; c.d100 = tab[bx1 + by0 + z0];
-  c.d001 = tab[bx0 + by0 + z1]; c.d101 = tab[bx1 + by0 + z1];
-  c.d010 = tab[bx0 + by1 + z0]; c.d110 = tab[bx1 + by1 + z0];
-  c.d011 = tab[bx0 + by1 + z1]; c.d111 = tab[bx1 + by1 + z1];
+  const char* __restrict__ tb = (const char*)tab;
+  const size_t ax0 = (size_t)(x0 >> 1) * g.sa[0] + (size_t)(x0 & 1) * g.sb[0], ax1 = (size_t)(x1 >> 1) * g.sa[0] + (size_t)(x1 & 1) * g.sb[0];
+  const size_t ay0 = (size_t)(y0 >> 1) * g.sa[1] + (size_t)(y0 & 1) * g.sb[1], ay1 = (size_t)(y1 >> 1) * g.sa[1] + (size_t)(y1 & 1) * g.sb[1];
+  const size_t az0 = (size_t)(z0 >> 1) * g.sa[2] + (size_t)(z0 & 1) * g.sb[2], az1 = (size_t)(z1 >> 1) * g.sa[2] + (size_t)(z1 & 1) * g.sb[2];
+  c.d000 = *(const float4*)(tb + (ax0 + ay0 + az0)); c.d100 = *(const float4*)(tb + (ax1 + ay0 + az0));
+  c.d001 = *(const float4*)(tb + (ax0 + ay0 + az1)); c.d101 = *(const float4*)(tb + (ax1 + ay0 + az1));
+  c.d010 = *(const float4*)(tb + (ax0 + ay1 + az0)); c.d110 = *(const float4*)(tb + (ax1 + ay1 + az0));
+  c.d011 = *(const float4*)(tb + (ax0 + ay1 + az1)); c.d111 = *(const float4*)(tb + (ax1 + ay1 + az1));
 }
 
 __device__ __forceinline__ float4 trilinear_finish(const TriCell& c) {

@@ -60,7 +60,7 @@ __global__ void build_table_kernel(const float* __restrict__ grid, float4* __res
     o.y = fdiv(fsub(grid[s1 * xp + s2 * y + z], grid[s1 * xm + s2 * y + z]), g.tdx);
     o.z = fdiv(fsub(grid[s1 * x + s2 * yp + z], grid[s1 * x + s2 * ym + z]), g.tdy);
     o.w = fdiv(fsub(grid[s1 * x + s2 * y + zp], grid[s1 * x + s2 * y + zm]), g.tdz);
-    table[i] = o;
+    *(float4*)((char*)table + table_offset(g, x, y, z)) = o;      // in the grid's table layout (reference order / 2x2x2 bricks)
   }
 }
 
@@ -124,10 +124,18 @@ extern "C" int rnerf_grid_prefilter(const float* src, float* dst, float* tmp, co
   return RNERF_OK;
 }
 
+extern "C" size_t rnerf_grid_table_floats(const rnerf_grid* g) {
+  GridParams p;
+  if (!make_grid_params(g, &p)) { set_error("rnerf_grid_table_floats: bad grid (dims >= 2, a known layout)"); return 0; }
+  return (size_t)(p.table_bytes / sizeof(float));
+}
+
 extern "C" int rnerf_grid_build_table(const float* grid, float* table, const rnerf_grid* g, void* stream) {
   RNERF_CHECK_ARG(grid && table && g, "rnerf_grid_build_table: null pointer");
   GridParams p;
-  RNERF_CHECK_ARG(make_grid_params(g, &p), "rnerf_grid_build_table: bad grid (dims must be >= 2)");
+  RNERF_CHECK_ARG(make_grid_params(g, &p), "rnerf_grid_build_table: bad grid (dims must be >= 2, layout a rnerf_table_layout)");
+  if (p.layout == RNERF_TABLE_BRICKS && ((p.dx | p.dy | p.dz) & 1))      // the padding entries of odd dimensions are never read; keep them defined
+    RNERF_CHECK_HIP(hipMemsetAsync(table, 0, (size_t)p.table_bytes, (hipStream_t)stream));
   RNERF_CHECK_ARG(((uintptr_t)table & 15) == 0, "rnerf_grid_build_table: table must be 16-byte aligned");
   const size_t total = (size_t)p.dx * p.dy * p.dz;
   const int block = 256;

@@ -8,12 +8,15 @@
 // positions and voxel indices are bit-identical to the fp32 oracle (no transcendental is involved).
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace rnerf {
 
 struct MarchParams {
   int dx, dy, dz;
   float nmin[3];
   double rcp_nd[3];   // RN_f64(1 / f32(ndelta))
+  unsigned sa[3], sb[3];   // table addressing per axis (GridParams::sa / sb): byte offset = (i >> 1) * sa + (i & 1) * sb
 };
 
 // Eikonal march, 4 lanes per ray.  Lane q = lane&3 of a quad owns coordinate q of the ray state (q = 0,1,2) and
@@ -40,19 +43,22 @@ static_assert(2 * kMarchChunk * 512 <= 12 * 1024, "the ring must fit beside the 
 
 __device__ __forceinline__ void march_chunk_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <bool WANT_IOR, bool WANT_VOX>
+// BRICKS: the table is in 2x2x2-brick order (rnerf_table_layout): two more integer instructions per gathered index, ~40 % fewer new cache
+// lines per step on a table that does not fit the caches.
+template <bool WANT_IOR, bool WANT_VOX, bool BRICKS>
 __global__ void __launch_bounds__(128) march_kernel(const float* __restrict__ table, MarchParams g,
                                                     const float* __restrict__ origins, const float* __restrict__ viewdirs,
                                                     int B, float near, float step, int num_nodes,
                                                     float* __restrict__ path_pd, float* __restrict__ path_dr,
-                                                    float* __restrict__ path_ior, int* __restrict__ vox) {
+                                                    float* __restrict__ path_ior, int* __restrict__ vox, int rays_per_wg) {
   constexpr int C = kMarchChunk;
   __shared__ float2 ring[2][C][64];               // (p, d) of the lane's coordinate, per node
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int gid = blockIdx.x * 64 + lane;
-  const int q = gid & 3;
-  int r = gid >> 2;
+  // rays_per_wg = 16 (product), 8 or 4 (experiment, RNERF_MARCH_RPW): with fewer than 16 the upper quads of the wave replay the lower ones
+  // (same values to the same addresses, no divergence).
+  const int q = lane & 3;
+  int r = blockIdx.x * rays_per_wg + ((lane >> 2) & (rays_per_wg - 1));
   if (r >= B) r = B - 1;   // surplus quads replay the last ray (same values to the same addresses, no divergence)
   const int qc = q < 3 ? q : 0;
   const int nchunks = (num_nodes + C - 1) / C;    // the marcher always runs whole chunks (surplus nodes: clamped gathers, nothing stored)
@@ -95,10 +101,10 @@ __global__ void __launch_bounds__(128) march_kernel(const float* __restrict__ ta
   const int dim_q = qc == 0 ? g.dx : (qc == 1 ? g.dy : g.dz);
   const unsigned comp = (q + 1) & 3;
   // byte offsets into the table fit 32 bits (checked by the launcher): one v_mad_u32_u24 + adds per corner, SGPR base
-  const unsigned s1 = (unsigned)g.dy * (unsigned)g.dz * 16u, s2 = (unsigned)g.dz * 16u;
   const char* __restrict__ tabc = (const char*)table;   // uniform base; this lane's component goes into the 32-bit offset
   const unsigned cofs = comp * 4u;
-  const unsigned stride_q = q == 0 ? s1 : (q == 1 ? s2 : 16u);      // byte stride of this lane's axis
+  const unsigned stride_q = g.sb[qc];                                // byte stride of this lane's axis (reference order)
+  const unsigned sa_q = g.sa[qc], sb_q = g.sb[qc];                   // brick stride / place inside the brick (BRICKS)
   const int hi_q = dim_q - 1;
   float d = q < 3 ? viewdirs[3 * r + qc] : 0.f;
   float p = q < 3 ? fadd(origins[3 * r + qc], fmul(near, d)) : 0.f;   // eikonal_utils.py:104-106
@@ -113,7 +119,13 @@ __global__ void __launch_bounds__(128) march_kernel(const float* __restrict__ ta
   auto gather = [&](int i0, int i1, Corners& o) {
     o.i0 = i0; o.i1 = i1;
     // every lane scales its own axis, the quad exchanges byte offsets (the broadcasts fold into the adds as DPP operands)
-    const unsigned m0 = __umul24((unsigned)i0, stride_q), m1 = __umul24((unsigned)i1, stride_q);
+    unsigned m0, m1;
+    if constexpr (BRICKS) {
+      m0 = __umul24((unsigned)i0 >> 1, sa_q) + __umul24((unsigned)i0 & 1u, sb_q);
+      m1 = __umul24((unsigned)i1 >> 1, sa_q) + __umul24((unsigned)i1 & 1u, sb_q);
+    } else {
+      m0 = __umul24((unsigned)i0, stride_q); m1 = __umul24((unsigned)i1, stride_q);
+    }
     const unsigned y0 = quad_bcast_i<1>(m0), y1 = quad_bcast_i<1>(m1);
     const unsigned z0 = quad_bcast_i<2>(m0) + cofs, z1 = quad_bcast_i<2>(m1) + cofs;
     const unsigned b00 = quad_bcast_i<0>(m0) + y0, b10 = quad_bcast_i<0>(m1) + y0, b01 = quad_bcast_i<0>(m0) + y1, b11 = quad_bcast_i<0>(m1) + y1;
@@ -203,24 +215,32 @@ extern "C" int rnerf_march(const float* table, const rnerf_grid* g, const float*
                   "rnerf_march: table/path buffers must be 16-byte aligned");
   GridParams gp;
   RNERF_CHECK_ARG(make_grid_params(g, &gp), "rnerf_march: bad grid");
-  RNERF_CHECK_ARG((double)gp.dx * gp.dy * gp.dz * 16.0 < 4294967296.0 && (double)gp.dy * gp.dz * 16.0 < 16777216.0 && gp.dx < 16777216,
-                  "rnerf_march: grid too large for 32-bit byte offsets (needs G^3 * 16 B < 4 GiB)");
+  RNERF_CHECK_ARG(grid_fits_u32(gp), "rnerf_march: grid too large for 32-bit byte offsets (needs a table < 4 GiB)");
   MarchParams p;
   p.dx = gp.dx; p.dy = gp.dy; p.dz = gp.dz;
   p.nmin[0] = gp.nminx; p.nmin[1] = gp.nminy; p.nmin[2] = gp.nminz;
   p.rcp_nd[0] = 1.0 / (double)gp.ndx; p.rcp_nd[1] = 1.0 / (double)gp.ndy; p.rcp_nd[2] = 1.0 / (double)gp.ndz;
+  for (int i = 0; i < 3; ++i) { p.sa[i] = gp.sa[i]; p.sb[i] = gp.sb[i]; }
   const float stepf = (float)((far - near) / (num_nodes - 1));  // models.py:122, Python double -> f32
   const float nearf = (float)near;
-  const dim3 block(128), grid((B + 15) / 16);   // 16 rays (quads) per workgroup = marcher + recorder wave: one workgroup per CU at B = 4096
+  // rays per workgroup (marcher + recorder wave): 16 = every quad of the wave.  Spreading a 4096-ray batch over twice / four times the
+  // workgroups (8 / 4 rays each, two / four marching waves per CU) was measured SLOWER (round 4, profiles/r04/march_experiments.txt:
+  // 0.35 -> 0.45 ms at 64^3, 0.53 -> 0.57 at 512^3): the waves of a CU share its vector-memory path, which is what a step waits on.
+  int rpw = 16;
+  if (const char* e = getenv("RNERF_MARCH_RPW")) rpw = atoi(e);       // experiment switch (tools/r04/march_rpw.sh)
+  RNERF_CHECK_ARG(rpw == 16 || rpw == 8 || rpw == 4, "rnerf_march: RNERF_MARCH_RPW must be 16, 8 or 4");
+  const dim3 block(128), grid((B + rpw - 1) / rpw);
   hipStream_t st = (hipStream_t)stream;
-#define LAUNCH(I, V)                                                                                               \
-  hipLaunchKernelGGL((march_kernel<I, V>), grid, block, 0, st, table, p, origins, viewdirs, B, nearf, stepf, num_nodes, \
-                     path_pd, path_dr, path_ior, vox)
+#define LAUNCH2(I, V, K)                                                                                           \
+  hipLaunchKernelGGL((march_kernel<I, V, K>), grid, block, 0, st, table, p, origins, viewdirs, B, nearf, stepf, num_nodes, \
+                     path_pd, path_dr, path_ior, vox, rpw)
+#define LAUNCH(I, V) do { if (gp.layout == RNERF_TABLE_BRICKS) LAUNCH2(I, V, true); else LAUNCH2(I, V, false); } while (0)
   if (path_ior && vox) LAUNCH(true, true);
   else if (path_ior) LAUNCH(true, false);
   else if (vox) LAUNCH(false, true);
   else LAUNCH(false, false);
 #undef LAUNCH
+#undef LAUNCH2
   RNERF_CHECK_LAUNCH();
   return RNERF_OK;
 }

@@ -2496,10 +2496,9 @@ __global__ void __launch_bounds__(256, 1) march_all_kernel(const float4* __restr
   const double rcp_q = 1.0 / (double)(qc == 0 ? gp.ndx : (qc == 1 ? gp.ndy : gp.ndz));
   const int dim_q = qc == 0 ? gp.dx : (qc == 1 ? gp.dy : gp.dz);
   const unsigned comp = (q + 1) & 3;
-  const unsigned s1 = (unsigned)gp.dy * (unsigned)gp.dz * 16u, s2 = (unsigned)gp.dz * 16u;
   const char* __restrict__ tabc = (const char*)table;
   const unsigned cofs = comp * 4u;
-  const unsigned stride_q = q == 0 ? s1 : (q == 1 ? s2 : 16u);      // byte stride of this lane's axis
+  const unsigned sa_q = gp.sa[qc], sb_q = gp.sb[qc];                // table addressing of this lane's axis, either layout (GridParams::sa / sb)
   const int hi_q = dim_q - 1;
   float d = q < 3 ? viewdirs[3 * r + qc] : 0.f;
   float p = q < 3 ? fadd(origins[3 * r + qc], fmul(near, d)) : 0.f;   // eikonal_utils.py:104-106
@@ -2508,7 +2507,8 @@ __global__ void __launch_bounds__(256, 1) march_all_kernel(const float4* __restr
   Corners ca, cb, cc;
   auto gather = [&](int i0, int i1, Corners& o) {       // (the integer glue as in march.hip: clamp0 / floor_to_int / lerp_pk, common.h)
     o.i0 = i0; o.i1 = i1;
-    const unsigned m0 = __umul24((unsigned)i0, stride_q), m1 = __umul24((unsigned)i1, stride_q);
+    const unsigned m0 = __umul24((unsigned)i0 >> 1, sa_q) + __umul24((unsigned)i0 & 1u, sb_q);
+    const unsigned m1 = __umul24((unsigned)i1 >> 1, sa_q) + __umul24((unsigned)i1 & 1u, sb_q);
     const unsigned y0 = quad_bcast_i<1>(m0), y1 = quad_bcast_i<1>(m1);
     const unsigned z0 = quad_bcast_i<2>(m0) + cofs, z1 = quad_bcast_i<2>(m1) + cofs;
     const unsigned b00 = quad_bcast_i<0>(m0) + y0, b10 = quad_bcast_i<0>(m1) + y0, b01 = quad_bcast_i<0>(m0) + y1, b11 = quad_bcast_i<0>(m1) + y1;
@@ -3398,8 +3398,7 @@ extern "C" int rnerf_march_all(const float* table, const rnerf_grid* g, const fl
   RNERF_CHECK_ARG(make_grid_params(g, &gp), "rnerf_march_all: bad grid");
   So3Window w;
   for (int i = 0; i < 10; ++i) w.w[i] = window10[i];
-  RNERF_CHECK_ARG((double)gp.dx * gp.dy * gp.dz * 16.0 < 4294967296.0 && (double)gp.dy * gp.dz * 16.0 < 16777216.0 && gp.dx < 16777216,
-                  "rnerf_march_all: grid too large for 32-bit byte offsets (needs G^3 * 16 B < 4 GiB)");
+  RNERF_CHECK_ARG(grid_fits_u32(gp), "rnerf_march_all: grid too large for 32-bit byte offsets (needs a table < 4 GiB)");
   const float stepf = (float)((far - near) / (num_nodes - 1));  // models.py:122
   hipLaunchKernelGGL(so3_pack16_kernel, dim3((kSo3Blocks * 64 + 255) / 256), dim3(256), 0, (hipStream_t)stream, so3_params, (uint4*)so3_packed);
   hipLaunchKernelGGL(march_all_kernel, dim3((unsigned)((B + 15) / 16)), dim3(256), 0, (hipStream_t)stream, (const float4*)table, gp, so3_params,

@@ -78,7 +78,7 @@ class NerfModel:
                  use_mask_bbox=False, bd_cut_dist=None, cfg_name=None, use_random_choice=True, use_online_sparsity=False,
                  use_fine_sparsity=False, net_depth=8, net_width=256, net_depth_condition=1, net_width_condition=128,
                  skip_layer=4, num_rgb_channels=3, num_sigma_channels=1, legacy_posenc_order=False, lindisp=False,
-                 precision="f16x3", eval_precision=None, device=None, **unused):
+                 precision="f16x3", eval_precision=None, table_layout="reference", device=None, **unused):
         if not (stage.startswith("radiance") or stage.startswith("all") or stage.startswith("ior")):
             raise NotImplementedError(f"stage={stage!r}: expected radiance*, ior* or all* (rnerf/eikonal_utils.py:34-39, train.py:286-310)")
         if (net_depth, net_width, net_depth_condition, net_width_condition, skip_layer) != (8, 256, 1, 128, 4):
@@ -112,7 +112,9 @@ class NerfModel:
         self.fine_step_size = (self.far - self.near) / (self.num_coarse_samples + self.num_fine_samples)
         self.num_samples = self.num_coarse_samples * self.num_path_samples               # rnerf/models.py:121
         self.step_size = (self.far - self.near) / (self.num_samples - 1)                 # :122
-        self.spec = Grid.make(self.ndim, self.nmin, self.nmax)
+        # table_layout: memory order of the (n, grad n) table (include/rnerf.h: rnerf_table_layout) — "reference" = the reference's flat index,
+        # "bricks" = 2x2x2 bricks of one cache line (fewer new lines per march step on tables beyond the caches).  Same values, same indices.
+        self.spec = Grid.make(self.ndim, self.nmin, self.nmax, table_layout)
         if device is None:
             device = grid.device if isinstance(grid, torch.Tensor) else torch.device("cuda", torch.cuda.current_device())
         self.device = torch.device(device)
@@ -129,6 +131,10 @@ class NerfModel:
         self.whole_path = os.environ.get("RNERF_STAGED") != "1"
         self._ws: Dict[Tuple[str, int], torch.Tensor] = {}
         self._key_cache: Dict[bytes, torch.Tensor] = {}
+
+    def table_reference(self) -> torch.Tensor:
+        """The (n, grad n) table in the reference's order [G^3, 4] whatever layout the kernels use (for the oracle and the tests)."""
+        return ops.table_reference_order(self.table, self.spec)
 
     # ---- parameters -------------------------------------------------------------------------------------------------------
     def init(self, key, **unused) -> Dict[str, Any]:

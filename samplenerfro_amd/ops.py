@@ -42,9 +42,25 @@ def grid_build_table(grid: torch.Tensor, spec: Grid) -> torch.Tensor:
     n = spec.dims[0] * spec.dims[1] * spec.dims[2]
     if g.numel() != n:
         raise _lib.RnerfError(f"grid has {g.numel()} voxels, spec says {n}")
-    table = torch.empty((n, 4), dtype=torch.float32, device=g.device)
+    nf = lib.rnerf_grid_table_floats(C.byref(spec))
+    if nf == 0:
+        check(-1, "rnerf_grid_table_floats")
+    table = torch.empty((nf // 4, 4), dtype=torch.float32, device=g.device)      # in spec.layout (bricks pad odd dimensions)
     check(lib.rnerf_grid_build_table(ptr(g), ptr(table), C.byref(spec), current_stream()), "rnerf_grid_build_table")
     return table
+
+
+def table_reference_order(table: torch.Tensor, spec: Grid) -> torch.Tensor:
+    """The table as the reference indexes it: [Gx*Gy*Gz, 4], flat index x*Gy*Gz + y*Gz + z (rnerf/ior_utils.py:161,214) — the table itself
+    for the reference layout, a gather out of the 2x2x2 bricks otherwise (rnerf_table_layout in include/rnerf.h).  For the oracle / tests."""
+    if spec.layout == _lib.TABLE_LAYOUTS["reference"]:
+        return table
+    dx, dy, dz = (int(v) for v in spec.dims)
+    by, bz = (dy + 1) // 2, (dz + 1) // 2
+    dev = table.device
+    x = torch.arange(dx, device=dev).view(dx, 1, 1); y = torch.arange(dy, device=dev).view(1, dy, 1); z = torch.arange(dz, device=dev).view(1, 1, dz)
+    idx = (((x >> 1) * by + (y >> 1)) * bz + (z >> 1)) * 8 + (x & 1) * 4 + (y & 1) * 2 + (z & 1)
+    return table.reshape(-1, 4)[idx.reshape(-1)]
 
 
 def grid_query(table: torch.Tensor, spec: Grid, pts: torch.Tensor, want_idx: bool = False):
