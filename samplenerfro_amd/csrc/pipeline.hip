@@ -396,11 +396,13 @@ namespace rnerf {
 #define RNERF_TAIL_DELAY_US 0
 #endif
 constexpr long long kTailDelayTicks = 100LL * RNERF_TAIL_DELAY_US;      // s_memrealtime counts at 100 MHz
+static inline bool co_requested(const rnerf_train_cfg* c) { return c->aux_stream && c->coresident_bkgd_wgrad; }
 struct TrainBuffers {
   FwdBuffers f;
   int32_t* jitter; uint32_t* key_u;
   void *packed_c, *packed_f, *packed_bwd, *packed_bwd_f, *save_c, *save_f, *save_bk, *dy, *dy_bk, *wgrad_ws;
-  float *out_all, *level_c, *level_f, *sums, *d_all, *d_raw, *env_sum;
+  void *dy_c, *wgrad_ws_c;           // hierarchical models with an aux stream: the coarse level's backward runs beside the fine level's
+  float *out_all, *level_c, *level_f, *sums, *d_all, *d_raw, *env_sum, *d_raw_c;
 };
 static size_t carve_train(const rnerf_model* m, const rnerf_train_cfg* c, int32_t B, bool own_path, void* ws, TrainBuffers* t) {
   const size_t Nc = m->num_coarse, Nf = m->num_fine, S = Nc + Nf;
@@ -443,6 +445,12 @@ static size_t carve_train(const rnerf_model* m, const rnerf_train_cfg* c, int32_
   t->env_sum = k.take<float>(4);
   t->d_all = k.take<float>((B + M) * 3);
   t->d_raw = k.take<float>(S * B * 4);
+  t->dy_c = t->wgrad_ws_c = nullptr; t->d_raw_c = nullptr;
+  if (Nf > 0 && c->aux_stream) {      // own buffers for the concurrent coarse backward (see rnerf_train_forward_backward)
+    t->dy_c = k.bytes(rnerf_nerfmlp_dy_bytes((int64_t)Nc * B, c->backward));
+    t->wgrad_ws_c = k.bytes(rnerf_nerfmlp_wgrad_workspace_bytes());
+    t->d_raw_c = k.take<float>(Nc * B * 4);
+  }
   return (k.off + 255) & ~(size_t)255;
 }
 }  // namespace rnerf
@@ -552,15 +560,37 @@ extern "C" int rnerf_train_forward_backward(const rnerf_model* m, const rnerf_tr
   // ---- backward, last level first ----
   if (aux) RNERF_TRY(rnerf_join(stream, aux));
   float* d_first = t.d_all;                      // rows [0,B): d loss / d bkgd of the rays; rows [B,B+M): the env-map patch
+  // Hierarchical models with an aux stream (round 4): the two levels' backward passes are independent once both compositing backwards have
+  // run (the coarse one accumulates d bkgd on top of the fine one's), so the coarse level's dgrad + wgrad go to the aux stream, with buffers
+  // of their own, BESIDE the fine level's.  Each NerfMLP kernel owns whole CUs, so the two never share one — but whenever one level's
+  // persistent grid leaves CUs idle (all of a small batch: 512 rays x (64 + 128) samples are 128 + 384 row tiles on 256 CUs) the other
+  // level's workgroups take them: 2 rounds of tiles instead of 1 + 2 at that size.  Only for batches whose two levels together fit two
+  // rounds: beyond that the kernels' static tile striding is delayed on the CUs the other level took first and the step gets SLOWER
+  // (profiles/r04/levels_side_by_side.txt: 512 rays 2.28 -> 2.18 ms, 128 rays 1.50 -> 1.33; 1024 rays 3.36 -> 3.45, 4096 rays 11.9 -> 12.4).
+  int cus = 0;
+  { int dev = 0; RNERF_CHECK_HIP(hipGetDevice(&dev)); RNERF_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)); }
+  const long long tiles_both = ((long long)Nc * B + 255) / 256 + ((long long)S * B + 255) / 256;
+  const bool split_levels = Nf > 0 && aux != nullptr && !co_requested(c) && tiles_both <= 2LL * cus;
+  float* d_raw_c = split_levels ? t.d_raw_c : t.d_raw;
+  void* dy_c = split_levels ? t.dy_c : t.dy;
   if (Nf > 0) {
     RNERF_TRY(rnerf_composite_backward(f.raw_f, f.rows_pd, f.rows_dr, nullptr, S, B, bkgd, m->rgb_padding, m->sigma_bias, lf.rgb, pixels, lf.trans, lf.tb, t.sums,
                                        mse_scale, c->bg_weight * bg_on, t.d_raw, d_first, 0, m->white_bkgd, m->bd_cut ? m->bd_cut_bbox : nullptr, stream));
+    if (split_levels) {
+      RNERF_TRY(rnerf_composite_backward(f.raw_c, path_pd, path_dr, jitter, Nc, B, bkgd, m->rgb_padding, m->sigma_bias, lc.rgb, pixels, nullptr, nullptr, nullptr,
+                                         mse_scale, 0.0, d_raw_c, d_first, 1, m->white_bkgd, nullptr, stream));
+      RNERF_TRY(rnerf_fork(stream, aux));
+      RNERF_TRY(rnerf_nerfmlp_dgrad(t.packed_bwd, t.packed_c, prec, bwd, t.save_c, d_raw_c, (int64_t)Nc * B, dy_c, aux));
+      RNERF_TRY(rnerf_nerfmlp_wgrad(prec, bwd, t.save_c, dy_c, (int64_t)Nc * B, g_c, t.wgrad_ws_c, aux));
+    }
     if (!aux) RNERF_TRY(rnerf_nerfmlp_pack_bwd(th_f, bwd, t.packed_bwd_f, stream));
     RNERF_TRY(rnerf_nerfmlp_dgrad(t.packed_bwd_f, t.packed_f, prec, bwd, t.save_f, t.d_raw, (int64_t)S * B, t.dy, stream));
     if (next && next->beside_wgrad) RNERF_TRY(march_next());
     RNERF_TRY(rnerf_nerfmlp_wgrad(prec, bwd, t.save_f, t.dy, (int64_t)S * B, g_f, t.wgrad_ws, stream));
-    RNERF_TRY(rnerf_composite_backward(f.raw_c, path_pd, path_dr, jitter, Nc, B, bkgd, m->rgb_padding, m->sigma_bias, lc.rgb, pixels, nullptr, nullptr, nullptr,
-                                       mse_scale, 0.0, t.d_raw, d_first, 1, m->white_bkgd, nullptr, stream));
+    if (split_levels) RNERF_TRY(rnerf_join(stream, aux));
+    else
+      RNERF_TRY(rnerf_composite_backward(f.raw_c, path_pd, path_dr, jitter, Nc, B, bkgd, m->rgb_padding, m->sigma_bias, lc.rgb, pixels, nullptr, nullptr, nullptr,
+                                         mse_scale, 0.0, t.d_raw, d_first, 1, m->white_bkgd, nullptr, stream));
   } else {
     RNERF_TRY(rnerf_composite_backward(f.raw_c, path_pd, path_dr, jitter, Nc, B, bkgd, m->rgb_padding, m->sigma_bias, lf.rgb, pixels, lf.trans, lf.tb, t.sums,
                                        mse_scale, c->bg_weight * bg_on, t.d_raw, d_first, 0, m->white_bkgd, nullptr, stream));
@@ -574,14 +604,14 @@ extern "C" int rnerf_train_forward_backward(const rnerf_model* m, const rnerf_tr
     RNERF_TRY(rnerf_bkgd_backward_dgrad(th_b, t.save_bk, t.d_all, (int64_t)B + M, m->rgb_padding, t.dy_bk, nullptr, stream));
   }
   if (!aux) RNERF_TRY(rnerf_nerfmlp_pack_bwd(th_c, bwd, t.packed_bwd, stream));
-  RNERF_TRY(rnerf_nerfmlp_dgrad(t.packed_bwd, t.packed_c, prec, bwd, t.save_c, t.d_raw, (int64_t)Nc * B, t.dy, stream));
+  if (!split_levels) RNERF_TRY(rnerf_nerfmlp_dgrad(t.packed_bwd, t.packed_c, prec, bwd, t.save_c, t.d_raw, (int64_t)Nc * B, t.dy, stream));
   if (co) {      // forked HERE, not earlier: the NerfMLP dgrad owns every CU whole, the wgrad below leaves room for these waves
     RNERF_TRY(rnerf_fork(stream, aux));
     if (kTailDelayTicks > 0) hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)aux, (long long)kTailDelayTicks);
     RNERF_TRY(rnerf_bkgd_backward_wgrad(t.save_bk, t.dy_bk, (int64_t)B + M, g_b, 1, aux));
   }
   if (next && next->beside_wgrad && Nf == 0) RNERF_TRY(march_next());
-  RNERF_TRY(rnerf_nerfmlp_wgrad(prec, bwd, t.save_c, t.dy, (int64_t)Nc * B, g_c, t.wgrad_ws, stream));
+  if (!split_levels) RNERF_TRY(rnerf_nerfmlp_wgrad(prec, bwd, t.save_c, t.dy, (int64_t)Nc * B, g_c, t.wgrad_ws, stream));
   if (c->grads_stream) RNERF_TRY(rnerf_fork(stream, c->grads_stream));      // the NerfMLP gradient segments are final: the caller's collective may start
   if (next && !next->beside_wgrad) RNERF_TRY(march_next());     // beside the tail below (background-MLP backward, loss glue) and the update
   if (co) {
