@@ -294,12 +294,12 @@ def timed_steps(stepper, warmup, steps, barrier, D, device):
 
 
 def pmc_lookup(workload, fine, B, mode, backward, rnerf_cus):
-    """HBM bytes and SQ / GRBM counters per launch from the committed rocprofv3 --pmc passes of THIS command (tools/r03/pmc_all.sh; PMC
+    """HBM bytes and SQ / GRBM counters per launch from the committed rocprofv3 --pmc passes of THIS command (tools/r04/pmc_all.sh; PMC
     counters cannot be read from inside the process).  The JSON is stamped with the sha of the kernel sources and of bench.py it was taken
     with: a stale stamp (or no profile of this workload) leaves every counter-derived field null."""
     import hashlib
     tag = ("%s_f%d_%s" % (workload, fine, mode if mode == "forward" else "train_" + backward))
-    rel = os.path.join("profiles", "r03", "pmc_%s.json" % tag)
+    rel = os.path.join("profiles", "r04", "pmc_%s.json" % tag)      # (tools/r04/pmc_all.sh)
     path = os.path.join(ROOT, rel)
     if B != 4096 or not os.path.exists(path):
         return {}, {}, None
