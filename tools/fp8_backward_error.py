@@ -53,6 +53,7 @@ def prod(a, b, mode, kaxis_a, kaxis_b):
 
 def dgrad(dy, w, mode):
     """dX = dY W^T (reduction over the layer's outputs)."""
+    mode = _split(mode)[0]
     if mode == "tf32":
         return f16(dy) @ w.T                       # exact weights (hi + lo), gradient rounded to f16
     return prod(dy, w.T, mode, -1, 0)
@@ -61,15 +62,26 @@ def dgrad(dy, w, mode):
 def wgrad(x, dy, m, mode):
     """dW = X^T diag(m) dY (reduction over the rows).  dY is the row-normalised gradient, m the per-row power of two it was divided by:
     like the kernels, the operands are rounded BEFORE the (exact) power-of-two row scale is applied."""
+    mode = _split(mode)[1]
     if mode == "f64":
         return (x * m).T @ dy
     xh, xl = parts(x); dh, dl = parts(dy)
+    if mode == "xy":
+        return (xh * m).T @ dh + (xl * m).T @ dh
+    if mode == "yx":
+        return (xh * m).T @ dh + (xh * m).T @ dl
     if mode == "tf32":
         return (xh * m).T @ dh
     if mode == "f32":
         return (xh * m).T @ dh + (xh * m).T @ dl + (xl * m).T @ dh
     q = lambda a: e4m3_block(a, 0)                  # blocks of 32 consecutive ROWS (the reduction axis) share a scale
     return (xh * m).T @ dh + (q(xh) * m).T @ q(dl) + (q(xl) * m).T @ q(dh)
+
+
+def _split(mode):
+    """mode "f32" / "tf32" / "fp8lo", or a mixed "<dgrad>+<wgrad>" pair (round 4: which HALF of the backward needs which arithmetic?):
+    dgrad in {f32, tf32 (exact weights x f16(dY): 2 passes), fp8lo}, wgrad in {f32, tf32, fp8lo, xy (X_hi + X_lo) x dY_hi, yx X_hi x (dY_hi + dY_lo)}."""
+    return mode.split("+") if "+" in mode else (mode, mode)
 
 
 def backward(P, enc, venc, cot, mode):
@@ -109,6 +121,9 @@ def backward(P, enc, venc, cot, mode):
     return g
 
 
+MODES = ("f32", "fp8lo", "tf32", "tf32+f32", "fp8lo+f32", "f32+fp8lo", "f32+xy", "f32+yx", "f32+tf32")
+
+
 def main():
     rows_list = [int(a) for a in sys.argv[1:]] or [581, 4096]
     pf = syn.init_params_flat(12, fine=False, bias_scale=0.1)["coarse_mlp"]
@@ -120,14 +135,14 @@ def main():
         cot = rng.standard_normal((rows, 4)) * np.array([1e-3, 1e-3, 1e-3, 3e-4])
         cot[5::83] = 0.0; cot[6::83] *= 1e-4; cot[7::83] *= 1e3          # rows whose gradients are orders of magnitude apart (bwd_err.py)
         ref = backward(P, enc, venc, cot, "f64")
-        for mode in ("f32", "fp8lo", "tf32"):
+        for mode in MODES:
             got = backward(P, enc, venc, cot, mode)
             worst, where = 0.0, ""
             for l in range(12):
                 e = np.abs(got[l][0] - ref[l][0]).max() / np.abs(ref[l][0]).max()
                 if e > worst:
                     worst, where = e, f"Dense_{l}.kernel"
-            print(f"rows {rows:6d}  {mode:6s} worst max|g - g64| / max|g64| = {worst:.2e}  ({where})")
+            print(f"rows {rows:6d}  {mode:10s} worst max|g - g64| / max|g64| = {worst:.2e}  ({where})")
 
 
 if __name__ == "__main__":
