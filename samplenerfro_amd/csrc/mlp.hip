@@ -870,6 +870,7 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
 #define RNERF_PE_KSTEP(S, FIRST_, SAVE_)                                                                             \
       {                                                                                                              \
         if (SAVE_) save_ops(SAVE_PE + S, cur);                                                                       \
+        watch(cur, true);      /* a non-finite position (a caller's NaN) must not come out as a colour either */    \
         SLAB_PREFETCH(true);   /* glds first: it is a scheduling boundary, conversion + MFMAs must share the region after it */ \
         if constexpr (S < 3) {                                                                                       \
           EncWork<PREC, S + 1, 30> ew(pd, h);                                                                        \
@@ -996,6 +997,7 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
       // last slab of the tile (the two view-encoding k-steps): prefetch the first slab of the next tile (stream restarts)
       save_ops(SAVE_VIEW, c0);
       save_ops(SAVE_VIEW + 1, c1);
+      watch(c0, true); watch(c1, true);
       next_tile = tileq != nullptr ? __builtin_amdgcn_readfirstlane(__hip_atomic_load(tileq + 1 + blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
                                    : tile + (int)gridDim.x;
       const bool has_next_tile = next_tile < n_tiles;

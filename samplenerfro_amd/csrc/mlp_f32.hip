@@ -37,7 +37,7 @@ __device__ __forceinline__ void dense_f32(const float* __restrict__ W, const flo
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const float y = fadd(acc[j], bias[n0 + j]);
-      out[(n0 + j) * F32_ROWS + row] = RELU ? fmaxf(y, 0.f) : y;
+      out[(n0 + j) * F32_ROWS + row] = RELU ? (y < 0.f ? 0.f : y) : y;      // (not fmaxf: that would turn a NaN into 0 — the arbiter must not hide one)
     }
   }
 }

@@ -443,3 +443,40 @@ def test_march_coresident_with_the_wgrad_changes_no_bit(world):
             pd, dr, _, _ = ops.march(m.table, m.spec, nxt.origins, nxt.viewdirs, m.near, m.far, N)
             assert torch.equal(h.pd, pd) and torch.equal(h.dr, dr)
     assert torch.equal(grads[0], grads[1])
+
+
+def test_bricked_table_at_full_size_renders_the_same_bits():
+    """BASELINE configs[2] at full size (4096 rays x (128 + 256) samples, N = 1536, 512^3 table after the (9, 3.0) prefilter) with the IoR
+    table in 2x2x2 bricks (include/rnerf.h: rnerf_table_layout) against the reference order: path, both levels' outputs — every bit."""
+    from samplenerfro_amd import models, ops, prng, synthetic as syn
+    from samplenerfro_amd.utils import Rays
+    dev = torch.device("cuda:0")
+    cfg = dict(syn.CONFIGS["ship_refractive"])
+    G, ext = cfg["G"], cfg["extent"]
+    a = torch.linspace(-ext, ext, G, dtype=torch.float64, device=dev)
+    r = torch.sqrt(a[:, None, None] ** 2 + a[None, :, None] ** 2 + a[None, None, :] ** 2)
+    h = 2.0 * ext / (G - 1)
+    grid = ((0.33 * torch.clamp((cfg["radius"] - r) / h + 0.5, 0.0, 1.0)) * cfg["ri"] / 0.33 + 1.0).float()
+    del r
+    grid = ops.grid_prefilter(grid, cfg["ksize"], cfg["ksigma"])
+    pf = syn.init_params_flat(0, fine=True)
+    o, d = syn.sphere_rays(4096, seed=syn.SEED)
+    rays = Rays(torch.from_numpy(o).to(dev), None, torch.from_numpy(d).to(dev), None)
+    key = prng.PRNGKey(3)
+    outs, paths = {}, {}
+    for layout in ("reference", "bricks"):
+        m = models.NerfModel(ndim=[G] * 3, nmin=[-ext] * 3, nmax=[ext] * 3, grid=grid, near=cfg["near"], far=cfg["far"], num_coarse_samples=cfg["S"],
+                             num_fine_samples=256, num_path_samples=cfg["P"], table_layout=layout, device=dev)
+        v = models.make_variables({k: torch.from_numpy(x).to(dev) for k, x in pf.items()})
+        paths[layout] = ops.march(m.table, m.spec, rays.origins, rays.viewdirs, m.near, m.far, m.num_samples)[:2]
+        outs[layout], _ = m.apply(v, key, key, rays, True)
+        del m
+        torch.cuda.empty_cache()
+    bent = (paths["reference"][1][-1, :, :3] - paths["reference"][1][0, :, :3]).abs().max()
+    assert float(bent) > 1e-3                                     # rays do bend through the sphere
+    for a_, b_ in zip(paths["reference"], paths["bricks"]):
+        assert torch.equal(a_, b_)
+    for lvl in range(2):
+        for a_, b_ in zip(outs["reference"][lvl], outs["bricks"][lvl]):
+            assert torch.equal(a_, b_)
+

@@ -318,6 +318,19 @@ def test_nerf_mlp_f16x3_range_is_never_silent(scene):
     out = run(hot, _lib.PREC_F16X3)
     assert not np.isfinite(out).any()
     assert np.isfinite(run(hot, _lib.PREC_F32)).all()
+    # a caller's non-finite POSITION (one row) comes out as a non-finite row in every arithmetic, the other rows untouched
+    flat = pf["coarse_mlp"]
+    ref = run(flat, _lib.PREC_F16X3)
+    pd_bad = pd.copy()
+    pd_bad[3, 5, 1] = np.nan
+    pd_bad[7, 2, 0] = np.inf
+    for prec in (_lib.PREC_F16X3, _lib.PREC_F16F8, _lib.PREC_F32):
+        out = ops.nerfmlp_forward(ops.nerfmlp_pack(T(flat), prec), prec, T(pd_bad), T(dr), None, S, B).cpu().numpy()
+        assert not np.isfinite(out[3, 5]).any() and not np.isfinite(out[7, 2]).any(), prec
+        good = np.ones((S, B), bool); good[3, 5] = False; good[7, 2] = False
+        assert np.isfinite(out[good]).all(), prec
+        if prec == _lib.PREC_F16X3:
+            np.testing.assert_array_equal(out[good], ref[good])
 
 
 def test_nerf_mlp_node_indirection(scene):
