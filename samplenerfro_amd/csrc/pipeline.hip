@@ -397,6 +397,15 @@ namespace rnerf {
 #endif
 constexpr long long kTailDelayTicks = 100LL * RNERF_TAIL_DELAY_US;      // s_memrealtime counts at 100 MHz
 static inline bool co_requested(const rnerf_train_cfg* c) { return c->aux_stream && c->coresident_bkgd_wgrad; }
+// hierarchical models with an aux stream: the two levels' backward passes side by side when together they are at most two rounds of row
+// tiles (see rnerf_train_forward_backward); also decides whether the workspace carries the coarse level's own dY / d raw / wgrad scratch
+static bool levels_side_by_side(const rnerf_model* m, const rnerf_train_cfg* c, int32_t B) {
+  if (m->num_fine <= 0 || !c->aux_stream || co_requested(c)) return false;
+  static int cus = 0;
+  if (cus == 0) { int dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256; }
+  const long long tiles_both = ((long long)m->num_coarse * B + 255) / 256 + ((long long)(m->num_coarse + m->num_fine) * B + 255) / 256;
+  return tiles_both <= 2LL * cus;
+}
 struct TrainBuffers {
   FwdBuffers f;
   int32_t* jitter; uint32_t* key_u;
@@ -446,7 +455,7 @@ static size_t carve_train(const rnerf_model* m, const rnerf_train_cfg* c, int32_
   t->d_all = k.take<float>((B + M) * 3);
   t->d_raw = k.take<float>(S * B * 4);
   t->dy_c = t->wgrad_ws_c = nullptr; t->d_raw_c = nullptr;
-  if (Nf > 0 && c->aux_stream) {      // own buffers for the concurrent coarse backward (see rnerf_train_forward_backward)
+  if (levels_side_by_side(m, c, B)) {      // own buffers for the concurrent coarse backward (see rnerf_train_forward_backward)
     t->dy_c = k.bytes(rnerf_nerfmlp_dy_bytes((int64_t)Nc * B, c->backward));
     t->wgrad_ws_c = k.bytes(rnerf_nerfmlp_wgrad_workspace_bytes());
     t->d_raw_c = k.take<float>(Nc * B * 4);
@@ -567,10 +576,7 @@ extern "C" int rnerf_train_forward_backward(const rnerf_model* m, const rnerf_tr
   // level's workgroups take them: 2 rounds of tiles instead of 1 + 2 at that size.  Only for batches whose two levels together fit two
   // rounds: beyond that the kernels' static tile striding is delayed on the CUs the other level took first and the step gets SLOWER
   // (profiles/r04/levels_side_by_side.txt: 512 rays 2.28 -> 2.18 ms, 128 rays 1.50 -> 1.33; 1024 rays 3.36 -> 3.45, 4096 rays 11.9 -> 12.4).
-  int cus = 0;
-  { int dev = 0; RNERF_CHECK_HIP(hipGetDevice(&dev)); RNERF_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)); }
-  const long long tiles_both = ((long long)Nc * B + 255) / 256 + ((long long)S * B + 255) / 256;
-  const bool split_levels = Nf > 0 && aux != nullptr && !co_requested(c) && tiles_both <= 2LL * cus;
+  const bool split_levels = levels_side_by_side(m, c, B);
   float* d_raw_c = split_levels ? t.d_raw_c : t.d_raw;
   void* dy_c = split_levels ? t.dy_c : t.dy;
   if (Nf > 0) {
