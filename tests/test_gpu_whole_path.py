@@ -237,6 +237,45 @@ def test_graph_replay_equals_the_eager_steps(Nf, prefetch):
     g.close()
 
 
+def test_graph_step_follows_the_annealed_alpha_ramp():
+    """train.py:350-351 ramps annealed_alpha from 0 every step, and loss_bg / loss_bg_smooth are gated on annealed_alpha > 0 (train.py:92,130).
+    The gate is a launch argument frozen into a captured graph: GraphTrainStep must read the batch's value every step and keep one graph per
+    gate (it used to replay the constructor's value for ever).  Steps with alpha = 0, 0, 0.3, 0.6, 0, 0.9 against eager steps."""
+    from samplenerfro_amd.graph import GraphTrainStep
+    from samplenerfro_amd.train import train_step
+    from samplenerfro_amd import synthetic as syn, utils
+    B, alphas = 96, [0.0, 0.0, 0.3, 0.6, 0.0, 0.9]
+    rays_k, pix_k = [], []
+    for k in range(len(alphas) + 1):
+        o, d = syn.sphere_rays(B, seed=300 + k)
+        rays_k.append(utils.Rays(T(o), None, T(d), None)); pix_k.append(T(np.random.default_rng(50 + k).uniform(0, 1, (B, 3)).astype(F32)))
+    model, state, batch, flags = _train_setup(12, B)
+    rng = np.array([8, 1], np.uint32)
+    eager, eager_bg = [], []
+    for k, a in enumerate(alphas):
+        state, stats, rng = train_step(model, rng, state, dict(batch, rays=rays_k[k], pixels=pix_k[k], annealed_alpha=a), flags)
+        eager.append(float(stats.loss)); eager_bg.append((float(stats.loss_bg), float(stats.loss_bg_smooth)))
+    theta_e = state.theta.clone()
+    assert eager_bg[0] == (0.0, 0.0) and eager_bg[4] == (0.0, 0.0) and eager_bg[2][1] > 0 and eager_bg[5][1] > 0      # the gate really switches the smoothness term on and off (loss_bg may be 0: no ray of this scene keeps trans > 0.5)
+    model2, state2, batch2, flags2 = _train_setup(12, B)
+    g = GraphTrainStep(model2, state2, flags2, B, np.array([8, 1], np.uint32), env_rays=batch2["env_rays"], annealed_alpha=0.5, prefetch=True)
+    g.load(dict(rays=rays_k[0], pixels=pix_k[0], annealed_alpha=alphas[0]))
+    replay, replay_bg = [], []
+    for k in range(len(alphas)):
+        nxt = dict(rays=rays_k[k + 1], pixels=pix_k[k + 1])
+        if k + 1 < len(alphas):
+            nxt["annealed_alpha"] = alphas[k + 1]
+        g.load_next(nxt)
+        st = g.step()
+        replay.append(float(st.loss)); replay_bg.append((float(st.loss_bg), float(st.loss_bg_smooth)))
+    g.synchronize()
+    assert np.allclose(replay, eager, rtol=1e-6, atol=0), (replay, eager)
+    assert np.allclose(np.array(replay_bg), np.array(eager_bg), rtol=1e-5, atol=1e-9), (replay_bg, eager_bg)
+    assert (state2.theta - theta_e).abs().max().item() < 1e-7
+    assert sum(1 for v in g.graphs.values() if isinstance(v, tuple)) >= 3                   # both gates were captured (per slot as needed)
+    g.close()
+
+
 def test_adam_update_counts_nonfinite_gradients():
     from samplenerfro_amd import _lib
     lib = _lib.load()
