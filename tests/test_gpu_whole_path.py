@@ -276,6 +276,23 @@ def test_graph_step_follows_the_annealed_alpha_ramp():
     g.close()
 
 
+def test_a_replaced_schedule_that_returns_zero_is_a_zero_step():
+    """a replaced lr_fn reaches rnerf_adam_update as (use_lr_override, lr_override); 0.0 — a warm-up, or the reference's own
+    start_rate at count 0 (rnerf/utils.py:521) — must be a ZERO learning rate, not "no override" (the device used to test lr_override > 0)."""
+    from samplenerfro_amd.train import train_step
+    model, state, batch, flags = _train_setup(0, 96)
+    assert getattr(model, "whole_path", False)
+    th0 = state.theta.clone()
+    state.lr_fn = lambda count: 0.0
+    state, stats, _ = train_step(model, np.array([1, 5], np.uint32), state, batch, flags)
+    torch.cuda.synchronize()
+    assert torch.equal(state.theta, th0)                              # the parameters did not move ...
+    assert float(state.mu.abs().max()) > 0 and state.step == 1        # ... although the step ran (moments updated, counter advanced)
+    state.lr_fn = lambda count: 1e-3
+    state, stats, _ = train_step(model, np.array([1, 6], np.uint32), state, batch, flags)
+    assert not torch.equal(state.theta, th0)
+
+
 def test_adam_update_counts_nonfinite_gradients():
     from samplenerfro_amd import _lib
     lib = _lib.load()
