@@ -554,6 +554,38 @@ def test_construct_nerf_surface():
     assert not torch.equal(ret[0][0], ret2[0][0])
 
 
+def test_eval_precision_of_the_reference_surface():
+    """construct_nerf (rnerf/models.py:538) renders in the default eval arithmetic f16f8 and trains in f16x3: model.apply as eval.py calls it
+    equals a NerfModel built with precision="f16f8" bit for bit, is within 1e-5 of the f16x3 render, the tapped / staged path (what the
+    parity tests and the training forward run) stays f16x3, and eval_precision=None restores one arithmetic for everything."""
+    from samplenerfro_amd import _lib, models, prng, utils
+    sc = Scene(B=96, seed=3)
+    flags = utils.default_flags(num_coarse_samples=16, num_fine_samples=24, num_path_samples=4, white_bkgd=False, use_online_sparsity=False)
+    kw = dict(ndim=sc.ndim, nmin=sc.nmin, nmax=sc.nmax, grid=T(sc.grid))
+    model, variables = models.construct_nerf(prng.PRNGKey(7), None, flags, **kw)
+    assert model.precision == _lib.PREC_F16X3 and model.eval_precision == _lib.PREC_F16F8
+    pf = syn.init_params_flat(2, fine=True, bias_scale=0.05)
+    variables = models.make_variables({k: T(v) for k, v in pf.items()})
+    rays = utils.Rays(T(sc.o), None, T(sc.d), None)
+    k0, k1 = prng.PRNGKey(1), prng.PRNGKey(2)
+    ret, _ = model.apply(variables, k0, k1, rays, False)
+    m8 = models.NerfModel(num_coarse_samples=16, num_fine_samples=24, num_path_samples=4, precision="f16f8", **kw)
+    m3 = models.NerfModel(num_coarse_samples=16, num_fine_samples=24, num_path_samples=4, precision="f16x3", **kw)
+    r8, _ = m8.apply(variables, k0, k1, rays, False)
+    r3, _ = m3.apply(variables, k0, k1, rays, False)
+    for lvl in range(2):
+        assert torch.equal(ret[lvl][0], r8[lvl][0])
+        assert float((ret[lvl][0] - r3[lvl][0]).abs().max()) < 1e-5
+    assert not torch.equal(ret[1][0], r3[1][0])                                 # (it really is another arithmetic)
+    taps = {}
+    rt, _ = model.apply(variables, k0, k1, rays, False, taps=taps)              # tapped = staged = the training arithmetic
+    assert torch.equal(rt[1][0], r3[1][0])
+    same, _ = models.construct_nerf(prng.PRNGKey(7), None, flags, eval_precision=None, **kw)
+    assert same.eval_precision == same.precision == _lib.PREC_F16X3
+    r, _ = same.apply(variables, k0, k1, rays, False)
+    assert torch.equal(r[1][0], r3[1][0])
+
+
 def test_bd_cut_dist_masks():
     """M4 (rnerf/models.py:479-524): the glass/pen/ball training masks overwrite trans and trans_rgb_bkgd of the fine level only."""
     from samplenerfro_amd import models, prng

@@ -229,3 +229,18 @@ def test_gradient_clipping_matches_the_reference_formulas(max_val, max_norm):
     err = np.abs(got - ref).max() / np.abs(ref).max()
     print(f"clip ({max_val}, {max_norm}): max err / max |g| {err:.2e}")
     assert err < 2e-5
+
+
+def test_an_activation_beyond_f16_reaches_the_nonfinite_gradient_count():
+    """The training forward carries activations as f16 hi + lo parts: a hidden activation above 65504 used to come out as a finite, plausible,
+    wrong loss (rounds 1-3).  Now the affected rows return NaN, the loss is non-finite and rnerf_adam_update counts the
+    non-finite gradient entries (TrainState.nonfinite_grads()) — visible, not silent."""
+    from samplenerfro_amd.train import train_step
+    model, state, batch, flags, _ev = _setup(0)
+    lo, hi = state.segments["coarse_mlp"]
+    state.theta[lo + 63 * 256: lo + 63 * 256 + 256] = 3.0e5            # Dense_0 biases: every first-layer activation ~3e5 > 65504
+    state, stats, _ = train_step(model, np.array([1, 2], np.uint32), state, batch, flags)
+    torch.cuda.synchronize()
+    assert not np.isfinite(float(stats.loss))
+    assert state.nonfinite_grads() > 0
+
