@@ -238,3 +238,32 @@ def test_frozen_so3_norm_follows_a_restore():
     st.frozen_sq = (1.0, so3.numel(), (id(so3), so3._version), weakref.ref(so3))
     so3.mul_(2.0)                                                                        # an in-place load bumps the version
     assert st.frozen_sq[2] != (id(so3), so3._version)
+
+
+def test_table_layouts_sizes_and_index_map():
+    """include/rnerf.h: rnerf_table_layout.  Host-side only (no kernel runs): the size query of both layouts, and the documented brick index
+    (((x>>1)*By + (y>>1))*Bz + (z>>1))*8 + (x&1)*4 + (y&1)*2 + (z&1) — written out here independently — against ops.table_reference_order,
+    the accessor the oracle / the tests read a bricked table through (reference order: x*Gy*Gz + y*Gz + z, rnerf/ior_utils.py:161,214)."""
+    import ctypes as C
+    from samplenerfro_amd import _lib, ops
+    lib = _lib.load()
+    for dims in ((24, 24, 24), (23, 26, 21), (2, 3, 5), (512, 512, 512)):
+        ref = _lib.Grid.make(dims, [-1.0] * 3, [1.0] * 3, "reference")
+        brk = _lib.Grid.make(dims, [-1.0] * 3, [1.0] * 3, "bricks")
+        assert lib.rnerf_grid_table_floats(C.byref(ref)) == 4 * dims[0] * dims[1] * dims[2]
+        bx, by, bz = [(d + 1) // 2 for d in dims]
+        assert lib.rnerf_grid_table_floats(C.byref(brk)) == 32 * bx * by * bz
+    bad = _lib.Grid.make((8, 8, 8), [-1.0] * 3, [1.0] * 3, 7)
+    assert lib.rnerf_grid_table_floats(C.byref(bad)) == 0 and b"layout" in lib.rnerf_last_error()
+    dims = (5, 6, 3)
+    spec = _lib.Grid.make(dims, [-1.0] * 3, [1.0] * 3, "bricks")
+    bx, by, bz = [(d + 1) // 2 for d in dims]
+    xmajor = np.arange(dims[0] * dims[1] * dims[2] * 4, dtype=np.float32).reshape(-1, 4)
+    bricked = np.full((bx * by * bz * 8, 4), -1.0, np.float32)
+    for x in range(dims[0]):
+        for y in range(dims[1]):
+            for z in range(dims[2]):
+                bricked[(((x >> 1) * by + (y >> 1)) * bz + (z >> 1)) * 8 + (x & 1) * 4 + (y & 1) * 2 + (z & 1)] = xmajor[(x * dims[1] + y) * dims[2] + z]
+    back = ops.table_reference_order(torch.from_numpy(bricked), spec)
+    assert torch.equal(back, torch.from_numpy(xmajor))
+    assert ops.table_reference_order(torch.from_numpy(xmajor), _lib.Grid.make(dims, [-1.0] * 3, [1.0] * 3)) is not None
