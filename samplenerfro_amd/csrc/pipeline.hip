@@ -12,6 +12,9 @@
 #include <vector>
 
 namespace rnerf {
+// csrc/mlp.hip: the operand-stream pack without its own memsets (the step zeroes every stream's range flags in one launch)
+int nerfmlp_pack_zero_flags(int precision, void* const* packed, int count, hipStream_t st);
+int nerfmlp_pack_impl(const float* params, int precision, void* packed, bool zero_flags, hipStream_t st);
 
 // ---- threefry2x32-20 (Random123), the block cipher behind jax.random (samplenerfro_amd/prng.py; KAT in tests/test_prng.py) ---------
 __device__ __forceinline__ unsigned rotl_u32(unsigned x, int r) { return (x << r) | (x >> (32 - r)); }
@@ -470,6 +473,9 @@ extern "C" size_t rnerf_train_workspace_bytes(const rnerf_model* m, const rnerf_
   return carve_train(m, c, B, true, nullptr, &t);
 }
 
+static int mark_point(hipStream_t first, hipEvent_t* out);
+static int wait_point(hipStream_t then, hipEvent_t e);
+
 extern "C" int rnerf_train_forward_backward(const rnerf_model* m, const rnerf_train_cfg* c, const float* theta, const float* origins, const float* viewdirs,
                                             const float* pixels, const float* env_dirs, int32_t B, const uint32_t* keys4, const int32_t* jitter_override,
                                             const float* u_override, int32_t u_per_ray, const float* path_pd, const float* path_dr, float* grads,
@@ -503,14 +509,18 @@ extern "C" int rnerf_train_forward_backward(const rnerf_model* m, const rnerf_tr
 
   // ---- everything that depends on the parameters only — the operand streams of both directions, the zeroing of the gradient buffer,
   //      sum theta^2 for weight_l2 — goes to cfg->aux_stream, beside the key kernels, the march and the background-MLP forward below
-  //      (~70 us of small launches off the critical path).  Two joins: the forward waits for the forward streams only; the backward's
-  //      streams and the sum are packed while the forward runs (its persistent grid leaves a few CUs free) and joined before the backward.
+  //      (~70 us of small launches off the critical path).  Three joins, each for what its consumer needs and no more: the coarse forward
+  //      waits for the COARSE operand stream only (one flag-zeroing launch + one pack kernel: ~20 us, shorter than the main stream's
+  //      keys + background forward beside it); the fine level's stream, the zeroing of the gradients, the backward's streams and the sum
+  //      follow on the aux stream while the coarse forward runs and are joined before the fine forward / the backward.
+  //      (Round 4: before, the coarse forward waited for five launches — three 16-byte memsets among them — and started at +88 us.)
   void* aux = c->aux_stream;
+  struct Mark { hipEvent_t e = nullptr; ~Mark() { if (e) (void)hipEventDestroy(e); } } fine_packed;      // (an early error return must not leak it)
   if (aux) {
     RNERF_TRY(rnerf_fork(stream, aux));
-    RNERF_CHECK_HIP(hipMemsetAsync(grads, 0, (size_t)(n_theta + 8) * sizeof(float), (hipStream_t)aux));
-    RNERF_TRY(rnerf_nerfmlp_pack(th_c, prec, t.packed_c, aux));
-    if (Nf > 0) RNERF_TRY(rnerf_nerfmlp_pack(th_f, prec, t.packed_f, aux));
+    void* streams[2] = {t.packed_c, t.packed_f};
+    RNERF_TRY(nerfmlp_pack_zero_flags(prec, streams, Nf > 0 ? 2 : 1, (hipStream_t)aux));
+    RNERF_TRY(nerfmlp_pack_impl(th_c, prec, t.packed_c, false, (hipStream_t)aux));
   }
   // ---- forward (models.forward with ctx) ----
   const int32_t* jitter = jitter_override;
@@ -528,7 +538,12 @@ extern "C" int rnerf_train_forward_backward(const rnerf_model* m, const rnerf_tr
   const float* bkgd = t.out_all;
   const float* rgb_env = t.out_all + (size_t)3 * B;
   if (aux) {
-    RNERF_TRY(rnerf_join(stream, aux));
+    RNERF_TRY(rnerf_join(stream, aux));                    // the aux stream's tail HERE is the coarse pack: everything below follows it
+    if (Nf > 0) {
+      RNERF_TRY(nerfmlp_pack_impl(th_f, prec, t.packed_f, false, (hipStream_t)aux));
+      RNERF_TRY(mark_point((hipStream_t)aux, &fine_packed.e));
+    }
+    RNERF_CHECK_HIP(hipMemsetAsync(grads, 0, (size_t)(n_theta + 8) * sizeof(float), (hipStream_t)aux));
     RNERF_TRY(rnerf_nerfmlp_pack_bwd(th_c, bwd, t.packed_bwd, aux));
     if (Nf > 0) RNERF_TRY(rnerf_nerfmlp_pack_bwd(th_f, bwd, t.packed_bwd_f, aux));
     RNERF_TRY(rnerf_theta_sumsq(theta, n_theta, stats8, aux));
@@ -546,6 +561,7 @@ extern "C" int rnerf_train_forward_backward(const rnerf_model* m, const rnerf_tr
     if (!u) { RNERF_TRY(make_u(m, B, c->randomized, t.key_u, f.u, &per_ray, stream)); u = f.u; }
     RNERF_TRY(rnerf_resample(path_pd, path_dr, N, B, jitter, Nc, f.weights, u, per_ray, Nf, f.rows_pd, f.rows_dr, nullptr, f.scratch, stream));
     if (!aux) RNERF_TRY(rnerf_nerfmlp_pack(th_f, prec, t.packed_f, stream));
+    else { hipEvent_t e = fine_packed.e; fine_packed.e = nullptr; RNERF_TRY(wait_point(st, e)); }      // the fine level's operand stream (packed beside the coarse forward) and no more
     RNERF_TRY(rnerf_nerfmlp_forward_train(t.packed_f, prec, f.rows_pd, f.rows_dr, nullptr, S, B, f.raw_f, t.save_f, bwd, max_workgroups, stream));
     lf = level_of(t.level_f, B);
     RNERF_TRY(rnerf_composite(f.raw_f, f.rows_pd, f.rows_dr, nullptr, S, B, bkgd, m->white_bkgd, m->rgb_padding, m->sigma_bias, lf.rgb, lf.dist, lf.acc, lf.trans,
@@ -730,6 +746,26 @@ static int order_after(hipStream_t first, hipStream_t then) {
     set_error("stream ordering failed: %s", hipGetErrorString(err));
     return RNERF_ERR_HIP;
   }
+  if (cs == hipStreamCaptureStatusNone) RNERF_CHECK_HIP(hipEventDestroy(e));
+  else tl_capture_events.push_back(e);
+  return RNERF_OK;
+}
+
+// order_after in two halves, for a dependency whose consumer is enqueued long after its producer: mark_point(first) now, wait_point(then)
+// where the consumer goes.  A mark that is never waited for must be passed to wait_point all the same (it owns the event).
+static int mark_point(hipStream_t first, hipEvent_t* out) {
+  hipEvent_t e = nullptr;
+  RNERF_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  const hipError_t err = hipEventRecord(e, first);
+  if (err != hipSuccess) { (void)hipEventDestroy(e); set_error("stream ordering failed: %s", hipGetErrorString(err)); return RNERF_ERR_HIP; }
+  *out = e;
+  return RNERF_OK;
+}
+static int wait_point(hipStream_t then, hipEvent_t e) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  hipError_t err = hipStreamIsCapturing(then, &cs);
+  if (err == hipSuccess) err = hipStreamWaitEvent(then, e, 0);
+  if (err != hipSuccess) { (void)hipEventDestroy(e); set_error("stream ordering failed: %s", hipGetErrorString(err)); return RNERF_ERR_HIP; }
   if (cs == hipStreamCaptureStatusNone) RNERF_CHECK_HIP(hipEventDestroy(e));
   else tl_capture_events.push_back(e);
   return RNERF_OK;

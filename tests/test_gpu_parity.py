@@ -201,6 +201,29 @@ def test_bkgd_mlp(scene):
     np.testing.assert_array_equal(out4, out)
 
 
+def test_bkgd_mlp_out_of_range_is_never_silent(scene):
+    """The background MLP runs on f16 hi + lo operands (weights x 2^8): a weight >= 256 or an activation above 65504 is outside that
+    arithmetic.  The outputs are then NaN — never finite, plausible colours (the ReLU keeps NaN; same contract as the NerfMLP engines)."""
+    from samplenerfro_amd import ops
+    import os
+    if os.environ.get("RNERF_BKGD_EXACT") == "1":
+        pytest.skip("the exact-fp32 kernels have no f16 range")
+    pf = syn.init_params_flat(3, bias_scale=0.1)["bkgd_mlp"].copy()
+    rng = np.random.default_rng(4)
+    dirs = R.safe_l2_normalize(rng.standard_normal((300, 3)).astype(F32))
+    good = ops.bkgd_forward(T(pf), T(dirs)).cpu().numpy()
+    assert np.isfinite(good).all()
+    k1 = 27 * 128 + 128                                     # Dense_1.kernel
+    hot = pf.copy(); hot[k1:k1 + 128 * 128] *= 3e4          # activations of Dense_1 far above 65504
+    out = ops.bkgd_forward(T(hot), T(dirs)).cpu().numpy()
+    assert not np.isfinite(out).any(), "an out-of-range activation must not give a finite colour"
+    big = pf.copy(); big[k1 + 5] = 300.0                    # one weight beyond the 2^8-scaled f16 range
+    out = ops.bkgd_forward(T(big), T(dirs)).cpu().numpy()
+    assert not np.isfinite(out).any()
+    out_t, _ = ops.bkgd_forward_train(T(big), T(dirs))
+    assert not np.isfinite(out_t.cpu().numpy()).any()
+
+
 # raw-output tolerance per MLP arithmetic (abs, on raw outputs of magnitude ~1): the X3 modes are the parity-graded
 # ones; the single-MFMA modes are reported with their measured error (SURVEY.md §7 hard part 1).
 MLP_TOL = {"f32": 2e-5, "f16x3": 2e-5, "bf16x3": 2e-4, "f16": 2e-2, "bf16": 1e-1, "f16x2": 2e-3, "f16f8": 2e-4}
