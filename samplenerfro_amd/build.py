@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "librnerf.so")
-SOURCES = ["grid.hip", "march.hip", "render.hip", "mlp.hip", "mlp_f32.hip", "pipeline.hip"]
+SOURCES = ["grid.hip", "march.hip", "render.hip", "mlp.hip", "mlp_f32.hip", "bkgd16.hip", "pipeline.hip"]
 # -ffp-contract=off + correctly rounded div/sqrt: the march/lookup/resample kernels reproduce the reference's
 # individually rounded fp32 op order so that integer indices are bit-exact against the oracle.
 # -fno-slp-vectorize: a performance choice first — hipcc's SLP pass packs adjacent scalar fp32 ops into v_pk_{mul,add,fma}_f32, which beside
@@ -45,7 +45,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = _hipcc()
     headers = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "rnerf.h"),
-               os.path.join(CSRC, "ior_train_kernels.inc"), os.path.join(CSRC, "ior_train_api.inc"), os.path.join(CSRC, "nerfmlp_layout.h")]
+               os.path.join(CSRC, "ior_train_kernels.inc"), os.path.join(CSRC, "ior_train_api.inc"), os.path.join(CSRC, "nerfmlp_layout.h"),
+               os.path.join(CSRC, "mfma_ops.h"), os.path.join(CSRC, "bkgd_layout.h")]
     objs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)

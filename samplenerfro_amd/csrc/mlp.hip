@@ -19,6 +19,8 @@
 //   * Persistent grid: each workgroup walks row tiles with stride gridDim.x and prefetches across layer and tile seams.
 #include "common.h"
 #include "nerfmlp_layout.h"
+#include "mfma_ops.h"
+#include "bkgd_layout.h"
 
 #include <stdlib.h>
 #include <type_traits>
@@ -27,12 +29,6 @@
 
 namespace rnerf {
 
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef _Float16 half2v __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 #define GLOBAL_AS __attribute__((address_space(1)))
 #define LDS_AS __attribute__((address_space(3)))
@@ -85,31 +81,6 @@ struct Prec {
   static constexpr size_t PACKED_BYTES = STREAM_BYTES + (size_t)AUX_FLOATS * 4;
 };
 
-// ---- 16-bit packing -------------------------------------------------------------------------------------------------
-template <bool F16>
-__device__ __forceinline__ uint32_t pack2(float a, float b) {
-  f32x2 v = {a, b};
-  if constexpr (F16) return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, half2v));
-  else return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
-}
-template <bool F16>
-__device__ __forceinline__ void unpack2(uint32_t p, float& a, float& b) {
-  if constexpr (F16) {
-    half2v hv = __builtin_bit_cast(half2v, p);
-    a = (float)hv[0]; b = (float)hv[1];
-  } else {
-    a = __uint_as_float(p << 16); b = __uint_as_float(p & 0xffff0000u);
-  }
-}
-// hi = round16(x), lo = round16(x - hi)
-template <bool F16>
-__device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
-  hi = pack2<F16>(a, b);
-  float ha, hb;
-  unpack2<F16>(hi, ha, hb);
-  lo = pack2<F16>(a - ha, b - hb);
-}
-
 // ---- fp8 (e4m3) cross-term operands of the f16f8 precision ------------------------------------------------------------------
 constexpr float F8X_LO_SCALE = 1024.f;       // x_lo is multiplied, the W image of the second cross term divided by it
 // two values -> two fp8 bytes in half `HI` of `old` (the other half is kept).  Written as the instruction: the LOW half is a plain output
@@ -157,20 +128,6 @@ __device__ __forceinline__ uint4 f8x_lo_part(const float (&x)[8], const uint32_t
   return make_uint4(o[0], o[1], o[2], o[3]);
 }
 
-template <bool F16>
-__device__ __forceinline__ f32x16 mfma16(const uint4 a, const uint4 b, const f32x16 c) {
-  if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
-  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-
-// ---- operand slot -> input feature maps (shared by the pack kernel and the forward kernel) -----------------------------
-// previous-layer activations: k-step s, half h, slot j  ->  feature index
-__host__ __device__ constexpr int prev_feature(int s, int h, int j) { return 16 * s + 8 * (j >> 2) + 4 * h + (j & 3); }
-// 63-d position encoding [x(3) | sin(2^d x)(30) | sin(2^d x + pi/2)(30)] (rnerf/model_utils.py:211-214):
-// slot q = 8*s + j (0..31); half 0 carries the sin block, half 1 the cos block, the identity terms ride in q = 30, 31.
-__host__ __device__ constexpr int pe_feature(int q, int h) { return q < 30 ? (h ? 33 + q : 3 + q) : (q == 30 ? (h ? 2 : 0) : (h ? -1 : 1)); }
-// 27-d view encoding [d(3) | sin(2^k d)(12) | sin(2^k d + pi/2)(12)], slot q = 0..15
-__host__ __device__ constexpr int view_feature(int q, int h) { return q < 12 ? (h ? 15 + q : 3 + q) : (q == 12 ? (h ? 2 : 0) : (q == 13 ? (h ? -1 : 1) : -1)); }
 
 // input feature (row of the Dense kernel) for MFMA layer l, k-step s, half h, slot j; -1 = zero padding
 __host__ __device__ constexpr int in_feature(int l, int s, int h, int j) {
@@ -535,7 +492,6 @@ struct SeamWork {
   }
 };
 
-#define RNERF_PIN() __builtin_amdgcn_sched_barrier(0)
 
 // one n-tile of one k-step: 6 (X3) or 2 MFMAs with the conversion chunks of pair PI in their shadow
 // PASSES (X3 modes): 3 = hi*hi + hi*lo + lo*hi (fp32-grade), 2 = drop the lo(weight) term, 1 = hi*hi only
@@ -1983,21 +1939,6 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
 // N2: the 4x128 background MLP (rnerf/models.py:116-118) in exact fp32 on v_mfma_f32_32x32x2_f32.
 // One wave = 32 rays; weights are read straight from the flat fp32 buffer (kernel[in][out], coalesced along out).
 // ------------------------------------------------------------------------------------------------------------------
-__host__ __device__ constexpr DenseShape bkgd_dense(int d) {
-  constexpr DenseShape t[5] = {{27, 128}, {128, 128}, {128, 128}, {155, 128}, {128, 3}};
-  return t[d];
-}
-__host__ __device__ constexpr int bkgd_koff(int d) {
-  int o = 0;
-  for (int i = 0; i < d; ++i) o += bkgd_dense(i).in * bkgd_dense(i).out + bkgd_dense(i).out;
-  return o;
-}
-__host__ __device__ constexpr int bkgd_boff(int d) { return bkgd_koff(d) + bkgd_dense(d).in * bkgd_dense(d).out; }
-static_assert(bkgd_koff(5) == RNERF_BKGDMLP_PARAMS, "bkgd MLP parameter count");
-
-// K=2 MFMA steps over the 27-d direction encoding: step q (0..13): half 0 / half 1 feature
-__host__ __device__ constexpr int dir_feature(int q, int h) { return q < 12 ? (h ? 15 + q : 3 + q) : (q == 12 ? (h ? 2 : 0) : (h ? -1 : 1)); }
-
 // acc[t] += W(step, t) * x(step) over NSTEP K=2 steps of v_mfma_f32_32x32x2_f32 for NT n-tiles, with the per-lane weight dwords fetched one
 // BATCH (4 steps) ahead of the MFMAs that consume them.  Left to itself hipcc emits load -> s_waitcnt vmcnt(0) -> MFMA for every single
 // product, re-using one register: a full L2 round trip (~650 cycles) per 64-cycle MFMA — the small-MLP kernels ran at a tenth of the
@@ -2080,11 +2021,6 @@ __device__ __forceinline__ void small_dir_layer(f32x16 (&acc)[4], const float (&
     return f < 0 ? 0.f : w;
   }, [&](int q) { return enc[q]; });
 }
-
-// save (training forward), fp32 row-major: [enc: n x 28][X1: n x 128][X2][X3][X4][out: n x 3]  (X_k = ReLU'd input of Dense_k)
-__host__ __device__ constexpr size_t bkgd_save_floats(long long n) { return (size_t)n * (28 + 4 * 128 + 3); }
-// scratch: [dY0..dY3: n x 128][d raw: n x 4, padded to n x 128 so that dY_k = base + k*n*128][wgrad partials: chunks x params]
-__host__ __device__ constexpr size_t bkgd_dy_floats(long long n) { return (size_t)n * (5 * 128) + (size_t)((n + 255) / 256) * RNERF_BKGDMLP_PARAMS; }
 
 template <bool TRAIN>
 __global__ void __launch_bounds__(64) bkgd_fwd_kernel(const float* __restrict__ params, const float* __restrict__ dirs, int dir_stride,
@@ -2179,210 +2115,6 @@ __global__ void __launch_bounds__(64) bkgd_fwd_kernel(const float* __restrict__ 
   }
 }
 
-
-// ---- the background MLP on the f16 matrix cores (round 4) ---------------------------------------------------------------------------
-// The exact-fp32 chain above (v_mfma_f32_32x32x2_f32: 64 cycles per K = 2 step, ~900 per 32 rows) is bound by the latency of its one wave
-// per row block: 64 us for the 20 480 rows of a bench step, at the head of every step.  The same network with the f16 hi + lo split of the
-// NerfMLP engine (3 x v_mfma_f32_32x32x16_f16 per tile: 340 MFMAs of 32 cycles per 32 rows, fp32 accumulate, weights x 2^8 so that the lo
-// parts stay normal; error class 2^-22 like f16x3) — the weights are converted on the fly from the flat fp32 buffer (every wave reads the
-// 57 k parameters through L1 / L2: no packed stream, no change to the C ABI), the transposed chain keeps the activations in registers
-// (accumulator layout = next layer's B operand: prev_feature / view_feature slot maps as in the NerfMLP engine).  Saved tensors of the
-// training forward: the same fp32 layout as bkgd_fwd_kernel (the backward kernels do not care which arithmetic produced X_k).
-// RNERF_BKGD_EXACT=1 selects the exact-fp32 kernels (they stay the arbiter of this one: tests/test_gpu_parity.py).
-// (A three-instruction split — v_cvt_pk_f16_f32, then v_fma_mixlo_f16 / v_fma_mixhi_f16 subtracting the f16 half straight from the packed
-//  word — gives the same bits alone (tools/r04/probes/mix_split_probe.hip) but NaNs in this kernel: inline asm hides the partial-register
-//  writes from the compiler's hazard recogniser.  It bought 1 us of 21: the kernel is bound by latency, not by its conversions.)
-__device__ __forceinline__ void bkgd16_split2(float a, float b, uint32_t& hi, uint32_t& lo) { split2<true>(a, b, hi, lo); }
-__device__ __forceinline__ void bkgd16_split8(const float (&w)[8], uint4& hi, uint4& lo) {
-  uint32_t h[4], l[4];
-#pragma unroll
-  for (int p = 0; p < 4; ++p) bkgd16_split2(w[2 * p], w[2 * p + 1], h[p], l[p]);
-  hi = make_uint4(h[0], h[1], h[2], h[3]); lo = make_uint4(l[0], l[1], l[2], l[3]);
-}
-// One layer's matrix part: acc[t] (+)= W^T(k-step s, n-tile t) x^T(s) for s = 0 .. NS-1, 3 MFMAs per tile (FIRST: the first k-step starts
-// from zero accumulators).  wload(s, t, j): the A operand's slot j of lane (n = 32 t + (lane & 31), half = lane >> 5) — the element [row of
-// slot j][n] of the layer's kernel, a pure load from a per-lane base pointer + a CONSTANT (immediate) offset: 32 dwords per lane and
-// k-step, 128 consecutive bytes per half-wave and load; live(s, j) = 0: zero padding (0: never, 1: always, 2: ask lanes(s, j)).  The BIAS is
-// one more such row, met by a 1.0 in the B operand (the free slot 14 of the direction encoding's second k-step, or a ninth k-step of its
-// own): split into hi + lo like every weight, no separate add.  The loads run DEPTH k-steps ahead of the MFMAs that consume them (left to
-// itself hipcc waits for every load where it is issued: an L2 round trip per product, the same disease as mfma_f32_stream's).
-// xop(s, bh, bl): the hi / lo B operands of k-step s.
-template <int NS, bool FIRST, typename WF, typename LF, typename XF>
-__device__ __forceinline__ void bkgd16_layer(f32x16 (&acc)[4], WF wload, LF live, bool half0, XF xop) {
-  constexpr int DEPTH = 2;
-  f32x2 w[DEPTH + 1][16];
-  auto load = [&](int s, f32x2 (&dst)[16]) {
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int j = 0; j < 8; ++j)
-        if (live(s, j) != 0) dst[4 * t + (j >> 1)][j & 1] = wload(s, t, j);
-  };
-#pragma unroll
-  for (int s = 0; s < DEPTH && s < NS; ++s) load(s, w[s]);
-  f32x16 zero;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) zero[r] = 0.f;
-#pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    if (s + DEPTH < NS) load(s + DEPTH, w[(s + DEPTH) % (DEPTH + 1)]);
-    RNERF_PIN();
-    uint4 bh, bl;
-    xop(s, bh, bl);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      uint32_t hh[4], ll[4];
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        const int l0 = live(s, 2 * p), l1 = live(s, 2 * p + 1);      // 0: padding, 1: every lane, 2: half 0 only
-        if (l0 == 0 && l1 == 0) { hh[p] = 0u; ll[p] = 0u; continue; }
-        f32x2 q = w[s % (DEPTH + 1)][4 * t + p];
-        if (l0 == 0) q[0] = 0.f;
-        if (l1 == 0) q[1] = 0.f;
-        q = q * 256.0f;                                               // x 2^8 as a packed fp32 multiply (one instruction per pair)
-        if (l0 == 2) q[0] = half0 ? q[0] : 0.f;
-        if (l1 == 2) q[1] = half0 ? q[1] : 0.f;
-        bkgd16_split2(q[0], q[1], hh[p], ll[p]);
-      }
-      const uint4 ah = make_uint4(hh[0], hh[1], hh[2], hh[3]), al = make_uint4(ll[0], ll[1], ll[2], ll[3]);
-      acc[t] = mfma16<true>(ah, bh, FIRST && s == 0 ? zero : acc[t]);
-      acc[t] = mfma16<true>(ah, bl, acc[t]);
-      acc[t] = mfma16<true>(al, bh, acc[t]);
-    }
-    RNERF_PIN();
-  }
-}
-// per-lane base pointers into the flat parameters (computed once): every load of the kernel is one of them + an immediate offset
-struct Bkgd16Lane {
-  const float* p0;      // params + m
-  const float* prev;    // + 4 h rows: prev_feature(s, h, j) = 16 s + 8 (j >> 2) + (j & 3)  + 4 h
-  const float* dir;     // + 12 h rows: view_feature(q < 12, h) = 3 + q + 12 h
-  const float* sp;      // + 2 h rows: view_feature(12, h) = 2 h
-  bool half0;
-};
-__device__ __forceinline__ Bkgd16Lane bkgd16_lane(const float* __restrict__ params, int m, int h) {
-  return {params + m, params + m + 4 * 128 * h, params + m + 12 * 128 * h, params + m + 2 * 128 * h, h == 0};
-}
-// acc = W[0..127][:] x + bias for a 128-wide previous activation x (fp32, accumulator layout); BIAS: with the ninth k-step [1 | 0 ...] x bias
-template <bool BIAS>
-__device__ __forceinline__ void bkgd16_prev_layer(f32x16 (&acc)[4], const f32x16 (&x)[4], const Bkgd16Lane& L, int koff, int boff) {
-  bkgd16_layer<BIAS ? 9 : 8, true>(acc,
-      [&](int s, int t, int j) { return s < 8 ? L.prev[koff + (16 * s + 8 * (j >> 2) + (j & 3)) * 128 + 32 * t] : L.p0[boff + 32 * t]; },
-      [&](int s, int j) { return s < 8 ? 1 : (j == 0 ? 2 : 0); }, L.half0,
-      [&](int s, uint4& bh, uint4& bl) {
-    if (s < 8) {
-      float xv[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) xv[j] = x[s >> 1][8 * (s & 1) + j];
-      bkgd16_split8(xv, bh, bl);
-    } else {
-      bh = make_uint4(L.half0 ? 0x3c00u : 0u, 0u, 0u, 0u);      // f16 1.0 in slot 0 of half 0
-      bl = make_uint4(0u, 0u, 0u, 0u);
-    }
-  });
-}
-// acc (+)= W[rows of the 27-d direction encoding][:] enc + bias: two k-steps in the slot order of view_feature (= dir_feature for the 14 used
-// slots: q < 12: rows 3 + q | 15 + q, q = 12: rows 0 | 2, q = 13: row 1 | nothing), the bias in slot 14 of half 0
-template <bool FIRST>
-__device__ __forceinline__ void bkgd16_dir_layer(f32x16 (&acc)[4], const float (&enc)[14], const Bkgd16Lane& L, int koff, int boff) {
-  bkgd16_layer<2, FIRST>(acc,
-      [&](int s, int t, int j) {
-        const int q = 8 * s + j;
-        return q < 12 ? L.dir[koff + (3 + q) * 128 + 32 * t] : (q == 12 ? L.sp[koff + 32 * t] : (q == 13 ? L.p0[koff + 128 + 32 * t] : L.p0[boff + 32 * t]));
-      },
-      [&](int s, int j) { const int q = 8 * s + j; return q < 13 ? 1 : (q < 15 ? 2 : 0); }, L.half0,
-      [&](int s, uint4& bh, uint4& bl) {
-    float xv[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) xv[j] = 8 * s + j < 14 ? enc[8 * s + j] : (8 * s + j == 14 && L.half0 ? 1.0f : 0.f);
-    bkgd16_split8(xv, bh, bl);
-  });
-}
-
-template <bool TRAIN>
-__global__ void __launch_bounds__(64) bkgd16_fwd_kernel(const float* __restrict__ params, const float* __restrict__ dirs, int dir_stride,
-                                                        long long n, float pad_scale, float pad, float* __restrict__ out_rgb,
-                                                        float* __restrict__ save) {
-  const int lane = threadIdx.x & 63, m = lane & 31, h = lane >> 5;
-  long long row = (long long)blockIdx.x * 32 + m;
-  const bool ok = row < n;
-  if (!ok) row = n - 1;
-  const float v0 = dirs[row * dir_stride], v1 = dirs[row * dir_stride + 1], v2 = dirs[row * dir_stride + 2];
-  float enc[14];                                     // as bkgd_fwd_kernel: the same values in the same slots
-  const float phase = h ? 1.5707963705062866f : 0.0f;
-#pragma unroll
-  for (int q = 0; q < 12; ++q) {
-    const int d = q / 3, c = q % 3;
-    const float x = c == 0 ? v0 : (c == 1 ? v1 : v2);
-    enc[q] = sinf(fadd(fmul(x, (float)(1 << d)), phase));
-  }
-  enc[12] = h ? v2 : v0;
-  enc[13] = h ? 0.f : v1;
-  auto save_x = [&](int k, const f32x16 (&xx)[4]) {     // X_k[row][f], f = 32t + 8g + 4h + i
-    if constexpr (TRAIN) {
-      if (ok) {
-        float* dst = save + (size_t)n * 28 + (size_t)(k - 1) * n * 128 + (size_t)row * 128;
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-          for (int g = 0; g < 4; ++g)
-            *(float4*)(dst + 32 * t + 8 * g + 4 * h) = make_float4(xx[t][4 * g], xx[t][4 * g + 1], xx[t][4 * g + 2], xx[t][4 * g + 3]);
-      }
-    }
-  };
-  if constexpr (TRAIN) {
-    if (ok) {
-#pragma unroll
-      for (int q = 0; q < 14; ++q) { const int f = h ? dir_feature(q, 1) : dir_feature(q, 0); if (f >= 0) save[(size_t)row * 28 + f] = enc[q]; }
-      if (h == 1) save[(size_t)row * 28 + 27] = 0.f;
-    }
-  }
-  constexpr float INV = 1.0f / 256.0f;
-  f32x16 acc[4], x[4];
-  auto relu_to_x = [&]() {      // x = ReLU(acc 2^-8)   (not fmaxf: a NaN of an out-of-range f16 operand must reach the output)
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { const float y = acc[t][r] * INV; x[t][r] = y < 0.f ? 0.f : y; }
-  };
-  const Bkgd16Lane L = bkgd16_lane(params, m, h);
-  // Dense_0: 27 -> 128, ReLU
-  bkgd16_dir_layer<true>(acc, enc, L, bkgd_koff(0), bkgd_boff(0));
-  relu_to_x();
-  save_x(1, x);
-  // Dense_1, Dense_2: 128 -> 128, ReLU
-  bkgd16_prev_layer<true>(acc, x, L, bkgd_koff(1), bkgd_boff(1));
-  relu_to_x();
-  save_x(2, x);
-  bkgd16_prev_layer<true>(acc, x, L, bkgd_koff(2), bkgd_boff(2));
-  relu_to_x();
-  save_x(3, x);
-  // Dense_3: [x(128), inputs(27)] -> 128, ReLU  (skip concat after i == 2, rnerf/model_utils.py:131-132)
-  bkgd16_prev_layer<false>(acc, x, L, bkgd_koff(3), 0);
-  bkgd16_dir_layer<false>(acc, enc, L, bkgd_koff(3) + 128 * 128, bkgd_boff(3));
-  relu_to_x();
-  if constexpr (TRAIN) save_x(4, x);
-  // Dense_4: 128 -> 3 on the VALU, then sigmoid*(1+2p)-p (rnerf/models.py:336-337)
-  float o[3] = {0.f, 0.f, 0.f};
-  const float* __restrict__ k4 = params + bkgd_koff(4);
-#pragma unroll
-  for (int t = 0; t < 4; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float v = x[t][r];
-      const int f = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
-      o[0] = fmaf(v, k4[f * 3 + 0], o[0]); o[1] = fmaf(v, k4[f * 3 + 1], o[1]); o[2] = fmaf(v, k4[f * 3 + 2], o[2]);
-    }
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    o[c] = o[c] + __shfl_xor(o[c], 32) + params[bkgd_boff(4) + c];
-    o[c] = fsub(fmul(fdiv(1.0f, fadd(1.0f, expf(-o[c]))), pad_scale), pad);
-  }
-  if (ok && h == 0) {
-    out_rgb[3 * row] = o[0]; out_rgb[3 * row + 1] = o[1]; out_rgb[3 * row + 2] = o[2];
-    if constexpr (TRAIN) { float* so = save + (size_t)n * (28 + 4 * 128) + (size_t)row * 3; so[0] = o[0]; so[1] = o[1]; so[2] = o[2]; }
-  }
-}
 
 // ------------------------------------------------------------------------------------------------------------------
 // G4 / P2 / E1 (stage "all"): so3_mlp = MLP(128, 4, skip 2, out 3) on annealed_pos_enc(x) (rnerf/ior_utils.py:148-152, :283;
@@ -3171,6 +2903,7 @@ extern "C" size_t rnerf_nerfmlp_packed_bytes(int precision) {
 }
 
 namespace rnerf {
+void* nerfmlp_dgrad_scale_ref(int backward, void* dy, int64_t rows);      // (defined with the dgrad launcher below)
 // the range flag(s) of a packed stream: 4 floats behind the aux block of every f16 stream (f16f8: its own and its f16x3 fallback's)
 static int pack_flag_regions(int precision, void* packed, void** out) {
   auto at = [&](size_t off) { return (void*)((char*)packed + off + AUX_FLAG * sizeof(float)); };
@@ -3182,16 +2915,21 @@ static int pack_flag_regions(int precision, void* packed, void** out) {
     default: return 0;
   }
 }
-struct FlagRegions { float4* p[8]; };
+struct FlagRegions { float4* p[12]; };
 __global__ void __launch_bounds__(64) zero_flags_kernel(FlagRegions r, int n) {
   if ((int)threadIdx.x < n) *r.p[threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
-// Zeroes the range flags of up to 4 packed streams in ONE launch (the training step packs 2 streams per step: as hipMemsetAsync each
-// flag was a fill kernel of its own, ~6 us apiece at the head of the step's critical chain).
-int nerfmlp_pack_zero_flags(int precision, void* const* packed, int count, hipStream_t st) {
+// Zeroes, in ONE launch, every 16-byte accumulator / flag word a training step needs cleared before its kernels run: the range flags of
+// the operand streams it packs (`packed`, `count` <= 2), the row-scale reference of each dgrad's dY buffer (`dy` / `dy_rows`, see
+// launch_dgrad) and up to 2 `extra` words (the env-map smoothness sum).  As hipMemsetAsync calls inside the producers each was a fill
+// kernel of its own, ~6 us apiece with its launch gap, three of them on the main stream's dependent chain (round 4).
+int nerfmlp_step_zero(int precision, void* const* packed, int count, int backward, void* const* dy, const int64_t* dy_rows, int dy_count,
+                      void* const* extra, int extra_count, hipStream_t st) {
   FlagRegions r;
   int n = 0;
-  for (int i = 0; i < count && i < 4; ++i) { void* o[2]; const int k = pack_flag_regions(precision, packed[i], o); for (int q = 0; q < k; ++q) r.p[n++] = (float4*)o[q]; }
+  for (int i = 0; i < count && i < 2; ++i) { void* o[2]; const int k = pack_flag_regions(precision, packed[i], o); for (int q = 0; q < k; ++q) r.p[n++] = (float4*)o[q]; }
+  for (int i = 0; i < dy_count && i < 4; ++i) { void* f = nerfmlp_dgrad_scale_ref(backward, dy[i], dy_rows[i]); if (f) r.p[n++] = (float4*)f; }
+  for (int i = 0; i < extra_count && i < 2; ++i) if (extra[i]) r.p[n++] = (float4*)extra[i];
   if (n == 0) return RNERF_OK;
   hipLaunchKernelGGL(zero_flags_kernel, dim3(1), dim3(64), 0, st, r, n);
   RNERF_CHECK_LAUNCH();
@@ -3377,8 +3115,18 @@ extern "C" int rnerf_nerfmlp_pack_bwd(const float* params, int backward, void* p
   return RNERF_OK;
 }
 
+// the dgrad's row-scale reference (m_ref, an atomicMax accumulator behind the row scales of the f16 modes' dY buffer; nullptr: none) — it
+// must be zero when the kernel starts: launch_dgrad zeroes it unless the caller already has (nerfmlp_step_zero)
+void* rnerf::nerfmlp_dgrad_scale_ref(int backward, void* dy, int64_t rows) {
+  const long long R = (rows + 255) / 256 * 256;
+  if (backward == RNERF_BWD_F16X2) return (char*)dy + dy_plane_uint4(R, Bwd<RNERF_BWD_F16X2>::NP) * sizeof(uint4) + (size_t)R * sizeof(float);
+  if (backward == RNERF_BWD_F16) return (char*)dy + dy_plane_uint4(R, Bwd<RNERF_BWD_F16>::NP) * sizeof(uint4) + (size_t)R * sizeof(float);
+  return nullptr;
+}
+
 template <int BWD>
-static int launch_dgrad(const void* packed_bwd, const float* fwd_aux, const void* save, const float* d_raw, int64_t rows, void* dy, hipStream_t st) {
+static int launch_dgrad(const void* packed_bwd, const float* fwd_aux, const void* save, const float* d_raw, int64_t rows, void* dy, hipStream_t st,
+                        bool zero_ref = true) {
   using PB = Prec<Bwd<BWD>::PREC>;
   const int n_tiles = (int)((rows + 255) / 256);
   int dev = 0, cus = 0;
@@ -3392,25 +3140,31 @@ static int launch_dgrad(const void* packed_bwd, const float* fwd_aux, const void
     attr_set = true;
   }
   const long long R = (long long)n_tiles * 256;
-  if (Bwd<BWD>::F16)       // m_ref accumulator (atomicMax) behind the row scales
-    RNERF_CHECK_HIP(hipMemsetAsync((char*)dy + dy_plane_uint4(R, Bwd<BWD>::NP) * sizeof(uint4) + (size_t)R * sizeof(float), 0, 4 * sizeof(float), st));
+  if (Bwd<BWD>::F16 && zero_ref) RNERF_CHECK_HIP(hipMemsetAsync(nerfmlp_dgrad_scale_ref(BWD, dy, rows), 0, 4 * sizeof(float), st));
   hipLaunchKernelGGL(nerfmlp_dgrad_kernel<BWD>, dim3(grid), dim3(256), lds, st, (const char*)packed_bwd, fwd_aux, (const uint4*)save, R,
                      (const float4*)d_raw, (long long)rows, n_tiles, (uint4*)dy);
   RNERF_CHECK_LAUNCH();
   return RNERF_OK;
 }
 
-extern "C" int rnerf_nerfmlp_dgrad(const void* packed_bwd, const void* packed_fwd, int fwd_precision, int backward, const void* save,
-                                   const float* d_raw, int64_t rows, void* dy, void* stream) {
+namespace rnerf {
+// zero_ref = false: the caller has zeroed nerfmlp_dgrad_scale_ref(backward, dy, rows) on `stream` already (nerfmlp_step_zero)
+int nerfmlp_dgrad_impl(const void* packed_bwd, const void* packed_fwd, int fwd_precision, int backward, const void* save, const float* d_raw, int64_t rows,
+                       void* dy, bool zero_ref, hipStream_t st) {
   RNERF_CHECK_ARG(packed_bwd && packed_fwd && save && d_raw && dy, "rnerf_nerfmlp_dgrad: null pointer");
   RNERF_CHECK_ARG(fwd_precision == RNERF_PREC_F16X3, "rnerf_nerfmlp_dgrad: forward precision must be f16x3");
   RNERF_CHECK_ARG(bwd_ok(backward), "rnerf_nerfmlp_dgrad: unknown backward mode %d", backward);
   RNERF_CHECK_ARG(rows >= 1, "rnerf_nerfmlp_dgrad: rows must be >= 1");
   const float* fwd_aux = (const float*)((const char*)packed_fwd + Prec<RNERF_PREC_F16X3>::STREAM_BYTES);
-  hipStream_t st = (hipStream_t)stream;
-  if (backward == RNERF_BWD_F16X2) return launch_dgrad<RNERF_BWD_F16X2>(packed_bwd, fwd_aux, save, d_raw, rows, dy, st);
-  if (backward == RNERF_BWD_F16) return launch_dgrad<RNERF_BWD_F16>(packed_bwd, fwd_aux, save, d_raw, rows, dy, st);
-  return launch_dgrad<RNERF_BWD_BF16>(packed_bwd, fwd_aux, save, d_raw, rows, dy, st);
+  if (backward == RNERF_BWD_F16X2) return launch_dgrad<RNERF_BWD_F16X2>(packed_bwd, fwd_aux, save, d_raw, rows, dy, st, zero_ref);
+  if (backward == RNERF_BWD_F16) return launch_dgrad<RNERF_BWD_F16>(packed_bwd, fwd_aux, save, d_raw, rows, dy, st, zero_ref);
+  return launch_dgrad<RNERF_BWD_BF16>(packed_bwd, fwd_aux, save, d_raw, rows, dy, st, zero_ref);
+}
+}  // namespace rnerf
+
+extern "C" int rnerf_nerfmlp_dgrad(const void* packed_bwd, const void* packed_fwd, int fwd_precision, int backward, const void* save,
+                                   const float* d_raw, int64_t rows, void* dy, void* stream) {
+  return nerfmlp_dgrad_impl(packed_bwd, packed_fwd, fwd_precision, backward, save, d_raw, rows, dy, true, (hipStream_t)stream);
 }
 
 // the wgrad jobs of one NerfMLP: {x slot base, x k-steps, dy slot base, dy k-steps, job, second-segment bases}
@@ -3445,7 +3199,8 @@ static const WgradPlan kWgradPlanTr[12] = {
 
 // legacy = the bf16 body (MFMA transposition): shares by MFMA count, 4 rounds of workgroups; otherwise the transpose-read bodies, paced
 // by HBM: shares by bytes streamed per row, 2 rounds (measured with RNERF_WGRAD_TRACE: all jobs' workgroups finish within 10 %)
-static size_t build_wgrad_table(int cus, WgradTable& t, bool legacy) {
+// mult: rounds of one-per-CU workgroups the rows are cut into (0: the default of the body — 4 legacy, 2 transposing)
+static size_t build_wgrad_table(int cus, WgradTable& t, bool legacy, int mult = 0) {
   const WgradPlan* plan = legacy ? kWgradPlan : kWgradPlanTr;
   int n = 0;
   double cost[16], total = 0;
@@ -3456,7 +3211,7 @@ static size_t build_wgrad_table(int cus, WgradTable& t, bool legacy) {
   }
   t.n = n;
   static const int mult_env = getenv("RNERF_WGRAD_MULT") ? atoi(getenv("RNERF_WGRAD_MULT")) : 0;
-  const int budget = (mult_env > 0 ? mult_env : (legacy ? 4 : 2)) * cus;       // rounds of one-per-CU workgroups
+  const int budget = (mult_env > 0 ? mult_env : (mult > 0 ? mult : (legacy ? 4 : 2))) * cus;
   size_t off = 0;
   int wg = 0;
   for (int i = 0; i < n; ++i) {
@@ -3479,14 +3234,23 @@ static int device_cus() {
   return cus;
 }
 
-struct WgradTables { WgradTable legacy, tr; size_t partial_floats; int max_wgs; };
+// tr_small: the transposing body's table for a FEW rows (<= kWgradSmallRows: both levels of a 128-ray shard of the reference's default
+// batch): one round of workgroups instead of two — every workgroup writes its whole partial dW block whatever its share of the rows, and
+// with < 100 rows per workgroup that fixed cost is the kernel (128 rays: 1.29 -> 1.23 ms per step; from 32 768 rows on — the coarse level of
+// a 512-ray batch — two rounds are faster: 2.14 against 2.18 ms, tools/r04/wgrad_mult.sh).  Smaller than `tr` in workgroups and partials:
+// the workspace size is unchanged.
+constexpr long long kWgradSmallRows = 24576;
+struct WgradTables { WgradTable legacy, tr, tr_small; size_t partial_floats; int max_wgs; };
 static const WgradTables& wgrad_tables() {
   static WgradTables w;
   static bool ready = false;
   if (!ready) {
     const size_t a = build_wgrad_table(device_cus(), w.legacy, true), b = build_wgrad_table(device_cus(), w.tr, false);
+    const size_t s = build_wgrad_table(device_cus(), w.tr_small, false, 1);
     w.partial_floats = a > b ? a : b;
+    if (s > w.partial_floats) w.partial_floats = s;
     w.max_wgs = w.legacy.wg0[w.legacy.n] > w.tr.wg0[w.tr.n] ? w.legacy.wg0[w.legacy.n] : w.tr.wg0[w.tr.n];
+    if (w.tr_small.wg0[w.tr_small.n] > w.max_wgs) w.max_wgs = w.tr_small.wg0[w.tr_small.n];
     ready = true;
   }
   return w;
@@ -3517,7 +3281,7 @@ extern "C" int rnerf_nerfmlp_wgrad(int fwd_precision, int backward, const void* 
   // RNERF_WGRAD_TRACE=1 (profiling aid): per-workgroup start / end times behind the partials -> per-job spans on stderr (synchronises)
   static const bool tracing = getenv("RNERF_WGRAD_TRACE") != nullptr;
   long long* trace = tracing ? (long long*)((char*)workspace + w.partial_floats * sizeof(float)) : nullptr;
-  const WgradTable& tab = backward == RNERF_BWD_BF16 ? w.legacy : w.tr;
+  const WgradTable& tab = backward == RNERF_BWD_BF16 ? w.legacy : (rows <= kWgradSmallRows ? w.tr_small : w.tr);
   if (backward == RNERF_BWD_BF16) {
     const int n_chunks = (int)((rows + 127) / 128);
     hipLaunchKernelGGL(nerfmlp_wgrad_kernel<true>, dim3(tab.wg0[tab.n]), dim3(512), 131072, st, (const uint4*)save, (const uint4*)dy, R,
@@ -3567,8 +3331,7 @@ extern "C" int rnerf_bkgd_forward(const float* params, const float* dirs, int32_
     hipLaunchKernelGGL(bkgd_fwd_kernel<false>, dim3((unsigned)((n + 31) / 32)), dim3(64), 0, (hipStream_t)stream, params, dirs, dir_stride,
                        (long long)n, (float)(1 + 2 * rgb_padding), (float)rgb_padding, out_rgb, (float*)nullptr);
   else
-    hipLaunchKernelGGL(bkgd16_fwd_kernel<false>, dim3((unsigned)((n + 31) / 32)), dim3(64), 0, (hipStream_t)stream, params, dirs, dir_stride,
-                       (long long)n, (float)(1 + 2 * rgb_padding), (float)rgb_padding, out_rgb, (float*)nullptr);
+    return launch_bkgd16_fwd(false, params, dirs, dir_stride, (long long)n, (float)(1 + 2 * rgb_padding), (float)rgb_padding, out_rgb, nullptr, (hipStream_t)stream);
   RNERF_CHECK_LAUNCH();
   return RNERF_OK;
 }
@@ -3584,8 +3347,7 @@ extern "C" int rnerf_bkgd_forward_train(const float* params, const float* dirs, 
     hipLaunchKernelGGL(bkgd_fwd_kernel<true>, dim3((unsigned)((n + 31) / 32)), dim3(64), 0, (hipStream_t)stream, params, dirs, dir_stride,
                        (long long)n, (float)(1 + 2 * rgb_padding), (float)rgb_padding, out_rgb, (float*)save);
   else
-    hipLaunchKernelGGL(bkgd16_fwd_kernel<true>, dim3((unsigned)((n + 31) / 32)), dim3(64), 0, (hipStream_t)stream, params, dirs, dir_stride,
-                       (long long)n, (float)(1 + 2 * rgb_padding), (float)rgb_padding, out_rgb, (float*)save);
+    return launch_bkgd16_fwd(true, params, dirs, dir_stride, (long long)n, (float)(1 + 2 * rgb_padding), (float)rgb_padding, out_rgb, (float*)save, (hipStream_t)stream);
   RNERF_CHECK_LAUNCH();
   return RNERF_OK;
 }

@@ -13,8 +13,13 @@
 
 namespace rnerf {
 // csrc/mlp.hip: the operand-stream pack without its own memsets (the step zeroes every stream's range flags in one launch)
-int nerfmlp_pack_zero_flags(int precision, void* const* packed, int count, hipStream_t st);
+int nerfmlp_step_zero(int precision, void* const* packed, int count, int backward, void* const* dy, const int64_t* dy_rows, int dy_count,
+                      void* const* extra, int extra_count, hipStream_t st);
 int nerfmlp_pack_impl(const float* params, int precision, void* packed, bool zero_flags, hipStream_t st);
+int nerfmlp_dgrad_impl(const void* packed_bwd, const void* packed_fwd, int fwd_precision, int backward, const void* save, const float* d_raw, int64_t rows,
+                       void* dy, bool zero_ref, hipStream_t st);
+// csrc/render.hip
+int env_smooth_backward_impl(const float* rgb_env, int32_t ps, double grad_scale, float* d_out, float* loss_sum, bool zero_sum, hipStream_t st);
 
 // ---- threefry2x32-20 (Random123), the block cipher behind jax.random (samplenerfro_amd/prng.py; KAT in tests/test_prng.py) ---------
 __device__ __forceinline__ unsigned rotl_u32(unsigned x, int r) { return (x << r) | (x >> (32 - r)); }
@@ -515,11 +520,19 @@ extern "C" int rnerf_train_forward_backward(const rnerf_model* m, const rnerf_tr
   //      follow on the aux stream while the coarse forward runs and are joined before the fine forward / the backward.
   //      (Round 4: before, the coarse forward waited for five launches — three 16-byte memsets among them — and started at +88 us.)
   void* aux = c->aux_stream;
+  bool pre_zeroed = false;      // the head of the step has cleared the accumulator words of its kernels (aux stream only)
   struct Mark { hipEvent_t e = nullptr; ~Mark() { if (e) (void)hipEventDestroy(e); } } fine_packed;      // (an early error return must not leak it)
   if (aux) {
     RNERF_TRY(rnerf_fork(stream, aux));
+    // one launch zeroes what the step's kernels need cleared: the streams' range flags, the row-scale reference of every dgrad that is the
+    // FIRST writer of its dY buffer (without an aux-stream coarse level the coarse dgrad reuses the fine level's buffer: it clears its own)
+    // and the env-map smoothness sum
     void* streams[2] = {t.packed_c, t.packed_f};
-    RNERF_TRY(nerfmlp_pack_zero_flags(prec, streams, Nf > 0 ? 2 : 1, (hipStream_t)aux));
+    void* dys[2] = {t.dy, t.dy_c};
+    const int64_t dy_rows[2] = {(int64_t)(Nf > 0 ? S : Nc) * B, (int64_t)Nc * B};
+    void* extra[1] = {smooth ? (void*)t.env_sum : nullptr};
+    RNERF_TRY(nerfmlp_step_zero(prec, streams, Nf > 0 ? 2 : 1, bwd, dys, dy_rows, t.dy_c ? 2 : 1, extra, 1, (hipStream_t)aux));
+    pre_zeroed = true;
     RNERF_TRY(nerfmlp_pack_impl(th_c, prec, t.packed_c, false, (hipStream_t)aux));
   }
   // ---- forward (models.forward with ctx) ----
@@ -593,6 +606,8 @@ extern "C" int rnerf_train_forward_backward(const rnerf_model* m, const rnerf_tr
   // rounds: beyond that the kernels' static tile striding is delayed on the CUs the other level took first and the step gets SLOWER
   // (profiles/r04/levels_side_by_side.txt: 512 rays 2.28 -> 2.18 ms, 128 rays 1.50 -> 1.33; 1024 rays 3.36 -> 3.45, 4096 rays 11.9 -> 12.4).
   const bool split_levels = levels_side_by_side(m, c, B);
+  static const bool bk_early_env = getenv("RNERF_BKGD_BWD_EARLY") ? atoi(getenv("RNERF_BKGD_BWD_EARLY")) != 0 : true;
+  const bool bk_early = split_levels && bk_early_env && !(aux && c->coresident_bkgd_wgrad);
   float* d_raw_c = split_levels ? t.d_raw_c : t.d_raw;
   void* dy_c = split_levels ? t.dy_c : t.dy;
   if (Nf > 0) {
@@ -602,11 +617,16 @@ extern "C" int rnerf_train_forward_backward(const rnerf_model* m, const rnerf_tr
       RNERF_TRY(rnerf_composite_backward(f.raw_c, path_pd, path_dr, jitter, Nc, B, bkgd, m->rgb_padding, m->sigma_bias, lc.rgb, pixels, nullptr, nullptr, nullptr,
                                          mse_scale, 0.0, d_raw_c, d_first, 1, m->white_bkgd, nullptr, stream));
       RNERF_TRY(rnerf_fork(stream, aux));
-      RNERF_TRY(rnerf_nerfmlp_dgrad(t.packed_bwd, t.packed_c, prec, bwd, t.save_c, d_raw_c, (int64_t)Nc * B, dy_c, aux));
+      if (bk_early) {      // d loss / d background is final (both compositing backwards have run): its whole backward goes first on the aux stream
+        const double env_on_ = c->annealed_alpha > 0 ? 1.0 : 0.0;
+        if (smooth) RNERF_TRY(env_smooth_backward_impl(rgb_env, ps, c->bg_smooth_weight * env_on_, t.d_all + (size_t)3 * B, t.env_sum, !pre_zeroed, (hipStream_t)aux));
+        RNERF_TRY(rnerf_bkgd_backward(th_b, t.save_bk, t.d_all, (int64_t)B + M, m->rgb_padding, t.dy_bk, g_b, nullptr, aux));
+      }
+      RNERF_TRY(nerfmlp_dgrad_impl(t.packed_bwd, t.packed_c, prec, bwd, t.save_c, d_raw_c, (int64_t)Nc * B, dy_c, !pre_zeroed, (hipStream_t)aux));
       RNERF_TRY(rnerf_nerfmlp_wgrad(prec, bwd, t.save_c, dy_c, (int64_t)Nc * B, g_c, t.wgrad_ws_c, aux));
     }
     if (!aux) RNERF_TRY(rnerf_nerfmlp_pack_bwd(th_f, bwd, t.packed_bwd_f, stream));
-    RNERF_TRY(rnerf_nerfmlp_dgrad(t.packed_bwd_f, t.packed_f, prec, bwd, t.save_f, t.d_raw, (int64_t)S * B, t.dy, stream));
+    RNERF_TRY(nerfmlp_dgrad_impl(t.packed_bwd_f, t.packed_f, prec, bwd, t.save_f, t.d_raw, (int64_t)S * B, t.dy, !pre_zeroed, st));
     if (next && next->beside_wgrad) RNERF_TRY(march_next());
     RNERF_TRY(rnerf_nerfmlp_wgrad(prec, bwd, t.save_f, t.dy, (int64_t)S * B, g_f, t.wgrad_ws, stream));
     if (split_levels) RNERF_TRY(rnerf_join(stream, aux));
@@ -622,11 +642,12 @@ extern "C" int rnerf_train_forward_backward(const rnerf_model* m, const rnerf_tr
   const double env_on = c->annealed_alpha > 0 ? 1.0 : 0.0;
   const bool co = aux && c->coresident_bkgd_wgrad;
   if (co) {
-    if (smooth) RNERF_TRY(rnerf_env_smooth_backward(rgb_env, ps, c->bg_smooth_weight * env_on, t.d_all + (size_t)3 * B, t.env_sum, stream));
+    if (smooth) RNERF_TRY(env_smooth_backward_impl(rgb_env, ps, c->bg_smooth_weight * env_on, t.d_all + (size_t)3 * B, t.env_sum, !pre_zeroed, st));
     RNERF_TRY(rnerf_bkgd_backward_dgrad(th_b, t.save_bk, t.d_all, (int64_t)B + M, m->rgb_padding, t.dy_bk, nullptr, stream));
   }
   if (!aux) RNERF_TRY(rnerf_nerfmlp_pack_bwd(th_c, bwd, t.packed_bwd, stream));
-  if (!split_levels) RNERF_TRY(rnerf_nerfmlp_dgrad(t.packed_bwd, t.packed_c, prec, bwd, t.save_c, t.d_raw, (int64_t)Nc * B, t.dy, stream));
+  if (!split_levels)      // (a hierarchical model's coarse dgrad is the SECOND writer of t.dy here: it clears its own reference)
+    RNERF_TRY(nerfmlp_dgrad_impl(t.packed_bwd, t.packed_c, prec, bwd, t.save_c, t.d_raw, (int64_t)Nc * B, t.dy, !(pre_zeroed && Nf == 0), st));
   if (co) {      // forked HERE, not earlier: the NerfMLP dgrad owns every CU whole, the wgrad below leaves room for these waves
     RNERF_TRY(rnerf_fork(stream, aux));
     if (kTailDelayTicks > 0) hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)aux, (long long)kTailDelayTicks);
@@ -638,8 +659,8 @@ extern "C" int rnerf_train_forward_backward(const rnerf_model* m, const rnerf_tr
   if (next && !next->beside_wgrad) RNERF_TRY(march_next());     // beside the tail below (background-MLP backward, loss glue) and the update
   if (co) {
     RNERF_TRY(rnerf_join(stream, aux));
-  } else {
-    if (smooth) RNERF_TRY(rnerf_env_smooth_backward(rgb_env, ps, c->bg_smooth_weight * env_on, t.d_all + (size_t)3 * B, t.env_sum, stream));
+  } else if (!bk_early) {
+    if (smooth) RNERF_TRY(env_smooth_backward_impl(rgb_env, ps, c->bg_smooth_weight * env_on, t.d_all + (size_t)3 * B, t.env_sum, !pre_zeroed, st));
     RNERF_TRY(rnerf_bkgd_backward(th_b, t.save_bk, t.d_all, (int64_t)B + M, m->rgb_padding, t.dy_bk, g_b, nullptr, stream));
   }
   RNERF_TRY(rnerf_train_stats(t.sums, B, Nf > 0, c->bg_weight * bg_on, smooth ? t.env_sum : nullptr, ps, env_on, aux ? nullptr : theta, n_theta, c->frozen_sq,

@@ -739,10 +739,16 @@ __global__ void train_stats_kernel(const float* __restrict__ sums, float inv3B, 
   st[5] = 0.f;
 }
 
+namespace rnerf {
+// zero_sum = false: the caller has zeroed *loss_sum on `stream` already (the training step: nerfmlp_step_zero)
+int env_smooth_backward_impl(const float* rgb_env, int32_t ps, double grad_scale, float* d_out, float* loss_sum, bool zero_sum, hipStream_t st);
+}
 extern "C" int rnerf_env_smooth_backward(const float* rgb_env, int32_t ps, double grad_scale, float* d_out, float* loss_sum, void* stream) {
+  return env_smooth_backward_impl(rgb_env, ps, grad_scale, d_out, loss_sum, true, (hipStream_t)stream);
+}
+int rnerf::env_smooth_backward_impl(const float* rgb_env, int32_t ps, double grad_scale, float* d_out, float* loss_sum, bool zero_sum, hipStream_t st) {
   RNERF_CHECK_ARG(rgb_env && d_out && loss_sum && ps >= 2, "rnerf_env_smooth_backward: null pointer or ps < 2");
-  hipStream_t st = (hipStream_t)stream;
-  RNERF_CHECK_HIP(hipMemsetAsync(loss_sum, 0, sizeof(float), st));
+  if (zero_sum) RNERF_CHECK_HIP(hipMemsetAsync(loss_sum, 0, sizeof(float), st));
   const int n = ps * ps * 3;
   const double m = (double)(ps - 1) * ps * 3;
   hipLaunchKernelGGL(env_smooth_kernel, dim3((n + 255) / 256), dim3(256), 0, st, rgb_env, ps, (float)(grad_scale / m), d_out, loss_sum);

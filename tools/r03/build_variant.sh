@@ -11,6 +11,6 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-c
 base=$(basename $src .hip)
 /opt/rocm/bin/hipcc $FLAGS "$@" -c $R/samplenerfro_amd/csrc/$src -o $L/var/${base}_$name.o
 objs=""
-for o in grid march render mlp mlp_f32 pipeline; do if [ $o = $base ]; then objs="$objs $L/var/${base}_$name.o"; else objs="$objs $L/$o.o"; fi; done
+for o in grid march render mlp mlp_f32 bkgd16 pipeline; do if [ $o = $base ]; then objs="$objs $L/var/${base}_$name.o"; else objs="$objs $L/$o.o"; fi; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs -o $L/var/librnerf_$name.so
 echo $L/var/librnerf_$name.so
