@@ -257,7 +257,11 @@ __device__ __forceinline__ float4 gload4(const float* p) {
   return make_float4(v.x, v.y, v.z, v.w);
 }
 
-struct KOps { uint4 h0, l0, h1, l1; };
+// B operands of one k-step for the two 32-row m-tiles of a wave.  ONE: the wave runs a single m-tile (128-row workgroup tiles for launches
+// that would leave more than half of the CUs without a 256-row tile): everything of m-tile 1 — MFMAs, conversions, LDS state, saves — is
+// compiled out; h1 / l1 are never read.
+template <bool ONE_> struct KOpsT { static constexpr bool ONE = ONE_; uint4 h0, l0, h1, l1; };
+typedef KOpsT<false> KOps;
 
 // ReLU as an INTEGER max on the bit pattern: max_i32(bits(x), 0) is x for x >= +0, +0 for every negative x (and -0), and — unlike
 // v_max_f32, which returns the non-NaN operand — it keeps +inf and NaN.  That matters because the activations travel as f16 parts: a hidden
@@ -307,7 +311,7 @@ __device__ __forceinline__ void split8(const float (&x)[8], uint4& hi, uint4& lo
 //   pair pi in [0,8): m-tile pi>>2, value pair pi&3 -> chunk 0: bias+scale+ReLU, chunk 1: hi + residual, chunk 2: lo
 // SIG: also accumulate sg0/sg1 += x * ws[j] (the sigma head, Dense_8, rides on the conversion of the trunk output that feeds Dense_9: the
 // same relu(acc / scale + b) values; for every other layer ws points at zeros — no branch in the shared loop body).
-template <int PREC, int S, bool MASK = false, bool SIG = false>
+template <int PREC, int S, bool MASK = false, bool SIG = false, bool ONE = false>
 struct PrevConv {
   using PP = Prec<PREC>;
   float ws[8];
@@ -327,6 +331,7 @@ struct PrevConv {
   template <int C, int PI>
   __device__ __forceinline__ void chunk() {
     constexpr int mt = PI >> 2, p = PI & 3;
+    if constexpr (ONE && mt == 1) return;
     constexpr float INV_SCALE = 1.0f / PP::WSCALE;
     float& x0 = mt == 0 ? x0m0 : x0m1;
     float& x1 = mt == 0 ? x1m0 : x1m1;
@@ -370,10 +375,11 @@ struct PrevConv {
 #endif
     }
   }
-  __device__ __forceinline__ KOps result() const {
-    KOps o;
+  __device__ __forceinline__ KOpsT<ONE> result() const {
+    KOpsT<ONE> o;
     o.h0 = make_uint4(hi[0][0], hi[0][1], hi[0][2], hi[0][3]); o.l0 = make_uint4(lo[0][0], lo[0][1], lo[0][2], lo[0][3]);
-    o.h1 = make_uint4(hi[1][0], hi[1][1], hi[1][2], hi[1][3]); o.l1 = make_uint4(lo[1][0], lo[1][1], lo[1][2], lo[1][3]);
+    if constexpr (ONE) { o.h1 = o.h0; o.l1 = o.l0; }
+    else { o.h1 = make_uint4(hi[1][0], hi[1][1], hi[1][2], hi[1][3]); o.l1 = make_uint4(lo[1][0], lo[1][1], lo[1][2], lo[1][3]); }
     return o;
   }
 };
@@ -396,7 +402,7 @@ struct PairOfPairs {
 // Position-encoding operands of k-step S (slot map pe_feature: slot q = 8 S + j < NSIN is sin(2^(q/3) x_(q%3) + phase(h)), then the
 // identity terms) for both m-tiles, one value pair per MFMA tile like PrevConv: stage 0 argument + reduction index, 1 reduced argument,
 // 2 sine polynomial, 3 cosine polynomial + selection, 4 hi / lo split.  Same arithmetic, same order as enc_ops() / pe_sin().
-template <int PREC, int S, int NSIN>
+template <int PREC, int S, int NSIN, bool ONE = false>
 struct EncWork {
   using PP = Prec<PREC>;
   const float4 (&v)[2];
@@ -419,6 +425,7 @@ struct EncWork {
   template <int C, int PI>
   __device__ __forceinline__ void chunk() {
     constexpr int mt = PI >> 2, p = PI & 3, q0 = 8 * S + 2 * p, q1 = q0 + 1;
+    if constexpr (ONE && mt == 1) return;
     const float phase = h ? 1.5707963705062866f : 0.0f;   // f32(0.5*pi) (rnerf/model_utils.py:213)
     if constexpr (C == 0) {
       if constexpr (q0 < NSIN) e0.s0(fadd(fmul(coord<mt, q0>(), (float)(1 << (q0 / 3))), phase));
@@ -443,10 +450,11 @@ struct EncWork {
       else { hi[mt][p] = pack2<PP::F16>(f0, f1); lo[mt][p] = 0; }
     }
   }
-  __device__ __forceinline__ KOps result() const {
-    KOps o;
+  __device__ __forceinline__ KOpsT<ONE> result() const {
+    KOpsT<ONE> o;
     o.h0 = make_uint4(hi[0][0], hi[0][1], hi[0][2], hi[0][3]); o.l0 = make_uint4(lo[0][0], lo[0][1], lo[0][2], lo[0][3]);
-    o.h1 = make_uint4(hi[1][0], hi[1][1], hi[1][2], hi[1][3]); o.l1 = make_uint4(lo[1][0], lo[1][1], lo[1][2], lo[1][3]);
+    if constexpr (ONE) { o.h1 = o.h0; o.l1 = o.l0; }
+    else { o.h1 = make_uint4(hi[1][0], hi[1][1], hi[1][2], hi[1][3]); o.l1 = make_uint4(lo[1][0], lo[1][1], lo[1][2], lo[1][3]); }
     return o;
   }
 };
@@ -458,23 +466,24 @@ struct EncWork {
 //   * the operands of the NEXT layer's k-step 0 (features 0..15 = tile 0, registers 0..7) are converted from the final accumulators
 //     (used to be prev_ops(0) at the head of the next layer, exposed together with its bias load).
 // Tile 7 is handed over by finish() after the k-step.
-template <int PREC, bool MASK>
+template <int PREC, bool MASK, bool ONE = false>
 struct SeamWork {
   f32x16 (&acc0)[8];
   f32x16 (&acc1)[8];
   f32x16 (&prev0)[8];
   float4* st1;
-  PrevConv<PREC, 0, MASK, true> cv;      // pairs 0..3: m-tile 0 from acc0[0], pairs 4..7: m-tile 1 from acc1[0]
+  PrevConv<PREC, 0, MASK, true, ONE> cv;      // pairs 0..3: m-tile 0 from acc0[0], pairs 4..7: m-tile 1 from acc1[0]
   __device__ __forceinline__ SeamWork(f32x16 (&a0)[8], f32x16 (&a1)[8], f32x16 (&p0)[8], float4* s1) : acc0(a0), acc1(a1), prev0(p0), st1(s1), cv(a0[0]) {}
   template <int C, int T>
   __device__ __forceinline__ void move() {            // piece C of the hand-over of tile T
     // (the m-tile 0 moves are plain assignments: hipcc sinks them to the head of the next layer, ~1 k clocks per layer; pinning them here
     // with volatile v_accvgpr_read asm made the allocator spill in the steady k-steps: 1.57 -> 1.79 ms)
     if constexpr (C == 0) prev0[T] = acc0[T];
-    else st1[(T * 4 + C - 1) * 64] = make_float4(acc1[T][4 * (C - 1)], acc1[T][4 * (C - 1) + 1], acc1[T][4 * (C - 1) + 2], acc1[T][4 * (C - 1) + 3]);
+    else if constexpr (!ONE) st1[(T * 4 + C - 1) * 64] = make_float4(acc1[T][4 * (C - 1)], acc1[T][4 * (C - 1) + 1], acc1[T][4 * (C - 1) + 2], acc1[T][4 * (C - 1) + 3]);
   }
   template <int C, int Q>
   __device__ __forceinline__ void conv() {
+    if constexpr (ONE && Q >= 4) return;
     if constexpr (C == 0 && Q >= 4) { cv.v1[2 * (Q & 3)] = acc1[0][2 * (Q & 3)]; cv.v1[2 * (Q & 3) + 1] = acc1[0][2 * (Q & 3) + 1]; }
     cv.template chunk<C, Q>();
   }
@@ -495,51 +504,52 @@ struct SeamWork {
 
 // one n-tile of one k-step: 6 (X3) or 2 MFMAs with the conversion chunks of pair PI in their shadow
 // PASSES (X3 modes): 3 = hi*hi + hi*lo + lo*hi (fp32-grade), 2 = drop the lo(weight) term, 1 = hi*hi only
-template <int PREC, bool FIRST, int PI, typename W, int PASSES = Prec<PREC>::PASSES>
-__device__ __forceinline__ void tile_mfma(f32x16& a0, f32x16& a1, const uint4 ah, const uint4 al, const KOps& b, W& work) {
+template <int PREC, bool FIRST, int PI, typename W, int PASSES = Prec<PREC>::PASSES, typename BOPS = KOps>
+__device__ __forceinline__ void tile_mfma(f32x16& a0, f32x16& a1, const uint4 ah, const uint4 al, const BOPS& b, W& work) {
   using PP = Prec<PREC>;
+  constexpr bool TWO = !BOPS::ONE;      // m-tile 1 exists
   const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   a0 = mfma16<PP::F16>(ah, b.h0, FIRST ? zero : a0);
   work.template chunk<0, PI>();
   RNERF_PIN();
-  a1 = mfma16<PP::F16>(ah, b.h1, FIRST ? zero : a1);
+  if constexpr (TWO) a1 = mfma16<PP::F16>(ah, b.h1, FIRST ? zero : a1);
   work.template chunk<1, PI>();
   RNERF_PIN();
   if constexpr (PP::NP == 2 && PASSES == 3) {
     a0 = mfma16<PP::F16>(ah, b.l0, a0);
     work.template chunk<2, PI>();
     RNERF_PIN();
-    a1 = mfma16<PP::F16>(ah, b.l1, a1);
+    if constexpr (TWO) a1 = mfma16<PP::F16>(ah, b.l1, a1);
     work.template chunk<3, PI>();
     RNERF_PIN();
     a0 = mfma16<PP::F16>(al, b.h0, a0);
     work.template chunk<4, PI>();
     RNERF_PIN();
-    a1 = mfma16<PP::F16>(al, b.h1, a1);
+    if constexpr (TWO) a1 = mfma16<PP::F16>(al, b.h1, a1);
   } else if constexpr (PP::NP == 2 && PASSES == 38) {      // f16 main term + the two cross terms on the fp8 MFMA
     a0 = mfma_f8(al.x, al.y, b.l0.x, b.l0.y, a0);            // fp8(W_lo) * fp8(x)
     work.template chunk<2, PI>();
     RNERF_PIN();
-    a1 = mfma_f8(al.x, al.y, b.l1.x, b.l1.y, a1);
+    if constexpr (TWO) a1 = mfma_f8(al.x, al.y, b.l1.x, b.l1.y, a1);
     work.template chunk<3, PI>();
     RNERF_PIN();
     a0 = mfma_f8(al.z, al.w, b.l0.z, b.l0.w, a0);            // fp8(W 2^-10) * fp8(x_lo 2^10)
     work.template chunk<4, PI>();
     RNERF_PIN();
-    a1 = mfma_f8(al.z, al.w, b.l1.z, b.l1.w, a1);
+    if constexpr (TWO) a1 = mfma_f8(al.z, al.w, b.l1.z, b.l1.w, a1);
   } else if constexpr (PP::NP == 2 && PASSES == 2) {
     a0 = mfma16<PP::F16>(ah, b.l0, a0);
     work.template chunk<2, PI>();
     work.template chunk<3, PI>();
     RNERF_PIN();
-    a1 = mfma16<PP::F16>(ah, b.l1, a1);
+    if constexpr (TWO) a1 = mfma16<PP::F16>(ah, b.l1, a1);
     work.template chunk<4, PI>();
   } else if constexpr (PP::NP == 2 && PASSES == 22) {      // (W_hi + W_lo) * x_hi: the operand is a single 16-bit part
     a0 = mfma16<PP::F16>(al, b.h0, a0);
     work.template chunk<2, PI>();
     work.template chunk<3, PI>();
     RNERF_PIN();
-    a1 = mfma16<PP::F16>(al, b.h1, a1);
+    if constexpr (TWO) a1 = mfma16<PP::F16>(al, b.h1, a1);
     work.template chunk<4, PI>();
   } else {
     work.template chunk<2, PI>();
@@ -559,8 +569,8 @@ struct NoDma { __device__ __forceinline__ void operator()() const {} };
 // number of reads in flight (latency x concurrency), not by the 256 B/clk peak.
 constexpr int FRAG_DEPTH = 4;
 
-template <int PREC, int NT, int KOFF, bool FIRST, typename W, bool NOREAD = false, typename D = NoDma, int PASSES = Prec<PREC>::PASSES>
-__device__ __forceinline__ void kstep_mfma(f32x16 (&acc0)[8], f32x16 (&acc1)[8], const KOps& b, const char* slab, int lane, W& work, D dma = D()) {
+template <int PREC, int NT, int KOFF, bool FIRST, typename W, bool NOREAD = false, typename D = NoDma, int PASSES = Prec<PREC>::PASSES, typename BOPS = KOps>
+__device__ __forceinline__ void kstep_mfma(f32x16 (&acc0)[8], f32x16 (&acc1)[8], const BOPS& b, const char* slab, int lane, W& work, D dma = D()) {
   using PP = Prec<PREC>;
   const uint4* a = (const uint4*)slab + lane + (size_t)KOFF * NT * PP::NP * 64;
   uint4 fh[FRAG_DEPTH], fl[FRAG_DEPTH];
@@ -584,7 +594,7 @@ __device__ __forceinline__ void kstep_mfma(f32x16 (&acc0)[8], f32x16 (&acc1)[8],
   if constexpr (T < NT) {                                                                                 \
     uint4 ah = fh[T % FRAG_DEPTH], al = fl[T % FRAG_DEPTH];                                               \
     if constexpr (NOREAD) { asm volatile("" : "+v"(ah.x), "+v"(al.x)); }  /* ablation: opaque, so tiles are not CSE'd */ \
-    tile_mfma<PREC, FIRST, (T & 7), W, PASSES>(acc0[T], acc1[T], ah, al, b, work);                        \
+    tile_mfma<PREC, FIRST, (T & 7), W, PASSES, BOPS>(acc0[T], acc1[T], ah, al, b, work);                  \
     if constexpr (T + FRAG_DEPTH < NT && !NOREAD) {                                                       \
       fh[T % FRAG_DEPTH] = a[((T + FRAG_DEPTH) * PP::NP) * 64];                                           \
       fl[T % FRAG_DEPTH] = load_lo(T + FRAG_DEPTH);                                                       \
@@ -626,7 +636,7 @@ __device__ __forceinline__ uint32_t nz_nibbles(const uint4& o) {
 __device__ __forceinline__ uint32_t nz_byte(uint32_t nib) { return (nib & 0xFu) | (nib >> 12); }   // even flags | odd flags << 4
 
 // TRAIN: 0 = evaluation, 1 = training forward keeping the hi 16-bit operand parts, 2 = hi and lo parts (fp32-grade backward)
-template <int PREC, int dbg, int TRAIN>
+template <int PREC, int dbg, int TRAIN, bool ONE = false>
 __global__ void __launch_bounds__(256, 1)
 nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ rows_pd, const float4* __restrict__ rows_dr,
                    const int* __restrict__ node_of_sample, int B, long long total_rows, int n_tiles, float4* __restrict__ out_raw,
@@ -642,8 +652,12 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
   //   bit0 = skip the weight-stream loads, bit1 = skip ds_read + MFMA, bit2 = skip the barrier.
   // Compile-time on purpose: a runtime branch per k-step would split the scheduling region and stop the compiler from
   // interleaving the operand conversion (VALU) with the MFMAs.
+  // ONE: 128-row tiles — every wave runs ONE 32-row m-tile (rows 128 tile + 32 wave + m): half the serial work per tile, for launches whose
+  // 256-row tiles would leave more than half of the CUs idle.  n_tiles then counts 128-row tiles; the save layout (32-row tiles) is the same.
   using PP = Prec<PREC>;
+  using KOps = KOpsT<ONE>;
   constexpr int SLAB = PP::SLAB;
+  constexpr int WROWS = ONE ? 32 : 64, TROWS = 4 * WROWS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if constexpr (PP::F8X) f8x_mode();
   const int tid = threadIdx.x, lane = tid & 63;
@@ -680,7 +694,8 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
     float4 pd[2], dr[2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-      row[mt] = (long long)tile * 256 + wave * 64 + mt * 32 + m;
+      if (ONE && mt == 1) { row[1] = row[0]; row_ok[1] = false; pd[1] = pd[0]; dr[1] = dr[0]; continue; }
+      row[mt] = (long long)tile * TROWS + wave * WROWS + mt * 32 + m;
       row_ok[mt] = row[mt] < total_rows;
       if (!row_ok[mt]) row[mt] = total_rows - 1;
       size_t rec = (size_t)row[mt];
@@ -693,18 +708,17 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
     PH(0);
 
     // training forward: keep the hi parts of the operands of slot q (see SAVE_* above); padded rows are written too
-    const long long srow0 = (long long)tile * 256 + wave * 64 + m;
-    const long long t32_0 = (long long)tile * 8 + wave * 2;                   // 32-row tile of m-tile 0 (m-tile 1: + 1)
+    const long long t32_0 = (long long)tile * (TROWS / 32) + wave * (WROWS / 32);      // 32-row tile of m-tile 0 (m-tile 1: + 1)
     auto save_ops = [&](int q, const KOps& o) {
       if constexpr (TRAIN != 0) {
 #ifndef RNERF_FWD_NOSAVE      /* profiling ablation */
         uint4* dst = save + sv_addr(q, t32_0, m, h);
         stream_store(dst, o.h0);
-        stream_store(dst + (size_t)SAVE_SLOTS * 64, o.h1);          // m-tile 1 = the next 32-row tile
+        if constexpr (!ONE) stream_store(dst + (size_t)SAVE_SLOTS * 64, o.h1);          // m-tile 1 = the next 32-row tile
         if constexpr (TRAIN == 2) {            // lo plane
           uint4* dl = dst + sv_lo0(save_rows);
           stream_store(dl, o.l0);
-          stream_store(dl + (size_t)SAVE_SLOTS * 64, o.l1);
+          if constexpr (!ONE) stream_store(dl + (size_t)SAVE_SLOTS * 64, o.l1);
         }
 #endif
       }
@@ -720,7 +734,7 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
       if constexpr (PP::F16) {
         const uint32_t am = is_signed ? 0x7FFF7FFFu : 0xFFFFFFFFu;      // the bottleneck has no ReLU: drop the sign bits
         ovf0 = pk_maxu(pk_maxu(ovf0, o.h0.x & am), pk_maxu(pk_maxu(o.h0.y & am, o.h0.z & am), o.h0.w & am));
-        ovf1 = pk_maxu(pk_maxu(ovf1, o.h1.x & am), pk_maxu(pk_maxu(o.h1.y & am, o.h1.z & am), o.h1.w & am));
+        if constexpr (!ONE) ovf1 = pk_maxu(pk_maxu(ovf1, o.h1.x & am), pk_maxu(pk_maxu(o.h1.y & am, o.h1.z & am), o.h1.w & am));
       }
 #endif
     };
@@ -736,7 +750,7 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
         if ((s & 3) == 3) {      // word-major: a wave's 64 dwords are contiguous (full-line writes)
           uint32_t* dst = (uint32_t*)(save + sv_mask0(save_rows)) + sv_mask_addr(set * 4 + (s >> 2), t32_0, m, h);
           __builtin_nontemporal_store(mw0, dst);
-          __builtin_nontemporal_store(mw1, dst + 36 * 64);
+          if constexpr (!ONE) __builtin_nontemporal_store(mw1, dst + 36 * 64);
         }
       }
     };
@@ -746,7 +760,7 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
       const float phase = h ? 1.5707963705062866f : 0.0f;   // f32(0.5*pi) (rnerf/model_utils.py:213)
       float f[2][8];
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < (ONE ? 1 : 2); ++mt)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int q = 8 * s + j;
@@ -760,7 +774,7 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
         }
       KOps o;
       split8<PREC>(f[0], o.h0, o.l0);
-      split8<PREC>(f[1], o.h1, o.l1);
+      if constexpr (ONE) { o.h1 = o.h0; o.l1 = o.l0; } else split8<PREC>(f[1], o.h1, o.l1);
       return o;
     };
 
@@ -768,8 +782,11 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
     auto prev_ops = [&](int s, const float* __restrict__ bias, int floor_v) -> KOps {
       const float4 b0 = *(const float4*)(bias + 16 * s + 4 * h), b1 = *(const float4*)(bias + 16 * s + 8 + 4 * h);
       const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-      const float4 u0 = st1[((s >> 1) * 4 + 2 * (s & 1)) * 64], u1 = st1[((s >> 1) * 4 + 2 * (s & 1) + 1) * 64];
-      const float r1[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+      float r1[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if constexpr (!ONE) {
+        const float4 u0 = st1[((s >> 1) * 4 + 2 * (s & 1)) * 64], u1 = st1[((s >> 1) * 4 + 2 * (s & 1) + 1) * 64];
+        r1[0] = u0.x; r1[1] = u0.y; r1[2] = u0.z; r1[3] = u0.w; r1[4] = u1.x; r1[5] = u1.y; r1[6] = u1.z; r1[7] = u1.w;
+      }
       float x0[8], x1[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -778,7 +795,7 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
       }
       KOps o;
       split8<PREC>(x0, o.h0, o.l0);
-      split8<PREC>(x1, o.h1, o.l1);
+      if constexpr (ONE) { o.h1 = o.h0; o.l1 = o.l0; } else split8<PREC>(x1, o.h1, o.l1);
       return o;
     };
 
@@ -790,6 +807,7 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
     };
     // raw accumulators of m-tile 1 for k-step s (this wave's LDS region)
     auto load_state8 = [&](int s, float (&v)[8]) {
+      if constexpr (ONE) return;
       const float4 u0 = st1[((s >> 1) * 4 + 2 * (s & 1)) * 64], u1 = st1[((s >> 1) * 4 + 2 * (s & 1) + 1) * 64];
       v[0] = u0.x; v[1] = u0.y; v[2] = u0.z; v[3] = u0.w; v[4] = u1.x; v[5] = u1.y; v[6] = u1.z; v[7] = u1.w;
     };
@@ -818,7 +836,7 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
     KOps cur;                                   // operands of the next k-step; across a layer seam: k-step 0 of the next layer (SeamWork)
     {
       cur = enc_ops(pd, 0, 30);
-      SeamWork<PREC, TRAIN != 0> seam(acc0, acc1, prev0, st1);
+      SeamWork<PREC, TRAIN != 0, ONE> seam(acc0, acc1, prev0, st1);
       seam.cv.floor_v = RELU_FLOOR;
       load_bias8(0, auxt + AUX_BIAS, seam.cv.b);
       load_bias8(0, auxt + AUX_ZERO, seam.cv.ws);
@@ -829,7 +847,7 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
         watch(cur, true);      /* a non-finite position (a caller's NaN) must not come out as a colour either */    \
         SLAB_PREFETCH(true);   /* glds first: it is a scheduling boundary, conversion + MFMAs must share the region after it */ \
         if constexpr (S < 3) {                                                                                       \
-          EncWork<PREC, S + 1, 30> ew(pd, h);                                                                        \
+          EncWork<PREC, S + 1, 30, ONE> ew(pd, h);                                                                        \
           if (!(dbg & 2)) kstep_mfma<PREC, 8, 0, FIRST_>(acc0, acc1, cur, smem + buf * SLAB, lane, ew);              \
           cur = ew.result();                                                                                         \
         } else {                                                                                                     \
@@ -855,7 +873,7 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
       const float* __restrict__ bias = auxt + AUX_BIAS + 256 * (l - 1);
       // the seam of this layer: hand-over of the outputs + conversion of the next layer's k-step 0 (bias of THIS layer; the bottleneck
       // Dense_9 = layer 8 has no activation), run by the layer's last k-step
-      SeamWork<PREC, TRAIN != 0> seam(acc0, acc1, prev0, st1);
+      SeamWork<PREC, TRAIN != 0, ONE> seam(acc0, acc1, prev0, st1);
       seam.cv.floor_v = l == 8 ? NO_FLOOR : RELU_FLOOR;
       // sigma head (Dense_8, rnerf/model_utils.py:70) = sum over the trunk output x7 = the inputs of layer 8: k-step 0 in layer 7's seam,
       // k-steps 1..15 in layer 8's conversions.  (The seam's bias / sigma weights are fetched at k-step 13: 16 registers less in the steady state.)
@@ -872,19 +890,19 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
         else if constexpr (S == 14) { load_bias8(1, bias + 256, bnn); load_bias8(1, wseam, wnn); }   /* k-step 1 of the NEXT layer */ \
         auto dma = [&]() { SLAB_PREFETCH(true); };                                                                   \
         if constexpr (S + 1 < 16) {                                                                                  \
-          PrevConv<PREC, S + 1, TRAIN != 0, true> cv(prev0[(S + 1) >> 1]);                                           \
+          PrevConv<PREC, S + 1, TRAIN != 0, true, ONE> cv(prev0[(S + 1) >> 1]);                                           \
           cv.floor_v = RELU_FLOOR;                                                                                        \
           _Pragma("unroll") for (int j = 0; j < 8; ++j) { cv.b[j] = bnext[j]; cv.ws[j] = wnext[j]; }                 \
           load_state8(S + 1, cv.v1);                                                                                 \
           if (dbg & 8) { kstep_mfma<PREC, 8, 0, S == 0, NoWork, (dbg & 16) != 0>(acc0, acc1, cur, smem + buf * SLAB, lane, nowork, dma); } \
-          else { if (!(dbg & 2)) kstep_mfma<PREC, 8, 0, S == 0, PrevConv<PREC, S + 1, TRAIN != 0, true>, (dbg & 16) != 0, decltype(dma)>(acc0, acc1, cur, smem + buf * SLAB, lane, cv, dma);              \
+          else { if (!(dbg & 2)) kstep_mfma<PREC, 8, 0, S == 0, PrevConv<PREC, S + 1, TRAIN != 0, true, ONE>, (dbg & 16) != 0, decltype(dma)>(acc0, acc1, cur, smem + buf * SLAB, lane, cv, dma);              \
           cur = cv.result();                                                                                         \
           sig0 += cv.sg0; sig1 += cv.sg1;                                                                            \
           save_mask(l - 1, S + 1, cv.nz[0], cv.nz[1]); }                                                             \
         } else {                                                                                                     \
           /* also for l == 5, whose last k-step is the 4th skip slab: that one runs the seam again on the final sums (no branch here: */ \
           /* a run-time choice of the work functor splits the accumulators' live ranges and hipcc spills them around it) */ \
-          if (!(dbg & 2)) kstep_mfma<PREC, 8, 0, false, SeamWork<PREC, TRAIN != 0>, false, decltype(dma)>(acc0, acc1, cur, smem + buf * SLAB, lane, seam, dma); \
+          if (!(dbg & 2)) kstep_mfma<PREC, 8, 0, false, SeamWork<PREC, TRAIN != 0, ONE>, false, decltype(dma)>(acc0, acc1, cur, smem + buf * SLAB, lane, seam, dma); \
         }                                                                                                            \
         if constexpr (S + 2 <= 16) { _Pragma("unroll") for (int j = 0; j < 8; ++j) { bnext[j] = bnn[j]; wnext[j] = wnn[j]; } } \
         SLAB_DONE();                                                                                                 \
@@ -924,8 +942,8 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
         if constexpr (SL + 1 < 8) {                                                                                  \
           float bA2[8], bB2[8];                                                                                      \
           if constexpr (SL + 2 < 8) { load_bias8(2 * SL + 4, bias, bA2); load_bias8(2 * SL + 5, bias, bB2); }        \
-          PrevConv<PREC, 2 * SL + 2, false> cvA(prev0[SL + 1]);                                                      \
-          PrevConv<PREC, 2 * SL + 3, false> cvB(prev0[SL + 1]);                                                      \
+          PrevConv<PREC, 2 * SL + 2, false, false, ONE> cvA(prev0[SL + 1]);                                                      \
+          PrevConv<PREC, 2 * SL + 3, false, false, ONE> cvB(prev0[SL + 1]);                                                      \
           cvA.floor_v = NO_FLOOR; cvB.floor_v = NO_FLOOR;                                                                \
           _Pragma("unroll") for (int j = 0; j < 8; ++j) { cvA.b[j] = bA[j]; cvB.b[j] = bB[j]; }                      \
           load_state8(2 * SL + 2, cvA.v1);                                                                           \
@@ -993,10 +1011,13 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const float v0 = relu_keep(fmaf(acc0[t][4 * g + i], INV_SCALE, bv[i]), RELU_FLOOR);
-            const float v1 = relu_keep(fmaf(acc1[t][4 * g + i], INV_SCALE, bv[i]), RELU_FLOOR);
             p0[0] = fmaf(v0, wrv[i], p0[0]); p0[1] = fmaf(v0, wgv[i], p0[1]); p0[2] = fmaf(v0, wbv[i], p0[2]);
-            p1[0] = fmaf(v1, wrv[i], p1[0]); p1[1] = fmaf(v1, wgv[i], p1[1]); p1[2] = fmaf(v1, wbv[i], p1[2]);
-            rv0[4 * g + i] = v0; rv1[4 * g + i] = v1;
+            rv0[4 * g + i] = v0;
+            if constexpr (!ONE) {
+              const float v1 = relu_keep(fmaf(acc1[t][4 * g + i], INV_SCALE, bv[i]), RELU_FLOOR);
+              p1[0] = fmaf(v1, wrv[i], p1[0]); p1[1] = fmaf(v1, wgv[i], p1[1]); p1[2] = fmaf(v1, wbv[i], p1[2]);
+              rv1[4 * g + i] = v1;
+            } else rv1[4 * g + i] = v0;
           }
         }
         if (t + 1 < 4) {
@@ -1113,7 +1134,7 @@ __global__ void nerfmlp_pack_bwd_kernel(const float* __restrict__ params, char* 
 
 // dgrad twin of PrevConv: the B operands of k-step S of the NEXT dgrad GEMM = (state / WSCALE [+ d sigma * w_sigma]) * ReLU mask, split
 // into 16-bit hi/lo parts, computed pair by pair in the shadow of the current k-step's MFMAs.
-template <int PREC, int S, bool NEED_LO>
+template <int PREC, int S, bool NEED_LO, bool ONE = false>
 struct GradConv {
   using PP = Prec<PREC>;
   const f32x16& p0;   // m-tile 0 state (accumulator registers of the previous dgrad layer)
@@ -1126,6 +1147,7 @@ struct GradConv {
   template <int C, int PI>
   __device__ __forceinline__ void chunk() {
     constexpr int mt = PI >> 2, p = PI & 3;
+    if constexpr (ONE && mt == 1) return;
     constexpr float INV_SCALE = 1.0f / PP::WSCALE;
     if constexpr (C == 0) {
       const float r0 = mt == 0 ? p0[8 * (S & 1) + 2 * p] : v1[2 * p];
@@ -1153,10 +1175,11 @@ struct GradConv {
       else lo[mt][p] = 0;
     }
   }
-  __device__ __forceinline__ KOps result() const {
-    KOps o;
+  __device__ __forceinline__ KOpsT<ONE> result() const {
+    KOpsT<ONE> o;
     o.h0 = make_uint4(hi[0][0], hi[0][1], hi[0][2], hi[0][3]); o.l0 = make_uint4(lo[0][0], lo[0][1], lo[0][2], lo[0][3]);
-    o.h1 = make_uint4(hi[1][0], hi[1][1], hi[1][2], hi[1][3]); o.l1 = make_uint4(lo[1][0], lo[1][1], lo[1][2], lo[1][3]);
+    if constexpr (ONE) { o.h1 = o.h0; o.l1 = o.l0; }
+    else { o.h1 = make_uint4(hi[1][0], hi[1][1], hi[1][2], hi[1][3]); o.l1 = make_uint4(lo[1][0], lo[1][1], lo[1][2], lo[1][3]); }
     return o;
   }
 };
@@ -1176,17 +1199,20 @@ template <int BWD> struct Bwd {
 __host__ __device__ constexpr size_t dy_plane_uint4(long long R, int np) { return (size_t)DY_SLOTS * np * (size_t)R * 2; }
 __host__ __device__ constexpr size_t dy_addr(int q, long long t32, int m, int h) { return (((size_t)t32 * DY_SLOTS + q) * 32 + m) * 2 + h; }     // tile-major, see sv_addr
 
-template <int BWD>
+template <int BWD, bool ONE = false>
 __global__ void __launch_bounds__(256, 1)
 nerfmlp_dgrad_kernel(const char* __restrict__ packed_bwd, const float* __restrict__ fwd_aux, const uint4* __restrict__ saved,
                      long long save_rows, const float4* __restrict__ d_raw, long long total_rows, int n_tiles,
                      uint4* __restrict__ dy) {
+  // ONE: 128-row tiles, one m-tile per wave (see nerfmlp_fwd_kernel); n_tiles then counts 128-row tiles
   using BW = Bwd<BWD>;
+  using KOps = KOpsT<ONE>;
   constexpr int PREC = BW::PREC;
   constexpr int DGP = BW::PASSES;
   constexpr bool NEED_LO = BW::NEED_LO;
   using PP = Prec<PREC>;
   constexpr int SLAB = PP::SLAB;
+  constexpr int WROWS = ONE ? 32 : 64, TROWS = 4 * WROWS;
   constexpr float INV_SCALE = 1.0f / PP::WSCALE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1214,11 +1240,12 @@ nerfmlp_dgrad_kernel(const char* __restrict__ packed_bwd, const float* __restric
 #endif
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const bool has_next_tile = tile + (int)gridDim.x < n_tiles;
-    const long long srow0 = (long long)tile * 256 + wave * 64 + m;
-    const long long t32_0 = (long long)tile * 8 + wave * 2;
+    const long long srow0 = (long long)tile * TROWS + wave * WROWS + m;
+    const long long t32_0 = (long long)tile * (TROWS / 32) + wave * (WROWS / 32);
     float4 g[2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
+      if (ONE && mt == 1) { g[1] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
       const long long row = srow0 + 32 * mt;
       g[mt] = row < total_rows ? d_raw[row] : make_float4(0.f, 0.f, 0.f, 0.f);
       if constexpr (BW::F16) {          // row normalisation
@@ -1242,11 +1269,11 @@ nerfmlp_dgrad_kernel(const char* __restrict__ packed_bwd, const float* __restric
 #ifndef RNERF_DGRAD_NOSTORE   /* profiling ablation */
       uint4* dst = dy + dy_addr(q, t32_0, m, h);
       stream_store(dst, o.h0);
-      stream_store(dst + (size_t)DY_SLOTS * 64, o.h1);
+      if constexpr (!ONE) stream_store(dst + (size_t)DY_SLOTS * 64, o.h1);
       if constexpr (BW::NP == 2) {
         uint4* dl = dst + dy_plane_uint4(save_rows, 1);
         stream_store(dl, o.l0);
-        stream_store(dl + (size_t)DY_SLOTS * 64, o.l1);
+        if constexpr (!ONE) stream_store(dl + (size_t)DY_SLOTS * 64, o.l1);
       }
 #endif
     };
@@ -1256,13 +1283,17 @@ nerfmlp_dgrad_kernel(const char* __restrict__ packed_bwd, const float* __restric
       constexpr size_t ws = 64, mt1 = 36 * 64;          // next mask word of the set / the wave's second 32-row tile
 #define RNERF_NTL(P) __builtin_nontemporal_load(P)
       a = make_uint4(RNERF_NTL(src), RNERF_NTL(src + ws), RNERF_NTL(src + 2 * ws), RNERF_NTL(src + 3 * ws));
-      b = make_uint4(RNERF_NTL(src + mt1), RNERF_NTL(src + ws + mt1), RNERF_NTL(src + 2 * ws + mt1), RNERF_NTL(src + 3 * ws + mt1));
+      if constexpr (ONE) b = make_uint4(0, 0, 0, 0);
+      else b = make_uint4(RNERF_NTL(src + mt1), RNERF_NTL(src + ws + mt1), RNERF_NTL(src + 2 * ws + mt1), RNERF_NTL(src + 3 * ws + mt1));
 #undef RNERF_NTL
     };
     // operands of k-step s from the state (prev0 / st1): x = (state + dsig * wadd) * 1[mask != 0]
     auto grad_ops = [&](int s, bool use_mask, const uint4 mk0, const uint4 mk1, const float* __restrict__ wadd) -> KOps {
-      const float4 u0 = st1[((s >> 1) * 4 + 2 * (s & 1)) * 64], u1 = st1[((s >> 1) * 4 + 2 * (s & 1) + 1) * 64];
-      const float r1[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+      float r1[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if constexpr (!ONE) {
+        const float4 u0 = st1[((s >> 1) * 4 + 2 * (s & 1)) * 64], u1 = st1[((s >> 1) * 4 + 2 * (s & 1) + 1) * 64];
+        r1[0] = u0.x; r1[1] = u0.y; r1[2] = u0.z; r1[3] = u0.w; r1[4] = u1.x; r1[5] = u1.y; r1[6] = u1.z; r1[7] = u1.w;
+      }
       const uint32_t w0 = (s >> 2) == 0 ? mk0.x : ((s >> 2) == 1 ? mk0.y : ((s >> 2) == 2 ? mk0.z : mk0.w));
       const uint32_t w1 = (s >> 2) == 0 ? mk1.x : ((s >> 2) == 1 ? mk1.y : ((s >> 2) == 2 ? mk1.z : mk1.w));
       float x0[8], x1[8];
@@ -1278,7 +1309,8 @@ nerfmlp_dgrad_kernel(const char* __restrict__ packed_bwd, const float* __restric
         x0[j] = a; x1[j] = b;
       }
       KOps o;
-      if constexpr (NEED_LO || BW::NP == 2) { split8<PREC>(x0, o.h0, o.l0); split8<PREC>(x1, o.h1, o.l1); }
+      if constexpr (ONE) { split8<PREC>(x0, o.h0, o.l0); if constexpr (!(NEED_LO || BW::NP == 2)) o.l0 = make_uint4(0, 0, 0, 0); o.h1 = o.h0; o.l1 = o.l0; }
+      else if constexpr (NEED_LO || BW::NP == 2) { split8<PREC>(x0, o.h0, o.l0); split8<PREC>(x1, o.h1, o.l1); }
       else {
         o.h0 = make_uint4(pack2<PP::F16>(x0[0], x0[1]), pack2<PP::F16>(x0[2], x0[3]), pack2<PP::F16>(x0[4], x0[5]), pack2<PP::F16>(x0[6], x0[7]));
         o.h1 = make_uint4(pack2<PP::F16>(x1[0], x1[1]), pack2<PP::F16>(x1[2], x1[3]), pack2<PP::F16>(x1[4], x1[5]), pack2<PP::F16>(x1[6], x1[7]));
@@ -1290,9 +1322,11 @@ nerfmlp_dgrad_kernel(const char* __restrict__ packed_bwd, const float* __restric
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
         prev0[t] = acc0[t];
+        if constexpr (!ONE) {
 #pragma unroll
-        for (int rq = 0; rq < 4; ++rq)
-          st1[(t * 4 + rq) * 64] = make_float4(acc1[t][4 * rq], acc1[t][4 * rq + 1], acc1[t][4 * rq + 2], acc1[t][4 * rq + 3]);
+          for (int rq = 0; rq < 4; ++rq)
+            st1[(t * 4 + rq) * 64] = make_float4(acc1[t][4 * rq], acc1[t][4 * rq + 1], acc1[t][4 * rq + 2], acc1[t][4 * rq + 3]);
+        }
       }
     };
 #define SLAB_PREFETCH(DO_NEXT)                                                                                       \
@@ -1305,7 +1339,7 @@ nerfmlp_dgrad_kernel(const char* __restrict__ packed_bwd, const float* __restric
       float hz0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, hz1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       if (h == 0) { hz0[0] = g[0].w; hz0[1] = g[0].x; hz0[2] = g[0].y; hz0[3] = g[0].z; hz1[0] = g[1].w; hz1[1] = g[1].x; hz1[2] = g[1].y; hz1[3] = g[1].z; }
       split8<PREC>(hz0, o.h0, o.l0);
-      split8<PREC>(hz1, o.h1, o.l1);
+      if constexpr (ONE) { o.h1 = o.h0; o.l1 = o.l0; } else split8<PREC>(hz1, o.h1, o.l1);
       dy_store(DY_HEADS, o);
 #pragma unroll
       for (int t = 0; t < 8; ++t)
@@ -1318,7 +1352,8 @@ nerfmlp_dgrad_kernel(const char* __restrict__ packed_bwd, const float* __restric
             a = (g[0].x * wr + g[0].y * wg + g[0].z * wb) * PP::WSCALE;       // the state is kept in the accumulators' units (x WSCALE)
             b = (g[1].x * wr + g[1].y * wg + g[1].z * wb) * PP::WSCALE;
           }
-          acc0[t][r] = a; acc1[t][r] = b;
+          acc0[t][r] = a;
+          if constexpr (!ONE) acc1[t][r] = b;
         }
       DPH(0);
       layer_end();
@@ -1336,8 +1371,8 @@ nerfmlp_dgrad_kernel(const char* __restrict__ packed_bwd, const float* __restric
         dy_store((SLOT0) + S, cur);                                                                                             \
         auto dma = [&]() { PREFETCH_STMT; };   /* issued after the first two tiles' MFMAs (an LDS-DMA instruction costs ~100 issue cycles) */ \
         if constexpr (S + 1 < NSTEPS) {                                                                                         \
-          GradConv<PREC, S + 1, NEED_LO> cv(prev0[(S + 1) >> 1]);                                                                        \
-          {                                                                                                                     \
+          GradConv<PREC, S + 1, NEED_LO, ONE> cv(prev0[(S + 1) >> 1]);                                                                   \
+          if constexpr (!ONE) {                                                                                                 \
             const float4 u0 = st1[(((S + 1) >> 1) * 4 + 2 * ((S + 1) & 1)) * 64], u1 = st1[(((S + 1) >> 1) * 4 + 2 * ((S + 1) & 1) + 1) * 64]; \
             cv.v1[0] = u0.x; cv.v1[1] = u0.y; cv.v1[2] = u0.z; cv.v1[3] = u0.w; cv.v1[4] = u1.x; cv.v1[5] = u1.y; cv.v1[6] = u1.z; cv.v1[7] = u1.w; \
           }                                                                                                                     \
@@ -1350,7 +1385,7 @@ nerfmlp_dgrad_kernel(const char* __restrict__ packed_bwd, const float* __restric
           }                                                                                                                     \
           cv.w0 = ((S + 1) >> 2) == 0 ? ma.x : (((S + 1) >> 2) == 1 ? ma.y : (((S + 1) >> 2) == 2 ? ma.z : ma.w));             \
           cv.w1 = ((S + 1) >> 2) == 0 ? mb.x : (((S + 1) >> 2) == 1 ? mb.y : (((S + 1) >> 2) == 2 ? mb.z : mb.w));             \
-          kstep_mfma<PREC, 8, 0, S == 0, GradConv<PREC, S + 1, NEED_LO>, false, decltype(dma), DGP>(acc0, acc1, cur, smem + buf * SLAB, lane, cv, dma); \
+          kstep_mfma<PREC, 8, 0, S == 0, GradConv<PREC, S + 1, NEED_LO, ONE>, false, decltype(dma), DGP>(acc0, acc1, cur, smem + buf * SLAB, lane, cv, dma); \
           cur = cv.result();                                                                                                    \
         } else {                                                                                                                \
           kstep_mfma<PREC, 8, 0, false, NoWork, false, decltype(dma), DGP>(acc0, acc1, cur, smem + buf * SLAB, lane, nowork, dma);  \
@@ -3021,6 +3056,26 @@ static int launch_fwd_dbg(const void* packed, const float* rows_pd, const float*
   RNERF_CHECK_HIP(hipGetDevice(&dev));
   RNERF_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
   const int lim = (max_wg > 0 && max_wg < cus) ? max_wg : cus;
+  // Few rows: 128-row tiles (one m-tile per wave) when all of them fit ONE round of workgroups — a tile's time is the serial work of its
+  // waves, so a launch that cannot fill the chip with 256-row tiles (a 512-ray shard's coarse level: 128 tiles on 256 CUs; both levels of a
+  // 128-ray one) finishes sooner on twice as many CUs with half the work each.  (Beyond one round the 256-row tiles' better reuse of the
+  // weight stream wins.)  RNERF_FWD_HALF_TILES=0 switches it off (A/B).
+  if constexpr (DBG == 0 && (PREC == RNERF_PREC_F16X3 || PREC == RNERF_PREC_F16F8)) {
+    static const bool half_ok = [] { const char* e = getenv("RNERF_FWD_HALF_TILES"); return !(e && e[0] == '0'); }();
+    if (half_ok && 2 * n_tiles <= lim) {
+      const size_t lds1 = 2 * (size_t)PP::SLAB;
+      static bool attr1_set = false;
+      if (!attr1_set) {
+        RNERF_CHECK_HIP(hipFuncSetAttribute((const void*)nerfmlp_fwd_kernel<PREC, 0, TRAIN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+        attr1_set = true;
+      }
+      hipLaunchKernelGGL((nerfmlp_fwd_kernel<PREC, 0, TRAIN, true>), dim3(2 * n_tiles), dim3(256), lds1, st, (const char*)packed, (const float4*)rows_pd,
+                         (const float4*)rows_dr, node_of_sample, B, total_rows, 2 * n_tiles, (float4*)out_raw, (uint4*)save, (long long)n_tiles * 256,
+                         (int*)nullptr, gate, gate_skip_if);
+      RNERF_CHECK_LAUNCH();
+      return RNERF_OK;
+    }
+  }
   const int grid = n_tiles < lim ? n_tiles : lim;
   const size_t lds = 2 * (size_t)PP::SLAB + 4 * 32768;
   static bool attr_set = false;
@@ -3126,7 +3181,7 @@ void* rnerf::nerfmlp_dgrad_scale_ref(int backward, void* dy, int64_t rows) {
 
 template <int BWD>
 static int launch_dgrad(const void* packed_bwd, const float* fwd_aux, const void* save, const float* d_raw, int64_t rows, void* dy, hipStream_t st,
-                        bool zero_ref = true) {
+                        bool zero_ref = true, bool allow_half = true) {
   using PB = Prec<Bwd<BWD>::PREC>;
   const int n_tiles = (int)((rows + 255) / 256);
   int dev = 0, cus = 0;
@@ -3141,6 +3196,24 @@ static int launch_dgrad(const void* packed_bwd, const float* fwd_aux, const void
   }
   const long long R = (long long)n_tiles * 256;
   if (Bwd<BWD>::F16 && zero_ref) RNERF_CHECK_HIP(hipMemsetAsync(nerfmlp_dgrad_scale_ref(BWD, dy, rows), 0, 4 * sizeof(float), st));
+  // Few rows: 128-row tiles when they all fit one round (see launch_fwd_dbg) — unless the caller runs another level's dgrad beside this one
+  // (allow_half = false): two kernels that each own whole CUs then share the chip, and with twice the workgroups of half the work the
+  // step measures the same or slower (512 rays, levels side by side: 2.05 -> 2.09 ms; alone, a 256-ray single-level step: 1.17 -> 1.12 ms).
+  if constexpr (BWD == RNERF_BWD_F16X2 || BWD == RNERF_BWD_F16) {
+    static const int half_lim = [] { const char* e = getenv("RNERF_DGRAD_HALF_TILES"); return e ? atoi(e) : -1; }();      // 0: off, n: at most n tiles
+    if (allow_half && half_lim != 0 && 2 * n_tiles <= (half_lim > 1 ? half_lim : cus)) {
+      const size_t lds1 = 2 * (size_t)PB::SLAB;
+      static bool attr1_set = false;
+      if (!attr1_set) {
+        RNERF_CHECK_HIP(hipFuncSetAttribute((const void*)nerfmlp_dgrad_kernel<BWD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+        attr1_set = true;
+      }
+      hipLaunchKernelGGL((nerfmlp_dgrad_kernel<BWD, true>), dim3(2 * n_tiles), dim3(256), lds1, st, (const char*)packed_bwd, fwd_aux, (const uint4*)save, R,
+                         (const float4*)d_raw, (long long)rows, 2 * n_tiles, (uint4*)dy);
+      RNERF_CHECK_LAUNCH();
+      return RNERF_OK;
+    }
+  }
   hipLaunchKernelGGL(nerfmlp_dgrad_kernel<BWD>, dim3(grid), dim3(256), lds, st, (const char*)packed_bwd, fwd_aux, (const uint4*)save, R,
                      (const float4*)d_raw, (long long)rows, n_tiles, (uint4*)dy);
   RNERF_CHECK_LAUNCH();
@@ -3150,21 +3223,21 @@ static int launch_dgrad(const void* packed_bwd, const float* fwd_aux, const void
 namespace rnerf {
 // zero_ref = false: the caller has zeroed nerfmlp_dgrad_scale_ref(backward, dy, rows) on `stream` already (nerfmlp_step_zero)
 int nerfmlp_dgrad_impl(const void* packed_bwd, const void* packed_fwd, int fwd_precision, int backward, const void* save, const float* d_raw, int64_t rows,
-                       void* dy, bool zero_ref, hipStream_t st) {
+                       void* dy, bool zero_ref, bool allow_half, hipStream_t st) {
   RNERF_CHECK_ARG(packed_bwd && packed_fwd && save && d_raw && dy, "rnerf_nerfmlp_dgrad: null pointer");
   RNERF_CHECK_ARG(fwd_precision == RNERF_PREC_F16X3, "rnerf_nerfmlp_dgrad: forward precision must be f16x3");
   RNERF_CHECK_ARG(bwd_ok(backward), "rnerf_nerfmlp_dgrad: unknown backward mode %d", backward);
   RNERF_CHECK_ARG(rows >= 1, "rnerf_nerfmlp_dgrad: rows must be >= 1");
   const float* fwd_aux = (const float*)((const char*)packed_fwd + Prec<RNERF_PREC_F16X3>::STREAM_BYTES);
-  if (backward == RNERF_BWD_F16X2) return launch_dgrad<RNERF_BWD_F16X2>(packed_bwd, fwd_aux, save, d_raw, rows, dy, st, zero_ref);
-  if (backward == RNERF_BWD_F16) return launch_dgrad<RNERF_BWD_F16>(packed_bwd, fwd_aux, save, d_raw, rows, dy, st, zero_ref);
-  return launch_dgrad<RNERF_BWD_BF16>(packed_bwd, fwd_aux, save, d_raw, rows, dy, st, zero_ref);
+  if (backward == RNERF_BWD_F16X2) return launch_dgrad<RNERF_BWD_F16X2>(packed_bwd, fwd_aux, save, d_raw, rows, dy, st, zero_ref, allow_half);
+  if (backward == RNERF_BWD_F16) return launch_dgrad<RNERF_BWD_F16>(packed_bwd, fwd_aux, save, d_raw, rows, dy, st, zero_ref, allow_half);
+  return launch_dgrad<RNERF_BWD_BF16>(packed_bwd, fwd_aux, save, d_raw, rows, dy, st, zero_ref, allow_half);
 }
 }  // namespace rnerf
 
 extern "C" int rnerf_nerfmlp_dgrad(const void* packed_bwd, const void* packed_fwd, int fwd_precision, int backward, const void* save,
                                    const float* d_raw, int64_t rows, void* dy, void* stream) {
-  return nerfmlp_dgrad_impl(packed_bwd, packed_fwd, fwd_precision, backward, save, d_raw, rows, dy, true, (hipStream_t)stream);
+  return nerfmlp_dgrad_impl(packed_bwd, packed_fwd, fwd_precision, backward, save, d_raw, rows, dy, true, true, (hipStream_t)stream);
 }
 
 // the wgrad jobs of one NerfMLP: {x slot base, x k-steps, dy slot base, dy k-steps, job, second-segment bases}

@@ -17,7 +17,7 @@ int nerfmlp_step_zero(int precision, void* const* packed, int count, int backwar
                       void* const* extra, int extra_count, hipStream_t st);
 int nerfmlp_pack_impl(const float* params, int precision, void* packed, bool zero_flags, hipStream_t st);
 int nerfmlp_dgrad_impl(const void* packed_bwd, const void* packed_fwd, int fwd_precision, int backward, const void* save, const float* d_raw, int64_t rows,
-                       void* dy, bool zero_ref, hipStream_t st);
+                       void* dy, bool zero_ref, bool allow_half, hipStream_t st);
 // csrc/render.hip
 int env_smooth_backward_impl(const float* rgb_env, int32_t ps, double grad_scale, float* d_out, float* loss_sum, bool zero_sum, hipStream_t st);
 
@@ -622,11 +622,11 @@ extern "C" int rnerf_train_forward_backward(const rnerf_model* m, const rnerf_tr
         if (smooth) RNERF_TRY(env_smooth_backward_impl(rgb_env, ps, c->bg_smooth_weight * env_on_, t.d_all + (size_t)3 * B, t.env_sum, !pre_zeroed, (hipStream_t)aux));
         RNERF_TRY(rnerf_bkgd_backward(th_b, t.save_bk, t.d_all, (int64_t)B + M, m->rgb_padding, t.dy_bk, g_b, nullptr, aux));
       }
-      RNERF_TRY(nerfmlp_dgrad_impl(t.packed_bwd, t.packed_c, prec, bwd, t.save_c, d_raw_c, (int64_t)Nc * B, dy_c, !pre_zeroed, (hipStream_t)aux));
+      RNERF_TRY(nerfmlp_dgrad_impl(t.packed_bwd, t.packed_c, prec, bwd, t.save_c, d_raw_c, (int64_t)Nc * B, dy_c, !pre_zeroed, false, (hipStream_t)aux));
       RNERF_TRY(rnerf_nerfmlp_wgrad(prec, bwd, t.save_c, dy_c, (int64_t)Nc * B, g_c, t.wgrad_ws_c, aux));
     }
     if (!aux) RNERF_TRY(rnerf_nerfmlp_pack_bwd(th_f, bwd, t.packed_bwd_f, stream));
-    RNERF_TRY(nerfmlp_dgrad_impl(t.packed_bwd_f, t.packed_f, prec, bwd, t.save_f, t.d_raw, (int64_t)S * B, t.dy, !pre_zeroed, st));
+    RNERF_TRY(nerfmlp_dgrad_impl(t.packed_bwd_f, t.packed_f, prec, bwd, t.save_f, t.d_raw, (int64_t)S * B, t.dy, !pre_zeroed, !split_levels, st));
     if (next && next->beside_wgrad) RNERF_TRY(march_next());
     RNERF_TRY(rnerf_nerfmlp_wgrad(prec, bwd, t.save_f, t.dy, (int64_t)S * B, g_f, t.wgrad_ws, stream));
     if (split_levels) RNERF_TRY(rnerf_join(stream, aux));
@@ -647,7 +647,7 @@ extern "C" int rnerf_train_forward_backward(const rnerf_model* m, const rnerf_tr
   }
   if (!aux) RNERF_TRY(rnerf_nerfmlp_pack_bwd(th_c, bwd, t.packed_bwd, stream));
   if (!split_levels)      // (a hierarchical model's coarse dgrad is the SECOND writer of t.dy here: it clears its own reference)
-    RNERF_TRY(nerfmlp_dgrad_impl(t.packed_bwd, t.packed_c, prec, bwd, t.save_c, t.d_raw, (int64_t)Nc * B, t.dy, !(pre_zeroed && Nf == 0), st));
+    RNERF_TRY(nerfmlp_dgrad_impl(t.packed_bwd, t.packed_c, prec, bwd, t.save_c, t.d_raw, (int64_t)Nc * B, t.dy, !(pre_zeroed && Nf == 0), true, st));
   if (co) {      // forked HERE, not earlier: the NerfMLP dgrad owns every CU whole, the wgrad below leaves room for these waves
     RNERF_TRY(rnerf_fork(stream, aux));
     if (kTailDelayTicks > 0) hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)aux, (long long)kTailDelayTicks);
