@@ -431,6 +431,9 @@ typedef struct rnerf_train_cfg {
                                   segments) are final there: a caller with more than one rank starts their all-reduce (jax.lax.pmean, train.py:166 —
                                   95 % of the bytes) on this stream as soon as the call returns, beside the background-MLP backward and the loss tail
                                   still queued on `stream`, and joins before rnerf_adam_update */
+  void* aux2_stream;           /* nullable (needs aux_stream): a third stream for hierarchical models at small batches, where the two levels' backward
+                                  passes run side by side: the background MLP's backward (it needs d loss / d background only, final once both
+                                  compositing backwards have run) goes there, beside both NerfMLP chains instead of in front of the coarse one */
 } rnerf_train_cfg;
 /* The march of the NEXT batch (it reads neither the parameters nor anything of this step): when `next` is given, its rays are marched on
  * next->side_stream, forked from `stream` right behind the last NerfMLP wgrad, so that the latency-bound march runs beside the small

@@ -55,7 +55,8 @@ class TrainCfg(C.Structure):
     """rnerf_train_cfg: the loss terms of train_step.loss_fn that the shipped configs switch on (train.py:75-162)."""
     _fields_ = [("backward", C.c_int32), ("randomized", C.c_int32), ("use_random_choice", C.c_int32), ("bg_patch_size", C.c_int32),
                 ("bg_weight", C.c_double), ("bg_smooth_weight", C.c_double), ("annealed_alpha", C.c_double), ("frozen_sq", C.c_double),
-                ("frozen_count", C.c_int64), ("aux_stream", C.c_void_p), ("coresident_bkgd_wgrad", C.c_int32), ("grads_stream", C.c_void_p)]
+                ("frozen_count", C.c_int64), ("aux_stream", C.c_void_p), ("coresident_bkgd_wgrad", C.c_int32), ("grads_stream", C.c_void_p),
+                ("aux2_stream", C.c_void_p)]
 
 
 class AdamCfg(C.Structure):

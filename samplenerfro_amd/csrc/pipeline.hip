@@ -608,6 +608,7 @@ extern "C" int rnerf_train_forward_backward(const rnerf_model* m, const rnerf_tr
   const bool split_levels = levels_side_by_side(m, c, B);
   static const bool bk_early_env = getenv("RNERF_BKGD_BWD_EARLY") ? atoi(getenv("RNERF_BKGD_BWD_EARLY")) != 0 : true;
   const bool bk_early = split_levels && bk_early_env && !(aux && c->coresident_bkgd_wgrad);
+  void* bk2 = nullptr;      // the third stream, when the background backward went there
   float* d_raw_c = split_levels ? t.d_raw_c : t.d_raw;
   void* dy_c = split_levels ? t.dy_c : t.dy;
   if (Nf > 0) {
@@ -617,10 +618,17 @@ extern "C" int rnerf_train_forward_backward(const rnerf_model* m, const rnerf_tr
       RNERF_TRY(rnerf_composite_backward(f.raw_c, path_pd, path_dr, jitter, Nc, B, bkgd, m->rgb_padding, m->sigma_bias, lc.rgb, pixels, nullptr, nullptr, nullptr,
                                          mse_scale, 0.0, d_raw_c, d_first, 1, m->white_bkgd, nullptr, stream));
       RNERF_TRY(rnerf_fork(stream, aux));
-      if (bk_early) {      // d loss / d background is final (both compositing backwards have run): its whole backward goes first on the aux stream
+      if (bk_early) {      // d loss / d background is final (both compositing backwards have run): its whole backward goes beside the NerfMLP
+        // chains — on the third stream when there is one (nothing waits behind it), else in front of the coarse level's on the aux stream.
+        // (Measured, tools/r04/env_ab.sh RNERF_NO_AUX2_STREAM: 256 rays 1.48 -> 1.39 ms, 512 rays the same, 128 rays 1.09 -> 1.11: with a
+        // quarter of the chip's tiles the coarse chain is not what the step waits for, and the third stream only adds its fork / join.)
+        const long long tiles_both = ((long long)Nc * B + 255) / 256 + ((long long)S * B + 255) / 256;
+        bk2 = (c->aux2_stream && tiles_both > 128) ? c->aux2_stream : nullptr;
+        void* bk = bk2 ? bk2 : aux;
+        if (bk2) RNERF_TRY(rnerf_fork(stream, bk));
         const double env_on_ = c->annealed_alpha > 0 ? 1.0 : 0.0;
-        if (smooth) RNERF_TRY(env_smooth_backward_impl(rgb_env, ps, c->bg_smooth_weight * env_on_, t.d_all + (size_t)3 * B, t.env_sum, !pre_zeroed, (hipStream_t)aux));
-        RNERF_TRY(rnerf_bkgd_backward(th_b, t.save_bk, t.d_all, (int64_t)B + M, m->rgb_padding, t.dy_bk, g_b, nullptr, aux));
+        if (smooth) RNERF_TRY(env_smooth_backward_impl(rgb_env, ps, c->bg_smooth_weight * env_on_, t.d_all + (size_t)3 * B, t.env_sum, !pre_zeroed, (hipStream_t)bk));
+        RNERF_TRY(rnerf_bkgd_backward(th_b, t.save_bk, t.d_all, (int64_t)B + M, m->rgb_padding, t.dy_bk, g_b, nullptr, bk));
       }
       RNERF_TRY(nerfmlp_dgrad_impl(t.packed_bwd, t.packed_c, prec, bwd, t.save_c, d_raw_c, (int64_t)Nc * B, dy_c, !pre_zeroed, false, (hipStream_t)aux));
       RNERF_TRY(rnerf_nerfmlp_wgrad(prec, bwd, t.save_c, dy_c, (int64_t)Nc * B, g_c, t.wgrad_ws_c, aux));
@@ -629,7 +637,10 @@ extern "C" int rnerf_train_forward_backward(const rnerf_model* m, const rnerf_tr
     RNERF_TRY(nerfmlp_dgrad_impl(t.packed_bwd_f, t.packed_f, prec, bwd, t.save_f, t.d_raw, (int64_t)S * B, t.dy, !pre_zeroed, !split_levels, st));
     if (next && next->beside_wgrad) RNERF_TRY(march_next());
     RNERF_TRY(rnerf_nerfmlp_wgrad(prec, bwd, t.save_f, t.dy, (int64_t)S * B, g_f, t.wgrad_ws, stream));
-    if (split_levels) RNERF_TRY(rnerf_join(stream, aux));
+    if (split_levels) {
+      RNERF_TRY(rnerf_join(stream, aux));
+      if (bk2) RNERF_TRY(rnerf_join(stream, bk2));
+    }
     else
       RNERF_TRY(rnerf_composite_backward(f.raw_c, path_pd, path_dr, jitter, Nc, B, bkgd, m->rgb_padding, m->sigma_bias, lc.rgb, pixels, nullptr, nullptr, nullptr,
                                          mse_scale, 0.0, t.d_raw, d_first, 1, m->white_bkgd, nullptr, stream));

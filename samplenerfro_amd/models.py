@@ -278,6 +278,12 @@ class NerfModel:
             self._tail = torch.cuda.Stream(device=self.device)
         return self._tail
 
+    def tail2_stream(self) -> torch.cuda.Stream:
+        """A third stream of the train step (rnerf_train_cfg.aux2_stream): the background MLP's backward of a small hierarchical batch."""
+        if getattr(self, "_tail2", None) is None:
+            self._tail2 = torch.cuda.Stream(device=self.device)
+        return self._tail2
+
     def comm_stream(self) -> torch.cuda.Stream:
         """The stream the train step's NerfMLP-gradient all-reduce is issued from (rnerf_train_cfg.grads_stream: ordered behind the last wgrad)."""
         if getattr(self, "_comm", None) is None:
