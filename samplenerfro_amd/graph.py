@@ -65,8 +65,9 @@ class GraphTrainStep:
         self.c = self._cfg(self.annealed)
         self.a = adam_cfg(state, flags, None)
         self.ws = torch.empty(self.lib.rnerf_train_workspace_bytes(C.byref(self.m), C.byref(self.c), B), dtype=torch.uint8, device=dev)
-        self.main = torch.cuda.Stream(device=dev)
-        self.side = torch.cuda.Stream(device=dev)
+        from .models import shared_stream      # (one stream per role and process: hardware queues are few)
+        self.main = shared_stream(dev, "graph")
+        self.side = shared_stream(dev, "march")
         self.slot = 0                    # the slot the NEXT step() trains on
         self.graphs: Dict[Any, Any] = {}
         self._marched = False

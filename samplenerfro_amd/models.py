@@ -29,6 +29,21 @@ BKGD_MLP_SHAPES = [(27, 128), (128, 128), (128, 128), (155, 128), (128, 3)]
 SO3_MLP_SHAPES = [(60, 128), (128, 128), (128, 128), (188, 128), (128, 3)]
 
 
+_STREAMS: Dict[Tuple[str, str], "torch.cuda.Stream"] = {}
+
+
+def shared_stream(device, role: str) -> "torch.cuda.Stream":
+    """ONE side stream per (device, role) for the whole process, whatever the number of models.  HIP streams are multiplexed onto a few
+    hardware queues (GPU_MAX_HW_QUEUES, 4 by default), assigned in creation order: a process that gives every model its own march / tail /
+    collective streams soon has two streams of ONE model on one queue, and the work they were meant to overlap runs in sequence (measured:
+    a 128-ray train step 1.11 -> 1.46 ms inside the bench, which builds seven models; tools/r04/variant_probe.sh)."""
+    key = (str(torch.device(device)), role)
+    s = _STREAMS.get(key)
+    if s is None:
+        s = _STREAMS[key] = torch.cuda.Stream(device=device)
+    return s
+
+
 def flat_size(shapes) -> int:
     return sum(i * o + o for i, o in shapes)
 
@@ -239,7 +254,7 @@ class NerfModel:
         if not self.stage.startswith("radiance"):
             raise NotImplementedError("prefetch_path: the all* march depends on the so3_mlp parameters; call apply() without a handle")
         if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
+            self._side = shared_stream(self.device, "march")
         # per-model cap of the MLP kernels' persistent grid, passed with every rnerf_nerfmlp_forward call (0 = every CU)
         self._mlp_wg_limit = max(_lib.load().rnerf_device_cus() - int(reserve_cus), 1) if reserve_cus > 0 else 0
         cur = torch.cuda.current_stream()
@@ -260,7 +275,7 @@ class NerfModel:
         if not self.stage.startswith("radiance"):
             raise NotImplementedError("prefetch: the all* march depends on the so3_mlp parameters")
         if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
+            self._side = shared_stream(self.device, "march")
         o, v = ops._chk(rays.origins, "origins"), ops._chk(rays.viewdirs, "viewdirs")
         B = o.shape[0]
         pd = torch.empty((self.num_samples, B, 4), dtype=torch.float32, device=self.device)
@@ -275,19 +290,21 @@ class NerfModel:
     def tail_stream(self) -> torch.cuda.Stream:
         """The stream rnerf_train_forward_backward uses for work that is independent of the NerfMLP backward (rnerf_train_cfg.aux_stream)."""
         if getattr(self, "_tail", None) is None:
-            self._tail = torch.cuda.Stream(device=self.device)
+            self._tail = shared_stream(self.device, "tail")
         return self._tail
 
     def tail2_stream(self) -> torch.cuda.Stream:
-        """A third stream of the train step (rnerf_train_cfg.aux2_stream): the background MLP's backward of a small hierarchical batch."""
+        """A third stream of the train step (rnerf_train_cfg.aux2_stream): the background MLP's backward of a small hierarchical batch.
+        Opt-in (RNERF_AUX2_STREAM=1, train.train_cfg): a fifth stream beside default / march / tail / comm no longer gets a hardware queue
+        of its own under the default GPU_MAX_HW_QUEUES=4."""
         if getattr(self, "_tail2", None) is None:
-            self._tail2 = torch.cuda.Stream(device=self.device)
+            self._tail2 = shared_stream(self.device, "tail2")
         return self._tail2
 
     def comm_stream(self) -> torch.cuda.Stream:
         """The stream the train step's NerfMLP-gradient all-reduce is issued from (rnerf_train_cfg.grads_stream: ordered behind the last wgrad)."""
         if getattr(self, "_comm", None) is None:
-            self._comm = torch.cuda.Stream(device=self.device)
+            self._comm = shared_stream(self.device, "comm")
         return self._comm
 
     def release_reserved_cus(self) -> None:

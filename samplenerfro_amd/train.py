@@ -257,7 +257,10 @@ def train_cfg(model: NerfModel, state: TrainState, flags, annealed: float) -> "_
     # runs there beside the head of the step (RNERF_NO_AUX_STREAM=1: everything on one stream)
     if os.environ.get("RNERF_NO_AUX_STREAM") != "1" and hasattr(model, "tail_stream"):
         c.aux_stream = model.tail_stream().cuda_stream
-        if hasattr(model, "tail2_stream") and os.environ.get("RNERF_NO_AUX2_STREAM") != "1":
+        # a third stream for the background backward of small hierarchical batches: opt-in.  It pays at 256 rays (1.48 -> 1.39 ms) when it
+        # gets a hardware queue of its own, and costs 30 % when it lands on the queue of the march or of the main stream — which is decided by
+        # how many streams the process has created (GPU_MAX_HW_QUEUES = 4)
+        if hasattr(model, "tail2_stream") and os.environ.get("RNERF_AUX2_STREAM") == "1":
             c.aux2_stream = model.tail2_stream().cuda_stream
         # RNERF_TAIL_STREAM=1 (experiment, off): the background-MLP weight gradient as a co-resident kernel beside the NerfMLP wgrad.  Measured
         # neutral at 4096 x 128 (what it saves on the critical path, ~0.12 ms, the wgrad loses to the extra waves: 2.04 -> 2.2-2.4 ms),
