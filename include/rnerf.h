@@ -250,15 +250,18 @@ int rnerf_loss_reduce(const float* rgb_c, const float* rgb_f, const float* trans
                       const float* pixels, int32_t B, float* sums, void* stream);
 
 /* ---- T1 (scalar tail of loss_fn).  rnerf_env_smooth_backward: the env-map smoothness term of train.py:127-130 on the patch
- * rgb_env float[ps][ps][3]: d_out float[ps*ps][3] = grad_scale * d mean(0.5 dv^2 + 0.5 dh^2) / d rgb_env; *loss_sum (device) =
- * the un-normalised sum.  rnerf_train_stats: utils.Stats scalars (train.py:147-162) into stats8 (device float[8], zeroed by the
+ * rgb_env float[ps][ps][3]: d_out float[ps*ps][3] = grad_scale * d mean(0.5 dv^2 + 0.5 dh^2) / d rgb_env; loss_sum (device,
+ * rnerf_env_smooth_sum_floats(ps) floats, need not be cleared) receives the un-normalised sum as one partial per workgroup behind 4 reserved
+ * floats — rnerf_train_stats (env_loss_sum = this buffer) adds them in index order: no float atomics, the same bits from run to run (round 4;
+ * the same holds for rnerf_theta_sumsq, one workgroup with a fixed summation order).  rnerf_train_stats: utils.Stats scalars (train.py:147-162) into stats8 (device float[8], zeroed by the
  * caller): [0] loss, [1] loss_c, [2] loss_bg = bg_scale * sums2 / (sums3 + 1) with bg_scale = bg_weight * 1[annealed_alpha > 0], [3] loss_bg_smooth, [4] weight_l2 = (sum theta^2 + frozen_sq) / n_all, [6] psnr,
  * [7] psnr_c; sums = rnerf_loss_reduce's output. */
+size_t rnerf_env_smooth_sum_floats(int32_t ps);
 int rnerf_env_smooth_backward(const float* rgb_env, int32_t ps, double grad_scale, float* d_out, float* loss_sum, void* stream);
 int rnerf_train_stats(const float* sums, int32_t B, int32_t two_levels, double bg_scale, const float* env_loss_sum, int32_t ps, double env_on,
                       const float* theta, int64_t n_theta, double frozen_sq, int64_t n_all, float* stats8, void* stream);
 /* rnerf_train_stats in two parts (the sum of squares of theta does not depend on the step's data and may run anywhere before the scalars):
- * rnerf_theta_sumsq accumulates sum theta^2 into stats8[5]; rnerf_train_stats with theta == NULL then only forms the scalars. */
+ * rnerf_theta_sumsq writes sum theta^2 to stats8[5]; rnerf_train_stats with theta == NULL then only forms the scalars. */
 int rnerf_theta_sumsq(const float* theta, int64_t n_theta, float* stats8, void* stream);
 
 /* ---- T1 (backward of V1 + activations): d loss / d raw of one level, replacing jax.value_and_grad through

@@ -96,6 +96,7 @@ SIGNATURES = {
     "rnerf_composite": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, C.c_int, _dbl, _dbl,
                                   _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.POINTER(C.c_double * 6), _vp]),
     "rnerf_loss_reduce": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
+    "rnerf_env_smooth_sum_floats": (C.c_size_t, [_i32]),
     "rnerf_env_smooth_backward": (C.c_int, [_vp, _i32, _dbl, _vp, _vp, _vp]),
     "rnerf_train_stats": (C.c_int, [_vp, _i32, _i32, _dbl, _vp, _i32, _dbl, _vp, _i64, _dbl, _i64, _vp, _vp]),
     "rnerf_composite_backward": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _dbl, _dbl, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl,

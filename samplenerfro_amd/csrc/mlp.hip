@@ -2955,16 +2955,14 @@ __global__ void __launch_bounds__(64) zero_flags_kernel(FlagRegions r, int n) {
   if ((int)threadIdx.x < n) *r.p[threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 // Zeroes, in ONE launch, every 16-byte accumulator / flag word a training step needs cleared before its kernels run: the range flags of
-// the operand streams it packs (`packed`, `count` <= 2), the row-scale reference of each dgrad's dY buffer (`dy` / `dy_rows`, see
-// launch_dgrad) and up to 2 `extra` words (the env-map smoothness sum).  As hipMemsetAsync calls inside the producers each was a fill
-// kernel of its own, ~6 us apiece with its launch gap, three of them on the main stream's dependent chain (round 4).
-int nerfmlp_step_zero(int precision, void* const* packed, int count, int backward, void* const* dy, const int64_t* dy_rows, int dy_count,
-                      void* const* extra, int extra_count, hipStream_t st) {
+// the operand streams it packs (`packed`, `count` <= 2) and the row-scale reference of each dgrad's dY buffer (`dy` / `dy_rows`, see
+// launch_dgrad).  As hipMemsetAsync calls inside the producers each was a fill kernel of its own, ~6 us apiece with its launch gap, on
+// the main stream's dependent chain (round 4; the env-map sum and sum theta^2 became fixed-order reductions that need no clearing).
+int nerfmlp_step_zero(int precision, void* const* packed, int count, int backward, void* const* dy, const int64_t* dy_rows, int dy_count, hipStream_t st) {
   FlagRegions r;
   int n = 0;
   for (int i = 0; i < count && i < 2; ++i) { void* o[2]; const int k = pack_flag_regions(precision, packed[i], o); for (int q = 0; q < k; ++q) r.p[n++] = (float4*)o[q]; }
   for (int i = 0; i < dy_count && i < 4; ++i) { void* f = nerfmlp_dgrad_scale_ref(backward, dy[i], dy_rows[i]); if (f) r.p[n++] = (float4*)f; }
-  for (int i = 0; i < extra_count && i < 2; ++i) if (extra[i]) r.p[n++] = (float4*)extra[i];
   if (n == 0) return RNERF_OK;
   hipLaunchKernelGGL(zero_flags_kernel, dim3(1), dim3(64), 0, st, r, n);
   RNERF_CHECK_LAUNCH();

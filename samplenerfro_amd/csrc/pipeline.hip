@@ -13,13 +13,11 @@
 
 namespace rnerf {
 // csrc/mlp.hip: the operand-stream pack without its own memsets (the step zeroes every stream's range flags in one launch)
-int nerfmlp_step_zero(int precision, void* const* packed, int count, int backward, void* const* dy, const int64_t* dy_rows, int dy_count,
-                      void* const* extra, int extra_count, hipStream_t st);
+int nerfmlp_step_zero(int precision, void* const* packed, int count, int backward, void* const* dy, const int64_t* dy_rows, int dy_count, hipStream_t st);
 int nerfmlp_pack_impl(const float* params, int precision, void* packed, bool zero_flags, hipStream_t st);
 int nerfmlp_dgrad_impl(const void* packed_bwd, const void* packed_fwd, int fwd_precision, int backward, const void* save, const float* d_raw, int64_t rows,
                        void* dy, bool zero_ref, bool allow_half, hipStream_t st);
-// csrc/render.hip
-int env_smooth_backward_impl(const float* rgb_env, int32_t ps, double grad_scale, float* d_out, float* loss_sum, bool zero_sum, hipStream_t st);
+
 
 // ---- threefry2x32-20 (Random123), the block cipher behind jax.random (samplenerfro_amd/prng.py; KAT in tests/test_prng.py) ---------
 __device__ __forceinline__ unsigned rotl_u32(unsigned x, int r) { return (x << r) | (x >> (32 - r)); }
@@ -459,7 +457,7 @@ static size_t carve_train(const rnerf_model* m, const rnerf_train_cfg* c, int32_
   t->level_c = k.take<float>((size_t)RNERF_LEVEL_FLOATS * B);
   t->level_f = Nf > 0 ? k.take<float>((size_t)RNERF_LEVEL_FLOATS * B) : nullptr;
   t->sums = k.take<float>(4);
-  t->env_sum = k.take<float>(4);
+  t->env_sum = k.take<float>(rnerf_env_smooth_sum_floats(c->bg_smooth_weight > 0 ? c->bg_patch_size : 0));
   t->d_all = k.take<float>((B + M) * 3);
   t->d_raw = k.take<float>(S * B * 4);
   t->dy_c = t->wgrad_ws_c = nullptr; t->d_raw_c = nullptr;
@@ -525,13 +523,12 @@ extern "C" int rnerf_train_forward_backward(const rnerf_model* m, const rnerf_tr
   if (aux) {
     RNERF_TRY(rnerf_fork(stream, aux));
     // one launch zeroes what the step's kernels need cleared: the streams' range flags, the row-scale reference of every dgrad that is the
-    // FIRST writer of its dY buffer (without an aux-stream coarse level the coarse dgrad reuses the fine level's buffer: it clears its own)
-    // and the env-map smoothness sum
+    // FIRST writer of its dY buffer (without an aux-stream coarse level the coarse dgrad reuses the fine level's buffer: it clears its own).
+    // (The env-map smoothness sum and sum theta^2 need no clearing: fixed-order reductions that assign their result.)
     void* streams[2] = {t.packed_c, t.packed_f};
     void* dys[2] = {t.dy, t.dy_c};
     const int64_t dy_rows[2] = {(int64_t)(Nf > 0 ? S : Nc) * B, (int64_t)Nc * B};
-    void* extra[1] = {smooth ? (void*)t.env_sum : nullptr};
-    RNERF_TRY(nerfmlp_step_zero(prec, streams, Nf > 0 ? 2 : 1, bwd, dys, dy_rows, t.dy_c ? 2 : 1, extra, 1, (hipStream_t)aux));
+    RNERF_TRY(nerfmlp_step_zero(prec, streams, Nf > 0 ? 2 : 1, bwd, dys, dy_rows, t.dy_c ? 2 : 1, (hipStream_t)aux));
     pre_zeroed = true;
     RNERF_TRY(nerfmlp_pack_impl(th_c, prec, t.packed_c, false, (hipStream_t)aux));
   }
@@ -627,7 +624,7 @@ extern "C" int rnerf_train_forward_backward(const rnerf_model* m, const rnerf_tr
         void* bk = bk2 ? bk2 : aux;
         if (bk2) RNERF_TRY(rnerf_fork(stream, bk));
         const double env_on_ = c->annealed_alpha > 0 ? 1.0 : 0.0;
-        if (smooth) RNERF_TRY(env_smooth_backward_impl(rgb_env, ps, c->bg_smooth_weight * env_on_, t.d_all + (size_t)3 * B, t.env_sum, !pre_zeroed, (hipStream_t)bk));
+        if (smooth) RNERF_TRY(rnerf_env_smooth_backward(rgb_env, ps, c->bg_smooth_weight * env_on_, t.d_all + (size_t)3 * B, t.env_sum, bk));
         RNERF_TRY(rnerf_bkgd_backward(th_b, t.save_bk, t.d_all, (int64_t)B + M, m->rgb_padding, t.dy_bk, g_b, nullptr, bk));
       }
       RNERF_TRY(nerfmlp_dgrad_impl(t.packed_bwd, t.packed_c, prec, bwd, t.save_c, d_raw_c, (int64_t)Nc * B, dy_c, !pre_zeroed, false, (hipStream_t)aux));
@@ -653,7 +650,7 @@ extern "C" int rnerf_train_forward_backward(const rnerf_model* m, const rnerf_tr
   const double env_on = c->annealed_alpha > 0 ? 1.0 : 0.0;
   const bool co = aux && c->coresident_bkgd_wgrad;
   if (co) {
-    if (smooth) RNERF_TRY(env_smooth_backward_impl(rgb_env, ps, c->bg_smooth_weight * env_on, t.d_all + (size_t)3 * B, t.env_sum, !pre_zeroed, st));
+    if (smooth) RNERF_TRY(rnerf_env_smooth_backward(rgb_env, ps, c->bg_smooth_weight * env_on, t.d_all + (size_t)3 * B, t.env_sum, stream));
     RNERF_TRY(rnerf_bkgd_backward_dgrad(th_b, t.save_bk, t.d_all, (int64_t)B + M, m->rgb_padding, t.dy_bk, nullptr, stream));
   }
   if (!aux) RNERF_TRY(rnerf_nerfmlp_pack_bwd(th_c, bwd, t.packed_bwd, stream));
@@ -671,7 +668,7 @@ extern "C" int rnerf_train_forward_backward(const rnerf_model* m, const rnerf_tr
   if (co) {
     RNERF_TRY(rnerf_join(stream, aux));
   } else if (!bk_early) {
-    if (smooth) RNERF_TRY(env_smooth_backward_impl(rgb_env, ps, c->bg_smooth_weight * env_on, t.d_all + (size_t)3 * B, t.env_sum, !pre_zeroed, st));
+    if (smooth) RNERF_TRY(rnerf_env_smooth_backward(rgb_env, ps, c->bg_smooth_weight * env_on, t.d_all + (size_t)3 * B, t.env_sum, stream));
     RNERF_TRY(rnerf_bkgd_backward(th_b, t.save_bk, t.d_all, (int64_t)B + M, m->rgb_padding, t.dy_bk, g_b, nullptr, stream));
   }
   RNERF_TRY(rnerf_train_stats(t.sums, B, Nf > 0, c->bg_weight * bg_on, smooth ? t.env_sum : nullptr, ps, env_on, aux ? nullptr : theta, n_theta, c->frozen_sq,

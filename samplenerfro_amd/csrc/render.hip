@@ -696,9 +696,11 @@ extern "C" int rnerf_loss_reduce(const float* rgb_c, const float* rgb_f, const f
 
 // ---- the scalar tail of loss_fn in two small kernels (instead of ~35 framework elementwise launches per step) ----------------
 // env-map smoothness (train.py:127-130): loss = mean(0.5 dv^2 + 0.5 dh^2) over the [ps-1, ps, 3] / [ps, ps-1, 3] differences of the
-// patch; d_out = scale * d loss / d rgb_env; the un-normalised sum of squares is accumulated into *loss_sum.
+// patch; d_out = scale * d loss / d rgb_env; the un-normalised sum of squares of block b goes to loss_sum[4 + b] — one partial per block,
+// summed in index order by train_stats_kernel: no float atomics, the same bits from run to run (and nothing to zero beforehand).
 __global__ void __launch_bounds__(256) env_smooth_kernel(const float* __restrict__ x, int ps, float k, float* __restrict__ d_out,
                                                          float* __restrict__ loss_sum) {
+  __shared__ float wsum[4];
   const int id = blockIdx.x * blockDim.x + threadIdx.x;
   const int n = ps * ps * 3;
   float part = 0.f;
@@ -714,19 +716,42 @@ __global__ void __launch_bounds__(256) env_smooth_kernel(const float* __restrict
     (void)c;
   }
   for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o);
-  if ((threadIdx.x & 63) == 0 && part != 0.f) atomicAdd(loss_sum, part);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = part;
+  __syncthreads();
+  if (threadIdx.x == 0) loss_sum[4 + blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
 }
 
-__global__ void __launch_bounds__(256) sumsq_kernel(const float* __restrict__ x, long long n, float* __restrict__ out) {
-  float s = 0.f;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) s += x[i] * x[i];
+// sum x^2 by ONE workgroup in a fixed order (per-thread strided partial sums, then a fixed tree): *out = the sum — assigned, not
+// accumulated; no float atomics, the same bits from run to run.  5 MB of parameters take ~40 us on one CU: in the training step it runs
+// on the aux stream beside the coarse forward (csrc/pipeline.hip), off the critical path.
+__global__ void __launch_bounds__(1024) sumsq_kernel(const float* __restrict__ x, long long n, float* __restrict__ out) {
+  __shared__ float wsum[16];
+  const int tid = threadIdx.x;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  const long long n4 = ((uintptr_t)x & 15) == 0 ? n / 4 : 0;               // float4 body (unaligned buffers: scalar loop only)
+  const float4* __restrict__ x4 = (const float4*)x;
+  for (long long i = tid; i < n4; i += 1024) { const float4 v = x4[i]; s0 += v.x * v.x; s1 += v.y * v.y; s2 += v.z * v.z; s3 += v.w * v.w; }
+  for (long long i = 4 * n4 + tid; i < n; i += 1024) s0 += x[i] * x[i];
+  float s = (s0 + s1) + (s2 + s3);
   for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
-  if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+  if ((tid & 63) == 0) wsum[tid >> 6] = s;
+  __syncthreads();
+  if (tid == 0) {
+    float t = 0.f;
+    for (int w = 0; w < 16; ++w) t += wsum[w];
+    *out = t;
+  }
 }
 
 // st[0] loss, st[1] loss_c, st[2] loss_bg, st[3] loss_bg_smooth, st[4] weight_l2, st[6] psnr, st[7] psnr_c (utils.Stats, train.py:147-162)
 __global__ void train_stats_kernel(const float* __restrict__ sums, float inv3B, int two_levels, float bg_on, const float* __restrict__ env_sum,
-                                   float env_scale, float frozen_sq, float inv_n_all, float* __restrict__ st) {
+                                   int env_blocks, float env_scale, float frozen_sq, float inv_n_all, float* __restrict__ st) {
+  // the env-map term's per-block partials (env_smooth_kernel), summed in index order: lane l takes partials l, l + 64, ..., then a fixed tree
+  float env = 0.f;
+  if (env_sum) {
+    for (int b = threadIdx.x; b < env_blocks; b += 64) env += env_sum[4 + b];
+    for (int o = 32; o > 0; o >>= 1) env += __shfl_down(env, o);
+  }
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const float kp = -4.342944819032518f;                 // -10 / ln 10 (utils.compute_psnr)
   const float loss = sums[0] * inv3B;
@@ -734,21 +759,16 @@ __global__ void train_stats_kernel(const float* __restrict__ sums, float inv3B, 
   st[6] = kp * logf(loss);
   if (two_levels) { const float lc = sums[1] * inv3B; st[1] = lc; st[7] = kp * logf(lc); }
   st[2] = bg_on * sums[2] / (sums[3] + 1.0f);
-  if (env_sum) st[3] = env_sum[0] * env_scale;
+  if (env_sum) st[3] = env * env_scale;
   st[4] = (st[5] + frozen_sq) * inv_n_all;              // st[5]: sum of squares of the trained parameters (sumsq_kernel)
   st[5] = 0.f;
 }
 
-namespace rnerf {
-// zero_sum = false: the caller has zeroed *loss_sum on `stream` already (the training step: nerfmlp_step_zero)
-int env_smooth_backward_impl(const float* rgb_env, int32_t ps, double grad_scale, float* d_out, float* loss_sum, bool zero_sum, hipStream_t st);
-}
+extern "C" size_t rnerf_env_smooth_sum_floats(int32_t ps) { return ps >= 2 ? 4 + (size_t)((ps * ps * 3 + 255) / 256) : 4; }
+
 extern "C" int rnerf_env_smooth_backward(const float* rgb_env, int32_t ps, double grad_scale, float* d_out, float* loss_sum, void* stream) {
-  return env_smooth_backward_impl(rgb_env, ps, grad_scale, d_out, loss_sum, true, (hipStream_t)stream);
-}
-int rnerf::env_smooth_backward_impl(const float* rgb_env, int32_t ps, double grad_scale, float* d_out, float* loss_sum, bool zero_sum, hipStream_t st) {
   RNERF_CHECK_ARG(rgb_env && d_out && loss_sum && ps >= 2, "rnerf_env_smooth_backward: null pointer or ps < 2");
-  if (zero_sum) RNERF_CHECK_HIP(hipMemsetAsync(loss_sum, 0, sizeof(float), st));
+  hipStream_t st = (hipStream_t)stream;
   const int n = ps * ps * 3;
   const double m = (double)(ps - 1) * ps * 3;
   hipLaunchKernelGGL(env_smooth_kernel, dim3((n + 255) / 256), dim3(256), 0, st, rgb_env, ps, (float)(grad_scale / m), d_out, loss_sum);
@@ -761,17 +781,17 @@ extern "C" int rnerf_train_stats(const float* sums, int32_t B, int32_t two_level
                                  void* stream) {
   RNERF_CHECK_ARG(sums && stats8 && B >= 1 && n_theta >= 1 && n_all >= n_theta, "rnerf_train_stats: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  if (theta) hipLaunchKernelGGL(sumsq_kernel, dim3(256), dim3(256), 0, st, theta, (long long)n_theta, stats8 + 5);      // NULL: rnerf_theta_sumsq ran already
+  if (theta) hipLaunchKernelGGL(sumsq_kernel, dim3(1), dim3(1024), 0, st, theta, (long long)n_theta, stats8 + 5);      // NULL: rnerf_theta_sumsq ran already
   const double m = ps >= 2 ? (double)(ps - 1) * ps * 3 : 1.0;
   hipLaunchKernelGGL(train_stats_kernel, dim3(1), dim3(64), 0, st, sums, (float)(1.0 / (3.0 * B)), two_levels, (float)bg_scale, env_loss_sum,
-                     (float)(env_on / m), (float)frozen_sq, (float)(1.0 / (double)n_all), stats8);
+                     ps >= 2 ? (ps * ps * 3 + 255) / 256 : 0, (float)(env_on / m), (float)frozen_sq, (float)(1.0 / (double)n_all), stats8);
   RNERF_CHECK_LAUNCH();
   return RNERF_OK;
 }
 
 extern "C" int rnerf_theta_sumsq(const float* theta, int64_t n_theta, float* stats8, void* stream) {
   RNERF_CHECK_ARG(theta && stats8 && n_theta >= 1, "rnerf_theta_sumsq: bad arguments");
-  hipLaunchKernelGGL(sumsq_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, theta, (long long)n_theta, stats8 + 5);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, theta, (long long)n_theta, stats8 + 5);
   RNERF_CHECK_LAUNCH();
   return RNERF_OK;
 }

@@ -495,7 +495,8 @@ def nerfmlp_input_grad(params_flat: torch.Tensor, backward: int, dy: torch.Tenso
 
 
 def env_smooth_backward(rgb_env: torch.Tensor, ps: int, grad_scale: float, d_out: torch.Tensor, loss_sum: torch.Tensor) -> None:
-    """train.py:127-130: gradient of the env-map smoothness term into d_out [ps*ps,3], un-normalised loss sum into loss_sum[1]."""
+    """train.py:127-130: gradient of the env-map smoothness term into d_out [ps*ps,3]; the un-normalised loss sum goes to loss_sum
+    (rnerf_env_smooth_sum_floats(ps) floats: per-workgroup partials that train_stats adds in a fixed order)."""
     lib = _lib.load()
     check(lib.rnerf_env_smooth_backward(ptr(_chk(rgb_env, "rgb_env")), int(ps), float(grad_scale), ptr(_chk(d_out, "d_out")), ptr(loss_sum),
                                         current_stream()), "rnerf_env_smooth_backward")

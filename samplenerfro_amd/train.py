@@ -463,7 +463,7 @@ def train_step(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], 
     if flags.bg_smooth_weight > 0:
         ps = batch["env_rays"].viewdirs.shape[0]
         on = 1.0 if annealed > 0 else 0.0
-        env_sum = torch.empty(1, dtype=torch.float32, device=pixels.device)
+        env_sum = torch.empty(_lib.load().rnerf_env_smooth_sum_floats(int(ps)), dtype=torch.float32, device=pixels.device)
         ops.env_smooth_backward(ctx["rgb_env"], ps, flags.bg_smooth_weight * on, d_all[B:], env_sum)
     if all_stage:
         _, d_bk_dirs = ops.bkgd_backward(bk_flat, ctx["save_bkgd"], d_all, g_bk, model.rgb_padding, want_d_dirs=True)

@@ -306,3 +306,38 @@ def test_adam_update_counts_nonfinite_gradients():
     _lib.check(lib.rnerf_adam_update(C.byref(a), th.data_ptr(), mu.data_ptr(), nu.data_ptr(), g.data_ptr(), n, None, 0, step.data_ptr(), scratch.data_ptr(),
                                      _lib.current_stream()), "rnerf_adam_update")
     assert float(scratch[3]) == 3.0
+
+
+@pytest.mark.parametrize("Nf,B", [(0, 160), (24, 160), (24, 2100)])
+def test_train_step_does_not_depend_on_what_its_workspace_held(Nf, B):
+    """Every accumulator word of a step (range flags of the operand streams, the dgrads' row-scale references, the env-map sum) is cleared by
+    ONE launch at the head of the step (csrc/mlp.hip: nerfmlp_step_zero) instead of a memset inside each producer: a workspace full of
+    0xFF bytes (NaN patterns), of 0x3F bytes (finite floats) or of the previous step's values must give the same gradient bits and the same
+    statistics as a zeroed one.  B = 2100 with 16 + 24 samples: 132 + 329 row tiles, the two levels NOT side by side (the coarse dgrad is
+    then the second writer of the shared dY buffer and clears its own reference)."""
+    from samplenerfro_amd.train import train_step
+    res = []
+    for fill in (0x00, 0xFF, 0x3F, None):
+        model, state, batch, flags = _train_setup(Nf, B)
+        rng = np.array([5, 6], np.uint32)
+        if fill is None:                                     # the previous step's values: a first step on other parameters' twin
+            train_step(model, np.array([9, 9], np.uint32), _train_setup(Nf, B)[1], batch, flags)
+        else:
+            train_step(model, rng, _train_setup(Nf, B)[1], batch, flags)          # sizes the model's cached workspace
+            model._ws["train"].fill_(fill)
+        state, stats, _ = train_step(model, rng, state, batch, flags)
+        torch.cuda.synchronize()
+        res.append((state.grads.clone(), [float(stats.loss), float(stats.loss_bg_smooth), float(stats.weight_l2)]))
+    for g, st in res[1:]:
+        assert torch.equal(g, res[0][0])
+        assert st == res[0][1]
+
+
+def test_side_streams_are_shared_by_every_model_of_the_process():
+    """HIP multiplexes streams onto GPU_MAX_HW_QUEUES (4) hardware queues: one stream per role and process, not per model (models.shared_stream)."""
+    from samplenerfro_amd.models import shared_stream
+    a, _, _, _ = _scene(Nf=0, B=32)
+    b, _, _, _ = _scene(Nf=24, B=32)
+    assert a.tail_stream() is b.tail_stream() and a.comm_stream() is b.comm_stream()
+    assert a.tail_stream().cuda_stream != a.comm_stream().cuda_stream
+    assert shared_stream(a.device, "march") is shared_stream(a.device, "march")
