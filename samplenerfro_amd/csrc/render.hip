@@ -15,10 +15,28 @@ __device__ __forceinline__ float sigmoidf_ref(float x) { return fdiv(1.0f, fadd(
 // jax.nn.softplus = logaddexp(x, 0) = max(x,0) + log1p(exp(-|x|))
 __device__ __forceinline__ float softplusf_ref(float x) { return fadd(fmaxf(x, 0.f), log1pf(expf(-fabsf(x)))); }
 
-// Four lanes (a DPP quad) per ray: lane q owns samples 4j + q.  Everything that does not depend on the running optical depth
-// (activations: 3 sigmoids + softplus, segment length, alpha) is computed by the four lanes at once; the recurrence itself —
-// cum += dd and the five ordered accumulations — is replayed in SAMPLE ORDER through quad broadcasts, so every sum is built
-// by the same sequence of individually rounded additions as the one-lane loop (and the reference's cumsum order).
+// L consecutive lanes per ray (L = 4: a DPP quad; 16 or 64: broadcasts through ds_bpermute): lane q owns samples L j + q.  Everything that
+// does not depend on the running optical depth (activations: 3 sigmoids + softplus, segment length, alpha — nearly all of the
+// instructions) is computed by the L lanes at once; the recurrence itself — cum += dd and the five ordered accumulations — is replayed in
+// SAMPLE ORDER through lane broadcasts, so every sum is built by the same sequence of individually rounded additions as a one-lane loop
+// (and the reference's cumsum order) whatever L: the kernels give the same bits for every L (tests/test_gpu_parity.py).  The kernels are
+// bound by the LATENCY of a ray's chain of groups (S / L iterations of ~250 dependent-ish instructions with one wave per SIMD): the
+// launcher picks the widest L that still leaves every SIMD a few waves (round 4: 4 lanes per ray at 4096 rays x 128 samples were 256 waves
+// on 1024 SIMDs: 36 us forward, 57 us backward; 128 rays x 192 samples 47 / 76 us).
+template <int L>
+__device__ __forceinline__ float ray_bcast(float v, int i) {      // value of lane i of this lane's group of L
+  if constexpr (L == 4) return i == 0 ? quad_bcast<0>(v) : (i == 1 ? quad_bcast<1>(v) : (i == 2 ? quad_bcast<2>(v) : quad_bcast<3>(v)));
+  else return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((int)((((threadIdx.x & 63) & ~(L - 1)) + i) << 2), __builtin_bit_cast(int, v)));
+}
+template <int L>
+__device__ __forceinline__ int ray_bcast_i(int v, int i) { return __builtin_bit_cast(int, ray_bcast<L>(__builtin_bit_cast(float, v), i)); }
+template <int L>
+__device__ __forceinline__ float ray_next(float v) {              // value of the NEXT lane of the group (the last lane's is unused)
+  if constexpr (L == 4) return quad_next(v);
+  else return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((int)(((threadIdx.x & 63) + 1) & 63) << 2, __builtin_bit_cast(int, v)));
+}
+
+template <int L>
 __global__ void __launch_bounds__(64) composite_kernel(const float4* __restrict__ raw, const float4* __restrict__ rows_pd,
                                                        const float4* __restrict__ rows_dr,
                                                        const int* __restrict__ node_of_sample, int S, int B,
@@ -29,50 +47,55 @@ __global__ void __launch_bounds__(64) composite_kernel(const float4* __restrict_
                                                        float* __restrict__ weights, float* __restrict__ alpha_out,
                                                        int mask_mode, float bx0, float by0, float bz0, float bx1, float by1, float bz1) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-  const int q = gid & 3;
-  int r = gid >> 2;
+  const int q = gid & (L - 1);
+  int r = gid / L;
   const bool live = r < B;
-  if (!live) r = B - 1;            // surplus quads replay the last ray (DPP needs whole quads); their stores are suppressed
+  if (!live) r = B - 1;            // surplus groups replay the last ray (the broadcasts need whole groups); their stores are suppressed
   auto rec = [&](int s) -> size_t { return (size_t)(node_of_sample ? node_of_sample[s] : s) * B + r; };
-  const int G = (S + 3) >> 2;
+  const int G = (S + L - 1) / L;
   // mask_bbox = (cumsum(inside[::-1]) > 0)[::-1] (rnerf/models.py:498-503): 1 up to and including the LAST sample inside the
   // box; mask_mode 1 uses it, mask_mode 2 uses 1 - mask (:505-523).
   int last_in = -1;
   if (mask_mode != 0) {
     for (int j = G - 1; j >= 0; --j) {
-      const int s = 4 * j + q;
+      const int s = L * j + q;
       if (s < S) {
         const float4 p = rows_pd[rec(s)];
         if (p.x >= bx0 && p.x <= bx1 && p.y >= by0 && p.y <= by1 && p.z >= bz0 && p.z <= bz1) { last_in = s; break; }
       }
     }
-    last_in = max(max(quad_bcast_i<0>(last_in), quad_bcast_i<1>(last_in)), max(quad_bcast_i<2>(last_in), quad_bcast_i<3>(last_in)));
+    int mx = ray_bcast_i<L>(last_in, 0);
+#pragma unroll
+    for (int i = 1; i < L; ++i) mx = max(mx, ray_bcast_i<L>(last_in, i));
+    last_in = mx;
   }
   float cum = 0.f, sr = 0.f, sg = 0.f, sb = 0.f, acc = 0.f, wt = 0.f;
   const float t0 = rows_pd[rec(0)].w;
   const float t_last = rows_pd[rec(S - 1)].w;
   struct Rec { float4 d, rw; float t; };
   auto load = [&](int j) -> Rec {
-    int s = 4 * j + q;
+    int s = L * j + q;
     if (s > S - 1) s = S - 1;
     const size_t o = rec(s);
     Rec x;
     x.d = rows_dr[o]; x.rw = raw[(size_t)s * B + r]; x.t = rows_pd[o].w;
     return x;
   };
-  // ordered accumulation of the four lanes' products: (((a + p0) + p1) + p2) + p3
+  // ordered accumulation of the L lanes' products: (((a + p0) + p1) + p2) + ...
   auto acc4 = [&](float a, float p) -> float {
-    return fadd(fadd(fadd(fadd(a, quad_bcast<0>(p)), quad_bcast<1>(p)), quad_bcast<2>(p)), quad_bcast<3>(p));
+#pragma unroll
+    for (int i = 0; i < L; ++i) a = fadd(a, ray_bcast<L>(p, i));
+    return a;
   };
   Rec cur = load(0);
   for (int j = 0; j < G; ++j) {
     const Rec nxt = load(j + 1 < G ? j + 1 : j);                // the next group's records are in flight during this group's arithmetic
-    const int s = 4 * j + q;
+    const int s = L * j + q;
     const bool valid = s < S;
     const float4 d = cur.d, rw = cur.rw;
     const float t_cur = cur.t;
-    const float t_up = quad_next(t_cur), t_grp = quad_bcast<0>(nxt.t);
-    const float t_next = q < 3 ? t_up : t_grp;
+    const float t_up = ray_next<L>(t_cur), t_grp = ray_bcast<L>(nxt.t, 0);
+    const float t_next = q < L - 1 ? t_up : t_grp;
     const float tdist = (s + 1 < S) ? fsub(t_next, t_cur) : 1e-3f;   // model_utils.py:265-268
     const float nrm = fsqrt(fadd(fadd(fmul(d.x, d.x), fmul(d.y, d.y)), fmul(d.z, d.z)));
     const float delta = fmul(tdist, nrm);                    // :270
@@ -84,10 +107,10 @@ __global__ void __launch_bounds__(64) composite_kernel(const float4* __restrict_
     if (mask_mode != 0) dd = fmul(dd, ((s <= last_in) == (mask_mode == 1)) ? 1.0f : 0.0f);   // density_delta *= mask_bbox (:275-276)
     if (!valid) dd = 0.f;                                    // padding lanes of the last group: alpha = 0, weight = 0
     const float a = fsub(1.0f, expf(-dd));                   // :285
-    // optical depth before each of the four samples, in order
-    const float c1 = fadd(cum, quad_bcast<0>(dd)), c2 = fadd(c1, quad_bcast<1>(dd)), c3 = fadd(c2, quad_bcast<2>(dd));
-    const float my_cum = q == 0 ? cum : (q == 1 ? c1 : (q == 2 ? c2 : c3));
-    cum = fadd(c3, quad_bcast<3>(dd));
+    // optical depth before each of the group's samples, in order
+    float my_cum = cum;
+#pragma unroll
+    for (int i = 0; i < L; ++i) { if (q == i) my_cum = cum; cum = fadd(cum, ray_bcast<L>(dd, i)); }
     const float T = expf(-my_cum);                           // :286-289
     const float w = fmul(a, T);                              // :296
     sr = acc4(sr, fmul(w, cr)); sg = acc4(sg, fmul(w, cg)); sb = acc4(sb, fmul(w, cb));
@@ -157,6 +180,7 @@ __global__ void __launch_bounds__(1024) loss_reduce_kernel(const float* __restri
 //   d/d dd_s = (gC . c_s) T_{s+1} - sum_{j>s} (gC . c_j) w_j - G_T T_S,   G_T = gC . bk + gTB . bk     (model_utils.py:285-299,309)
 //   gC = 2 (C - pix) / (3B);  gTB = bg_scale * mask * sign(T_S bk - pix) / (sum(mask) + 1)  (fine level only; bk is stop_gradient there)
 // One lane per ray: a forward sweep for the total optical depth, then a reverse sweep that recomputes T on the way back.
+template <int L>
 __global__ void __launch_bounds__(64) composite_bwd_kernel(const float4* __restrict__ raw, const float4* __restrict__ rows_pd,
                                                            const float4* __restrict__ rows_dr, const int* __restrict__ node_of_sample,
                                                            int S, int B, const float* __restrict__ bkgd, float pad_scale, float pad,
@@ -166,13 +190,13 @@ __global__ void __launch_bounds__(64) composite_bwd_kernel(const float4* __restr
                                                            float4* __restrict__ d_raw, float* __restrict__ d_bkgd, int accumulate_bkgd,
                                                            int bd_cut, float bx0, float by0, float bz0, float bx1, float by1, float bz1,
                                                            int white_bkgd) {
-  // four lanes per ray, lane q owns samples 4j + q (see composite_kernel): the ordered chains run through quad broadcasts
+  // L lanes per ray, lane q owns samples L j + q (see composite_kernel): the ordered chains run through lane broadcasts
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-  const int q = gid & 3;
-  int r = gid >> 2;
+  const int q = gid & (L - 1);
+  int r = gid / L;
   const bool live = r < B;
   if (!live) r = B - 1;
-  const int G = (S + 3) >> 2;
+  const int G = (S + L - 1) / L;
   auto rec = [&](int s) -> size_t { return (size_t)(node_of_sample ? node_of_sample[s] : s) * B + r; };
   const float wb1 = white_bkgd ? 1.0f : 0.0f;       // comp_rgb += 1 - acc (model_utils.py:307-308): every weight also carries -1 per channel
   float gC[3], bk[3], gTB[3] = {0.f, 0.f, 0.f};
@@ -188,13 +212,16 @@ __global__ void __launch_bounds__(64) composite_bwd_kernel(const float4* __restr
   }
   if (bd_cut) {
     for (int j = G - 1; j >= 0; --j) {
-      const int s = 4 * j + q;
+      const int s = L * j + q;
       if (s < S) {
         const float4 p = rows_pd[rec(s)];
         if (p.x >= bx0 && p.x <= bx1 && p.y >= by0 && p.y <= by1 && p.z >= bz0 && p.z <= bz1) { last_in = s; break; }
       }
     }
-    last_in = max(max(quad_bcast_i<0>(last_in), quad_bcast_i<1>(last_in)), max(quad_bcast_i<2>(last_in), quad_bcast_i<3>(last_in)));
+    int mx = ray_bcast_i<L>(last_in, 0);
+#pragma unroll
+    for (int i = 1; i < L; ++i) mx = max(mx, ray_bcast_i<L>(last_in, i));
+    last_in = mx;
   }
   float trA = 1.f;
   if (bg_scale != 0.f && trans[r] > 0.5f) {
@@ -213,7 +240,7 @@ __global__ void __launch_bounds__(64) composite_bwd_kernel(const float4* __restr
   }
   struct Rec { float4 d, rw; float t; };
   auto load = [&](int j) -> Rec {
-    int s = 4 * j + q;
+    int s = L * j + q;
     if (s > S - 1) s = S - 1;
     const size_t o = rec(s);
     Rec x;
@@ -235,13 +262,17 @@ __global__ void __launch_bounds__(64) composite_bwd_kernel(const float4* __restr
     Rec cur = load(0);
     for (int j = 0; j < G; ++j) {
       const Rec nxt = load(j + 1 < G ? j + 1 : j);
-      const int s = 4 * j + q;
-      const float t_up = quad_next(cur.t), t_grp = quad_bcast<0>(nxt.t);
+      const int s = L * j + q;
+      const float t_up = ray_next<L>(cur.t), t_grp = ray_bcast<L>(nxt.t, 0);
       float a, b2;
-      const float dd = dd_of(cur, s, q < 3 ? t_up : t_grp, a, b2);
+      const float dd = dd_of(cur, s, q < L - 1 ? t_up : t_grp, a, b2);
       const float ddB = (bd_cut && s > last_in) ? dd : 0.f;
-      cum = fadd(fadd(fadd(fadd(cum, quad_bcast<0>(dd)), quad_bcast<1>(dd)), quad_bcast<2>(dd)), quad_bcast<3>(dd));
-      cumB = fadd(fadd(fadd(fadd(cumB, quad_bcast<0>(ddB)), quad_bcast<1>(ddB)), quad_bcast<2>(ddB)), quad_bcast<3>(ddB));
+#pragma unroll
+      for (int i = 0; i < L; ++i) cum = fadd(cum, ray_bcast<L>(dd, i));
+      if (bd_cut) {
+#pragma unroll
+        for (int i = 0; i < L; ++i) cumB = fadd(cumB, ray_bcast<L>(ddB, i));
+      }
       cur = nxt;
     }
   }
@@ -252,28 +283,35 @@ __global__ void __launch_bounds__(64) composite_bwd_kernel(const float4* __restr
   // a chain that runs from the group's LAST sample to its first: x3 = v - b3, x2 = x3 - b2, ...; `mine` = value before this lane's
   // own term (lane 3: v), `out` = value after all four
   auto chain_sub = [&](float v, float term, float& mine_after, float& mine_before) -> float {
-    const float x3 = fsub(v, quad_bcast<3>(term)), x2 = fsub(x3, quad_bcast<2>(term)), x1 = fsub(x2, quad_bcast<1>(term));
-    const float x0 = fsub(x1, quad_bcast<0>(term));
-    mine_after = q == 3 ? v : (q == 2 ? x3 : (q == 1 ? x2 : x1));
-    mine_before = q == 3 ? x3 : (q == 2 ? x2 : (q == 1 ? x1 : x0));
-    return x0;
+    mine_after = v; mine_before = v;
+#pragma unroll
+    for (int i = L - 1; i >= 0; --i) {
+      if (q == i) mine_after = v;
+      v = fsub(v, ray_bcast<L>(term, i));
+      if (q == i) mine_before = v;
+    }
+    return v;
   };
-  auto chain_add = [&](float v, float term, float& mine) -> float {       // suffix sums: lane 3 sees v, lane 2 v + p3, ...
-    const float y3 = v + quad_bcast<3>(term), y2 = y3 + quad_bcast<2>(term), y1 = y2 + quad_bcast<1>(term);
-    mine = q == 3 ? v : (q == 2 ? y3 : (q == 1 ? y2 : y1));
-    return y1 + quad_bcast<0>(term);
+  auto chain_add = [&](float v, float term, float& mine) -> float {       // suffix sums: the last lane sees v, the one before it v + p_last, ...
+    mine = v;
+#pragma unroll
+    for (int i = L - 1; i >= 0; --i) {
+      if (q == i) mine = v;
+      v = v + ray_bcast<L>(term, i);
+    }
+    return v;
   };
   {
     Rec cur = load(G - 1);
     float t_first_of_next = 0.f;                            // depth of sample 4(j+1): lane 0 of the group processed before
     for (int j = G - 1; j >= 0; --j) {
       const Rec nxt = load(j > 0 ? j - 1 : 0);
-      const int s = 4 * j + q;
+      const int s = L * j + q;
       const bool valid = s < S;
-      const float t_up = quad_next(cur.t);
+      const float t_up = ray_next<L>(cur.t);
       float sgp, delta;
-      const float dd = dd_of(cur, s, q < 3 ? t_up : t_first_of_next, sgp, delta);
-      t_first_of_next = quad_bcast<0>(cur.t);
+      const float dd = dd_of(cur, s, q < L - 1 ? t_up : t_first_of_next, sgp, delta);
+      t_first_of_next = ray_bcast<L>(cur.t, 0);
       float my_after, my_before;
       cum_after = chain_sub(cum_after, dd, my_after, my_before);
       const float T_next = expf(-my_after);
@@ -470,6 +508,16 @@ __global__ void __launch_bounds__(256) resample_gather_kernel(const float4* __re
 
 using namespace rnerf;
 
+// lanes per ray of the compositing kernels (they are bound by the latency of a ray's chain of sample groups, not by throughput): 64 while a
+// ray per wave still fits one wave per SIMD (<= 1024 rays), 16 up to 8192 rays, 4 beyond.  Measured, forward / backward in us incl. launch
+// (tools/r04/composite_time.py): 128 or 512 rays x 192 samples 41 / 69 (4 lanes), 19 / 26 (16), 20 / 14-17 (64); 4096 x 128: 28 / 48, 20 / 22,
+// 63 / 81; 4096 x 192: 48 / 72, 27 / 32, 85 / 112; 32768 x 128: 53 / 85, 92 / 140, 364 / 444.  RNERF_COMPOSITE_LANES=4|16|64 forces one (A/B, tests).
+static int composite_lanes(int32_t B) {
+  static const int forced = [] { const char* e = getenv("RNERF_COMPOSITE_LANES"); const int v = e ? atoi(e) : 0; return (v == 4 || v == 16 || v == 64) ? v : 0; }();
+  if (forced) return forced;
+  return B <= 1024 ? 64 : (B <= 8192 ? 16 : 4);
+}
+
 extern "C" int rnerf_composite(const float* raw, const float* rows_pd, const float* rows_dr,
                                const int32_t* node_of_sample, int32_t S, int32_t B, const float* bkgd, int white_bkgd,
                                double rgb_padding, double sigma_bias, float* rgb, float* dist, float* acc, float* trans,
@@ -480,10 +528,14 @@ extern "C" int rnerf_composite(const float* raw, const float* rows_pd, const flo
   if (mask_mode != 0) for (int i = 0; i < 6; ++i) bb[i] = (float)bbox[i];
   RNERF_CHECK_ARG(S >= 1 && B >= 1, "rnerf_composite: need S >= 1 and B >= 1");
   RNERF_CHECK_ARG((((uintptr_t)raw | (uintptr_t)rows_pd | (uintptr_t)rows_dr) & 15) == 0, "rnerf_composite: float4 buffers must be 16-byte aligned");
-  hipLaunchKernelGGL(composite_kernel, dim3((B + 15) / 16), dim3(64), 0, (hipStream_t)stream, (const float4*)raw,
-                     (const float4*)rows_pd, (const float4*)rows_dr, node_of_sample, S, B, bkgd, white_bkgd,
-                     (float)(1 + 2 * rgb_padding), (float)rgb_padding, (float)sigma_bias, rgb, dist, acc, trans, trans_bkgd,
-                     weights, alpha, mask_mode, bb[0], bb[1], bb[2], bb[3], bb[4], bb[5]);
+#define RNERF_COMPOSITE_LAUNCH(LL)                                                                                              \
+  hipLaunchKernelGGL(composite_kernel<LL>, dim3((unsigned)(((long long)B * LL + 63) / 64)), dim3(64), 0, (hipStream_t)stream, (const float4*)raw, \
+                     (const float4*)rows_pd, (const float4*)rows_dr, node_of_sample, S, B, bkgd, white_bkgd,                     \
+                     (float)(1 + 2 * rgb_padding), (float)rgb_padding, (float)sigma_bias, rgb, dist, acc, trans, trans_bkgd,     \
+                     weights, alpha, mask_mode, bb[0], bb[1], bb[2], bb[3], bb[4], bb[5])
+  const int lanes = composite_lanes(B);
+  if (lanes == 4) RNERF_COMPOSITE_LAUNCH(4); else if (lanes == 16) RNERF_COMPOSITE_LAUNCH(16); else RNERF_COMPOSITE_LAUNCH(64);
+#undef RNERF_COMPOSITE_LAUNCH
   RNERF_CHECK_LAUNCH();
   return RNERF_OK;
 }
@@ -806,12 +858,16 @@ extern "C" int rnerf_composite_backward(const float* raw, const float* rows_pd, 
   RNERF_CHECK_ARG(S >= 1 && B >= 1, "rnerf_composite_backward: need S >= 1 and B >= 1");
   RNERF_CHECK_ARG((((uintptr_t)raw | (uintptr_t)rows_pd | (uintptr_t)rows_dr | (uintptr_t)d_raw) & 15) == 0,
                   "rnerf_composite_backward: float4 buffers must be 16-byte aligned");
-  hipLaunchKernelGGL(composite_bwd_kernel, dim3((B + 15) / 16), dim3(64), 0, (hipStream_t)stream, (const float4*)raw,
-                     (const float4*)rows_pd, (const float4*)rows_dr, node_of_sample, S, B, bkgd, (float)(1 + 2 * rgb_padding),
-                     (float)rgb_padding, (float)sigma_bias, rgb, pixels, trans, trans_bkgd, sums, (float)mse_scale, (float)bg_scale,
-                     (float4*)d_raw, d_bkgd, accumulate_bkgd, bd_cut_bbox != nullptr, bd_cut_bbox ? (float)bd_cut_bbox[0] : 0.f,
-                     bd_cut_bbox ? (float)bd_cut_bbox[1] : 0.f, bd_cut_bbox ? (float)bd_cut_bbox[2] : 0.f, bd_cut_bbox ? (float)bd_cut_bbox[3] : 0.f,
-                     bd_cut_bbox ? (float)bd_cut_bbox[4] : 0.f, bd_cut_bbox ? (float)bd_cut_bbox[5] : 0.f, white_bkgd);
+#define RNERF_COMPOSITE_BWD_LAUNCH(LL)                                                                                          \
+  hipLaunchKernelGGL(composite_bwd_kernel<LL>, dim3((unsigned)(((long long)B * LL + 63) / 64)), dim3(64), 0, (hipStream_t)stream, (const float4*)raw, \
+                     (const float4*)rows_pd, (const float4*)rows_dr, node_of_sample, S, B, bkgd, (float)(1 + 2 * rgb_padding),   \
+                     (float)rgb_padding, (float)sigma_bias, rgb, pixels, trans, trans_bkgd, sums, (float)mse_scale, (float)bg_scale, \
+                     (float4*)d_raw, d_bkgd, accumulate_bkgd, bd_cut_bbox != nullptr, bd_cut_bbox ? (float)bd_cut_bbox[0] : 0.f,  \
+                     bd_cut_bbox ? (float)bd_cut_bbox[1] : 0.f, bd_cut_bbox ? (float)bd_cut_bbox[2] : 0.f, bd_cut_bbox ? (float)bd_cut_bbox[3] : 0.f, \
+                     bd_cut_bbox ? (float)bd_cut_bbox[4] : 0.f, bd_cut_bbox ? (float)bd_cut_bbox[5] : 0.f, white_bkgd)
+  const int lanes = composite_lanes(B);
+  if (lanes == 4) RNERF_COMPOSITE_BWD_LAUNCH(4); else if (lanes == 16) RNERF_COMPOSITE_BWD_LAUNCH(16); else RNERF_COMPOSITE_BWD_LAUNCH(64);
+#undef RNERF_COMPOSITE_BWD_LAUNCH
   RNERF_CHECK_LAUNCH();
   return RNERF_OK;
 }
