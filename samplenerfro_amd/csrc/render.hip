@@ -373,12 +373,13 @@ __global__ void __launch_bounds__(64) composite_bwd_kernel(const float4* __restr
 //      (:415-421) from an arithmetic guess + gallop + bisection (node depths are near + ~k*step), then the gather
 //      pos = path_pos[idx] + dir[idx]*(z - z_vals[idx]) (:423-427).  Neighbouring lanes = neighbouring rays at the same
 //      sample index, whose node indices nearly coincide, so the probes and gathers of a wave are near-contiguous.
-template <int RPB>      // rays per 64-lane block: 16 (a quad per ray); 4 or 1 when S and F do not fit the LDS staging at 16 (quads then duplicate rays)
+template <int RPB>      // rays per 64-lane block: 16 (a quad per ray), 4 (16 lanes per ray) or 1 (the whole wave): few rays, or S and F beyond the LDS staging at 16
 __global__ void __launch_bounds__(64) resample_depths_kernel(const float4* __restrict__ path_pd, int B,
                                                              const int* __restrict__ jitter, int S,
                                                              const float* __restrict__ weights, const float* __restrict__ u,
                                                              int u_per_ray, int F, float* __restrict__ zbuf) {
-  // Four lanes (a quad) per ray, 16 rays per wave.  LDS arrays are [index][16 rays] (quad lanes hit consecutive banks):
+  // L = 64 / RPB lanes per ray (like the compositing kernels: the work is a per-ray chain of dependent LDS round trips, so few rays are
+  // given more lanes each).  LDS arrays are [index][RPB rays] (a ray's lanes hit consecutive banks):
   //   tcA[S] coarse depths, wA[S] coarse weights -> pdf terms, cdfA[S-1], zfA[F] fine depths, mgA[S+F] merged depths.
   // Only two chains are inherently sequential — the weight sum and the cdf prefix sum; both are replayed in index order through
   // quad broadcasts (same individually rounded additions as a one-lane loop).  The inverse-CDF lookups and the merge of the two
@@ -386,22 +387,25 @@ __global__ void __launch_bounds__(64) resample_depths_kernel(const float4* __res
   extern __shared__ float lds[];
   float* tcA = lds; float* wA = tcA + (size_t)S * RPB; float* cdfA = wA + (size_t)S * RPB; float* zfA = cdfA + (size_t)S * RPB;
   float* mgA = zfA + (size_t)F * RPB;
-  const int lane = threadIdx.x, q = lane & 3, rl = (lane >> 2) % RPB;  // rl = ray within the block
+  constexpr int L = 64 / RPB;
+  const int lane = threadIdx.x, q = lane & (L - 1), rl = lane / L;     // rl = ray within the block
   const int r0 = blockIdx.x * RPB + rl;
   const int r = r0 < B ? r0 : B - 1;
   const int nb = S - 1;        // number of bin edges / cdf entries
   const int nw = S - 2;        // number of weights
-  for (int i = q; i < S; i += 4) {
+  for (int i = q; i < S; i += L) {
     tcA[i * RPB + rl] = path_pd[(size_t)jitter[i] * B + r].w;
     wA[i * RPB + rl] = weights[(size_t)i * B + r];
   }
   __syncthreads();
-  auto acc4 = [&](float a, float p) -> float {      // (((a + p0) + p1) + p2) + p3
-    return fadd(fadd(fadd(fadd(a, quad_bcast<0>(p)), quad_bcast<1>(p)), quad_bcast<2>(p)), quad_bcast<3>(p));
+  auto acc4 = [&](float a, float p) -> float {      // (((a + p0) + p1) + p2) + ...
+#pragma unroll
+    for (int i = 0; i < L; ++i) a = fadd(a, ray_bcast<L>(p, i));
+    return a;
   };
   // weight_sum, padding (model_utils.py:327-331): sequential sum of w[1..S-2]
   float wsum = 0.f;
-  for (int j = 0; j < nw; j += 4) {
+  for (int j = 0; j < nw; j += L) {
     const int i = j + q;
     wsum = acc4(wsum, i < nw ? wA[(i + 1) * RPB + rl] : 0.f);
   }
@@ -410,21 +414,23 @@ __global__ void __launch_bounds__(64) resample_depths_kernel(const float4* __res
   wsum = fadd(wsum, padding);
   // cdf[0] = 0, cdf[k] = min(1, P_{k-1}) for 1 <= k <= nb-2 with P_m = P_{m-1} + (w[m+1] + padw) / wsum, cdf[nb-1] = 1  (:335-340)
   float cum = 0.f;
-  for (int j = 0; j < nw; j += 4) {
+  for (int j = 0; j < nw; j += L) {
     const int m = j + q;
     const float term = m < nw ? fdiv(fadd(wA[(m + 1) * RPB + rl], padw), wsum) : 0.f;
-    const float t0 = quad_bcast<0>(term), t1 = quad_bcast<1>(term), t2 = quad_bcast<2>(term), t3 = quad_bcast<3>(term);
     // the serial code starts the running sum AT the first term (no 0 + term), so P_0 is the term itself
-    const float c0 = (j == 0) ? t0 : fadd(cum, t0);
-    const float c1 = fadd(c0, t1), c2 = fadd(c1, t2), c3 = fadd(c2, t3);
-    const float mine = q == 0 ? c0 : (q == 1 ? c1 : (q == 2 ? c2 : c3));
+    float mine = 0.f;
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+      const float ti = ray_bcast<L>(term, i);
+      cum = (j == 0 && i == 0) ? ti : fadd(cum, ti);
+      if (q == i) mine = cum;
+    }
     if (m + 1 <= nb - 2) cdfA[(m + 1) * RPB + rl] = fminf(1.f, mine);
-    cum = c3;
   }
   if (q == 0) { cdfA[rl] = 0.f; cdfA[(nb - 1) * RPB + rl] = 1.f; }
   __syncthreads();
   // fine depths: interval i = #{k in [1, nb-2] : cdf[k] <= u} (the walk of :360-370), then the affine map inside it (:372-373)
-  for (int j = q; j < F; j += 4) {
+  for (int j = q; j < F; j += L) {
     const float uj = u_per_ray ? u[(size_t)j * B + r] : u[j];
     int lo = 1, hi = nb - 1;                                       // first k in [1, nb-1) with cdf[k] > uj
     while (lo < hi) { const int mid = (lo + hi) >> 1; if (cdfA[mid * RPB + rl] > uj) hi = mid; else lo = mid + 1; }
@@ -439,13 +445,13 @@ __global__ void __launch_bounds__(64) resample_depths_kernel(const float4* __res
   }
   __syncthreads();
   // merge of the two sorted lists (jnp.sort of the concatenation, :405; coarse first on ties): rank by binary search
-  for (int i = q; i < S; i += 4) {
+  for (int i = q; i < S; i += L) {
     const float z = tcA[i * RPB + rl];
     int lo = 0, hi = F;                                            // #{j : zf[j] < z}
     while (lo < hi) { const int mid = (lo + hi) >> 1; if (zfA[mid * RPB + rl] < z) lo = mid + 1; else hi = mid; }
     mgA[(i + lo) * RPB + rl] = z;
   }
-  for (int j = q; j < F; j += 4) {
+  for (int j = q; j < F; j += L) {
     const float z = zfA[j * RPB + rl];
     int lo = 0, hi = S;                                            // #{i : tc[i] <= z}
     while (lo < hi) { const int mid = (lo + hi) >> 1; if (tcA[mid * RPB + rl] <= z) lo = mid + 1; else hi = mid; }
@@ -552,7 +558,11 @@ extern "C" int rnerf_resample(const float* path_pd, const float* path_dr, int32_
   RNERF_CHECK_ARG((((uintptr_t)path_pd | (uintptr_t)path_dr | (uintptr_t)rows_pd | (uintptr_t)rows_dr) & 15) == 0,
                   "rnerf_resample: float4 buffers must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
-  const int rpb = need <= 2560 ? 16 : (need <= 10240 ? 4 : 1);             // rays per block: as many as the 160 KiB of LDS hold
+  // rays per block: 64 / (lanes per ray), the lanes as for the compositing kernels (few rays: more lanes each), and no more rays than the
+  // 160 KiB of LDS hold
+  int rpb = 64 / composite_lanes(B);
+  if (rpb > 4 && need > 2560) rpb = 4;
+  if (rpb > 1 && need > 10240) rpb = 1;
   const size_t lds = (size_t)need * rpb * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {

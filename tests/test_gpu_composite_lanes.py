@@ -1,4 +1,4 @@
-"""Compositing forward / backward with 4, 16 or 64 lanes per ray: the same bits.
+"""Compositing forward / backward and the resampling with 4, 16 or 64 lanes per ray: the same bits.
 
 The kernels replay every ordered sum (optical depth, the five accumulations, the backward's suffix chains) in sample order whatever the
 number of lanes that share a ray's activations (csrc/render.hip: composite_kernel<L>, composite_bwd_kernel<L>), so the width is a pure
@@ -42,6 +42,19 @@ for tag, (S, B, bd) in {"a": (67, 301, False), "b": (192, 50, True), "c": (5, 9,
                                          bd_cut_bbox=bbox)
     torch.cuda.synchronize()
     out["bwd_" + tag] = [h(d_raw), h(d_bk)]
+# resampling along a path (sample_pdf): the weight-sum / cdf chains and the searches with 4 / 16 / 64 lanes per ray
+for tag, (Sc, P, F, B) in {"r1": (16, 4, 24, 77), "r2": (64, 3, 128, 19)}.items():
+    rng = np.random.default_rng(Sc + B)
+    N = Sc * P
+    tn = np.sort(rng.uniform(2, 6, (N, B)).astype(np.float32), 0)
+    ppd = np.concatenate([rng.uniform(-1, 1, (N, B, 3)).astype(np.float32), tn[..., None]], -1)
+    pdr = np.concatenate([rng.standard_normal((N, B, 3)).astype(np.float32), np.zeros((N, B, 1), np.float32)], -1)
+    jit = (np.arange(Sc) * P + rng.integers(0, P, Sc)).astype(np.int32)
+    wts = rng.uniform(0, 1, (Sc, B)).astype(np.float32); wts[:, 3] = 0.0                      # one ray without any weight (the padding branch)
+    u = np.sort(rng.uniform(0, 1 - 1e-6, (F, B)).astype(np.float32), 0)
+    rp, rd, idx = ops.resample(T(ppd), T(pdr), T(jit), T(wts), T(u), F, want_idx=True)
+    out["resample_" + tag] = [h(rp), h(rd), h(idx)]
+torch.cuda.synchronize()
 print("RESULT " + json.dumps(out))
 """ % ROOT
 
@@ -56,7 +69,7 @@ def _run(lanes):
 @pytest.mark.gpu
 def test_compositing_gives_the_same_bits_for_every_lane_count():
     ref = _run(4)
-    assert len(ref) >= 8
+    assert len(ref) >= 10
     for lanes in (16, 64):
         got = _run(lanes)
         for k in sorted(ref):
