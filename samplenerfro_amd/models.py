@@ -302,10 +302,11 @@ class NerfModel:
         return self._tail2
 
     def comm_stream(self) -> torch.cuda.Stream:
-        """The stream the train step's NerfMLP-gradient all-reduce is issued from (rnerf_train_cfg.grads_stream: ordered behind the last wgrad)."""
-        if getattr(self, "_comm", None) is None:
-            self._comm = shared_stream(self.device, "comm")
-        return self._comm
+        """The stream the train step's NerfMLP-gradient all-reduce is issued from (rnerf_train_cfg.grads_stream: ordered behind the last wgrad).
+        It IS the tail stream: that one is idle from the step's last join to the next step's first fork — exactly where the collective is
+        issued (the process group runs it on a stream of its own and only takes its ordering from here) —, and one stream fewer is one
+        hardware queue more for the others (shared_stream)."""
+        return self.tail_stream()
 
     def release_reserved_cus(self) -> None:
         """Give the CUs reserved by prefetch_path(reserve_cus > 0) back to the MLP kernels."""

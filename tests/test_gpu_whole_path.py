@@ -338,6 +338,6 @@ def test_side_streams_are_shared_by_every_model_of_the_process():
     from samplenerfro_amd.models import shared_stream
     a, _, _, _ = _scene(Nf=0, B=32)
     b, _, _, _ = _scene(Nf=24, B=32)
-    assert a.tail_stream() is b.tail_stream() and a.comm_stream() is b.comm_stream()
-    assert a.tail_stream().cuda_stream != a.comm_stream().cuda_stream
+    assert a.tail_stream() is b.tail_stream() and a.comm_stream() is b.tail_stream()      # the collective is issued from the (then idle) tail stream
+    assert a.tail_stream().cuda_stream != shared_stream(a.device, "march").cuda_stream
     assert shared_stream(a.device, "march") is shared_stream(a.device, "march")
