@@ -37,10 +37,13 @@ def shared_stream(device, role: str) -> "torch.cuda.Stream":
     hardware queues (GPU_MAX_HW_QUEUES, 4 by default), assigned in creation order: a process that gives every model its own march / tail /
     collective streams soon has two streams of ONE model on one queue, and the work they were meant to overlap runs in sequence (measured:
     a 128-ray train step 1.11 -> 1.46 ms inside the bench, which builds seven models; tools/r04/variant_probe.sh)."""
-    key = (str(torch.device(device)), role)
+    d = torch.device(device)
+    if d.index is None:                     # "cuda" and "cuda:<current>" are one device: one key
+        d = torch.device("cuda", torch.cuda.current_device())
+    key = (str(d), role)
     s = _STREAMS.get(key)
     if s is None:
-        s = _STREAMS[key] = torch.cuda.Stream(device=device)
+        s = _STREAMS[key] = torch.cuda.Stream(device=d)
     return s
 
 
