@@ -719,19 +719,19 @@ def main():
                        "pipeline": ("none" if not args.pipeline else ("march(k+1) on a side branch beside the tail of step k" if train
                                                                           else "march(k+1) on a side stream overlaps MLP(k)"))},
             "roofline": {"kernel": "nerfmlp_fwd_kernel", "bound": "mfma", "achieved": mlp_achieved / 1e12, "peak": PEAK_MFMA_16BIT / 1e12,
-                         "unit": "TFLOP/s", "frac": mlp_achieved / PEAK_MFMA_16BIT, "traffic": traffic_of("nerfmlp_fwd_kernel<%d, 0, 0>" % prec_fwd),
+                         "unit": "TFLOP/s", "frac": mlp_achieved / PEAK_MFMA_16BIT, "traffic": traffic_of("nerfmlp_fwd_kernel<%d, 0, 0," % prec_fwd),
                          "avg_launch_ms": mlp_ms, "algorithmic_flop_per_launch": mlp_flops,
                          # computed, not a counter: MFMA flops issued (3 passes in the x3 modes) / (launch time x 2.5 PF)
                          "precision": prec_fwd_name,
                          "mfma_issue_frac_computed": {"f16x3": 3, "bf16x3": 3, "f16x2": 2, "f16f8": 3}.get(prec_fwd_name, 1) * mlp_achieved / PEAK_MFMA_16BIT,
-                         "counters": counters_of("nerfmlp_fwd_kernel<%d, 0, 0>" % prec_fwd)},
+                         "counters": counters_of("nerfmlp_fwd_kernel<%d, 0, 0," % prec_fwd)},
             "roofline_march": {"kernel": "march_kernel", "bound": "hbm", "achieved": march_achieved / 1e9, "peak": PEAK_HBM / 1e9,
                                "unit": "GB/s", "frac": march_achieved / PEAK_HBM, "traffic": traffic_of("march_kernel"), "avg_launch_ms": march_ms,
                                "algorithmic_bytes_per_launch": march_bytes},
         }
         if train:
             # the dominant kernel of a train step: the longest of training forward / dgrad / wgrad (algorithmic FLOP against the MFMA peak)
-            fk = "nerfmlp_fwd_kernel<1, 0, 2>" if args.backward == "f32" else "nerfmlp_fwd_kernel<1, 0, 1>"
+            fk = "nerfmlp_fwd_kernel<1, 0, 2," if args.backward == "f32" else "nerfmlp_fwd_kernel<1, 0, 1,"      # (+ the tile-size argument)
             for tk, pref in zip(train_kernels, (fk, "nerfmlp_dgrad_kernel", "nerfmlp_wgrad")):
                 tk["traffic"] = traffic_of(pref)
                 tk["counters"] = counters_of(pref)
