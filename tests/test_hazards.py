@@ -41,3 +41,22 @@ def test_the_checker_flags_both_patterns():
     f = H.check(mk([("v_mfma_f32_32x32x16_f16 v[0:15], v[20:23], v[24:27], v[0:15]", False), ("s_nop 7", False), ("s_nop 3", False),
                     ("v_fma_mix_f32 v30, v3, v31, v32", True)]))
     assert f == []
+    # the incident of round 4 (csrc/bkgd16.hip, never shipped): a three-instruction f16 hi / lo split as inline asm whose last partial-register
+    # write (v_fma_mixhi_f16) sat right in front of the MFMA that read the word — NaN outputs on the device, bit-correct in isolation
+    f = H.check(mk([("v_cvt_pk_f16_f32 v30, v122, v123", True), ("v_fma_mixlo_f16 v33, v141, -1.0, v148 op_sel_hi:[1,0,0]", True),
+                    ("v_fma_mixhi_f16 v33, v141, -1.0, v149 op_sel:[1,0,0] op_sel_hi:[1,0,0]", True),
+                    ("v_mfma_f32_32x32x16_f16 a[0:15], v[138:141], v[30:33], a[0:15]", False)]))
+    assert f and all(x[0] == "H1" for x in f)
+
+
+def test_no_hazards_in_the_background_mlp_build():
+    """csrc/bkgd16.hip (f16 hi + lo background MLP): MFMAs but, since the incident above, no inline asm — the scan must stay clean if any returns."""
+    import hazard_check as H
+    asm = H.compile_to_asm(os.path.join(ROOT, "samplenerfro_amd", "csrc", "bkgd16.hip"), [])
+    try:
+        funcs = H.parse(asm)
+    finally:
+        os.unlink(asm)
+    assert sum(1 for c in funcs.values() for ins in c if ins[0].startswith("v_mfma")) > 300
+    assert not H.check(funcs)
+
