@@ -573,11 +573,12 @@ def main():
             vrays = Rays(torch.from_numpy(ov).to(device), None, torch.from_numpy(dv).to(device), None)
             sv = Stepper(args, vcfg, vmodel, vvars, vrays, key, vB, world, rank, vfine, device, args.backward, "train", vstage,
                          args.pipeline and vstage == "radiance", args.graph and vstage == "radiance")
-            dtv = timed_steps(sv, 2, 5, barrier, D, device)
+            nv = 5 if vB >= 4096 else 20          # sub-millisecond steps: 5 timed steps are ~5 ms of wall clock — too few to be a steady state
+            dtv = timed_steps(sv, 2 if vB >= 4096 else 4, nv, barrier, D, device)
             sv.close()
             torch.cuda.empty_cache()
-            variants[tag] = {"ms_per_step": 1e3 * dtv / 5, "rays_per_s": vB * world * 5 / dtv, "rays_per_gpu": vB, "coarse": vcfg["S"], "fine": vfine,
-                             "what": note}
+            variants[tag] = {"ms_per_step": 1e3 * dtv / nv, "rays_per_s": vB * world * nv / dtv, "rays_per_gpu": vB, "steps": nv, "coarse": vcfg["S"],
+                             "fine": vfine, "what": note}
 
         vm = models_with_fine(model, cfg, 256, device, args.precision)
         run_variant("ship_straight_128+256", cfg, vm[0], vm[1], 256, 4096, "BASELINE configs[1], hierarchical (N_f = 2S: 512 MLP rows per ray)")
