@@ -737,7 +737,9 @@ def main():
                 tk["traffic"] = traffic_of(pref)
                 tk["counters"] = counters_of(pref)
             line["roofline_forward_kernel"] = line["roofline"]
-            line["roofline"] = max(train_kernels, key=lambda t: t["avg_launch_ms"])
+            # (the three are within 5 % of each other alone; IN the step the wgrad carries the next batch's march as co-resident waves and is
+            #  the longest by 8-10 % — profiles/r04/train_step_timeline.txt —, so a near-tie goes to it: the named kernel does not flip from box to box)
+            line["roofline"] = max(train_kernels, key=lambda t: t["avg_launch_ms"] * (1.08 if "wgrad" in t["kernel"] else 1.0))
             line["roofline_train_kernels"] = train_kernels
             # the whole step against the MFMA peak: SURVEY §8(d)'s algorithmic FLOP (forward + dgrad + wgrad ~ 3 x forward) / ms_per_step
             step_flop = 3.0 * flop_per_ray_fwd * B
