@@ -46,7 +46,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = _hipcc()
     headers = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "rnerf.h"),
                os.path.join(CSRC, "ior_train_kernels.inc"), os.path.join(CSRC, "ior_train_api.inc"), os.path.join(CSRC, "nerfmlp_layout.h"),
-               os.path.join(CSRC, "mfma_ops.h"), os.path.join(CSRC, "bkgd_layout.h")]
+               os.path.join(CSRC, "mfma_ops.h"), os.path.join(CSRC, "bkgd_layout.h"), os.path.join(CSRC, "so3_layout.h")]
     objs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)

@@ -3,6 +3,7 @@
 // The exact-fp32 kernels of the same network (the arbiter of this file: RNERF_BKGD_EXACT=1) and the backward kernels live in csrc/mlp.hip.
 #include "mfma_ops.h"
 #include "bkgd_layout.h"
+#include "so3_layout.h"
 
 namespace rnerf {
 
@@ -215,6 +216,90 @@ int launch_bkgd16_fwd(bool train, const float* params, const float* dirs, int di
   const dim3 grid((unsigned)((n + 31) / 32));
   if (train) hipLaunchKernelGGL(bkgd16_fwd_kernel<true>, grid, dim3(64), 0, st, params, dirs, dir_stride, n, pad_scale, pad, out_rgb, save);
   else hipLaunchKernelGGL(bkgd16_fwd_kernel<false>, grid, dim3(64), 0, st, params, dirs, dir_stride, n, pad_scale, pad, out_rgb, save);
+  RNERF_CHECK_LAUNCH();
+  return RNERF_OK;
+}
+
+// ---- so3_mlp: the training forward of stage "all*" on the same arithmetic --------------------------------------------------------------
+// MLP(128, 4, skip 2, out 3) on the 60 windowed encoding features (rnerf/ior_utils.py:148-152, rnerf/model_utils.py:236-245): lane half h
+// holds feature 2 p + h in enc[p] (so3_encode), i.e. four k-steps of 8 slots with p = 8 s + j, slot p = 30 free for the bias.  The prev-layer
+// blocks are the background MLP's (same [128][128] kernels, same slot map).  Saved tensors: the layout of so3_fwd_train_kernel (the exact-fp32
+// kernel of csrc/ior_train_kernels.inc, which stays selectable with RNERF_BKGD_EXACT=1 and is what the backward kernels were written against).
+template <bool FIRST>
+__device__ __forceinline__ void so3_16_enc_layer(f32x16 (&acc)[4], const float (&enc)[30], const float* __restrict__ pe, const Bkgd16Lane& L, int koff, int boff) {
+  bkgd16_layer<4, FIRST>(acc,
+      [&](int s, int t, int j) { const int p = 8 * s + j; return p < 30 ? pe[koff + 2 * p * 128 + 32 * t] : L.p0[boff + 32 * t]; },
+      [&](int s, int j) { const int p = 8 * s + j; return p < 30 ? 1 : (p == 30 ? 2 : 0); }, L.half0,
+      [&](int s, uint4& bh, uint4& bl) {
+    float xv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const int p = 8 * s + j; xv[j] = p < 30 ? enc[p < 30 ? p : 0] : ((p == 30 && L.half0) ? 1.0f : 0.f); }
+    bkgd16_split8(xv, bh, bl);
+  });
+}
+
+__global__ void __launch_bounds__(64) so3_16_fwd_train_kernel(const float* __restrict__ params, So3Window win, const float4* __restrict__ pts, long long n,
+                                                              float* __restrict__ save) {
+  const int lane = threadIdx.x & 63, m = lane & 31, h = lane >> 5;
+  long long row = (long long)blockIdx.x * 32 + m;
+  const bool ok = row < n;
+  if (!ok) row = n - 1;
+  const float4 pt = pts[row];
+  float enc[30];
+  so3_encode(pt.x, pt.y, pt.z, win, h, enc);
+  if (ok) {
+#pragma unroll
+    for (int p = 0; p < 30; ++p) save[(size_t)row * 60 + 2 * p + h] = enc[p];
+  }
+  auto save_x = [&](int k, const f32x16 (&xx)[4]) {     // X_k[row][f], f = 32t + 8g + 4h + i
+    if (ok) {
+      float* dst = save + (size_t)n * 60 + (size_t)(k - 1) * n * 128 + (size_t)row * 128;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *(float4*)(dst + 32 * t + 8 * g + 4 * h) = make_float4(xx[t][4 * g], xx[t][4 * g + 1], xx[t][4 * g + 2], xx[t][4 * g + 3]);
+    }
+  };
+  constexpr float INV = 1.0f / 256.0f;
+  f32x16 acc[4], x[4];
+  auto relu_to_x = [&]() {      // x = ReLU(acc 2^-8)   (not fmaxf: a NaN of an out-of-range f16 operand must reach the output)
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { const float y = acc[t][r] * INV; x[t][r] = y < 0.f ? 0.f : y; }
+  };
+  const Bkgd16Lane L = bkgd16_lane(params, m, h);
+  const float* __restrict__ pe = params + m + 128 * h;       // kernel row 2 p + h of an encoding block = pe[block + 2 p * 128]
+  so3_16_enc_layer<true>(acc, enc, pe, L, so3_koff(0), so3_boff(0));
+  relu_to_x();
+  save_x(1, x);
+  bkgd16_prev_layer<true>(acc, x, L, so3_koff(1), so3_boff(1));
+  relu_to_x();
+  save_x(2, x);
+  bkgd16_prev_layer<true>(acc, x, L, so3_koff(2), so3_boff(2));
+  relu_to_x();
+  save_x(3, x);
+  bkgd16_prev_layer<false>(acc, x, L, so3_koff(3), 0);                                   // Dense_3: [x(128), inputs(60)] (skip concat after i == 2)
+  so3_16_enc_layer<false>(acc, enc, pe, L, so3_koff(3) + 128 * 128, so3_boff(3));
+  relu_to_x();
+  save_x(4, x);
+  float o[3] = {0.f, 0.f, 0.f};
+  const float* __restrict__ k4 = params + so3_koff(4);
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int f = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+      o[0] = fmaf(x[t][r], k4[f * 3 + 0], o[0]); o[1] = fmaf(x[t][r], k4[f * 3 + 1], o[1]); o[2] = fmaf(x[t][r], k4[f * 3 + 2], o[2]);
+    }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) o[c] = o[c] + __shfl_xor(o[c], 32) + params[so3_boff(4) + c];
+  if (ok && h == 0) *(float4*)(save + (size_t)n * (60 + 4 * 128) + (size_t)row * 4) = make_float4(o[0], o[1], o[2], 0.f);
+}
+
+int launch_so3_16_fwd_train(const float* params, So3Window win, const float* pts4, long long n, float* save, hipStream_t st) {
+  hipLaunchKernelGGL(so3_16_fwd_train_kernel, dim3((unsigned)((n + 31) / 32)), dim3(64), 0, st, params, win, (const float4*)pts4, n, save);
   RNERF_CHECK_LAUNCH();
   return RNERF_OK;
 }

@@ -21,6 +21,7 @@
 #include "nerfmlp_layout.h"
 #include "mfma_ops.h"
 #include "bkgd_layout.h"
+#include "so3_layout.h"
 
 #include <stdlib.h>
 #include <type_traits>
@@ -2156,20 +2157,6 @@ __global__ void __launch_bounds__(64) bkgd_fwd_kernel(const float* __restrict__ 
 // rnerf/model_utils.py:236-245), the Rodrigues rotation of grad n by that axis-angle (ior_utils.py:305-312), and the march
 // that uses it (rnerf/eikonal_utils.py:34-39).  Same exact-fp32 MFMA chain as the background MLP; one wave = 32 points.
 // ------------------------------------------------------------------------------------------------------------------
-__host__ __device__ constexpr DenseShape so3_dense(int d) {
-  constexpr DenseShape t[5] = {{60, 128}, {128, 128}, {128, 128}, {188, 128}, {128, 3}};
-  return t[d];
-}
-__host__ __device__ constexpr int so3_koff(int d) {
-  int o = 0;
-  for (int i = 0; i < d; ++i) o += so3_dense(i).in * so3_dense(i).out + so3_dense(i).out;
-  return o;
-}
-__host__ __device__ constexpr int so3_boff(int d) { return so3_koff(d) + so3_dense(d).in * so3_dense(d).out; }
-static_assert(so3_koff(5) == RNERF_SO3MLP_PARAMS, "so3 MLP parameter count");
-
-struct So3Window { float w[10]; };   // cosine_easing_window(0, 9, 10, annealed_alpha * 10), computed by the host (model_utils.py:218-233)
-
 // K=2 steps over the 60 annealed features: step p, half h -> feature 2p + h = 6d + 3*is_cos + c with d = p / 3 for both halves
 __device__ __forceinline__ void so3_enc_layer(f32x16 (&acc)[4], const float (&enc)[30], const float* __restrict__ kern, int m, int h) {
   const float* __restrict__ kl = kern + h * 128 + m;
