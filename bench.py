@@ -367,6 +367,17 @@ def main():
                          "(BASELINE config 4 as written: 4096 rays = 512 per GPU on 8 GPUs)")
     ap.add_argument("--mode", choices=["train", "forward"], default="train",
                     help="train: the whole optimisation step (BASELINE metric 'rays/sec (train step)'); forward: the render pass only")
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                    help="nccl = RCCL over xGMI, one rank per GPU (default); gloo lets the tests drive the multi-rank branch with several ranks on one device")
+    ap.add_argument("--dist-timeout", type=float, default=300.0,
+                    help="seconds a rendezvous / collective may take before the rank fails (a dead rank takes the job down, it never hangs it)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="bring the process group up and issue every collective with ONE rank too (how RCCL itself is exercised on a one-GPU box)")
+    ap.add_argument("--no-curve", dest="curve", action="store_false",
+                    help="N > 1: skip the in-run scaling curve (the same step on the first 1, 2, 4, ... ranks of this launch)")
+    ap.add_argument("--variant-rays", type=int, default=4096, help=argparse.SUPPRESS)   # rays per rank of the ship_* variants: several ranks that SHARE one
+    ap.add_argument("--fail-rank", type=int, default=-1, help=argparse.SUPPRESS)      # fault injection for tests/test_rank_failure.py: this rank
+    ap.add_argument("--fail-mode", choices=["exit", "hang"], default="exit", help=argparse.SUPPRESS)   # dies / stops responding after the warm-up
     args = ap.parse_args()
     relaunch_for_gpus(args)
     if args.pipeline is None:
@@ -387,14 +398,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit(f"bench.py needs a ROCm GPU (the hot path has no CPU implementation) [rank {rank} of {world}]")
-    # one process per GPU (RCCL).  RNERF_DIST_BACKEND=gloo lets the tests drive this very branch with two ranks on one device
-    backend = os.environ.get("RNERF_DIST_BACKEND", "nccl")
-    local_rank = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
+    # one process per GPU (RCCL).  --dist-backend gloo lets the tests drive this very branch with several ranks on one device
+    backend = args.dist_backend
+    if backend == "nccl" and local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} has LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} device(s) are visible "
+                         "(RCCL runs one rank per GPU)")
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     from samplenerfro_amd import distributed as D
     os.environ["LOCAL_RANK"] = str(local_rank)
-    D.init(backend)   # the train step's gradient all-reduce, the timing barrier and the max over ranks
+    if args.force_dist:
+        D.force_single_rank_group(True)
+    D.init(backend, timeout_s=args.dist_timeout)   # the train step's gradient all-reduce, the timing barrier and the max over ranks
 
     cfg = dict(syn.CONFIGS[args.workload])
     fine = cfg["F"] if args.fine is None else args.fine
@@ -416,16 +432,36 @@ def main():
     train = args.mode == "train"
 
     def barrier():
-        if D.active():
-            dist.barrier()
+        D.barrier()             # (over the ranks the collectives currently run on: all of them, or the scaling curve's sub-group)
         torch.cuda.synchronize()
 
     # ---- the headline: W untimed warm-up steps, then exactly K timed steps between barriers, max over ranks --------------------------
     # Every step does its whole work inside the timed region; with the pipeline on, step k also marches the rays of step k+1 (one march
     # per step either way: the first timed step consumes the march the last warm-up step issued, the last one issues one nobody reads).
     stepper = Stepper(args, cfg, model, variables, rays, key, B, world, rank, fine, device, args.backward, args.mode, args.stage, args.pipeline, args.graph)
+    if args.fail_rank == rank:          # fault injection (tests/test_rank_failure.py): the others must exit non-zero within --dist-timeout
+        if args.fail_mode == "exit":
+            os._exit(17)
+        time.sleep(20.0 * args.dist_timeout)
     dt = timed_steps(stepper, args.warmup, args.steps, barrier, D, device)
     graph_used = stepper.g is not None
+    replicas = None
+    if train and D.active():
+        # data-parallel invariants after every step so far (prime + warm-up + timed): the replicas' parameters are the same BITS (every rank
+        # applied the same Adam arithmetic to the same reduced gradient) although every rank drew its own rays and keys (train.py:338-339)
+        iv = stepper.tstate.theta.detach().view(torch.int32).to(torch.int64)
+        sig = torch.stack([iv.sum(), (iv * (torch.arange(iv.numel(), device=device) % 65521 + 1)).sum()])
+        lo_s, hi_s = sig.clone(), sig.clone()
+        dist.all_reduce(lo_s, op=dist.ReduceOp.MIN); dist.all_reduce(hi_s, op=dist.ReduceOp.MAX)
+        keys = torch.zeros((world, 2), dtype=torch.int64, device=device)
+        keys[rank, 0], keys[rank, 1] = int(key[0]), int(key[1])
+        dist.all_reduce(keys, op=dist.ReduceOp.SUM)
+        o_sig = torch.zeros((world,), dtype=torch.float64, device=device)
+        o_sig[rank] = rays.origins.double().sum()
+        dist.all_reduce(o_sig, op=dist.ReduceOp.SUM)
+        replicas = {"ranks": world, "parameters_bit_identical": bool(torch.equal(lo_s, hi_s)), "after_steps": PRIME_STEPS + args.warmup + args.steps + (3 if graph_used else 0),
+                    "distinct_rank_keys": len({(int(a), int(b)) for a, b in keys.tolist()}), "distinct_rank_batches": len({float(v) for v in o_sig.tolist()}),
+                    "what": "signature of the flat parameter buffer's bits, MIN == MAX over the ranks; one jax.random key and one ray batch per rank"}
     # dispersion of the same measurement: five more windows of K steps each on the same stepper, outside the headline
     stability = None
     if args.extra:
@@ -434,6 +470,23 @@ def main():
                      "min_ms": float(min(wins)), "max_ms": float(max(wins)), "spread_frac": float((max(wins) - min(wins)) / np.median(wins)),
                      "note": "boxes of the pool differ by +-3 %; A/B deltas are only meaningful as same-box pairs (DESIGN.md §4)"}
 
+    curve = None
+    if train and world > 1 and args.curve:
+        # the same step on the first n ranks of THIS launch (the others wait at the barrier): absolute rays/s at n = 1, 2, 4, ... world from
+        # one run.  Per-rank work is fixed (weak); the gradient all-reduce runs over the n ranks only.  (Afterwards the replicas have taken
+        # different numbers of steps: everything below builds fresh steppers from the seeded initial weights.)
+        import datetime
+        curve = {"n": [], "rays_per_s": [], "ms_per_step": [], "steps": 10, "rays_per_gpu": B,
+                 "what": "weak: the step of this line on the first n ranks of the same launch, gradient all-reduce over those n ranks, max over them"}
+        for n in [m for m in (1, 2, 4, 8, 16, 32) if m < world] + [world]:
+            grp = dist.new_group(ranks=list(range(n)), timeout=datetime.timedelta(seconds=args.dist_timeout)) if n < world else None
+            dt_n = None
+            if rank < n:
+                with D.use_group(grp):
+                    dt_n = timed_steps(stepper, 2, curve["steps"], barrier, D, device)
+            barrier()
+            if rank == 0:
+                curve["n"].append(n); curve["ms_per_step"].append(1e3 * dt_n / curve["steps"]); curve["rays_per_s"].append(B * n * curve["steps"] / dt_n)
     coll = None
     if train and D.active():
         # the step's one exchange, timed with events on the launch stream: the all-reduce alone (back to back, nothing else queued), and what
@@ -446,9 +499,8 @@ def main():
             D.allreduce_mean_([G]); ev[i + 1].record()
         torch.cuda.synchronize()
         ar_us = float(np.median([1e3 * ev[i].elapsed_time(ev[i + 1]) for i in range(10)]))
-        os.environ["RNERF_SKIP_ALLREDUCE"] = "1"
-        dt_skip = timed_steps(stepper, 1, 10, barrier, D, device) / 10
-        del os.environ["RNERF_SKIP_ALLREDUCE"]
+        with D.skip_allreduce():
+            dt_skip = timed_steps(stepper, 1, 10, barrier, D, device) / 10
         dt_with = timed_steps(stepper, 1, 10, barrier, D, device) / 10
         coll = {"allreduce_us": ar_us, "allreduce_bytes": int(G.numel() * 4), "exposed_us": 1e6 * (dt_with - dt_skip),
                 "step_ms_with": 1e3 * dt_with, "step_ms_without": 1e3 * dt_skip,
@@ -585,7 +637,8 @@ def main():
                              "fine": vfine, "what": note}
 
         vm = models_with_fine(model, cfg, 256, device, args.precision)
-        run_variant("ship_straight_128+256", cfg, vm[0], vm[1], 256, 4096, "BASELINE configs[1], hierarchical (N_f = 2S: 512 MLP rows per ray)")
+        vR = args.variant_rays        # (4096; tests/test_gpu_bench_world8.py puts eight ranks on one device and shrinks the 35 GB-per-rank hierarchical legs)
+        run_variant("ship_straight_128+256", cfg, vm[0], vm[1], 256, vR, "BASELINE configs[1], hierarchical (N_f = 2S: 512 MLP rows per ray)")
         del vm
         del model, variables
         torch.cuda.empty_cache()
@@ -594,14 +647,14 @@ def main():
         rmodel, rvars, _ = build_scene(rcfg, device, args.precision, 0, "radiance")
         torch.cuda.synchronize()
         t_refr = time.perf_counter() - t0
-        run_variant("ship_refractive_128", rcfg, rmodel, rvars, 0, 4096, "BASELINE configs[2]: 512^3 sphere grid after the (9, 3.0) prefilter; the speculative "
+        run_variant("ship_refractive_128", rcfg, rmodel, rvars, 0, vR, "BASELINE configs[2]: 512^3 sphere grid after the (9, 3.0) prefilter; the speculative "
                     "march mispredicts where rays bend")
         vm = models_with_fine(rmodel, rcfg, 256, device, args.precision)
-        run_variant("ship_refractive_128+256", rcfg, vm[0], vm[1], 256, 4096, "BASELINE configs[2], hierarchical")
+        run_variant("ship_refractive_128+256", rcfg, vm[0], vm[1], 256, vR, "BASELINE configs[2], hierarchical")
         del vm, rmodel, rvars
         torch.cuda.empty_cache()
         amodel, avars, _ = build_scene(rcfg, device, args.precision, 0, "all")
-        run_variant("ship_refractive_128_stage_all", rcfg, amodel, avars, 0, 4096, "stage all* (train.py:302-310): so3_mlp bends the gradient inside the march "
+        run_variant("ship_refractive_128_stage_all", rcfg, amodel, avars, 0, vR, "stage all* (train.py:302-310): so3_mlp bends the gradient inside the march "
                     "(evaluated by four waves per 32-ray block at every node of the boundary shell) and is trained through the march's adjoint", "all")
         del amodel, avars
         torch.cuda.empty_cache()
@@ -741,9 +794,12 @@ def main():
                 tk["traffic"] = traffic_of(pref)
                 tk["counters"] = counters_of(pref)
             line["roofline_forward_kernel"] = line["roofline"]
-            # (the three are within 5 % of each other alone; IN the step the wgrad carries the next batch's march as co-resident waves and is
-            #  the longest by 8-10 % — profiles/r04/train_step_timeline.txt —, so a near-tie goes to it: the named kernel does not flip from box to box)
-            line["roofline"] = max(train_kernels, key=lambda t: t["avg_launch_ms"] * (1.08 if "wgrad" in t["kernel"] else 1.0))
+            # plain maximum of the measured stand-alone launch times; the three are within a few % of each other, so the line also says how
+            # close the runner-up is (in the step itself the wgrad hosts the next batch's march and is the longest: profiles/r04/train_step_timeline.txt)
+            by_ms = sorted(train_kernels, key=lambda t: -t["avg_launch_ms"])
+            line["roofline"] = dict(by_ms[0])
+            line["roofline"]["tie_within_frac"] = 1.0 - by_ms[1]["avg_launch_ms"] / by_ms[0]["avg_launch_ms"]
+            line["roofline"]["runner_up"] = by_ms[1]["kernel"]
             line["roofline_train_kernels"] = train_kernels
             # the whole step against the MFMA peak: SURVEY §8(d)'s algorithmic FLOP (forward + dgrad + wgrad ~ 3 x forward) / ms_per_step
             step_flop = 3.0 * flop_per_ray_fwd * B
@@ -757,6 +813,10 @@ def main():
                                             "segments (95 % of the bytes) start on a side stream right behind the last wgrad, beside the step's tail")}
         if coll:
             line["collectives"].update(coll)
+        if replicas:
+            line["collectives"]["replicas"] = replicas
+        if curve:
+            line["scaling_curve"] = curve
         if stability:
             line["stability"] = stability
         if pmc_meta is not None:

@@ -17,12 +17,16 @@ import os, sys, json
 sys.path.insert(0, %r)
 import numpy as np, torch, torch.distributed as dist
 from samplenerfro_amd import distributed as D
-rank, world = D.init("nccl")
-if not dist.is_initialized():           # D.init is a no-op for one rank: bring the group up explicitly
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group("nccl", rank=0, world_size=1)
+D.force_single_rank_group(True)         # D.init is a no-op for one rank otherwise
+rank, world = D.init("nccl", timeout_s=120.0)      # bound to the device (device_id): the RCCL communicator is created here, eagerly
+assert dist.is_initialized() and (rank, world) == (0, 1)
 dev = torch.device("cuda", torch.cuda.current_device())
 assert dist.get_backend() == "nccl"
+sub = dist.new_group(ranks=[0])         # what bench.py's in-run scaling curve does: a communicator split off the bound group
+with D.use_group(sub):
+    probe = torch.ones(8, device=dev)
+    D.allreduce_mean_([probe]); D.barrier()
+    assert D.world() == (0, 1) and bool((probe == 1).all())
 buf = torch.arange(1 << 20, dtype=torch.float32, device=dev)
 ref = buf.clone()
 side = torch.cuda.Stream()
@@ -60,11 +64,10 @@ def test_bench_under_torchrun_nccl_one_rank():
     """bench.py exactly as the driver launches N ranks (torch.distributed.run, backend nccl), with N = 1: the launcher environment,
     RCCL group init, barrier and max-over-ranks all go through librccl."""
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", RNERF_FORCE_DIST="1")
-    env.pop("RNERF_DIST_BACKEND", None)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--workload", "example", "--rays", "256", "--no-frame",
-           "--no-cpu-baseline", "--no-extra"]
+           "--no-cpu-baseline", "--no-extra", "--force-dist"]
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=560)
     assert out.returncode == 0, out.stderr[-3000:]
     import json
