@@ -180,7 +180,7 @@ def dtype_label(precision, backward, train):
     fwd = {"f16x3": "f16x3", "bf16x3": "bf16x3", "f16x2": "f16x2", "f16f8": "f16+fp8x2", "f16": "f16", "bf16": "bf16", "f32": "f32"}.get(precision, precision)
     if not train:
         return fwd + "/fp32-acc"
-    bwd = {"f32": "f16x3", "tf32": "f16", "bf16": "bf16"}[backward]
+    bwd = backward
     return (fwd if bwd == fwd else fwd + " fwd, " + bwd + " bwd") + "/fp32-acc"
 
 
@@ -298,17 +298,24 @@ def pmc_lookup(workload, fine, B, mode, backward, rnerf_cus):
     counters cannot be read from inside the process).  The JSON is stamped with the sha of the kernel sources and of bench.py it was taken
     with: a stale stamp (or no profile of this workload) leaves every counter-derived field null."""
     import hashlib
-    tag = ("%s_f%d_%s" % (workload, fine, mode if mode == "forward" else "train_" + backward))
-    rel = os.path.join("profiles", "r04", "pmc_%s.json" % tag)      # (tools/r04/pmc_all.sh)
-    path = os.path.join(ROOT, rel)
-    if B != 4096 or not os.path.exists(path):
+    old = {"f16x3": "f32", "f16": "tf32"}.get(backward, backward)       # (the mode names of rounds 2-4, in the file names of profiles/r04)
+    rel = None
+    for rnd, bw in (("r05", backward), ("r04", old)):                   # the newest committed pass whose stamp still matches wins
+        cand = os.path.join("profiles", rnd, "pmc_%s_f%d_%s.json" % (workload, fine, mode if mode == "forward" else "train_" + bw))
+        if os.path.exists(os.path.join(ROOT, cand)):
+            rel = cand
+            break
+    if B != 4096 or rel is None:
         return {}, {}, None
+    path = os.path.join(ROOT, rel)
     try:
         pj = json.load(open(path))
         sha = lambda q: hashlib.sha256(open(q, "rb").read()).hexdigest()[:16]
         now = {f: sha(os.path.join(ROOT, "samplenerfro_amd", "csrc", f)) for f in pj.get("csrc_sha16", {})}
         fresh = bool(now) and now == pj.get("csrc_sha16")
-        meta = {"file": rel, "head": pj.get("head"), "bench_py_sha16": pj.get("bench_py_sha16"), "kernels_unchanged_since": fresh}
+        meta = {"file": rel, "head": pj.get("head"), "bench_py_sha16": pj.get("bench_py_sha16"), "kernels_unchanged_since": fresh,
+                "source": "every `traffic` / `counters` field of this line is read from this COMMITTED rocprofv3 --pmc pass of the same command (counters cannot "
+                          "be read from inside the process); nothing counter-derived is measured in this run, and a stale source stamp nulls them"}
         traffic, sq = {}, {}
         if fresh:
             for k, v in pj["counters"].items():
@@ -356,9 +363,10 @@ def main():
                     help="skip the 800x800 full-frame render (ms/frame, the second part of BASELINE's metric; ~1 s)")
     ap.add_argument("--reserve-cus", type=int, default=32, help="CUs kept free of MLP workgroups for the overlapped march (forward mode)")
     ap.add_argument("--cpu-rays", type=int, default=None, help="rays in the CPU baseline sample (default 4096 forward / 512 train)")
-    ap.add_argument("--backward", choices=["f32", "tf32", "bf16"], default="f32",
-                    help="arithmetic of the NerfMLP backward: f32 = hi + lo f16 parts (fp32-grade, the reference differentiates in fp32; "
-                         "default), tf32 = f16 parts (11-bit significand), bf16 = 8-bit significand (round 1's arithmetic)")
+    ap.add_argument("--backward", choices=["f16x3", "f16", "bf16", "f32", "tf32"], default="f16x3",
+                    help="arithmetic of the NerfMLP backward: f16x3 = hi + lo f16 parts, 3 MFMAs per product (fp32-grade, the reference differentiates "
+                         "in fp32; default), f16 = f16 parts (11-bit significand), bf16 = 8-bit significand (round 1's arithmetic); f32 / tf32 = the "
+                         "older names of the first two")
     ap.add_argument("--stage", choices=["radiance", "all"], default="radiance",
                     help="all: so3_mlp bends the gradient inside the march and is trained through its adjoint (train.py:302-310); needs a "
                          "refractive workload (e.g. ship_refractive)")
@@ -379,6 +387,7 @@ def main():
     ap.add_argument("--fail-rank", type=int, default=-1, help=argparse.SUPPRESS)      # fault injection for tests/test_rank_failure.py: this rank
     ap.add_argument("--fail-mode", choices=["exit", "hang"], default="exit", help=argparse.SUPPRESS)   # dies / stops responding after the warm-up
     args = ap.parse_args()
+    args.backward = {"f32": "f16x3", "tf32": "f16"}.get(args.backward, args.backward)
     relaunch_for_gpus(args)
     if args.pipeline is None:
         args.pipeline = args.mode == "train"
@@ -511,7 +520,7 @@ def main():
         # the same step with the other backward arithmetics (5 steps each, after 2 warm-up steps), for the record in the same line
         other_modes = {}
         stepper.close()
-        for name in ("f32", "tf32", "bf16"):
+        for name in ("f16x3", "f16", "bf16"):
             if name == args.backward or (args.stage == "all" and name == "bf16"):
                 continue
             s2 = Stepper(args, cfg, model, variables, rays, key, B, world, rank, fine, device, name, args.mode, args.stage, args.pipeline, args.graph)
@@ -584,7 +593,7 @@ def main():
         # sum over the wgrad jobs of (X slots + dY slots) x R x 32 B (x 2: hi + lo).  f16 modes: 11 jobs (the Dense_5 / Dense_10 concat rows and
         # the sigma head share their operand streams with the main block: 316 slot planes); bf16 body: 14 single-segment jobs (356)
         wgrad_slots = (8 * 32 + 2 * 20 + 17 + 24 + 10 + 9) if args.backward == "bf16" else (20 + 4 * 32 + 36 + 2 * 32 + 33 + 26 + 9)
-        wgrad_bytes = wgrad_slots * R_pad * 32 * (2 if args.backward == "f32" else 1)
+        wgrad_bytes = wgrad_slots * R_pad * 32 * (2 if args.backward == "f16x3" else 1)
         # the MLP phase is MFMA-bound and its algorithmic work is 2 x 593 408 FLOP per row (forward and wgrad) / 2 x 557 696
         # (dgrad: the encodings take no gradient).  The saved-operand / dY planes the kernels stream through HBM are an implementation
         # choice (like the path record): reported next to it as `operand_stream`, never as the algorithmic fraction.
@@ -767,8 +776,8 @@ def main():
                        "eval_precision": args.eval_precision,
                        "backward_precision": (None if not train else args.backward),
                        "backward_precision_note": (None if not train else {
-                           "f32": "row-normalised f16 hi + lo parts of every saved activation and gradient (22 bits), 3 MFMAs per product: within 1e-5 of max|g| vs float64",
-                           "tf32": "row-normalised f16 parts (11-bit significand), 1-2 MFMAs per product: ~1e-3 of max|g| on small batches, ~1e-5 at this size",
+                           "f16x3": "row-normalised f16 hi + lo parts of every saved activation and gradient (22 bits), 3 MFMAs per product: within 1e-5 of max|g| vs float64",
+                           "f16": "row-normalised f16 parts (11-bit significand), 1-2 MFMAs per product: ~1e-3 of max|g| on small batches, ~1e-5 at this size",
                            "bf16": "bf16 parts (8-bit significand), round 1's arithmetic: ~6e-3 of max|g| on small batches"}[args.backward]),
                        "launch": ("one hipGraph launch per step (key split, march branch, forward, backward, Adam: csrc/pipeline.hip)" if graph_used
                                   else ("two whole-path C calls per step (rnerf_train_forward_backward + rnerf_adam_update, csrc/pipeline.hip): "
@@ -789,7 +798,7 @@ def main():
         }
         if train:
             # the dominant kernel of a train step: the longest of training forward / dgrad / wgrad (algorithmic FLOP against the MFMA peak)
-            fk = "nerfmlp_fwd_kernel<1, 0, 2," if args.backward == "f32" else "nerfmlp_fwd_kernel<1, 0, 1,"      # (+ the tile-size argument)
+            fk = "nerfmlp_fwd_kernel<1, 0, 2," if args.backward == "f16x3" else "nerfmlp_fwd_kernel<1, 0, 1,"      # (+ the tile-size argument)
             for tk, pref in zip(train_kernels, (fk, "nerfmlp_dgrad_kernel", "nerfmlp_wgrad")):
                 tk["traffic"] = traffic_of(pref)
                 tk["counters"] = counters_of(pref)

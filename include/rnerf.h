@@ -28,7 +28,11 @@
 extern "C" {
 #endif
 
-#define RNERF_VERSION 1
+/* Version of this header: entry points AND struct layouts.  2 (round 5): rnerf_grid carries `layout` (so every later field of rnerf_model
+ * moved), rnerf_train_cfg carries grads_stream / aux2_stream, rnerf_adam_cfg carries use_lr_override (lr_override alone is ignored).  A
+ * consumer compares rnerf_version() with the RNERF_VERSION it was compiled against before the first call (the Python binding does:
+ * samplenerfro_amd/_lib.py load()). */
+#define RNERF_VERSION 2
 
 enum rnerf_status {
   RNERF_OK = 0,
@@ -66,12 +70,13 @@ enum rnerf_precision {
  *   F16   : every row's gradient chain is normalised by a power of two m_row ~ max |d raw[row]| (the chain is linear in d raw[row], so
  *           the normalised values fit f16's range whatever the loss scale); f16 operands (11-bit significand, the class of the TF32
  *           tensor-core arithmetic XLA uses for fp32 matmuls on the authors' Ampere GPU): 1 MFMA per product, same HBM traffic as BF16.
- *   F16X2 : as F16 with hi + lo parts of the saved activations and of every gradient (22 bits), 3 MFMAs per product: fp32-grade
+ *   F16X3 : as F16 with hi + lo parts of the saved activations and of every gradient (22 bits), 3 MFMAs per product: fp32-grade
  *           (<= 1e-5 of the largest gradient entry against float64); twice the saved bytes. */
 enum rnerf_backward {
   RNERF_BWD_BF16 = 0,
   RNERF_BWD_F16 = 1,
-  RNERF_BWD_F16X2 = 2
+  RNERF_BWD_F16X3 = 2,   /* hi + lo f16 planes, 3 MFMAs per product */
+  RNERF_BWD_F16X2 = 2    /* the name of versions <= 1 (two planes); same value */
 };
 
 /* Voxel grid geometry: reference VoxMLP.ndim/nmin/nmax (rnerf/ior_utils.py:124-144).  Doubles, because the
@@ -217,9 +222,12 @@ int rnerf_so3_query(const float* table, const rnerf_grid* g, const float* so3_pa
  * ray_order (nullable): int32[B], a permutation of the rays: workgroup i marches rays ray_order[16 i .. 16 i + 15] (a group of 16
  * evaluates the MLP whenever ANY of its rays is inside the boundary shell, so rays with similar shell intervals should share a group).
  * Every record is written at the ray's own index: the order changes no output.
- * Grid size limit (rnerf_march_all and rnerf_march_all_train; rnerf_march has none): the table is addressed with 32-bit byte offsets and
- * 24-bit row strides — dims[0] * dims[1] * dims[2] * 16 B < 4 GiB and dims[1] * dims[2] * 16 < 2^24, i.e. cubic grids up to 645^3
- * (every shipped config: 128^3 .. 512^3); larger grids are rejected with RNERF_ERR_ARG, never mis-addressed. */
+ * Grid size limit of every marching entry point: the table is addressed with 32-bit byte offsets and 24-bit strides —
+ * dims[0] * dims[1] * dims[2] * 16 B < 4 GiB in all of them; rnerf_march_all / rnerf_march_all_train / rnerf_march_adjoint (and
+ * rnerf_march on a BRICKS table) need the stride of TWO x-planes below 2^24: dims[1] * dims[2] * 32 < 2^24 (reference order;
+ * ceil(dims[1]/2) * ceil(dims[2]/2) * 128 < 2^24 for bricks); rnerf_march on a REFERENCE-order table needs only dims[1] * dims[2] * 16 < 2^24.
+ * Cubic grids up to 645^3 pass every check (every shipped config: 128^3 .. 512^3); larger grids are rejected with RNERF_ERR_ARG, never
+ * mis-addressed. */
 size_t rnerf_so3_packed_bytes(void);
 int rnerf_march_all(const float* table, const rnerf_grid* g, const float* so3_params, void* so3_packed, const float* window10, const float* origins,
                     const float* viewdirs, int32_t B, double near, double far, int32_t num_nodes, float* path_pd, float* path_dr,

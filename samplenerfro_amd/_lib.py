@@ -13,10 +13,15 @@ LIB_PATH = os.path.join(HERE, "lib", "librnerf.so")
 
 PREC_F32, PREC_F16X3, PREC_BF16X3, PREC_F16, PREC_BF16, PREC_F16X2, PREC_F16F8 = 0, 1, 2, 3, 4, 5, 6
 PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3, "bf16x3": PREC_BF16X3, "f16": PREC_F16, "bf16": PREC_BF16, "f16x2": PREC_F16X2, "f16f8": PREC_F16F8}
-# enum rnerf_backward (include/rnerf.h): arithmetic of the NerfMLP dgrad + wgrad.  "f32" = hi + lo f16 parts (fp32-grade, the reference
-# differentiates in fp32, train.py:164); "tf32" = single f16 parts (11-bit significand); "bf16" = 8-bit significand.
+# enum rnerf_backward (include/rnerf.h): arithmetic of the NerfMLP dgrad + wgrad.  "f16x3" = hi + lo f16 parts (fp32-grade, the reference
+# differentiates in fp32, train.py:164); "f16" = single f16 parts (11-bit significand); "bf16" = 8-bit significand.
 BWD_BF16, BWD_F16, BWD_F16X2 = 0, 1, 2
-BACKWARDS = {"f32": BWD_F16X2, "tf32": BWD_F16, "bf16": BWD_BF16}
+BWD_F16X3 = BWD_F16X2
+# named for what they compute in (gfx950 has neither an fp32 nor a TF32 matrix path worth the name): "f16x3" = hi + lo f16 planes, 3 MFMAs per
+# product; "f16" = one f16 plane; "bf16".  "f32" / "tf32" are the names of rounds 2-4, kept as aliases.
+BACKWARDS = {"f16x3": BWD_F16X3, "f16": BWD_F16, "bf16": BWD_BF16, "f32": BWD_F16X3, "tf32": BWD_F16}
+BACKWARD_NAMES = {BWD_F16X3: "f16x3", BWD_F16: "f16", BWD_BF16: "bf16"}
+ABI_VERSION = 2          # == RNERF_VERSION of include/rnerf.h; load() refuses a library that answers anything else
 NERFMLP_PARAMS = 595844
 BKGDMLP_PARAMS = 56963
 SO3MLP_PARAMS = 65411
@@ -159,7 +164,7 @@ def load(path: Optional[str] = None) -> C.CDLL:
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or os.environ.get("RNERF_LIB") or LIB_PATH   # RNERF_LIB: load an alternative build (profiling variants)
+    p = path or LIB_PATH          # load(path) first thing in a process binds an alternative build (tools' profiling variants) for everything after
     if not os.path.exists(p):
         raise RnerfError(f"{p} not found: build it with `python -m samplenerfro_amd.build` "
                          "(there is no CPU fallback for the hot path)")
@@ -168,7 +173,11 @@ def load(path: Optional[str] = None) -> C.CDLL:
         fn = getattr(lib, name)   # AttributeError if a declared symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if path is None:
+    got = lib.rnerf_version()
+    if got != ABI_VERSION:          # struct layouts (rnerf_grid / rnerf_model / rnerf_train_cfg / rnerf_adam_cfg) are part of the version
+        raise RnerfError(f"{p} speaks ABI version {got}, this binding was written for {ABI_VERSION} (include/rnerf.h RNERF_VERSION): rebuild with "
+                         "`python -m samplenerfro_amd.build --force`")
+    if path is None or _lib is None:
         _lib = lib
     return lib
 

@@ -13,6 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "librnerf.so")
+LIB_EXPERIMENTS = os.path.join(LIBDIR, "librnerf_experiments.so")
 SOURCES = ["grid.hip", "march.hip", "render.hip", "mlp.hip", "mlp_f32.hip", "bkgd16.hip", "pipeline.hip"]
 # -ffp-contract=off + correctly rounded div/sqrt: the march/lookup/resample kernels reproduce the reference's
 # individually rounded fp32 op order so that integer indices are bit-exact against the oracle.
@@ -41,29 +42,48 @@ def _stale(out: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def _compile(job) -> None:
+    cmd, verbose = job
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+
+
+def build(force: bool = False, verbose: bool = False, experiments: bool = True) -> str:
+    """Compile every translation unit (in parallel) and link librnerf.so; returns its path.
+
+    experiments=True also builds librnerf_experiments.so from the same sources with -DRNERF_EXPERIMENTS: the experiment / test switches
+    (RNERF_* environment variables, csrc/common.h RNERF_ENV) exist only there — the product library reads no environment."""
+    from concurrent.futures import ThreadPoolExecutor
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = _hipcc()
     headers = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "rnerf.h"),
                os.path.join(CSRC, "ior_train_kernels.inc"), os.path.join(CSRC, "ior_train_api.inc"), os.path.join(CSRC, "nerfmlp_layout.h"),
                os.path.join(CSRC, "mfma_ops.h"), os.path.join(CSRC, "bkgd_layout.h"), os.path.join(CSRC, "so3_layout.h")]
-    objs = []
-    for src in SOURCES:
-        s = os.path.join(CSRC, src)
-        o = os.path.join(LIBDIR, src.replace(".hip", ".o"))
-        objs.append(o)
-        if force or _stale(o, [s] + headers):
-            cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
-            if verbose:
-                print(" ".join(cmd), file=sys.stderr)
-            subprocess.check_call(cmd)
-    if force or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB]
-        if verbose:
-            print(" ".join(cmd), file=sys.stderr)
-        subprocess.check_call(cmd)
+    variants = [(LIB, LIBDIR, [])]
+    if experiments:
+        variants.append((LIB_EXPERIMENTS, os.path.join(LIBDIR, "exp"), ["-DRNERF_EXPERIMENTS"]))
+    jobs, links = [], []
+    for lib, objdir, extra in variants:
+        os.makedirs(objdir, exist_ok=True)
+        objs = []
+        for src in SOURCES:
+            s = os.path.join(CSRC, src)
+            o = os.path.join(objdir, src.replace(".hip", ".o"))
+            objs.append(o)
+            if force or _stale(o, [s] + headers):
+                jobs.append(([hipcc] + FLAGS + extra + ["-c", s, "-o", o], verbose))
+        links.append((lib, objs))
+    if jobs:
+        # longest first (mlp.hip takes ~2 min, the rest seconds): the two mlp.o builds run side by side
+        jobs.sort(key=lambda j: -os.path.getsize(j[0][-3]))
+        with ThreadPoolExecutor(max_workers=min(len(jobs), max(2, (os.cpu_count() or 2) // 2))) as ex:
+            list(ex.map(_compile, jobs))
+    for lib, objs in links:
+        if force or _stale(lib, objs):
+            _compile(([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib], verbose))
     return LIB
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, experiments="--no-experiments" not in sys.argv))

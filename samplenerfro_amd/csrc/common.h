@@ -7,9 +7,29 @@
 
 #include "../../include/rnerf.h"
 
+// Experiment / test switches.  The product library reads NO environment variable (include/rnerf.h: no global state, nothing a stray
+// RNERF_* variable on a bench box could change): RNERF_ENV folds to a null pointer and every switch to its default at compile time.
+// librnerf_experiments.so (build.py, -DRNERF_EXPERIMENTS) is the same source with the switches live, for tools/ and for the tests that
+// compare two launch shapes bit for bit (tests/test_gpu_half_tiles.py, tests/test_gpu_composite_lanes.py).
+#ifdef RNERF_EXPERIMENTS
+#include <stdlib.h>
+#define RNERF_ENV(name) getenv(name)
+#else
+#define RNERF_ENV(name) (static_cast<const char*>(nullptr))
+#endif
+
 namespace rnerf {
 
 void set_error(const char* fmt, ...);
+
+// "Once per device" for the lazy kernel attributes (hipFuncSetAttribute is per device; a process may drive several).  Racing host threads
+// at worst repeat an idempotent call: the flag is only ever set after the call succeeded.
+struct DeviceOnce {
+  volatile unsigned char done[64] = {0};
+  int dev() const { int d = 0; return (hipGetDevice(&d) == hipSuccess && d >= 0 && d < 64) ? d : 0; }
+  bool need() const { return !done[dev()]; }
+  void set() { done[dev()] = 1; }
+};
 
 #define RNERF_CHECK_ARG(cond, ...)                 \
   do {                                             \
@@ -78,8 +98,15 @@ inline bool make_grid_params(const rnerf_grid* g, GridParams* p) {
   return true;
 }
 // the marching kernels address the table with 32-bit byte offsets formed by 24-bit multiplies: table < 4 GiB, every factor < 2^24
+// (the so3 / adjoint kernels multiply by sa in either layout)
 inline bool grid_fits_u32(const GridParams& p) {
   return p.table_bytes < 4294967296ull && p.sa[0] < 16777216u && p.sa[1] < 16777216u && p.dx < 16777216 && p.dy < 16777216 && p.dz < 16777216;
+}
+// march_kernel: the REFERENCE layout multiplies the index by sb (the plain row strides), only BRICKS by sa — a non-cubic reference-order
+// grid with dims[1] * dims[2] * 16 in [2^23, 2^24) is fine here although the so3 march rejects it
+inline bool grid_fits_march(const GridParams& p) {
+  const unsigned* s = p.layout == RNERF_TABLE_REFERENCE ? p.sb : p.sa;
+  return p.table_bytes < 4294967296ull && s[0] < 16777216u && s[1] < 16777216u && p.dx < 16777216 && p.dy < 16777216 && p.dz < 16777216;
 }
 
 // Individually rounded fp32 ops: the march / lookup / resample kernels must not contract a*b+c

@@ -215,7 +215,7 @@ extern "C" int rnerf_march(const float* table, const rnerf_grid* g, const float*
                   "rnerf_march: table/path buffers must be 16-byte aligned");
   GridParams gp;
   RNERF_CHECK_ARG(make_grid_params(g, &gp), "rnerf_march: bad grid");
-  RNERF_CHECK_ARG(grid_fits_u32(gp), "rnerf_march: grid too large for 32-bit byte offsets (needs a table < 4 GiB)");
+  RNERF_CHECK_ARG(grid_fits_march(gp), "rnerf_march: grid too large for 32-bit byte offsets (needs a table < 4 GiB and 24-bit row strides)");
   MarchParams p;
   p.dx = gp.dx; p.dy = gp.dy; p.dz = gp.dz;
   p.nmin[0] = gp.nminx; p.nmin[1] = gp.nminy; p.nmin[2] = gp.nminz;
@@ -227,7 +227,7 @@ extern "C" int rnerf_march(const float* table, const rnerf_grid* g, const float*
   // workgroups (8 / 4 rays each, two / four marching waves per CU) was measured SLOWER (round 4, profiles/r04/march_experiments.txt:
   // 0.35 -> 0.45 ms at 64^3, 0.53 -> 0.57 at 512^3): the waves of a CU share its vector-memory path, which is what a step waits on.
   int rpw = 16;
-  if (const char* e = getenv("RNERF_MARCH_RPW")) rpw = atoi(e);       // experiment switch (tools/r04/march_rpw.sh)
+  if (const char* e = RNERF_ENV("RNERF_MARCH_RPW")) rpw = atoi(e);       // experiment switch (tools/r04/march_rpw.sh)
   RNERF_CHECK_ARG(rpw == 16 || rpw == 8 || rpw == 4, "rnerf_march: RNERF_MARCH_RPW must be 16, 8 or 4");
   const dim3 block(128), grid((B + rpw - 1) / rpw);
   hipStream_t st = (hipStream_t)stream;

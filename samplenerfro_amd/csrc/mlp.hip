@@ -2998,7 +2998,7 @@ static size_t save_payload_bytes(long long padded, bool with_lo) {
 
 static int mlp_debug_flags() {
   static int v = -1;
-  if (v < 0) { const char* e = getenv("RNERF_MLP_DEBUG"); v = e ? atoi(e) : 0; }
+  if (v < 0) { const char* e = RNERF_ENV("RNERF_MLP_DEBUG"); v = e ? atoi(e) : 0; }
   return v;
 }
 
@@ -3046,7 +3046,7 @@ static int launch_fwd_dbg(const void* packed, const float* rows_pd, const float*
   // 128-ray one) finishes sooner on twice as many CUs with half the work each.  (Beyond one round the 256-row tiles' better reuse of the
   // weight stream wins.)  RNERF_FWD_HALF_TILES=0 switches it off (A/B).
   if constexpr (DBG == 0 && (PREC == RNERF_PREC_F16X3 || PREC == RNERF_PREC_F16F8)) {
-    static const bool half_ok = [] { const char* e = getenv("RNERF_FWD_HALF_TILES"); return !(e && e[0] == '0'); }();
+    static const bool half_ok = [] { const char* e = RNERF_ENV("RNERF_FWD_HALF_TILES"); return !(e && e[0] == '0'); }();
     if (half_ok && 2 * n_tiles <= lim) {
       const size_t lds1 = 2 * (size_t)PP::SLAB;
       static bool attr1_set = false;
@@ -3063,10 +3063,10 @@ static int launch_fwd_dbg(const void* packed, const float* rows_pd, const float*
   }
   const int grid = n_tiles < lim ? n_tiles : lim;
   const size_t lds = 2 * (size_t)PP::SLAB + 4 * 32768;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DeviceOnce attr_set;
+  if (attr_set.need()) {
     RNERF_CHECK_HIP(hipFuncSetAttribute((const void*)nerfmlp_fwd_kernel<PREC, DBG, TRAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
+    attr_set.set();
   }
   int* tileq = nullptr;
   if (TRAIN != 0 && grid < cus && grid < n_tiles) {      // capped training forward: dynamic tile queue in the tail of the save buffer
@@ -3174,10 +3174,10 @@ static int launch_dgrad(const void* packed_bwd, const float* fwd_aux, const void
   RNERF_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
   const int grid = n_tiles < cus ? n_tiles : cus;
   const size_t lds = 2 * (size_t)PB::SLAB + 4 * 32768;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DeviceOnce attr_set;
+  if (attr_set.need()) {
     RNERF_CHECK_HIP(hipFuncSetAttribute((const void*)nerfmlp_dgrad_kernel<BWD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
+    attr_set.set();
   }
   const long long R = (long long)n_tiles * 256;
   if (Bwd<BWD>::F16 && zero_ref) RNERF_CHECK_HIP(hipMemsetAsync(nerfmlp_dgrad_scale_ref(BWD, dy, rows), 0, 4 * sizeof(float), st));
@@ -3185,7 +3185,7 @@ static int launch_dgrad(const void* packed_bwd, const float* fwd_aux, const void
   // (allow_half = false): two kernels that each own whole CUs then share the chip, and with twice the workgroups of half the work the
   // step measures the same or slower (512 rays, levels side by side: 2.05 -> 2.09 ms; alone, a 256-ray single-level step: 1.17 -> 1.12 ms).
   if constexpr (BWD == RNERF_BWD_F16X2 || BWD == RNERF_BWD_F16) {
-    static const int half_lim = [] { const char* e = getenv("RNERF_DGRAD_HALF_TILES"); return e ? atoi(e) : -1; }();      // 0: off, n: at most n tiles
+    static const int half_lim = [] { const char* e = RNERF_ENV("RNERF_DGRAD_HALF_TILES"); return e ? atoi(e) : -1; }();      // 0: off, n: at most n tiles
     if (allow_half && half_lim != 0 && 2 * n_tiles <= (half_lim > 1 ? half_lim : cus)) {
       const size_t lds1 = 2 * (size_t)PB::SLAB;
       static bool attr1_set = false;
@@ -3268,7 +3268,7 @@ static size_t build_wgrad_table(int cus, WgradTable& t, bool legacy, int mult = 
     total += cost[n];
   }
   t.n = n;
-  static const int mult_env = getenv("RNERF_WGRAD_MULT") ? atoi(getenv("RNERF_WGRAD_MULT")) : 0;
+  static const int mult_env = RNERF_ENV("RNERF_WGRAD_MULT") ? atoi(RNERF_ENV("RNERF_WGRAD_MULT")) : 0;
   const int budget = (mult_env > 0 ? mult_env : (mult > 0 ? mult : (legacy ? 4 : 2))) * cus;
   size_t off = 0;
   int wg = 0;
@@ -3300,18 +3300,19 @@ static int device_cus() {
 constexpr long long kWgradSmallRows = 24576;
 struct WgradTables { WgradTable legacy, tr, tr_small; size_t partial_floats; int max_wgs; };
 static const WgradTables& wgrad_tables() {
-  static WgradTables w;
-  static bool ready = false;
-  if (!ready) {
+  // built once, by whichever host thread comes first (a function-local static's initialisation is thread-safe); sized by the compute units
+  // of that thread's current device — every device a process drives is assumed to be the same part
+  static const WgradTables tables = [] {
+    WgradTables w;
     const size_t a = build_wgrad_table(device_cus(), w.legacy, true), b = build_wgrad_table(device_cus(), w.tr, false);
     const size_t s = build_wgrad_table(device_cus(), w.tr_small, false, 1);
     w.partial_floats = a > b ? a : b;
     if (s > w.partial_floats) w.partial_floats = s;
     w.max_wgs = w.legacy.wg0[w.legacy.n] > w.tr.wg0[w.tr.n] ? w.legacy.wg0[w.legacy.n] : w.tr.wg0[w.tr.n];
     if (w.tr_small.wg0[w.tr_small.n] > w.max_wgs) w.max_wgs = w.tr_small.wg0[w.tr_small.n];
-    ready = true;
-  }
-  return w;
+    return w;
+  }();
+  return tables;
 }
 
 extern "C" size_t rnerf_nerfmlp_wgrad_workspace_bytes(void) {
@@ -3326,18 +3327,18 @@ extern "C" int rnerf_nerfmlp_wgrad(int fwd_precision, int backward, const void* 
   RNERF_CHECK_ARG(bwd_ok(backward), "rnerf_nerfmlp_wgrad: unknown backward mode %d", backward);
   RNERF_CHECK_ARG(rows >= 1, "rnerf_nerfmlp_wgrad: rows must be >= 1");
   const WgradTables& w = wgrad_tables();
-  static bool ready = false;
-  if (!ready) {
+  static DeviceOnce ready;
+  if (ready.need()) {
     RNERF_CHECK_HIP(hipFuncSetAttribute((const void*)nerfmlp_wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
     RNERF_CHECK_HIP(hipFuncSetAttribute((const void*)nerfmlp_wgrad_tr_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, wgtr_lds_bytes<1>()));
     RNERF_CHECK_HIP(hipFuncSetAttribute((const void*)nerfmlp_wgrad_tr_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, wgtr_lds_bytes<2>()));
-    ready = true;
+    ready.set();
   }
   const long long R = (rows + 255) / 256 * 256;
   hipStream_t st = (hipStream_t)stream;
   const float* out_scale = nullptr;
   // RNERF_WGRAD_TRACE=1 (profiling aid): per-workgroup start / end times behind the partials -> per-job spans on stderr (synchronises)
-  static const bool tracing = getenv("RNERF_WGRAD_TRACE") != nullptr;
+  static const bool tracing = RNERF_ENV("RNERF_WGRAD_TRACE") != nullptr;
   long long* trace = tracing ? (long long*)((char*)workspace + w.partial_floats * sizeof(float)) : nullptr;
   const WgradTable& tab = backward == RNERF_BWD_BF16 ? w.legacy : (rows <= kWgradSmallRows ? w.tr_small : w.tr);
   if (backward == RNERF_BWD_BF16) {
@@ -3376,7 +3377,7 @@ extern "C" int rnerf_nerfmlp_wgrad(int fwd_precision, int backward, const void* 
 
 // RNERF_BKGD_EXACT=1: the exact-fp32 background-MLP kernels (v_mfma_f32_32x32x2_f32) instead of the f16 hi + lo ones (read once)
 static bool bkgd_exact() {
-  static const bool v = [] { const char* e = getenv("RNERF_BKGD_EXACT"); return e && e[0] == '1'; }();
+  static const bool v = [] { const char* e = RNERF_ENV("RNERF_BKGD_EXACT"); return e && e[0] == '1'; }();
   return v;
 }
 

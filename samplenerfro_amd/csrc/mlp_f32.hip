@@ -115,10 +115,10 @@ __global__ void __launch_bounds__(256) nerfmlp_fwd_f32_kernel(const float* __res
 int launch_fwd_f32(const void* packed, const float* rows_pd, const float* rows_dr, const int32_t* node_of_sample, int32_t B, long long total_rows,
                    float* out_raw, hipStream_t st) {
   const size_t lds = (size_t)(F32_XSTRIDE + 256 + 4) * F32_ROWS * sizeof(float);      // 145 KiB
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DeviceOnce attr_set;
+  if (attr_set.need()) {
     RNERF_CHECK_HIP(hipFuncSetAttribute((const void*)nerfmlp_fwd_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
+    attr_set.set();
   }
   const unsigned grid = (unsigned)((total_rows + F32_ROWS - 1) / F32_ROWS);
   hipLaunchKernelGGL(nerfmlp_fwd_f32_kernel, dim3(grid), dim3(256), lds, st, (const float*)packed, (const float4*)rows_pd, (const float4*)rows_dr, node_of_sample, B,

@@ -12,6 +12,44 @@
 #include <vector>
 
 namespace rnerf {
+// Compute units of the CURRENT device, cached per device ordinal (a process may drive several devices; one cached count would mis-size the
+// side-by-side decisions — and the workspace carve that follows them — on the second).
+static int current_device_cus() {
+  static int cache[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cache[dev] == 0) {
+    int cus = 0;
+    cache[dev] = (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) ? cus : 256;
+  }
+  return cache[dev];
+}
+
+// Ordering events (timing disabled) are pooled per host thread and device: a step orders its streams ~10 times, and creating / destroying an
+// event each time costs two driver calls apiece.  An event goes back to the pool as soon as the wait on it is ENQUEUED: hipStreamWaitEvent
+// captures the record it waits for at call time, a later re-record of the same event does not move it.  Events recorded inside a stream
+// capture belong to the graph (tl_capture_events below) and never return.  The pool is not torn down at thread / process exit on purpose
+// (the runtime may be gone by then); it holds at most kPoolCap events per device.
+namespace {
+constexpr size_t kPoolCap = 32;
+struct EventPool { std::vector<hipEvent_t> free_[64]; };
+thread_local EventPool tl_pool;
+inline hipError_t pool_get(hipEvent_t* e) {
+  int dev = 0;
+  if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !tl_pool.free_[dev].empty()) {
+    *e = tl_pool.free_[dev].back();
+    tl_pool.free_[dev].pop_back();
+    return hipSuccess;
+  }
+  return hipEventCreateWithFlags(e, hipEventDisableTiming);
+}
+inline void pool_put(hipEvent_t e) {
+  int dev = 0;
+  if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && tl_pool.free_[dev].size() < kPoolCap) tl_pool.free_[dev].push_back(e);
+  else (void)hipEventDestroy(e);
+}
+}  // namespace
+
 // csrc/mlp.hip: the operand-stream pack without its own memsets (the step zeroes every stream's range flags in one launch)
 int nerfmlp_step_zero(int precision, void* const* packed, int count, int backward, void* const* dy, const int64_t* dy_rows, int dy_count, hipStream_t st);
 int nerfmlp_pack_impl(const float* params, int precision, void* packed, bool zero_flags, hipStream_t st);
@@ -407,8 +445,7 @@ static inline bool co_requested(const rnerf_train_cfg* c) { return c->aux_stream
 // tiles (see rnerf_train_forward_backward); also decides whether the workspace carries the coarse level's own dY / d raw / wgrad scratch
 static bool levels_side_by_side(const rnerf_model* m, const rnerf_train_cfg* c, int32_t B) {
   if (m->num_fine <= 0 || !c->aux_stream || co_requested(c)) return false;
-  static int cus = 0;
-  if (cus == 0) { int dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256; }
+  const int cus = current_device_cus();
   const long long tiles_both = ((long long)m->num_coarse * B + 255) / 256 + ((long long)(m->num_coarse + m->num_fine) * B + 255) / 256;
   return tiles_both <= 2LL * cus;
 }
@@ -519,7 +556,7 @@ extern "C" int rnerf_train_forward_backward(const rnerf_model* m, const rnerf_tr
   //      (Round 4: before, the coarse forward waited for five launches — three 16-byte memsets among them — and started at +88 us.)
   void* aux = c->aux_stream;
   bool pre_zeroed = false;      // the head of the step has cleared the accumulator words of its kernels (aux stream only)
-  struct Mark { hipEvent_t e = nullptr; ~Mark() { if (e) (void)hipEventDestroy(e); } } fine_packed;      // (an early error return must not leak it)
+  struct Mark { hipEvent_t e = nullptr; ~Mark() { if (e) pool_put(e); } } fine_packed;      // (an early error return must not leak it)
   if (aux) {
     RNERF_TRY(rnerf_fork(stream, aux));
     // one launch zeroes what the step's kernels need cleared: the streams' range flags, the row-scale reference of every dgrad that is the
@@ -603,7 +640,7 @@ extern "C" int rnerf_train_forward_backward(const rnerf_model* m, const rnerf_tr
   // rounds: beyond that the kernels' static tile striding is delayed on the CUs the other level took first and the step gets SLOWER
   // (profiles/r04/levels_side_by_side.txt: 512 rays 2.28 -> 2.18 ms, 128 rays 1.50 -> 1.33; 1024 rays 3.36 -> 3.45, 4096 rays 11.9 -> 12.4).
   const bool split_levels = levels_side_by_side(m, c, B);
-  static const bool bk_early_env = getenv("RNERF_BKGD_BWD_EARLY") ? atoi(getenv("RNERF_BKGD_BWD_EARLY")) != 0 : true;
+  static const bool bk_early_env = RNERF_ENV("RNERF_BKGD_BWD_EARLY") ? atoi(RNERF_ENV("RNERF_BKGD_BWD_EARLY")) != 0 : true;
   const bool bk_early = split_levels && bk_early_env && !(aux && c->coresident_bkgd_wgrad);
   void* bk2 = nullptr;      // the third stream, when the background backward went there
   float* d_raw_c = split_levels ? t.d_raw_c : t.d_raw;
@@ -620,7 +657,7 @@ extern "C" int rnerf_train_forward_backward(const rnerf_model* m, const rnerf_tr
         // (Measured, tools/r04/env_ab.sh RNERF_NO_AUX2_STREAM: 256 rays 1.48 -> 1.39 ms, 512 rays the same, 128 rays 1.09 -> 1.11: with a
         // quarter of the chip's tiles the coarse chain is not what the step waits for, and the third stream only adds its fork / join.)
         const long long tiles_both = ((long long)Nc * B + 255) / 256 + ((long long)S * B + 255) / 256;
-        bk2 = (c->aux2_stream && tiles_both > 128) ? c->aux2_stream : nullptr;
+        bk2 = (c->aux2_stream && tiles_both > current_device_cus() / 2) ? c->aux2_stream : nullptr;
         void* bk = bk2 ? bk2 : aux;
         if (bk2) RNERF_TRY(rnerf_fork(stream, bk));
         const double env_on_ = c->annealed_alpha > 0 ? 1.0 : 0.0;
@@ -765,17 +802,17 @@ extern "C" int rnerf_graph_destroy(void* graph_exec) {
 
 static int order_after(hipStream_t first, hipStream_t then) {
   hipEvent_t e = nullptr;
-  RNERF_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  RNERF_CHECK_HIP(pool_get(&e));
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   hipError_t err = hipStreamIsCapturing(first, &cs);
   if (err == hipSuccess) err = hipEventRecord(e, first);
   if (err == hipSuccess) err = hipStreamWaitEvent(then, e, 0);
-  if (err != hipSuccess) {      // no leak on the error path
+  if (err != hipSuccess) {      // no leak on the error path (an event in an unknown state is destroyed, not pooled)
     (void)hipEventDestroy(e);
     set_error("stream ordering failed: %s", hipGetErrorString(err));
     return RNERF_ERR_HIP;
   }
-  if (cs == hipStreamCaptureStatusNone) RNERF_CHECK_HIP(hipEventDestroy(e));
+  if (cs == hipStreamCaptureStatusNone) pool_put(e);
   else tl_capture_events.push_back(e);
   return RNERF_OK;
 }
@@ -784,7 +821,7 @@ static int order_after(hipStream_t first, hipStream_t then) {
 // where the consumer goes.  A mark that is never waited for must be passed to wait_point all the same (it owns the event).
 static int mark_point(hipStream_t first, hipEvent_t* out) {
   hipEvent_t e = nullptr;
-  RNERF_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  RNERF_CHECK_HIP(pool_get(&e));
   const hipError_t err = hipEventRecord(e, first);
   if (err != hipSuccess) { (void)hipEventDestroy(e); set_error("stream ordering failed: %s", hipGetErrorString(err)); return RNERF_ERR_HIP; }
   *out = e;
@@ -795,7 +832,7 @@ static int wait_point(hipStream_t then, hipEvent_t e) {
   hipError_t err = hipStreamIsCapturing(then, &cs);
   if (err == hipSuccess) err = hipStreamWaitEvent(then, e, 0);
   if (err != hipSuccess) { (void)hipEventDestroy(e); set_error("stream ordering failed: %s", hipGetErrorString(err)); return RNERF_ERR_HIP; }
-  if (cs == hipStreamCaptureStatusNone) RNERF_CHECK_HIP(hipEventDestroy(e));
+  if (cs == hipStreamCaptureStatusNone) pool_put(e);
   else tl_capture_events.push_back(e);
   return RNERF_OK;
 }

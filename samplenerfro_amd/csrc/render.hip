@@ -519,7 +519,7 @@ using namespace rnerf;
 // (tools/r04/composite_time.py): 128 or 512 rays x 192 samples 41 / 69 (4 lanes), 19 / 26 (16), 20 / 14-17 (64); 4096 x 128: 28 / 48, 20 / 22,
 // 63 / 81; 4096 x 192: 48 / 72, 27 / 32, 85 / 112; 32768 x 128: 53 / 85, 92 / 140, 364 / 444.  RNERF_COMPOSITE_LANES=4|16|64 forces one (A/B, tests).
 static int composite_lanes(int32_t B) {
-  static const int forced = [] { const char* e = getenv("RNERF_COMPOSITE_LANES"); const int v = e ? atoi(e) : 0; return (v == 4 || v == 16 || v == 64) ? v : 0; }();
+  static const int forced = [] { const char* e = RNERF_ENV("RNERF_COMPOSITE_LANES"); const int v = e ? atoi(e) : 0; return (v == 4 || v == 16 || v == 64) ? v : 0; }();
   if (forced) return forced;
   return B <= 1024 ? 64 : (B <= 8192 ? 16 : 4);
 }
@@ -564,12 +564,12 @@ extern "C" int rnerf_resample(const float* path_pd, const float* path_dr, int32_
   if (rpb > 4 && need > 2560) rpb = 4;
   if (rpb > 1 && need > 10240) rpb = 1;
   const size_t lds = (size_t)need * rpb * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DeviceOnce attr_set;
+  if (attr_set.need()) {
     RNERF_CHECK_HIP(hipFuncSetAttribute((const void*)resample_depths_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
     RNERF_CHECK_HIP(hipFuncSetAttribute((const void*)resample_depths_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
     RNERF_CHECK_HIP(hipFuncSetAttribute((const void*)resample_depths_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
-    attr_set = true;
+    attr_set.set();
   }
   const dim3 rgrid((unsigned)((B + rpb - 1) / rpb));
   if (rpb == 16)

@@ -136,7 +136,7 @@ class GraphTrainStep:
         nxt = None
         if self.prefetch:          # the march of the other slot: forked behind the last wgrad inside the call, joined by the caller
             nxt = _lib.Prefetch(self.origins[1 - slot].data_ptr(), self.viewdirs[1 - slot].data_ptr(), self.path_pd[1 - slot].data_ptr(),
-                                self.path_dr[1 - slot].data_ptr(), sd, int(os.environ.get("RNERF_MARCH_BESIDE_WGRAD", "1")))
+                                self.path_dr[1 - slot].data_ptr(), sd, int(getattr(self.model, "march_beside_wgrad", True)))
         _lib.check(lib.rnerf_train_forward_backward(C.byref(self.m), C.byref(self.c), self.state.theta.data_ptr(), self.origins[slot].data_ptr(),
                                                     self.viewdirs[slot].data_ptr(), self.pixels[slot].data_ptr(), _lib.ptr(self.env), self.B,
                                                     self.keys4.data_ptr(), None, None, 0, self.path_pd[k].data_ptr(), self.path_dr[k].data_ptr(),

@@ -145,8 +145,10 @@ class NerfModel:
         self._u_lin: Optional[torch.Tensor] = None
         self._side: Optional[torch.cuda.Stream] = None
         self._mlp_wg_limit = 0
-        # whole_path: apply() goes through rnerf_forward (one C call per batch); RNERF_STAGED=1 keeps the stage-by-stage host sequence
-        self.whole_path = os.environ.get("RNERF_STAGED") != "1"
+        # whole_path: apply() goes through rnerf_forward (one C call per batch); False keeps the stage-by-stage host sequence (tests / taps)
+        self.whole_path = True
+        # the next batch's march as co-resident waves of the wgrad (rnerf_prefetch.beside_wgrad); False queues it behind the wgrad (round 2's form)
+        self.march_beside_wgrad = True
         self._ws: Dict[Tuple[str, int], torch.Tensor] = {}
         self._key_cache: Dict[bytes, torch.Tensor] = {}
 
@@ -288,7 +290,7 @@ class NerfModel:
         h = PathHandle(pd, dr, None, torch.cuda.Event(), B)
         h.keep = (o, v)
         return h, _lib.Prefetch(o.data_ptr(), v.data_ptr(), pd.data_ptr(), dr.data_ptr(), self._side.cuda_stream,
-                                 int(os.environ.get("RNERF_MARCH_BESIDE_WGRAD", "1")))
+                                 int(self.march_beside_wgrad))
 
     def tail_stream(self) -> torch.cuda.Stream:
         """The stream rnerf_train_forward_backward uses for work that is independent of the NerfMLP backward (rnerf_train_cfg.aux_stream)."""
@@ -428,7 +430,11 @@ class NerfModel:
             return self._forward_whole(variables, rng_0, rng_1, rays, randomized, jitter, u_fine, path), 0.0
         Nc, Nf, N = self.num_coarse_samples, self.num_fine_samples, self.num_samples
         key, rng_0 = prng.split(np.asarray(rng_0, np.uint32))
-        want_ior = self.use_online_sparsity or (taps is not None and not (ctx is not None and self.stage.startswith("all")))
+        # loss_sp (rnerf/models.py:351-357,526-530): always in a pure forward; in a training forward only when the caller asks for its VALUE
+        # (ctx["loss_sp"], set by train_step with taps) — train.py:156 multiplies the term by annealing_rate = 0.0, so neither the loss nor any
+        # gradient depends on it and the product step does not pay for the IoR record it would need
+        sparsity = self.use_online_sparsity and (ctx is None or (bool(ctx.get("loss_sp")) and not self.stage.startswith("all")))
+        want_ior = sparsity or (taps is not None and not (ctx is not None and self.stage.startswith("all")))
         if path is not None:
             if path.batch != B:
                 raise ValueError("path handle was marched for a different batch size")
@@ -464,9 +470,6 @@ class NerfModel:
             raw_c = ops.nerfmlp_forward(self._packed_weights(variables, "coarse_mlp"), self.precision, path_pd, path_dr, jit, Nc, B,
                                         max_workgroups=self._mlp_wg_limit)
         else:
-            if self.use_online_sparsity:
-                raise NotImplementedError("training with use_online_sparsity: the term carries annealing_rate = 0.0 (train.py:156), i.e. "
-                                          "no gradient; run the model with use_online_sparsity=False (every shipped yaml does)")
             env = ctx.get("env_dirs")
             if env is None:
                 bkgd, ctx["save_bkgd"] = ops.bkgd_forward_train(bkgd_flat, path_dr[last], self.rgb_padding)
@@ -482,9 +485,9 @@ class NerfModel:
             ctx.update(path_pd=path_pd, path_dr=path_dr, jit=jit, raw_c=raw_c, bkgd=bkgd, B=B)
         rgb, dist, acc, trans, trans_bkgd, weights, alpha = ops.composite(
             raw_c, path_pd, path_dr, jit, Nc, B, bkgd, self.white_bkgd, self.rgb_padding, self.sigma_bias,
-            want_weights=True, want_alpha=self.use_online_sparsity)
+            want_weights=True, want_alpha=sparsity)
         loss_sp = 0.0
-        if self.use_online_sparsity:                                                      # rnerf/models.py:351-357
+        if sparsity:                                                      # rnerf/models.py:351-357
             g = path_ior[jit.long()][..., 1:4]
             mask = (torch.sqrt((g * g).sum(-1)) > 1e-6).float()
             loss_sp = (mask * torch.log(torch.clamp(alpha, min=1e-6))).sum() / (mask.sum() + 1)
@@ -495,7 +498,7 @@ class NerfModel:
         if Nf > 0:
             key, rng_1 = prng.split(np.asarray(rng_1, np.uint32))
             u = u_fine if u_fine is not None else self.make_u(key, B, randomized)
-            fine_sp = self.use_online_sparsity and self.use_fine_sparsity
+            fine_sp = sparsity and self.use_fine_sparsity
             rows_pd, rows_dr, idx = ops.resample(path_pd, path_dr, jit, weights, u, Nf, want_idx=(taps is not None) or fine_sp)
             S = Nc + Nf
             if ctx is None:
@@ -508,7 +511,7 @@ class NerfModel:
                 ctx.update(rows_pd=rows_pd, rows_dr=rows_dr, raw_f=raw_f)
             rgb, dist, acc, trans, trans_bkgd, w_f, alpha_f = ops.composite(
                 raw_f, rows_pd, rows_dr, None, S, B, bkgd, self.white_bkgd, self.rgb_padding, self.sigma_bias,
-                want_weights=taps is not None, want_alpha=self.use_online_sparsity and self.use_fine_sparsity)
+                want_weights=taps is not None, want_alpha=fine_sp)
             if fine_sp:                                                                   # rnerf/models.py:526-530
                 g = path_ior[idx.long(), torch.arange(B, device=self.device)[None, :]][..., 1:4]
                 mask = (torch.sqrt((g * g).sum(-1)) > 1e-6).float()

@@ -348,8 +348,9 @@ _SHELL_CACHE: dict = {}
 # Default of the `coherent` argument of march_all / march_all_train: hand the kernel a ray order in which the 16 rays of a workgroup meet
 # the boundary shell over similar node ranges (a group evaluates so3_mlp whenever ANY of its rays is in the shell).  The order comes from a
 # COARSE plain pre-march (num_nodes / 8 nodes of 8 x the step: ~0.1 ms at 4096 rays) + one sort; the kernel writes every record at the
-# ray's own index, so nothing is permuted back.  RNERF_SHELL_ORDER=0 marches the rays in the given order.
-SHELL_ORDER = os.environ.get("RNERF_SHELL_ORDER", "1") == "1"
+# ray's own index, so nothing is permuted back.  ops.SHELL_ORDER = False marches the rays in the given order (a module attribute, set by tools /
+# tests; the product reads no environment variable for it).
+SHELL_ORDER = True
 
 
 def _shell_order(table: torch.Tensor, spec: Grid, o: torch.Tensor, v: torch.Tensor, near: float, far: float, num_nodes: int):
@@ -396,8 +397,8 @@ def march_all(table: torch.Tensor, spec: Grid, so3_flat: torch.Tensor, origins: 
 
 
 # order of the compacted (ray, node) pair list of the stage-all* march: "sorted" (default) = by (node, ray), deterministic from run to run;
-# "atomic" = the kernel's arrival order (RNERF_PAIR_ORDER=atomic: saves a sort of n_pairs keys and a gather over [N, B] per step)
-PAIR_ORDER = os.environ.get("RNERF_PAIR_ORDER", "sorted")
+# "atomic" = the kernel's arrival order (ops.PAIR_ORDER = "atomic": saves a sort of n_pairs keys and a gather over [N, B] per step)
+PAIR_ORDER = "sorted"
 
 
 def march_all_train(table: torch.Tensor, spec: Grid, so3_flat: torch.Tensor, origins: torch.Tensor, viewdirs: torch.Tensor, near: float, far: float,

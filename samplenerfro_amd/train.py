@@ -32,13 +32,17 @@ from . import _lib, distributed, ops, prng
 from .models import BKGD_MLP_SHAPES, NERF_MLP_SHAPES, SO3_MLP_SHAPES, NerfModel, make_variables
 from .utils import Rays, Stats, learning_rate_decay
 
-_MARCH_EARLY = os.environ.get("RNERF_MARCH_BEFORE_WGRAD") is not None  # experiment switch, see train_step (measured slower: off)
+# Experiment switches of the step's stream placement: module attributes (tools set them: `train._MARCH_EARLY = True`), never environment reads.
+_MARCH_EARLY = False                    # see train_step (measured slower: off)
 # CUs the training forward leaves to the next step's march (issued at the START of the step, see train_step); 0 = march after the wgrad.
 # Measured slower (6.8 -> 7.0 ms): the march's 256 one-wave workgroups are dispatched over ALL CUs, and every MLP workgroup (a whole CU
 # each) waits for the wave on its CU; confining the march with a CU-masked stream (hipExtStreamCreateWithCUMask) serialised the two
 # streams instead (7.6 ms), and packing it into 16-wave workgroups on 16 / 32 CUs makes it bound by those CUs' gather units (9.7 / 7.5 ms):
 # the march wants one wave on EVERY CU, the MLP kernels want every CU whole.  Off.
-_MARCH_RESERVE = int(os.environ.get("RNERF_MARCH_RESERVE_CUS", "0"))
+_MARCH_RESERVE = 0
+_AUX_STREAM = True                      # the second stream of rnerf_train_cfg (False: everything on one stream)
+_AUX2_STREAM = False                    # a third stream for the background backward of small hierarchical batches (see train_cfg)
+_CORESIDENT_BKGD_WGRAD = False          # the background-MLP weight gradient as a co-resident kernel beside the NerfMLP wgrad (see train_cfg)
 
 _N_STATS = 8        # loss, loss_c, loss_bg, loss_bg_smooth, weight_l2, (3 spare)
 
@@ -66,7 +70,7 @@ class TrainState:
 
     def nonfinite_grads(self) -> int:
         """Non-finite gradient entries met by the last rnerf_adam_update (reads a device scalar: synchronises).  Non-zero means a row's
-        f16 gradient chain left its 2^10 of headroom (backward modes "f32" / "tf32") or the loss itself went non-finite."""
+        f16 gradient chain left its 2^10 of headroom (backward modes "f16x3" / "f16") or the loss itself went non-finite."""
         return int(self.adam_scratch[3].item()) if self.adam_scratch is not None else 0
 
     def sync_step_counter(self) -> None:
@@ -162,9 +166,10 @@ def _bwd_packed(model: NerfModel, state: TrainState, name: str, backward: int) -
 
 
 def backward_mode(flags, model: NerfModel) -> int:
-    """flags.backward_precision: "f32" (default; hi + lo f16 parts, fp32-grade like the reference's jax.value_and_grad, train.py:164),
-    "tf32" (single f16 parts: the 11-bit class of Ampere's TF32 matmuls) or "bf16" (8-bit significand, the round-1 arithmetic)."""
-    name = getattr(flags, "backward_precision", "f32")
+    """flags.backward_precision: "f16x3" (default; hi + lo f16 parts, fp32-grade like the reference's jax.value_and_grad, train.py:164),
+    "f16" (single f16 parts: the 11-bit class of Ampere's TF32 matmuls) or "bf16" (8-bit significand, the round-1 arithmetic).  "f32" / "tf32"
+    are accepted as the older names of the first two."""
+    name = getattr(flags, "backward_precision", "f16x3")
     if name not in _lib.BACKWARDS:
         raise ValueError(f"backward_precision must be one of {sorted(_lib.BACKWARDS)}")
     mode = _lib.BACKWARDS[name]
@@ -254,18 +259,18 @@ def train_cfg(model: NerfModel, state: TrainState, flags, annealed: float) -> "_
     fs = frozen_sq_of(state, state.variables)
     c.frozen_sq, c.frozen_count = fs[0], fs[1]
     # the second stream of rnerf_train_cfg: what depends on the parameters only (operand packing, zeroing the gradient buffer, sum theta^2)
-    # runs there beside the head of the step (RNERF_NO_AUX_STREAM=1: everything on one stream)
-    if os.environ.get("RNERF_NO_AUX_STREAM") != "1" and hasattr(model, "tail_stream"):
+    # runs there beside the head of the step (_AUX_STREAM = False: everything on one stream)
+    if _AUX_STREAM and hasattr(model, "tail_stream"):
         c.aux_stream = model.tail_stream().cuda_stream
         # a third stream for the background backward of small hierarchical batches: opt-in.  It pays at 256 rays (1.48 -> 1.39 ms) when it
         # gets a hardware queue of its own, and costs 30 % when it lands on the queue of the march or of the main stream — which is decided by
         # how many streams the process has created (GPU_MAX_HW_QUEUES = 4)
-        if hasattr(model, "tail2_stream") and os.environ.get("RNERF_AUX2_STREAM") == "1":
+        if hasattr(model, "tail2_stream") and _AUX2_STREAM:
             c.aux2_stream = model.tail2_stream().cuda_stream
-        # RNERF_TAIL_STREAM=1 (experiment, off): the background-MLP weight gradient as a co-resident kernel beside the NerfMLP wgrad.  Measured
+        # _CORESIDENT_BKGD_WGRAD (experiment, off): the background-MLP weight gradient as a co-resident kernel beside the NerfMLP wgrad.  Measured
         # neutral at 4096 x 128 (what it saves on the critical path, ~0.12 ms, the wgrad loses to the extra waves: 2.04 -> 2.2-2.4 ms),
         # +1-2 % at 1024 rays x (64 + 128)
-        c.coresident_bkgd_wgrad = int(os.environ.get("RNERF_TAIL_STREAM") == "1")
+        c.coresident_bkgd_wgrad = int(_CORESIDENT_BKGD_WGRAD)
     return c
 
 
@@ -398,8 +403,8 @@ def train_step(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], 
     Nc, Nf = model.num_coarse_samples, model.num_fine_samples
     bwd = backward_mode(flags, model)
     if all_stage and bwd == _lib.BWD_BF16:
-        raise ValueError('stage all*: the input gradients are built on the row-normalised backward modes (backward_precision "f32" or "tf32")')
-    ctx: Dict[str, Any] = {"backward": bwd}
+        raise ValueError('stage all*: the input gradients are built on the row-normalised backward modes (backward_precision "f16x3" or "f16")')
+    ctx: Dict[str, Any] = {"backward": bwd, "loss_sp": taps is not None}      # the sparsity term's value: only when somebody will look at it
     if flags.bg_smooth_weight > 0:
         ev = batch["env_rays"].viewdirs
         ctx["env_dirs"] = ev.reshape(-1, 3)
@@ -496,10 +501,13 @@ def train_step(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], 
         norm = torch.sqrt(sq)
         grads.mul_(torch.clamp(flags.grad_max_norm / (1e-7 + norm), max=1.0))
     if taps is not None:
-        taps.update(grads=grads.clone(), sums=sums, ctx=ctx)
+        taps.update(grads=grads.clone(), sums=sums, ctx=ctx, loss_sp=_loss_sp)
     state.apply_gradients(grads)
+    # train.py:153-160: Stats.loss_sp = sparsity_weight * annealing_rate * loss_sp with annealing_rate = 0.0 — the reference's number is 0.0
+    # whatever the term's value (models.py:351-357 keeps it finite: safe_log, a denominator >= 1); the value itself is in taps["loss_sp"]
+    annealing_rate = 0.0
     stats = Stats(loss=st[0], psnr=st[6], loss_c=st[1], psnr_c=(st[7] if rgb_c is not None else 0.0),
-                  weight_l2=st[4], loss_sp=0.0, loss_nrm=0.0, annealing_rate=annealed, coarse_alpha_target=0.0, fine_alpha_target=0.0,
+                  weight_l2=st[4], loss_sp=flags.sparsity_weight * annealing_rate * _loss_sp, loss_nrm=0.0, annealing_rate=annealed, coarse_alpha_target=0.0, fine_alpha_target=0.0,
                   loss_bg=st[2], loss_bg_c=0.0, loss_bg_smooth=st[3])
     state.next_path = next_path
     return state, stats, rng

@@ -55,7 +55,7 @@ def default_flags(**overrides) -> types.SimpleNamespace:
         grad_max_val=0.0, max_steps=1000000, num_path_samples=8, sparsity_weight=0.0, use_fine_sparsity=False,
         use_online_sparsity=True, normal_loss_weight=0.0, normal_smooth_weight=0.0, beta_weight=0.0, bg_weight=0.0,
         bg_smooth_weight=0.0, bg_patch_size=0, chunk=8192,
-        backward_precision="f32",      # not a reference flag: arithmetic of the HIP backward (train.backward_mode)
+        backward_precision="f16x3",      # not a reference flag: arithmetic of the HIP backward (train.backward_mode)
     )
     f.update(overrides)
     return types.SimpleNamespace(**f)

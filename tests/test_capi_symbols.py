@@ -25,7 +25,7 @@ def test_header_symbols_exported(lib_path):
 def test_binding_covers_header(lib_path):
     assert sorted(_lib.SIGNATURES) == declared_symbols()
     lib = _lib.load()
-    assert lib.rnerf_version() == 1
+    assert lib.rnerf_version() == 2
     assert lib.rnerf_nerfmlp_packed_bytes(_lib.PREC_F16X3) == 1160 * 2 * 1024 + 3468 * 4      # operand stream + aux floats (biases, heads, the zero block, the f16f8 range flag)
     assert lib.rnerf_nerfmlp_packed_bytes(_lib.PREC_BF16) == 1160 * 1024 + 3468 * 4
     x3 = lib.rnerf_nerfmlp_packed_bytes(_lib.PREC_F16X3)
@@ -78,3 +78,28 @@ def test_whole_path_structs_match_the_header_layout(lib_path):
     assert lib.rnerf_train_workspace_bytes(ctypes.byref(m), ctypes.byref(c), 512) > t2
     rc = lib.rnerf_adam_update(None, None, None, None, None, 0, None, 0, None, None, None)
     assert rc == -1 and b"rnerf_adam_update" in lib.rnerf_last_error()
+
+
+def test_the_product_library_reads_no_environment(lib_path):
+    """Experiment switches compile in only under -DRNERF_EXPERIMENTS (csrc/common.h RNERF_ENV): librnerf.so must not even import getenv,
+    librnerf_experiments.so (same sources) does; no source file calls getenv() directly."""
+    import glob
+    import subprocess
+    from samplenerfro_amd import build
+    und = lambda p: subprocess.run(["nm", "-D", "--undefined-only", p], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in und(lib_path)
+    assert os.path.exists(build.LIB_EXPERIMENTS) and "getenv" in und(build.LIB_EXPERIMENTS)
+    for src in glob.glob(os.path.join(ROOT, "samplenerfro_amd", "csrc", "*")):
+        text = re.sub(r"//.*", "", open(src).read())
+        if not src.endswith("common.h"):
+            assert not re.search(r"(?<![A-Z_])getenv\s*\(", text), src
+    for py in glob.glob(os.path.join(ROOT, "samplenerfro_amd", "*.py")):        # the host layer: only the launcher's variables (distributed.py)
+        for m in re.finditer(r"environ(?:\.get|\.setdefault)?\s*[\(\[]\s*[\"']([A-Z_0-9]+)", open(py).read()):
+            assert m.group(1) in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"), (py, m.group(1))
+
+
+def test_a_library_of_another_abi_version_is_refused(lib_path, monkeypatch):
+    import pytest
+    monkeypatch.setattr(_lib, "ABI_VERSION", 1)
+    with pytest.raises(_lib.RnerfError, match="ABI version"):
+        _lib.load(lib_path)

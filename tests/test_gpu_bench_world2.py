@@ -30,7 +30,7 @@ def test_bench_two_ranks(scaling):
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == scaling and d["config"]["rays_per_gpu"] == per
     assert d["metric"] == "rays/sec (train step)" and d["unit"] == "rays/s" and d["value"] > 0
     assert abs(d["value"] - 2 * per * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]      # whole-job rays / max-over-ranks time
-    assert d["roofline"]["frac"] > 0 and d["config"]["backward_precision"] == "f32"
+    assert d["roofline"]["frac"] > 0 and d["config"]["backward_precision"] == "f16x3"
     c = d["collectives"]                       # the step's one exchange, timed
     assert c["ranks"] == 2 and c["allreduce_us"] > 0 and c["allreduce_bytes"] > 4 * 1_000_000 and "exposed_us" in c
     r = c["replicas"]                          # every rank applied the same update to the same reduced gradient; own key and rays per rank

@@ -2,7 +2,8 @@
 
 The kernels replay every ordered sum (optical depth, the five accumulations, the backward's suffix chains) in sample order whatever the
 number of lanes that share a ray's activations (csrc/render.hip: composite_kernel<L>, composite_bwd_kernel<L>), so the width is a pure
-scheduling choice of the launcher (composite_lanes).  RNERF_COMPOSITE_LANES is read once per process: one child process per width.
+scheduling choice of the launcher (composite_lanes).  RNERF_COMPOSITE_LANES (librnerf_experiments.so only) is read once per process: one
+child process per width.
 """
 import json
 import os
@@ -17,7 +18,8 @@ CHILD = r"""
 import hashlib, json, sys
 import numpy as np, torch
 sys.path.insert(0, %r)
-from samplenerfro_amd import _lib, ops
+from samplenerfro_amd import _lib, build, ops
+_lib.load(build.LIB_EXPERIMENTS)                # RNERF_COMPOSITE_LANES exists only in the -DRNERF_EXPERIMENTS build of the same sources
 dev = torch.device("cuda:0")
 T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 h = lambda x: hashlib.sha256(x.detach().cpu().numpy().tobytes()).hexdigest()

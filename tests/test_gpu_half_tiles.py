@@ -3,7 +3,8 @@
 Launches whose 256-row tiles would leave more than half of the CUs idle run 128-row tiles instead (csrc/mlp.hip: launch_fwd_dbg,
 launch_dgrad).  A row's arithmetic does not depend on the tile it sits in, so raw outputs, the saved operands the backward kernels read
 (the padded rows included) and the dY planes must be IDENTICAL between the two tilings.  The switches are read once per process
-(RNERF_FWD_HALF_TILES / RNERF_DGRAD_HALF_TILES), hence one child process per setting.
+(RNERF_FWD_HALF_TILES / RNERF_DGRAD_HALF_TILES; they exist only in librnerf_experiments.so, the same sources with -DRNERF_EXPERIMENTS),
+hence one child process per setting; a third child runs the PRODUCT library with the switches set and must give the default's bits.
 """
 import hashlib
 import json
@@ -19,7 +20,9 @@ CHILD = r"""
 import hashlib, json, sys
 import numpy as np, torch
 sys.path.insert(0, %r)
-from samplenerfro_amd import _lib, ops, synthetic as syn
+from samplenerfro_amd import _lib, build, ops, synthetic as syn
+import os
+_lib.load(build.LIB if os.environ.get("RNERF_TEST_PRODUCT_LIB") else build.LIB_EXPERIMENTS)                # the switches exist only in the -DRNERF_EXPERIMENTS build; the product library reads no environment
 dev = torch.device("cuda:0")
 T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 pf = syn.init_params_flat(7, bias_scale=0.1)["coarse_mlp"]
@@ -64,3 +67,6 @@ def test_half_tiles_give_the_same_bits_as_full_tiles():
     assert set(half) == set(full) and len(half) == 10
     for k in sorted(half):
         assert half[k] == full[k], f"{k}: 128-row tiles and 256-row tiles disagree"
+    # the product library with the same variables set: deaf to them, and the same bits again
+    prod = _run({"RNERF_FWD_HALF_TILES": "0", "RNERF_DGRAD_HALF_TILES": "0", "RNERF_TEST_PRODUCT_LIB": "1"})
+    assert prod == half

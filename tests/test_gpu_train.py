@@ -244,3 +244,54 @@ def test_an_activation_beyond_f16_reaches_the_nonfinite_gradient_count():
     assert not np.isfinite(float(stats.loss))
     assert state.nonfinite_grads() > 0
 
+
+
+@pytest.mark.parametrize("fine_sp", [False, True])
+def test_train_step_accepts_the_references_default_flags(fine_sp):
+    """use_online_sparsity=True is the reference's flag default (rnerf/utils.py:219-222).  Its term enters loss_fn times annealing_rate = 0.0
+    (train.py:156-161): the step's gradient and parameters are the bits of the same step without it, Stats.loss_sp is 0.0 like the
+    reference's, and the term's VALUE (rnerf/models.py:351-357,526-530; handed out through taps) equals the oracle's on the same rows."""
+    from samplenerfro_amd import models, synthetic as syn, utils
+    from samplenerfro_amd.train import TrainState, train_step
+    Nf, B, seed = 12, 96, 5
+    G = 24
+    grid = syn.scale_ior(syn.sphere_grid(G, 1.5, 0.6), 0.5).astype(F32)
+    grid = R.conv3d_normal(grid.reshape(-1, 1), [G] * 3, 3, 1.0).reshape([G] * 3)
+    table = R.build_table(grid, [G] * 3, [-1.5] * 3, [1.5] * 3)
+    o, d = syn.sphere_rays(B, seed=seed)
+    pf = syn.init_params_flat(seed, fine=True, bias_scale=0.1)
+    rng = np.random.default_rng(seed)
+    pix = rng.uniform(0, 1, (B, 3)).astype(F32)
+    jitter = np.arange(0, 32, 4) + 2
+
+    def run(sparsity, whole):
+        flags = utils.default_flags(num_coarse_samples=8, num_fine_samples=Nf, num_path_samples=4, white_bkgd=False, bg_weight=0.025,
+                                    bg_smooth_weight=0.0, lr_delay_steps=0, max_steps=1000, randomized=False, near=2.0, far=6.0,
+                                    use_fine_sparsity=fine_sp, sparsity_weight=0.01,
+                                    **({} if sparsity else {"use_online_sparsity": False}))         # default_flags' own default is the reference's: True
+        assert flags.use_online_sparsity is sparsity
+        model, variables = models.construct_nerf(np.array([0, 7], np.uint32), None, flags, [G] * 3, [-1.5] * 3, [1.5] * 3, T(grid))
+        assert model.use_online_sparsity is sparsity
+        for k in ("coarse_mlp", "fine_mlp", "bkgd_mlp"):
+            variables["flat"][k].copy_(T(pf[k]))
+        state = TrainState.create(model, variables, flags)
+        batch = {"rays": utils.Rays(T(o), None, T(d), None), "pixels": T(pix), "annealed_alpha": 0.5}
+        taps = None if whole else {}
+        state, stats, _ = train_step(model, np.array([1, 2], np.uint32), state, batch, flags, jitter=jitter, taps=taps)
+        return state.theta.detach().clone(), stats, taps, model
+
+    th_off, st_off, taps_off, _ = run(False, False)
+    th_on, st_on, taps_on, model = run(True, False)
+    assert torch.equal(taps_on["grads"], taps_off["grads"]) and torch.equal(th_on, th_off)       # the term has no gradient
+    assert float(st_on.loss_sp) == 0.0 and float(st_on.loss) == float(st_off.loss)
+    # the product step (two C calls, no taps) with the default flags: runs, and gives the same parameters
+    th_whole, st_whole, _, _ = run(True, True)
+    assert float(st_whole.loss_sp) == 0.0
+    assert (th_whole - th_on).abs().max().item() <= 1e-6
+    # the value against the oracle on the same coarse jitter (deterministic resampling: randomized=False)
+    cfg = R.ModelConfig([G] * 3, [-1.5] * 3, [1.5] * 3, num_coarse_samples=8, num_fine_samples=Nf, num_path_samples=4,
+                        use_online_sparsity=True, use_fine_sparsity=fine_sp)
+    _, want = R.nerf_forward(cfg, syn.params_tree(pf), table, o, d, jitter)
+    got = float(taps_on["loss_sp"])
+    assert want != 0.0 and abs(got - float(want)) < 1e-4 * max(1.0, abs(float(want))), (got, want)
+    assert float(taps_off["loss_sp"]) == 0.0

@@ -128,7 +128,8 @@ def test_whole_train_step_equals_the_staged_sequence(Nf, bd_cut, bwd, tail, monk
     same order, same device-drawn jitter / stratified draws), parameters after three Adam steps within float rounding."""
     from samplenerfro_amd.train import train_step
     if tail:                      # the opt-in second stream: background-MLP weight gradient by the co-resident kernel beside the NerfMLP wgrad
-        monkeypatch.setenv("RNERF_TAIL_STREAM", "1")
+        from samplenerfro_amd import train as _train
+        monkeypatch.setattr(_train, "_CORESIDENT_BKGD_WGRAD", True)
     out = {}
     for whole in (True, False):
         model, state, batch, flags = _train_setup(Nf, 160, bd_cut, backward_precision=bwd)
