@@ -104,7 +104,7 @@ def cpu_baseline(cfg, pf, fine, sample_rays, seed, train=False):
     return sample_rays / dt, dt
 
 
-def parity_vs_oracle(model, pf, cfg, fine, device, n_rays=4096):
+def parity_vs_oracle(model, pf, cfg, fine, device, n_rays=4096, others=None):
     """BASELINE metric 'PSNR vs ref' / max-abs error: the GPU path against the fp32 oracle on a small sample of the SAME workload
     (same table, initial weights, rays, jitter).  The oracle is the checker here, never the thing measured."""
     import torch
@@ -123,11 +123,17 @@ def parity_vs_oracle(model, pf, cfg, fine, device, n_rays=4096):
     fresh = models.make_variables({k: torch.from_numpy(v).to(device) for k, v in pf.items()})
     rays = Rays(torch.from_numpy(o).to(device), None, torch.from_numpy(d).to(device), None)
     key = np.array([0, 1], np.uint32)
-    ret, _ = model.apply(fresh, key, key, rays, False, jitter=jitter)
-    rgb = ret[-1][0].cpu().numpy().astype(np.float64); dist = ret[-1][1].cpu().numpy().astype(np.float64)
-    mse = float(((rgb - oret[-1][0]) ** 2).mean())
-    return {"rays": n_rays, "max_abs_rgb": float(np.abs(rgb - oret[-1][0]).max()), "max_abs_dist": float(np.abs(dist - oret[-1][1]).max()),
-            "psnr_db_vs_oracle": (-10.0 * np.log10(mse)) if mse > 0 else float("inf")}
+    def against(mdl):
+        ret, _ = mdl.apply(fresh, key, key, rays, False, jitter=jitter)
+        rgb = ret[-1][0].cpu().numpy().astype(np.float64); dist = ret[-1][1].cpu().numpy().astype(np.float64)
+        mse = float(((rgb - oret[-1][0]) ** 2).mean())
+        return {"rays": n_rays, "max_abs_rgb": float(np.abs(rgb - oret[-1][0]).max()), "max_abs_dist": float(np.abs(dist - oret[-1][1]).max()),
+                "psnr_db_vs_oracle": (-10.0 * np.log10(mse)) if mse > 0 else float("inf")}
+
+    out = against(model)
+    for name, mdl in (others or {}).items():          # the labelled single-pass legs: the same oracle pass, the same rays
+        out[name] = against(mdl)
+    return out
 
 
 def cpu_train_step(R, mc, pf, params, table, o, d, jitter, cfg, fine, seed):
@@ -173,6 +179,47 @@ def cpu_train_step(R, mc, pf, params, table, o, d, jitter, cfg, fine, seed):
     opt.step()
     dt = time.perf_counter() - t0
     return B / dt, dt
+
+
+MFMA_PASSES = {"f16x3": 3, "bf16x3": 3, "f16f8": 3, "f16x2": 2, "f16": 1, "bf16": 1}     # MFMAs issued per algorithmic product
+
+
+def sustained_mfma_tflops(device, cus):
+    """The matrix pipe's ceiling on THIS chip in THIS run: back-to-back v_mfma_f32_32x32x16_f16 on every CU, no memory traffic
+    (csrc/ubench/mfma_rate.hip -> librnerf_ubench.so, measurement infrastructure, not the product library), timed with events."""
+    import ctypes as C
+    import torch
+    from samplenerfro_amd import build as B_
+    if not os.path.exists(B_.LIB_UBENCH):
+        return None
+    ub = C.CDLL(B_.LIB_UBENCH)
+    ub.rnerf_ubench_mfma.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_void_p]
+    out = torch.empty(cus * 256, dtype=torch.float32, device=device)
+    flop = C.c_double(0.0)
+    st = torch.cuda.current_stream().cuda_stream
+    res = {}
+    for kind, name in ((0, "f16"), (1, "bf16")):
+        assert ub.rnerf_ubench_mfma(kind, cus, 200, out.data_ptr(), C.byref(flop), st) == 0
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):                                   # ~3 x 12 ms: long enough for the clocks to settle under the power limit
+            ub.rnerf_ubench_mfma(kind, cus, 6000, out.data_ptr(), C.byref(flop), st)
+        e1.record()
+        torch.cuda.synchronize()
+        res[name] = 3.0 * flop.value / (e0.elapsed_time(e1) * 1e-3) / 1e12
+    return res
+
+
+def with_pass_ceiling(roof, passes, sustained):
+    """roofline object + what separates 'cost of the fp32-grade arithmetic' from 'engine efficiency': MFMAs issued per algorithmic
+    product, the measured all-CU MFMA rate of this run, and the algorithmic rate as a fraction of (that rate / passes)."""
+    if roof is None or roof.get("bound") != "mfma":
+        return roof
+    roof["passes"] = passes
+    roof["sustained_mfma_tflops"] = sustained
+    roof["frac_of_pass_ceiling"] = (roof["achieved"] * passes / sustained) if sustained else None
+    return roof
 
 
 def dtype_label(precision, backward, train):
@@ -293,7 +340,7 @@ def timed_steps(stepper, warmup, steps, barrier, D, device):
     return dt
 
 
-def pmc_lookup(workload, fine, B, mode, backward, rnerf_cus):
+def pmc_lookup(workload, fine, B, mode, backward, rnerf_cus, precision="f16x3"):
     """HBM bytes and SQ / GRBM counters per launch from the committed rocprofv3 --pmc passes of THIS command (tools/r04/pmc_all.sh; PMC
     counters cannot be read from inside the process).  The JSON is stamped with the sha of the kernel sources and of bench.py it was taken
     with: a stale stamp (or no profile of this workload) leaves every counter-derived field null."""
@@ -301,7 +348,8 @@ def pmc_lookup(workload, fine, B, mode, backward, rnerf_cus):
     old = {"f16x3": "f32", "f16": "tf32"}.get(backward, backward)       # (the mode names of rounds 2-4, in the file names of profiles/r04)
     rel = None
     for rnd, bw in (("r05", backward), ("r04", old)):                   # the newest committed pass whose stamp still matches wins
-        cand = os.path.join("profiles", rnd, "pmc_%s_f%d_%s.json" % (workload, fine, mode if mode == "forward" else "train_" + bw))
+        psuf = "" if precision in ("f16x3", "f16f8") else "_p" + precision        # (the default arithmetics carry no suffix: forward f16f8, train f16x3)
+        cand = os.path.join("profiles", rnd, "pmc_%s_f%d_%s%s.json" % (workload, fine, mode if mode == "forward" else "train_" + bw, psuf))
         if os.path.exists(os.path.join(ROOT, cand)):
             rel = cand
             break
@@ -521,7 +569,7 @@ def main():
         other_modes = {}
         stepper.close()
         for name in ("f16x3", "f16", "bf16"):
-            if name == args.backward or (args.stage == "all" and name == "bf16"):
+            if name == args.backward or (args.stage == "all" and name == "bf16") or (name == "f16x3" and args.precision != "f16x3"):
                 continue
             s2 = Stepper(args, cfg, model, variables, rays, key, B, world, rank, fine, device, name, args.mode, args.stage, args.pipeline, args.graph)
             dt_m = timed_steps(s2, 2, 5, barrier, D, device)
@@ -562,6 +610,8 @@ def main():
         torch.cuda.synchronize()
         return float(np.mean([e[i].elapsed_time(e[i + 1]) for i in range(reps)]))
 
+    sustained = sustained_mfma_tflops(device, rnerf_cus)       # this chip, this run: the all-CU MFMA ceiling (f16 / bf16 32x32x16)
+    sus16 = sustained["f16"] if sustained else None
     out_raw = torch.empty((S, B, 4), dtype=torch.float32, device=device)
     mlp_ms = timed(lambda: ops.nerfmlp_forward(packed, prec_fwd, path_pd, path_dr, jit, S, B, out=out_raw))
     mlp_flops = MLP_FLOP_PER_ROW * S * B
@@ -602,6 +652,9 @@ def main():
                                     ("nerfmlp_wgrad_kernel" if args.backward == "bf16" else "nerfmlp_wgrad_tr_kernel", t_w, MLP_FLOP_PER_ROW * rows, wgrad_bytes)):
             tk = {"kernel": name, "bound": "mfma", "achieved": flop / (ms * 1e-3) / 1e12, "peak": PEAK_MFMA_16BIT / 1e12,
                   "unit": "TFLOP/s", "frac": flop / (ms * 1e-3) / PEAK_MFMA_16BIT, "avg_launch_ms": ms, "algorithmic_flop_per_launch": flop}
+            # MFMAs per algorithmic product: the forward in its precision; dgrad / wgrad: 3 with hi + lo planes, (W hi + W lo) x dY = 2 / 1 in f16, 2 / 1 in bf16
+            npass = MFMA_PASSES[args.precision] if "fwd" in name else ({"f16x3": 3, "f16": 2, "bf16": 2}[args.backward] if "dgrad" in name else {"f16x3": 3, "f16": 1, "bf16": 1}[args.backward])
+            with_pass_ceiling(tk, npass, sustained["bf16"] if (sustained and args.backward == "bf16" and "fwd" not in name) else sus16)
             if byt is not None:
                 tk["operand_stream"] = {"operand_stream_bytes": byt, "GB_per_s": byt / (ms * 1e-3) / 1e9, "frac_of_hbm_peak": byt / (ms * 1e-3) / PEAK_HBM,
                                         "note": "hi + lo f16 planes of the saved activations and of dY, read once: what paces this kernel (an "
@@ -610,7 +663,65 @@ def main():
         del raw_t, save_t, dy_t, ws_t
         torch.cuda.empty_cache()
 
-    traffic, sq, pmc_meta = pmc_lookup(args.workload, fine, B, args.mode, args.backward, rnerf_cus)
+    # ---- the arithmetic `north_star` names — ONE 16-bit MFMA per product — as labelled legs of the same workload (never the headline: 11 / 8
+    #      significand bits against the reference's fp32).  They separate "cost of fp32 grade" from "engine efficiency": same engines, same
+    #      tiling, a third of the matrix work.  Counter fields / rocprof stats of the legs: profiles/r05 (each leg is also a bench.py command
+    #      of its own: --precision f16 --backward f16, --mode forward --precision f16 | bf16).
+    legs = None
+    if train and args.extra and args.stage == "radiance" and args.precision == "f16x3" and args.backward == "f16x3":
+        legs = {}
+        from samplenerfro_amd.train import TrainState, train_step
+        from samplenerfro_amd import utils as U
+
+        def grads_of(mdl, bw):            # the gradient of ONE step on the bench batch (staged path with taps; same keys -> same jitter and draws)
+            vv = models_fresh_variables(pf, device)
+            fl = U.default_flags(num_coarse_samples=cfg["S"], num_fine_samples=fine, num_path_samples=cfg["P"], white_bkgd=False, bg_weight=0.025,
+                                 bg_smooth_weight=0.0, use_online_sparsity=False, randomized=True, near=cfg["near"], far=cfg["far"],
+                                 batch_size=B * world, backward_precision=bw, stage="radiance")
+            ts = TrainState.create(mdl, vv, fl)
+            gen = np.random.default_rng(syn.SEED + 1000 + rank)
+            bt = {"rays": rays, "pixels": torch.from_numpy(gen.uniform(0, 1, (B, 3)).astype(np.float32)).to(device), "annealed_alpha": 0.5}
+            tp = {}
+            with D.skip_allreduce():      # this rank's own gradient: the comparison is per rank
+                train_step(mdl, key, ts, bt, fl, taps=tp)
+            g = tp["grads"][:_lib.NERFMLP_PARAMS].clone()
+            del ts, tp
+            return g
+
+        g_ref = grads_of(model, "f16x3")
+        for pname in ("f16", "bf16"):
+            mp = model_with_precision(model, pname)
+            vp = models_fresh_variables(pf, device)
+            P = _lib.PRECISIONS[pname]
+            pk = mp._packed_weights(vp, "coarse_mlp", P)
+            ms_k = timed(lambda: ops.nerfmlp_forward(pk, P, path_pd, path_dr, jit, S, B, out=out_raw))
+            ach = mlp_flops / (ms_k * 1e-3) / 1e12
+            sp = Stepper(args, cfg, mp, vp, rays, key, B, world, rank, fine, device, args.backward, "forward", "radiance", False, False)
+            dt_p = timed_steps(sp, 2, 10, barrier, D, device)
+            sp.close()
+            leg = {"forward": {"ms_per_step": 1e3 * dt_p / 10, "rays_per_s": B * world * 10 / dt_p,
+                               "roofline": with_pass_ceiling({"kernel": "nerfmlp_fwd_kernel", "bound": "mfma", "achieved": ach, "peak": PEAK_MFMA_16BIT / 1e12,
+                                                              "unit": "TFLOP/s", "frac": ach * 1e12 / PEAK_MFMA_16BIT, "avg_launch_ms": ms_k,
+                                                              "algorithmic_flop_per_launch": mlp_flops}, 1, (sustained or {}).get(pname))}}
+            legs[pname] = leg
+            legs[pname]["_model"] = (mp, vp)
+        # the single-pass TRAIN step: f16 forward (hi plane = the operand) + f16 backward; bf16 has no training forward (its saved operands would
+        # be 8-bit): its train leg is the bf16 BACKWARD behind the f16 forward
+        for tag, bw in (("f16", "f16"), ("bf16", "bf16")):
+            mp, vp = model_with_precision(model, "f16"), models_fresh_variables(pf, device)
+            st = Stepper(args, cfg, mp, vp, rays, key, B, world, rank, fine, device, bw, "train", "radiance", args.pipeline, False)
+            dt_t = timed_steps(st, 2, 10, barrier, D, device)
+            st.close()
+            g = grads_of(mp, bw)
+            legs[tag]["train"] = {"ms_per_step": 1e3 * dt_t / 10, "rays_per_s": B * world * 10 / dt_t, "forward_precision": "f16", "backward_precision": bw,
+                                  "grad_err_rel_max_vs_f16x3": float((g - g_ref).abs().max() / g_ref.abs().max()),
+                                  "what": "NerfMLP gradient of one step on the bench batch against the default (f16x3 forward + f16x3 backward, itself held to "
+                                          "1e-5 of max|g| vs float64 autograd by tests/test_gpu_backward.py), relative to max|g|"}
+            del mp, vp, g
+        del g_ref
+        torch.cuda.empty_cache()
+
+    traffic, sq, pmc_meta = pmc_lookup(args.workload, fine, B, args.mode, args.backward, rnerf_cus, prec_fwd_name)
 
     def traffic_of(prefix):
         for k, v in traffic.items():
@@ -620,7 +731,7 @@ def main():
 
     # the PMC passes of the forward workload were taken in the DEFAULT eval precision: with another one (--eval-precision f16x3) the profile holds
     # that precision's kernel only as the gated-off fallback launch (a few KB of traffic) — no counter fields then
-    pmc_matches_precision = train or prec_fwd_name == "f16f8"
+    pmc_matches_precision = True       # (pmc_lookup's file name carries the precision)
 
     def counters_of(prefix):
         for k, v in sq.items():
@@ -630,7 +741,7 @@ def main():
 
     # ---- the harder variants of the same metric, in the same driver-run record ------------------------------------
     variants = None
-    if train and args.extra and args.stage == "radiance" and args.workload == "ship_straight" and args.rays is None and args.fine is None:
+    if train and args.extra and args.stage == "radiance" and args.workload == "ship_straight" and args.rays is None and args.fine is None and args.precision == "f16x3":
         variants = {}
 
         def run_variant(tag, vcfg, vmodel, vvars, vfine, vB, note, vstage="radiance"):
@@ -791,14 +902,17 @@ def main():
                          # computed, not a counter: MFMA flops issued (3 passes in the x3 modes) / (launch time x 2.5 PF)
                          "precision": prec_fwd_name,
                          "mfma_issue_frac_computed": {"f16x3": 3, "bf16x3": 3, "f16x2": 2, "f16f8": 3}.get(prec_fwd_name, 1) * mlp_achieved / PEAK_MFMA_16BIT,
-                         "counters": counters_of("nerfmlp_fwd_kernel<%d, 0, 0," % prec_fwd) if pmc_matches_precision else None},
+                         "counters": counters_of("nerfmlp_fwd_kernel<%d, 0, 0," % prec_fwd) if pmc_matches_precision else None,
+                         "passes": MFMA_PASSES.get(prec_fwd_name, 1), "sustained_mfma_tflops": (sustained or {}).get("bf16" if prec_fwd_name.startswith("bf16") else "f16"),
+                         "frac_of_pass_ceiling": (MFMA_PASSES.get(prec_fwd_name, 1) * mlp_achieved / 1e12 / (sustained or {}).get("bf16" if prec_fwd_name.startswith("bf16") else "f16"))
+                         if sustained else None},
             "roofline_march": {"kernel": "march_kernel", "bound": "hbm", "achieved": march_achieved / 1e9, "peak": PEAK_HBM / 1e9,
                                "unit": "GB/s", "frac": march_achieved / PEAK_HBM, "traffic": traffic_of("march_kernel"), "avg_launch_ms": march_ms,
                                "algorithmic_bytes_per_launch": march_bytes},
         }
         if train:
             # the dominant kernel of a train step: the longest of training forward / dgrad / wgrad (algorithmic FLOP against the MFMA peak)
-            fk = "nerfmlp_fwd_kernel<1, 0, 2," if args.backward == "f16x3" else "nerfmlp_fwd_kernel<1, 0, 1,"      # (+ the tile-size argument)
+            fk = "nerfmlp_fwd_kernel<%d, 0, %d," % (_lib.PRECISIONS[args.precision], 2 if args.backward == "f16x3" else 1)      # (+ the tile-size argument)
             for tk, pref in zip(train_kernels, (fk, "nerfmlp_dgrad_kernel", "nerfmlp_wgrad")):
                 tk["traffic"] = traffic_of(pref)
                 tk["counters"] = counters_of(pref)
@@ -816,6 +930,9 @@ def main():
                                      "peak": PEAK_MFMA_16BIT / 1e12, "unit": "TFLOP/s", "frac": step_flop / (dt / args.steps) / PEAK_MFMA_16BIT,
                                      "note": "3 x (mlp_rows_per_ray x 1 186 816 + 112 896) FLOP per ray; the fp32-grade modes issue 3 MFMAs per product, "
                                              "so MFMA issue is ~3 x this fraction (DESIGN.md §4: the 3-pass floor)"}
+        line["sustained_mfma"] = {"tflops": sustained, "what": "back-to-back v_mfma_f32_32x32x16 on every CU, no memory traffic, measured in this run "
+                                  "(csrc/ubench/mfma_rate.hip): the matrix pipe's ceiling under this chip's power limit; `frac_of_pass_ceiling` of a "
+                                  "roofline object = achieved x passes / this"}
         line["collectives"] = {"backend": (dist.get_backend() if dist.is_initialized() else None), "ranks": world,
                                "per_step": ("none" if not (train and D.active()) else
                                             "all-reduce(mean) of the flat gradient + stats buffer between the backward and the update; the NerfMLP "
@@ -836,6 +953,10 @@ def main():
             line["graph_replay"] = graph_replay
         if variants:
             line["variants"] = variants
+        if legs:
+            line["precision_legs"] = legs
+            legs["what"] = ("the arithmetic north_star names (one 16-bit MFMA per product) on the headline workload, next to the fp32-grade default: "
+                            "never the headline (narrower than the reference's fp32); parity_vs_oracle is filled when the CPU-baseline leg runs")
         if frame is not None:
             line["frame"] = frame
         if not args.no_cpu_baseline and args.stage == "radiance":      # (the oracle legs below restate the radiance stage)
@@ -848,13 +969,35 @@ def main():
             except Exception:
                 blas = os.cpu_count()
             used = torch.get_num_threads() if train else blas
-            line["parity"] = parity_vs_oracle(model, pf, cfg, fine, device)
+            par = parity_vs_oracle(model, pf, cfg, fine, device, others={k: v["_model"][0] for k, v in (legs or {}).items() if isinstance(v, dict) and "_model" in v})
+            for k in [k for k, v in (legs or {}).items() if isinstance(v, dict) and "_model" in v]:
+                legs[k]["forward"]["parity_vs_oracle"] = par.pop(k)
+            line["parity"] = par
             line["cpu_baseline"] = {"value": cpu_rps, "unit": "rays/s", "cores": used, "host_cpus": os.cpu_count(), "kind": "port",
                                     "sample": f"{args.cpu_rays} rays of the same workload, {what} (threaded BLAS); {CPU_WARMUP} warm-up + median of "
                                               f"{CPU_TIMED} timed passes, {cpu_dt:.1f} s each"}
+        for v in (legs or {}).values():
+            if isinstance(v, dict):
+                v.pop("_model", None)
         print(json.dumps(line))
     if dist.is_initialized():
         dist.destroy_process_group()
+
+
+def model_with_precision(model, precision):
+    """The same scene (shared IoR table) with every NerfMLP pass in `precision`."""
+    import copy
+    from samplenerfro_amd import _lib
+    m2 = copy.copy(model)
+    m2.precision = m2.eval_precision = _lib.PRECISIONS[precision]
+    m2._packed, m2._jit_cache, m2._ws, m2._key_cache, m2._u_lin, m2._side = {}, {}, {}, {}, None, None
+    return m2
+
+
+def models_fresh_variables(pf, device):
+    import torch
+    from samplenerfro_amd import models
+    return models.make_variables({k: torch.from_numpy(v).to(device) for k, v in pf.items()})
 
 
 def models_with_fine(model, cfg, fine, device, precision):

@@ -14,6 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "librnerf.so")
 LIB_EXPERIMENTS = os.path.join(LIBDIR, "librnerf_experiments.so")
+LIB_UBENCH = os.path.join(LIBDIR, "librnerf_ubench.so")       # csrc/ubench/mfma_rate.hip: the measured MFMA ceiling bench.py quotes (not the product)
 SOURCES = ["grid.hip", "march.hip", "render.hip", "mlp.hip", "mlp_f32.hip", "bkgd16.hip", "pipeline.hip"]
 # -ffp-contract=off + correctly rounded div/sqrt: the march/lookup/resample kernels reproduce the reference's
 # individually rounded fp32 op order so that integer indices are bit-exact against the oracle.
@@ -79,6 +80,9 @@ def build(force: bool = False, verbose: bool = False, experiments: bool = True) 
         jobs.sort(key=lambda j: -os.path.getsize(j[0][-3]))
         with ThreadPoolExecutor(max_workers=min(len(jobs), max(2, (os.cpu_count() or 2) // 2))) as ex:
             list(ex.map(_compile, jobs))
+    ub = os.path.join(CSRC, "ubench", "mfma_rate.hip")
+    if force or _stale(LIB_UBENCH, [ub]):
+        _compile(([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", ub, "-o", LIB_UBENCH], verbose))
     for lib, objs in links:
         if force or _stale(lib, objs):
             _compile(([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib], verbose))

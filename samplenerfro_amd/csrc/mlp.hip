@@ -3122,7 +3122,10 @@ extern "C" int rnerf_nerfmlp_forward_train(const void* packed, int precision, co
   RNERF_CHECK_ARG(max_workgroups >= 0, "rnerf_nerfmlp_forward_train: max_workgroups must be >= 0");
   RNERF_CHECK_ARG(bwd_ok(backward), "rnerf_nerfmlp_forward_train: unknown backward mode %d", backward);
   // (the bf16x3 forward is an inference-only precision: its 8-bit saved operands would cap every backward mode at bf16 accuracy)
-  RNERF_CHECK_ARG(precision == RNERF_PREC_F16X3, "rnerf_nerfmlp_forward_train: the training forward is built for precision f16x3");
+  // F16: the single-pass training forward (one MFMA per product, the hi plane IS the operand) — with the single-plane backward modes only:
+  // the north-star arithmetic as a labelled bench leg, never the default (11-bit products against the reference's fp32)
+  RNERF_CHECK_ARG(precision == RNERF_PREC_F16X3 || (precision == RNERF_PREC_F16 && backward != RNERF_BWD_F16X2),
+                  "rnerf_nerfmlp_forward_train: the training forward is built for precision f16x3 (and f16 with the single-plane backward modes)");
   RNERF_CHECK_ARG(S >= 1 && B >= 1, "rnerf_nerfmlp_forward_train: need S >= 1 and B >= 1");
   RNERF_CHECK_ARG((((uintptr_t)packed | (uintptr_t)rows_pd | (uintptr_t)rows_dr | (uintptr_t)out_raw | (uintptr_t)save) & 15) == 0,
                   "rnerf_nerfmlp_forward_train: buffers must be 16-byte aligned");
@@ -3133,6 +3136,7 @@ extern "C" int rnerf_nerfmlp_forward_train(const void* packed, int precision, co
     return launch_fwd_dbg<RNERF_PREC_F16X3, 256, 2>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, save, max_workgroups);
 #endif
   if (backward == RNERF_BWD_F16X2) return launch_fwd_dbg<RNERF_PREC_F16X3, 0, 2>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, save, max_workgroups);
+  if (precision == RNERF_PREC_F16) return launch_fwd_dbg<RNERF_PREC_F16, 0, 1>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, save, max_workgroups);
   return launch_fwd_dbg<RNERF_PREC_F16X3, 0, 1>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, save, max_workgroups);
 }
 
@@ -3210,10 +3214,12 @@ namespace rnerf {
 int nerfmlp_dgrad_impl(const void* packed_bwd, const void* packed_fwd, int fwd_precision, int backward, const void* save, const float* d_raw, int64_t rows,
                        void* dy, bool zero_ref, bool allow_half, hipStream_t st) {
   RNERF_CHECK_ARG(packed_bwd && packed_fwd && save && d_raw && dy, "rnerf_nerfmlp_dgrad: null pointer");
-  RNERF_CHECK_ARG(fwd_precision == RNERF_PREC_F16X3, "rnerf_nerfmlp_dgrad: forward precision must be f16x3");
+  RNERF_CHECK_ARG(fwd_precision == RNERF_PREC_F16X3 || (fwd_precision == RNERF_PREC_F16 && backward != RNERF_BWD_F16X2),
+                  "rnerf_nerfmlp_dgrad: forward precision must be f16x3 (or f16 with a single-plane backward mode)");
   RNERF_CHECK_ARG(bwd_ok(backward), "rnerf_nerfmlp_dgrad: unknown backward mode %d", backward);
   RNERF_CHECK_ARG(rows >= 1, "rnerf_nerfmlp_dgrad: rows must be >= 1");
-  const float* fwd_aux = (const float*)((const char*)packed_fwd + Prec<RNERF_PREC_F16X3>::STREAM_BYTES);
+  // the aux floats (biases, heads) sit behind the forward's operand stream, whose length depends on its precision
+  const float* fwd_aux = (const float*)((const char*)packed_fwd + (fwd_precision == RNERF_PREC_F16 ? Prec<RNERF_PREC_F16>::STREAM_BYTES : Prec<RNERF_PREC_F16X3>::STREAM_BYTES));
   if (backward == RNERF_BWD_F16X2) return launch_dgrad<RNERF_BWD_F16X2>(packed_bwd, fwd_aux, save, d_raw, rows, dy, st, zero_ref, allow_half);
   if (backward == RNERF_BWD_F16) return launch_dgrad<RNERF_BWD_F16>(packed_bwd, fwd_aux, save, d_raw, rows, dy, st, zero_ref, allow_half);
   return launch_dgrad<RNERF_BWD_BF16>(packed_bwd, fwd_aux, save, d_raw, rows, dy, st, zero_ref, allow_half);
@@ -3323,7 +3329,8 @@ extern "C" size_t rnerf_nerfmlp_wgrad_workspace_bytes(void) {
 extern "C" int rnerf_nerfmlp_wgrad(int fwd_precision, int backward, const void* save, const void* dy, int64_t rows, float* grads, void* workspace,
                                    void* stream) {
   RNERF_CHECK_ARG(save && dy && grads && workspace, "rnerf_nerfmlp_wgrad: null pointer");
-  RNERF_CHECK_ARG(fwd_precision == RNERF_PREC_F16X3, "rnerf_nerfmlp_wgrad: forward precision must be f16x3");
+  RNERF_CHECK_ARG(fwd_precision == RNERF_PREC_F16X3 || (fwd_precision == RNERF_PREC_F16 && backward != RNERF_BWD_F16X2),
+                  "rnerf_nerfmlp_wgrad: forward precision must be f16x3 (or f16 with a single-plane backward mode)");
   RNERF_CHECK_ARG(bwd_ok(backward), "rnerf_nerfmlp_wgrad: unknown backward mode %d", backward);
   RNERF_CHECK_ARG(rows >= 1, "rnerf_nerfmlp_wgrad: rows must be >= 1");
   const WgradTables& w = wgrad_tables();

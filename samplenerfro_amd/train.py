@@ -173,8 +173,9 @@ def backward_mode(flags, model: NerfModel) -> int:
     if name not in _lib.BACKWARDS:
         raise ValueError(f"backward_precision must be one of {sorted(_lib.BACKWARDS)}")
     mode = _lib.BACKWARDS[name]
-    if model.precision != _lib.PREC_F16X3:
-        raise ValueError('training is built on the f16x3 forward (NerfModel(precision="f16x3")); the other precisions are inference modes')
+    if model.precision != _lib.PREC_F16X3 and not (model.precision == _lib.PREC_F16 and mode != _lib.BWD_F16X3):
+        raise ValueError('training is built on the f16x3 forward (NerfModel(precision="f16x3")), or — one MFMA per product, the north-star '
+                         'arithmetic as a labelled leg — on the f16 forward with backward_precision "f16" / "bf16"; the other precisions are inference modes')
     return mode
 
 
