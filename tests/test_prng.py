@@ -51,3 +51,26 @@ def test_published_jax_values():
     k42 = prng.PRNGKey(42)
     assert k42.tolist() == [0, 42]
     assert prng.split(k42).tolist() == [[2465931498, 3679230171], [255383827, 267815257]]
+
+
+def test_two_independent_restatements_agree_on_a_million_draws():
+    """oracle/prng_ref.py is a second reading of jax 0.2.22's random.py, written separately in plain Python integers (one draw at a time,
+    explicit wraps); the vectorised numpy implementation the product uses must agree with it word for word: 2^18 key splits' worth of
+    bits, 2^19 uniforms and 2^18 randints over several spans (the reference's P = 8, 12, 24 and awkward ones) — ~10^6 draws."""
+    from oracle import prng_ref as PR
+    key = prng.PRNGKey(20200823)
+    kt = (int(key[0]), int(key[1]))
+    assert PR.threefry2x32(0x13198a2e, 0x03707344, 0x243f6a88, 0x85a308d3) == (0xc4923a9c, 0x483df7a0)      # the same Random123 vector
+    n = 1 << 18
+    assert prng.random_bits(key, (n + 1,)).tolist() == PR.bits(kt, n + 1)                    # odd count: the padded counter
+    assert [tuple(r) for r in prng.split(key, 5).tolist()] == PR.split(kt, 5)
+    sub = prng.split(key, 8)
+    eps = float(np.finfo(np.float32).eps)
+    u = prng.uniform(sub[0], (1 << 19,), maxval=1.0 / 192 - eps)                              # the stratum width of 64 + 128 samples
+    ur = PR.uniform((int(sub[0][0]), int(sub[0][1])), 1 << 19, 0.0, 1.0 / 192 - eps)
+    assert u.tolist() == [float(np.float32(v)) for v in ur]
+    for i, span in enumerate((8, 12, 24, 3, 65537, 1 << 20)):
+        k = sub[1 + i]
+        m = (1 << 18) // 6 + 7
+        assert prng.randint(k, (m,), 0, span).tolist() == PR.randint((int(k[0]), int(k[1])), m, 0, span), span
+    assert prng.randint(sub[7], (1001,), -5, 7).tolist() == PR.randint((int(sub[7][0]), int(sub[7][1])), 1001, -5, 7)
