@@ -677,11 +677,48 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
   float prof_ph[12] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #define PH(K) do { if constexpr ((dbg & 256) != 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); prof_ph[K] += (float)(t_ - prof_last); prof_last = t_; } } while (0)
 
-  if ((int)blockIdx.x < n_tiles) { if (!(dbg & 1)) issue_slab<SLAB>(packed, 0u, wave, lane); off = SLAB; }
+  // dbg & 512 — REDO, the range-safe second pass (rnerf_nerfmlp_forward queues it behind every f16-based evaluation launch, in bf16x3: fp32's
+  // exponent range): it walks the same tiles but works only on those that hold a row the first pass returned as NaN (an activation above
+  // f16's 65504 or a weight >= 256, see `watch` / AUX_FLAG below) and rewrites only those rows.  The flags ARE the first pass's outputs: no
+  // scratch, nothing to clear, and a launch without such a row costs one read of out_raw (8 tiles' rows in flight per barrier).
+  constexpr bool REDO = (dbg & 512) != 0;
+  // bit k of `todo`: this workgroup's k-th tile (blockIdx.x + k gridDim.x) holds a NaN row.  Found in the prologue, while the LDS is still
+  // free (four 8-byte words for the cross-wave OR; the kernel owns all 160 KiB later).  A workgroup with more than 64 tiles works on every
+  // tile beyond the 64th (correct — only NaN rows are rewritten — just not skipped: > 4 M rows per launch on this chip).
+  unsigned long long todo = ~0ull;
+  if constexpr (REDO) {
+    unsigned long long mine = 0;
+#pragma unroll 8
+    for (int k = 0; k < 64; ++k) {
+      const long long tk = (long long)blockIdx.x + (long long)k * gridDim.x;
+      const long long r = tk * TROWS + tid;
+      const bool bad = tk < n_tiles && r < total_rows && __builtin_isnan(out_raw[r].x);
+      if (__ballot(bad) != 0ull) mine |= 1ull << k;
+    }
+    unsigned long long* red = (unsigned long long*)smem;
+    if (lane == 0) red[wave] = mine;
+    __syncthreads();
+    todo = red[0] | red[1] | red[2] | red[3];
+    __syncthreads();
+  }
+  auto find_next = [&](int t) -> int {      // first tile >= t of this workgroup's sequence that is to be worked on; n_tiles if none
+    if constexpr (REDO) {
+      while (t < n_tiles) {
+        const int k = (t - (int)blockIdx.x) / (int)gridDim.x;
+        if (k >= 64 || ((todo >> k) & 1ull)) return t;
+        t += (int)gridDim.x;
+      }
+      return n_tiles;
+    } else {
+      return t;
+    }
+  };
+  const int first_tile = find_next((int)blockIdx.x);
+  if (first_tile < n_tiles) { if (!(dbg & 1)) issue_slab<SLAB>(packed, 0u, wave, lane); off = SLAB; }
   slab_wait_dma();
   __syncthreads();
 
-  for (int tile = blockIdx.x; tile < n_tiles;) {
+  for (int tile = first_tile; tile < n_tiles;) {
     if (tileq != nullptr && tid == 0)      // read back by every wave at the end of the tile, ~145 barriers later
       __hip_atomic_store(tileq + 1 + blockIdx.x, (int)gridDim.x + atomicAdd(tileq, 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // The aux vectors (biases, head weights) are read at lane-dependent but tile-invariant addresses.  Left alone, hipcc hoists the ~100
@@ -732,7 +769,7 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
     uint32_t ovf0 = 0, ovf1 = 0;
     auto watch = [&](const KOps& o, bool is_signed) {
 #ifndef RNERF_FWD_NORANGE
-      if constexpr (PP::F16) {
+      {                                                                 // (bf16 modes too — round 5: a non-finite position used to come out FINITE there)
         const uint32_t am = is_signed ? 0x7FFF7FFFu : 0xFFFFFFFFu;      // the bottleneck has no ReLU: drop the sign bits
         ovf0 = pk_maxu(pk_maxu(ovf0, o.h0.x & am), pk_maxu(pk_maxu(o.h0.y & am, o.h0.z & am), o.h0.w & am));
         if constexpr (!ONE) ovf1 = pk_maxu(pk_maxu(ovf1, o.h1.x & am), pk_maxu(pk_maxu(o.h1.y & am, o.h1.z & am), o.h1.w & am));
@@ -974,7 +1011,7 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
       save_ops(SAVE_VIEW + 1, c1);
       watch(c0, true); watch(c1, true);
       next_tile = tileq != nullptr ? __builtin_amdgcn_readfirstlane(__hip_atomic_load(tileq + 1 + blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-                                   : tile + (int)gridDim.x;
+                                   : find_next(tile + (int)gridDim.x);
       const bool has_next_tile = next_tile < n_tiles;
       if (has_next_tile) off = 0;
       SLAB_PREFETCH(has_next_tile);
@@ -1051,20 +1088,29 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
       sig0 = sig0 + __shfl_xor(sig0, 32) + bsig;
       sig1 = sig1 + __shfl_xor(sig1, 32) + bsig;
 #ifndef RNERF_FWD_NORANGE
-      if constexpr (PP::F16) {      // an activation outside f16's range somewhere along this row's chain (either half of its features)
+      {      // an activation outside the operand type's range somewhere along this row's chain (either half of its features); bf16: inf / NaN only
         ovf0 = pk_maxu(ovf0, (uint32_t)__shfl_xor((int)ovf0, 32));
         ovf1 = pk_maxu(ovf1, (uint32_t)__shfl_xor((int)ovf1, 32));
         const float qn = __builtin_nanf("");
-        if ((ovf0 & 0xFFFFu) >= 0x7C00u || (ovf0 >> 16) >= 0x7C00u) { p0[0] = p0[1] = p0[2] = qn; sig0 = qn; }
-        if ((ovf1 & 0xFFFFu) >= 0x7C00u || (ovf1 >> 16) >= 0x7C00u) { p1[0] = p1[1] = p1[2] = qn; sig1 = qn; }
+        // f16f8 runs with MODE.FP16_OVFL (f8x_mode: the fp8 conversions must clamp) — and that bit also makes every f16 conversion clamp an
+        // overflow to 65504 (0x7BFF) instead of producing inf: the watch has to take the clamp value itself as "left the range" there (found
+        // in round 5 by the second-pass test: hidden activations of 3e5 rendered finite, wrong colours in the default eval precision)
+        constexpr uint32_t OVF = PP::F8X ? 0x7BFFu : (PP::F16 ? 0x7C00u : 0x7F80u);
+        if ((ovf0 & 0xFFFFu) >= OVF || (ovf0 >> 16) >= OVF) { p0[0] = p0[1] = p0[2] = qn; sig0 = qn; }
+        if ((ovf1 & 0xFFFFu) >= OVF || (ovf1 >> 16) >= OVF) { p1[0] = p1[1] = p1[2] = qn; sig1 = qn; }
       }
 #endif
       if constexpr (PP::F16 && !PP::F8X) {      // a weight outside the range of this precision's operand stream (|W| >= 256): fail loudly, not plausibly
         if (auxt[AUX_FLAG] != 0.f) { const float qn = __builtin_nanf(""); p0[0] = p0[1] = p0[2] = qn; p1[0] = p1[1] = p1[2] = qn; sig0 = qn; sig1 = qn; }
       }
       if (h == 0) {
-        if (row_ok[0]) out_raw[row[0]] = make_float4(p0[0], p0[1], p0[2], sig0);
-        if (row_ok[1]) out_raw[row[1]] = make_float4(p1[0], p1[1], p1[2], sig1);
+        if constexpr (REDO) {      // only the rows the first pass gave up on: every other row keeps the first pass's bits
+          if (row_ok[0] && __builtin_isnan(out_raw[row[0]].x)) out_raw[row[0]] = make_float4(p0[0], p0[1], p0[2], sig0);
+          if (row_ok[1] && __builtin_isnan(out_raw[row[1]].x)) out_raw[row[1]] = make_float4(p1[0], p1[1], p1[2], sig1);
+        } else {
+          if (row_ok[0]) out_raw[row[0]] = make_float4(p0[0], p0[1], p0[2], sig0);
+          if (row_ok[1]) out_raw[row[1]] = make_float4(p1[0], p1[1], p1[2], sig1);
+        }
       }
       PH(8);
     }
@@ -2905,6 +2951,19 @@ using namespace rnerf;
 // f16f8 packs TWO streams: its own, and behind it (256-byte aligned) the f16x3 stream a launch falls back to when a weight is out of its range
 constexpr size_t kF8Fallback = (Prec<RNERF_PREC_F16F8>::PACKED_BYTES + 255) & ~(size_t)255;
 
+// Every f16-based EVALUATION stream is followed (256-byte aligned) by a bf16x3 stream of the same weights: the range-safe second pass of
+// rnerf_nerfmlp_forward (nerfmlp_fwd_kernel's REDO mode) recomputes, in fp32's exponent range, the rows the f16 pass returned as NaN.
+constexpr size_t kX3Bytes = (Prec<RNERF_PREC_F16X3>::PACKED_BYTES + 255) & ~(size_t)255;
+constexpr size_t kSafeBytes = Prec<RNERF_PREC_BF16X3>::PACKED_BYTES;
+static size_t safe_stream_offset(int precision) {      // offset of that bf16x3 stream in a packed buffer of `precision` (0: it has none)
+  switch (precision) {
+    case RNERF_PREC_F16X3:
+    case RNERF_PREC_F16X2: return kX3Bytes;
+    case RNERF_PREC_F16F8: return kF8Fallback + kX3Bytes;
+    default: return 0;
+  }
+}
+
 #define RNERF_TRY_(expr) do { int rc_ = (expr); if (rc_ != RNERF_OK) return rc_; } while (0)
 
 static bool prec_ok(int p) {
@@ -2915,8 +2974,8 @@ extern "C" size_t rnerf_nerfmlp_packed_bytes(int precision) {
   switch (precision) {
     case RNERF_PREC_F32: return (size_t)RNERF_NERFMLP_PARAMS * sizeof(float);  // the flat fp32 buffer itself
     case RNERF_PREC_F16X3:
-    case RNERF_PREC_F16X2: return Prec<RNERF_PREC_F16X3>::PACKED_BYTES;       // f16x2 reads the f16x3 stream
-    case RNERF_PREC_F16F8: return kF8Fallback + Prec<RNERF_PREC_F16X3>::PACKED_BYTES;   // its own stream, then the f16x3 stream it falls back to
+    case RNERF_PREC_F16X2: return kX3Bytes + kSafeBytes;                      // f16x2 reads the f16x3 stream; + the range-safe bf16x3 stream
+    case RNERF_PREC_F16F8: return kF8Fallback + kX3Bytes + kSafeBytes;        // its own stream, the f16x3 stream it falls back to, the bf16x3 stream
     case RNERF_PREC_BF16X3: return Prec<RNERF_PREC_BF16X3>::PACKED_BYTES;
     case RNERF_PREC_F16: return Prec<RNERF_PREC_F16>::PACKED_BYTES;
     case RNERF_PREC_BF16: return Prec<RNERF_PREC_BF16>::PACKED_BYTES;
@@ -2957,7 +3016,9 @@ int nerfmlp_step_zero(int precision, void* const* packed, int count, int backwar
 }
 
 // zero_flags = false: the caller has zeroed the stream's range flags on `stream` already (nerfmlp_pack_zero_flags)
-int nerfmlp_pack_impl(const float* params, int precision, void* packed, bool zero_flags, hipStream_t st) {
+// with_safe = false: leave the range-safe bf16x3 stream of an f16-based buffer unwritten (the training step's own streams: the training
+// forward has no second pass — a row out of range reaches the non-finite-gradient count instead)
+int nerfmlp_pack_impl(const float* params, int precision, void* packed, bool zero_flags, hipStream_t st, bool with_safe) {
   const int threads = kTotalBlocks * 64, block = 256, grid = (threads + block - 1) / block;
   if (zero_flags) {
     void* o[2];
@@ -2978,6 +3039,8 @@ int nerfmlp_pack_impl(const float* params, int precision, void* packed, bool zer
     case RNERF_PREC_BF16X3: hipLaunchKernelGGL(nerfmlp_pack_kernel<RNERF_PREC_BF16X3>, dim3(grid), dim3(block), 0, st, params, (char*)packed); break;
     default: hipLaunchKernelGGL(nerfmlp_pack_kernel<RNERF_PREC_BF16>, dim3(grid), dim3(block), 0, st, params, (char*)packed); break;
   }
+  if (with_safe && safe_stream_offset(precision) != 0)
+    hipLaunchKernelGGL(nerfmlp_pack_kernel<RNERF_PREC_BF16X3>, dim3(grid), dim3(block), 0, st, params, (char*)packed + safe_stream_offset(precision));
   RNERF_CHECK_LAUNCH();
   return RNERF_OK;
 }
@@ -2987,7 +3050,7 @@ extern "C" int rnerf_nerfmlp_pack(const float* params, int precision, void* pack
   RNERF_CHECK_ARG(params && packed, "rnerf_nerfmlp_pack: null pointer");
   RNERF_CHECK_ARG(prec_ok(precision), "rnerf_nerfmlp_pack: unsupported precision %d", precision);
   RNERF_CHECK_ARG(((uintptr_t)packed & 15) == 0, "rnerf_nerfmlp_pack: packed must be 16-byte aligned");
-  return nerfmlp_pack_impl(params, precision, packed, true, (hipStream_t)stream);
+  return nerfmlp_pack_impl(params, precision, packed, true, (hipStream_t)stream, true);
 }
 
 // saved operands + masks of `padded` rows; behind them SAVE_QUEUE_BYTES for the dynamic tile queue of a capped training forward
@@ -3049,10 +3112,10 @@ static int launch_fwd_dbg(const void* packed, const float* rows_pd, const float*
     static const bool half_ok = [] { const char* e = RNERF_ENV("RNERF_FWD_HALF_TILES"); return !(e && e[0] == '0'); }();
     if (half_ok && 2 * n_tiles <= lim) {
       const size_t lds1 = 2 * (size_t)PP::SLAB;
-      static bool attr1_set = false;
-      if (!attr1_set) {
+      static DeviceOnce attr1_set;
+      if (attr1_set.need()) {
         RNERF_CHECK_HIP(hipFuncSetAttribute((const void*)nerfmlp_fwd_kernel<PREC, 0, TRAIN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
-        attr1_set = true;
+        attr1_set.set();
       }
       hipLaunchKernelGGL((nerfmlp_fwd_kernel<PREC, 0, TRAIN, true>), dim3(2 * n_tiles), dim3(256), lds1, st, (const char*)packed, (const float4*)rows_pd,
                          (const float4*)rows_dr, node_of_sample, B, total_rows, 2 * n_tiles, (float4*)out_raw, (uint4*)save, (long long)n_tiles * 256,
@@ -3093,14 +3156,21 @@ extern "C" int rnerf_nerfmlp_forward(const void* packed, int precision, const fl
   hipStream_t st = (hipStream_t)stream;
   switch (precision) {
     case RNERF_PREC_F32: return launch_fwd_f32(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st);
-    case RNERF_PREC_F16X3: return launch_fwd<RNERF_PREC_F16X3>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, max_workgroups);
-    case RNERF_PREC_F16X2: return launch_fwd<RNERF_PREC_F16X2>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, max_workgroups);
+    // every f16-based launch is followed by the range-safe second pass: bf16x3 (fp32's exponent range) on the rows the first pass returned
+    // as NaN — an activation above f16's 65504, a weight >= 256 —, nothing else touched; without such a row it reads out_raw once and ends
+    case RNERF_PREC_F16X3:
+      RNERF_TRY_(launch_fwd<RNERF_PREC_F16X3>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, max_workgroups));
+      return launch_fwd_dbg<RNERF_PREC_BF16X3, 512>((const char*)packed + safe_stream_offset(precision), rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, nullptr, max_workgroups);
+    case RNERF_PREC_F16X2:
+      RNERF_TRY_(launch_fwd<RNERF_PREC_F16X2>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, max_workgroups));
+      return launch_fwd_dbg<RNERF_PREC_BF16X3, 512>((const char*)packed + safe_stream_offset(precision), rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, nullptr, max_workgroups);
     case RNERF_PREC_F16F8: {
       // the f16f8 launch steps aside when its pack kernel flagged a weight outside the range of the 2^14-scaled stream (|W| >= 3.99); the f16x3
       // launch behind it (its stream sits in the same packed buffer) runs only then: a fallback per launch, decided on the device
       const float* flag = (const float*)((const char*)packed + Prec<RNERF_PREC_F16F8>::STREAM_BYTES) + AUX_FLAG;
       RNERF_TRY_(launch_fwd<RNERF_PREC_F16F8>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, max_workgroups, flag, 1));
-      return launch_fwd<RNERF_PREC_F16X3>((const char*)packed + kF8Fallback, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, max_workgroups, flag, 0);
+      RNERF_TRY_(launch_fwd<RNERF_PREC_F16X3>((const char*)packed + kF8Fallback, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, max_workgroups, flag, 0));
+      return launch_fwd_dbg<RNERF_PREC_BF16X3, 512>((const char*)packed + safe_stream_offset(precision), rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, nullptr, max_workgroups);
     }
     case RNERF_PREC_BF16X3: return launch_fwd<RNERF_PREC_BF16X3>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, max_workgroups);
     case RNERF_PREC_F16: return launch_fwd<RNERF_PREC_F16>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, max_workgroups);
@@ -3192,10 +3262,10 @@ static int launch_dgrad(const void* packed_bwd, const float* fwd_aux, const void
     static const int half_lim = [] { const char* e = RNERF_ENV("RNERF_DGRAD_HALF_TILES"); return e ? atoi(e) : -1; }();      // 0: off, n: at most n tiles
     if (allow_half && half_lim != 0 && 2 * n_tiles <= (half_lim > 1 ? half_lim : cus)) {
       const size_t lds1 = 2 * (size_t)PB::SLAB;
-      static bool attr1_set = false;
-      if (!attr1_set) {
+      static DeviceOnce attr1_set;
+      if (attr1_set.need()) {
         RNERF_CHECK_HIP(hipFuncSetAttribute((const void*)nerfmlp_dgrad_kernel<BWD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
-        attr1_set = true;
+        attr1_set.set();
       }
       hipLaunchKernelGGL((nerfmlp_dgrad_kernel<BWD, true>), dim3(2 * n_tiles), dim3(256), lds1, st, (const char*)packed_bwd, fwd_aux, (const uint4*)save, R,
                          (const float4*)d_raw, (long long)rows, 2 * n_tiles, (uint4*)dy);

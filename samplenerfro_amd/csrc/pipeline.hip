@@ -52,7 +52,7 @@ inline void pool_put(hipEvent_t e) {
 
 // csrc/mlp.hip: the operand-stream pack without its own memsets (the step zeroes every stream's range flags in one launch)
 int nerfmlp_step_zero(int precision, void* const* packed, int count, int backward, void* const* dy, const int64_t* dy_rows, int dy_count, hipStream_t st);
-int nerfmlp_pack_impl(const float* params, int precision, void* packed, bool zero_flags, hipStream_t st);
+int nerfmlp_pack_impl(const float* params, int precision, void* packed, bool zero_flags, hipStream_t st, bool with_safe);
 int nerfmlp_dgrad_impl(const void* packed_bwd, const void* packed_fwd, int fwd_precision, int backward, const void* save, const float* d_raw, int64_t rows,
                        void* dy, bool zero_ref, bool allow_half, hipStream_t st);
 
@@ -568,7 +568,7 @@ extern "C" int rnerf_train_forward_backward(const rnerf_model* m, const rnerf_tr
     const int64_t dy_rows[2] = {(int64_t)(Nf > 0 ? S : Nc) * B, (int64_t)Nc * B};
     RNERF_TRY(nerfmlp_step_zero(prec, streams, Nf > 0 ? 2 : 1, bwd, dys, dy_rows, t.dy_c ? 2 : 1, (hipStream_t)aux));
     pre_zeroed = true;
-    RNERF_TRY(nerfmlp_pack_impl(th_c, prec, t.packed_c, false, (hipStream_t)aux));
+    RNERF_TRY(nerfmlp_pack_impl(th_c, prec, t.packed_c, false, (hipStream_t)aux, false));
   }
   // ---- forward (models.forward with ctx) ----
   const int32_t* jitter = jitter_override;
@@ -588,7 +588,7 @@ extern "C" int rnerf_train_forward_backward(const rnerf_model* m, const rnerf_tr
   if (aux) {
     RNERF_TRY(rnerf_join(stream, aux));                    // the aux stream's tail HERE is the coarse pack: everything below follows it
     if (Nf > 0) {
-      RNERF_TRY(nerfmlp_pack_impl(th_f, prec, t.packed_f, false, (hipStream_t)aux));
+      RNERF_TRY(nerfmlp_pack_impl(th_f, prec, t.packed_f, false, (hipStream_t)aux, false));
       RNERF_TRY(mark_point((hipStream_t)aux, &fine_packed.e));
     }
     RNERF_CHECK_HIP(hipMemsetAsync(grads, 0, (size_t)(n_theta + 8) * sizeof(float), (hipStream_t)aux));

@@ -26,10 +26,14 @@ def test_binding_covers_header(lib_path):
     assert sorted(_lib.SIGNATURES) == declared_symbols()
     lib = _lib.load()
     assert lib.rnerf_version() == 2
-    assert lib.rnerf_nerfmlp_packed_bytes(_lib.PREC_F16X3) == 1160 * 2 * 1024 + 3468 * 4      # operand stream + aux floats (biases, heads, the zero block, the f16f8 range flag)
+    stream3 = 1160 * 2 * 1024 + 3468 * 4      # a three-pass operand stream + aux floats (biases, heads, the zero block, the range flag)
+    al = lambda n: (n + 255) // 256 * 256
+    assert lib.rnerf_nerfmlp_packed_bytes(_lib.PREC_BF16X3) == stream3
     assert lib.rnerf_nerfmlp_packed_bytes(_lib.PREC_BF16) == 1160 * 1024 + 3468 * 4
-    x3 = lib.rnerf_nerfmlp_packed_bytes(_lib.PREC_F16X3)
-    assert lib.rnerf_nerfmlp_packed_bytes(_lib.PREC_F16F8) == (x3 + 255) // 256 * 256 + x3      # its own stream (same blocks, other contents) + the f16x3 stream it falls back to
+    # every f16-based evaluation buffer ends with the bf16x3 stream of the range-safe second pass
+    assert lib.rnerf_nerfmlp_packed_bytes(_lib.PREC_F16X3) == al(stream3) + stream3
+    assert lib.rnerf_nerfmlp_packed_bytes(_lib.PREC_F16X2) == al(stream3) + stream3
+    assert lib.rnerf_nerfmlp_packed_bytes(_lib.PREC_F16F8) == al(stream3) + al(stream3) + stream3      # its own stream, the f16x3 stream it falls back to, bf16x3
     assert lib.rnerf_nerfmlp_packed_bytes(_lib.PREC_F32) == 595844 * 4                            # the exact-fp32 arbiter reads the flat buffer itself
     # the Python names follow enum rnerf_precision of the header
     hdr = open(os.path.join(ROOT, "include", "rnerf.h")).read()
@@ -89,7 +93,7 @@ def test_the_product_library_reads_no_environment(lib_path):
     und = lambda p: subprocess.run(["nm", "-D", "--undefined-only", p], capture_output=True, text=True, check=True).stdout
     assert "getenv" not in und(lib_path)
     assert os.path.exists(build.LIB_EXPERIMENTS) and "getenv" in und(build.LIB_EXPERIMENTS)
-    for src in glob.glob(os.path.join(ROOT, "samplenerfro_amd", "csrc", "*")):
+    for src in glob.glob(os.path.join(ROOT, "samplenerfro_amd", "csrc", "**", "*.*"), recursive=True):
         text = re.sub(r"//.*", "", open(src).read())
         if not src.endswith("common.h"):
             assert not re.search(r"(?<![A-Z_])getenv\s*\(", text), src
