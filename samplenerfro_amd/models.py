@@ -448,7 +448,7 @@ class NerfModel:
                 raise ValueError("path handle lacks the IoR record (prefetch it from a model with the same options)")
         elif self.stage.startswith("all") and ctx is not None:                            # training: the march also records what its adjoint needs
             rec = ops.march_all_train(self.table, self.spec, self._flat(variables, "so3_mlp", SO3_MLP_SHAPES).detach(), origins, viewdirs,
-                                      self.near, self.far, N, annealed_alpha)
+                                      self.near, self.far, N, annealed_alpha, lazy=True)      # pairs finalised by train._all_stage_backward
             ctx["march_rec"] = rec
             path_pd, path_dr, path_ior = rec["path_pd"], rec["path_dr"], None
             if want_ior:

@@ -361,6 +361,10 @@ def _shell_order(table: torch.Tensor, spec: Grid, o: torch.Tensor, v: torch.Tens
     key = (id(o), o._version, id(v), v._version, o.shape[0], int(num_nodes), table.data_ptr(), float(near), float(far))
     ent = _SHELL_CACHE.get(key)
     if ent is not None and ent[0]() is o and ent[1]() is v:
+        if ent[3] is not None:      # computed ahead on another stream (prefetch_shell_order): this stream waits for it, once
+            torch.cuda.current_stream().wait_event(ent[3])
+            ent[2].record_stream(torch.cuda.current_stream())
+            _SHELL_CACHE[key] = (ent[0], ent[1], ent[2], None)
         return ent[2]
     nc = max(int(num_nodes) // 8, 16)
     _, _, ior, _ = march(table, spec, o, v, near, far, nc, want_ior=True)
@@ -373,8 +377,29 @@ def _shell_order(table: torch.Tensor, spec: Grid, o: torch.Tensor, v: torch.Tens
     perm = torch.argsort(skey, stable=True).to(torch.int32)
     if len(_SHELL_CACHE) >= 8:
         _SHELL_CACHE.clear()
-    _SHELL_CACHE[key] = (weakref.ref(o), weakref.ref(v), perm)
+    _SHELL_CACHE[key] = (weakref.ref(o), weakref.ref(v), perm, None)
     return perm
+
+
+def prefetch_shell_order(table: torch.Tensor, spec: Grid, origins: torch.Tensor, viewdirs: torch.Tensor, near: float, far: float, num_nodes: int,
+                         stream: "torch.cuda.Stream") -> None:
+    """The shell-coherent ray order of a batch the stage-all* march will meet LATER (the next training batch), computed now on `stream`: the
+    coarse pre-march (a 50-register kernel: it fits beside the NerfMLP kernels' tails and the weight-gradient kernel) and the sort depend on
+    the rays and the grid only, not on so3_mlp.  march_all / march_all_train pick the result up from the cache and wait for its event."""
+    if not (SHELL_ORDER and origins.shape[0] > 16):
+        return
+    o = _chk(origins, "origins"); v = _chk(viewdirs, "viewdirs")
+    key = (id(o), o._version, id(v), v._version, o.shape[0], int(num_nodes), table.data_ptr(), float(near), float(far))
+    if key in _SHELL_CACHE:
+        return
+    stream.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(stream):
+        o.record_stream(stream); v.record_stream(stream)
+        _shell_order(table, spec, o, v, near, far, num_nodes)
+        ev = torch.cuda.Event()
+        ev.record(stream)
+    ent = _SHELL_CACHE[key]
+    _SHELL_CACHE[key] = (ent[0], ent[1], ent[2], ev)
 
 
 def march_all(table: torch.Tensor, spec: Grid, so3_flat: torch.Tensor, origins: torch.Tensor, viewdirs: torch.Tensor, near: float, far: float,
@@ -402,9 +427,11 @@ PAIR_ORDER = "sorted"
 
 
 def march_all_train(table: torch.Tensor, spec: Grid, so3_flat: torch.Tensor, origins: torch.Tensor, viewdirs: torch.Tensor, near: float, far: float,
-                    num_nodes: int, annealed_alpha: float = 1.0, pair_cap: Optional[int] = None, coherent: Optional[bool] = None):
-    """rnerf_march_all_train: the stage "all*" march + the record its backward needs.  Returns a dict (pairs trimmed to their count:
-    this reads the device counter, i.e. synchronises once per step)."""
+                    num_nodes: int, annealed_alpha: float = 1.0, pair_cap: Optional[int] = None, coherent: Optional[bool] = None, lazy: bool = False):
+    """rnerf_march_all_train: the stage "all*" march + the record its backward needs.  Returns a dict; the pairs are trimmed to their count
+    and ordered by finalize_pairs(rec), which reads the device counter (one host synchronisation per step).  lazy=True leaves that call
+    to the consumer (train._all_stage_backward): the forward kernels of the step, which need the path record only, are then queued
+    BEFORE the host waits for the march — the synchronisation costs no idle device time (round 5: 0.35 ms of every stage-all* step)."""
     lib = _lib.load()
     o = _chk(origins, "origins"); v = _chk(viewdirs, "viewdirs")
     B, N, dev = o.shape[0], int(num_nodes), o.device
@@ -422,6 +449,17 @@ def march_all_train(table: torch.Tensor, spec: Grid, so3_flat: torch.Tensor, ori
     check(lib.rnerf_march_all_train(ptr(table), C.byref(spec), ptr(_chk(so3_flat, "so3_flat")), ptr(packed), w.ctypes.data_as(C.c_void_p), ptr(o), ptr(v), B,
                                     float(near), float(far), N, ptr(pd), ptr(dr), ptr(rdn), ptr(count), cap, ptr(pair_id), ptr(pair_x), ptr(pair_g),
                                     ptr(pair_of_node), ptr(order), current_stream()), "rnerf_march_all_train")
+    rec = dict(path_pd=pd, path_dr=dr, path_rdn=rdn, window=w, _raw=(count, cap, pair_id, pair_x, pair_g, pair_of_node, B, N))
+    return rec if lazy else finalize_pairs(rec)
+
+
+def finalize_pairs(rec: dict) -> dict:
+    """Trim the compacted (ray, node) pair list of a march_all_train record to its count (reads the device counter: synchronises) and put it
+    into its run-to-run deterministic order.  Idempotent."""
+    if "_raw" not in rec:
+        return rec
+    count, cap, pair_id, pair_x, pair_g, pair_of_node, B, N = rec.pop("_raw")
+    dev = pair_x.device
     n = int(count.item())
     if n > cap:
         raise _lib.RnerfError(f"march_all_train: {n} boundary-shell pairs exceed pair_cap = {cap}")
@@ -437,8 +475,8 @@ def march_all_train(table: torch.Tensor, spec: Grid, so3_flat: torch.Tensor, ori
         pid, px, pg = pid[perm], px[perm], pg[perm]
         flat = pair_of_node.view(-1)
         pair_of_node = torch.where(flat >= 0, inv[flat.clamp(min=0).to(torch.int64)], flat).view(N, B)
-    return dict(path_pd=pd, path_dr=dr, path_rdn=rdn, n_pairs=n, pair_id=pid, pair_x=px.contiguous(), pair_g=pg.contiguous(),
-                pair_of_node=pair_of_node, window=w)
+    rec.update(n_pairs=n, pair_id=pid, pair_x=px.contiguous(), pair_g=pg.contiguous(), pair_of_node=pair_of_node)
+    return rec
 
 def so3_forward_train(so3_flat: torch.Tensor, window, pts4: torch.Tensor):
     """so3_mlp(annealed_pos_enc(x)) on pts4 [n,4] with saved activations -> (raw [n,4] view into save, save)."""

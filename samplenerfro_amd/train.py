@@ -215,7 +215,7 @@ def _all_stage_backward(model: NerfModel, state: TrainState, variables, ctx, dy_
     colour reach the path: sample_pdf stops the gradient of everything it returns (rnerf/model_utils.py:406-411), ray_dist is
     stop_gradient'ed (eikonal_utils.py:121), and |ray_dir| = 1 makes the compositing's delta independent of the direction."""
     B, Nc, N = ctx["B"], model.num_coarse_samples, model.num_samples
-    rec = ctx["march_rec"]
+    rec = ops.finalize_pairs(ctx["march_rec"])      # the step's one host synchronisation: here, with the forward and the NerfMLP backward already queued
     coarse_flat = variables["flat"]["coarse_mlp"]
     so3_flat = variables["flat"]["so3_mlp"]
     a_pos, a_dir = ops.nerfmlp_input_grad(coarse_flat, bwd, dy_c, ctx["path_pd"], ctx["path_dr"], ctx["jit"], Nc, B)
@@ -401,6 +401,14 @@ def train_step(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], 
     pixels = batch["pixels"][..., :3].contiguous()
     variables = state.variables
     prec = model.precision
+    if all_stage and next_rays is not None:
+        # the NEXT batch's march needs this step's so3 update and cannot start early, but the ray order it marches in (a coarse pre-march
+        # without so3 + a sort, ~0.3 ms) depends on the rays and the grid only: computed on the side stream beside this step
+        if model._side is None:
+            from .models import shared_stream
+            model._side = shared_stream(model.device, "march")
+        ops.prefetch_shell_order(model.table, model.spec, next_rays.origins, next_rays.viewdirs, model.near, model.far, model.num_samples, model._side)
+        next_rays = None                  # (no path prefetch in this stage)
     Nc, Nf = model.num_coarse_samples, model.num_fine_samples
     bwd = backward_mode(flags, model)
     if all_stage and bwd == _lib.BWD_BF16:
