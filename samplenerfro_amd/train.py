@@ -43,6 +43,7 @@ _MARCH_RESERVE = 0
 _AUX_STREAM = True                      # the second stream of rnerf_train_cfg (False: everything on one stream)
 _AUX2_STREAM = False                    # a third stream for the background backward of small hierarchical batches (see train_cfg)
 _CORESIDENT_BKGD_WGRAD = False          # the background-MLP weight gradient as a co-resident kernel beside the NerfMLP wgrad (see train_cfg)
+_ALL_CHAIN_BESIDE_WGRAD = True          # stage all*: the march's adjoint chain on the side stream beside the NerfMLP wgrad (see train_step)
 
 _N_STATS = 8        # loss, loss_c, loss_bg, loss_bg_smooth, weight_l2, (3 spare)
 
@@ -460,13 +461,19 @@ def train_step(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], 
     def issue_next_march():
         hold["path"] = model.prefetch_path(next_rays, sync_inputs=True, reserve_cus=0) if next_rays is not None else None
     early = _MARCH_EARLY and next_rays is not None and "path" not in hold
-    _, dy_c = ops.nerfmlp_backward(_bwd_packed(model, state, "coarse_mlp", bwd), model._packed_weights(variables, "coarse_mlp"), prec, ctx["save_c"],
-                                   d_raw_c, Nc * B, grads=state.grad_view("coarse_mlp"), backward=bwd, return_dy=True,
-                                   between=issue_next_march if early else None)
+    chain_beside = all_stage and _ALL_CHAIN_BESIDE_WGRAD and hasattr(model, "tail_stream")
+    if chain_beside:
+        # stage all*: only the dgrad here; the (HBM-paced) wgrad is issued further down, beside the adjoint chain that needs dY but not dW
+        dy_c = ops.nerfmlp_backward(_bwd_packed(model, state, "coarse_mlp", bwd), model._packed_weights(variables, "coarse_mlp"), prec, ctx["save_c"],
+                                    d_raw_c, Nc * B, backward=bwd, stages="d")
+    else:
+        _, dy_c = ops.nerfmlp_backward(_bwd_packed(model, state, "coarse_mlp", bwd), model._packed_weights(variables, "coarse_mlp"), prec, ctx["save_c"],
+                                       d_raw_c, Nc * B, grads=state.grad_view("coarse_mlp"), backward=bwd, return_dy=True,
+                                       between=issue_next_march if early else None)
     # jax.lax.pmean of the gradients (train.py:166), first part: the NerfMLP segments are final here, their all-reduce (95 % of the
     # bytes) starts now and runs beside the rest of the step; the background-MLP gradients and the stats follow in a small second one
     n_big = state.segments["bkgd_mlp"][0]
-    pending = distributed.allreduce_begin(G[:n_big])
+    pending = None if chain_beside else distributed.allreduce_begin(G[:n_big])
     if "path" not in hold:
         issue_next_march()
     next_path = hold["path"]
@@ -479,7 +486,22 @@ def train_step(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], 
         on = 1.0 if annealed > 0 else 0.0
         env_sum = torch.empty(_lib.load().rnerf_env_smooth_sum_floats(int(ps)), dtype=torch.float32, device=pixels.device)
         ops.env_smooth_backward(ctx["rgb_env"], ps, flags.bg_smooth_weight * on, d_all[B:], env_sum)
-    if all_stage:
+    if all_stage and chain_beside:
+        _, d_bk_dirs = ops.bkgd_backward(bk_flat, ctx["save_bkgd"], d_all, g_bk, model.rgb_padding, want_d_dirs=True)
+        # Two independent consumers of dY from here on: the NerfMLP weight gradient (one big kernel that streams 10.6 GB and leaves the matrix
+        # pipe half idle) and the adjoint chain of the march (input gradients, so3 forward / Jacobians, the reverse scan, so3 backward: ~3.9 ms
+        # of small fp32-MFMA / latency-bound kernels that stream little).  They cannot share a CU (registers), but they can share
+        # the CHIP: the wgrad goes to this stream, the chain to the side stream, and the dispatcher interleaves their workgroups CU by CU.
+        # The wgrad is queued first: the chain's one host synchronisation (the pair count) then idles nothing.
+        main, side = torch.cuda.current_stream(), model.tail_stream()
+        side.wait_stream(main)
+        ops.nerfmlp_backward(_bwd_packed(model, state, "coarse_mlp", bwd), model._packed_weights(variables, "coarse_mlp"), prec, ctx["save_c"],
+                             d_raw_c, Nc * B, grads=state.grad_view("coarse_mlp"), backward=bwd, dy=dy_c, stages="w")
+        pending = distributed.allreduce_begin(G[:n_big])
+        with torch.cuda.stream(side):
+            _all_stage_backward(model, state, variables, ctx, dy_c, d_bk_dirs, bwd, annealed, taps)
+        main.wait_stream(side)
+    elif all_stage:
         _, d_bk_dirs = ops.bkgd_backward(bk_flat, ctx["save_bkgd"], d_all, g_bk, model.rgb_padding, want_d_dirs=True)
         _all_stage_backward(model, state, variables, ctx, dy_c, d_bk_dirs, bwd, annealed, taps)
     else:

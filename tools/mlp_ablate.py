@@ -3,6 +3,8 @@ import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from samplenerfro_amd import ops, _lib, synthetic as syn
+if os.environ.get("RNERF_LIB"):          # an ablation / experiments build (tools/r03/build_variant.sh): bound before anything else loads the product library
+    _lib.load(os.environ["RNERF_LIB"])
 prec = sys.argv[1] if len(sys.argv) > 1 else "f16x3"
 S, B = 128, 4096
 dev = torch.device("cuda:0")

@@ -1,0 +1,24 @@
+"""A/B of the stage-all* step with the adjoint chain on the side stream beside the NerfMLP wgrad (train._ALL_CHAIN_BESIDE_WGRAD) — one process,
+alternating, same model and batch.  usage (GPU box): python tools/r05/ab_all.py"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np, torch
+import bench
+from samplenerfro_amd import synthetic as syn, prng, train, distributed as D
+from samplenerfro_amd.utils import Rays
+dev = torch.device("cuda:0")
+cfg = dict(syn.CONFIGS["ship_refractive"])
+model, variables, pf = bench.build_scene(cfg, dev, "f16x3", 0, "all", None)
+o, d = syn.sphere_rays(4096, seed=syn.SEED)
+rays = Rays(torch.from_numpy(o).to(dev), None, torch.from_numpy(d).to(dev), None)
+key = prng.PRNGKey(syn.SEED)
+class A: pass
+args = A(); args.reserve_cus = 0
+def barrier(): torch.cuda.synchronize()
+for rep in range(3):
+    for flag in (False, True):
+        train._ALL_CHAIN_BESIDE_WGRAD = flag
+        st = bench.Stepper(args, cfg, model, variables, rays, key, 4096, 1, 0, 0, dev, "f16x3", "train", "all", False, False)
+        dt = bench.timed_steps(st, 3, 20, barrier, D, dev)
+        st.close()
+        print(f"chain beside wgrad = {flag}: {1e3 * dt / 20:.3f} ms per step", flush=True)
