@@ -473,6 +473,22 @@ def main():
     if args.force_dist:
         D.force_single_rank_group(True)
     D.init(backend, timeout_s=args.dist_timeout)   # the train step's gradient all-reduce, the timing barrier and the max over ranks
+    # sub-groups of the in-run scaling curve, created up front (every rank takes part in creating each): a backend that cannot split its
+    # communicator says so here, before any work — the curve is then left out (all ranks agree through one all-reduce), the line is not
+    curve_groups = None
+    if world > 1 and args.curve and args.mode == "train":
+        import datetime
+        ok, curve_groups = 1, {}
+        try:
+            for n in [m for m in (1, 2, 4, 8, 16, 32) if m < world]:
+                curve_groups[n] = dist.new_group(ranks=list(range(n)), timeout=datetime.timedelta(seconds=args.dist_timeout))
+        except Exception as e:      # noqa: BLE001
+            ok = 0
+            print(f"bench.py [rank {rank}]: sub-group creation failed ({type(e).__name__}: {e}); scaling_curve is left out", file=sys.stderr)
+        flag = torch.tensor([ok], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            curve_groups = None
 
     cfg = dict(syn.CONFIGS[args.workload])
     fine = cfg["F"] if args.fine is None else args.fine
@@ -533,15 +549,14 @@ def main():
                      "note": "boxes of the pool differ by +-3 %; A/B deltas are only meaningful as same-box pairs (DESIGN.md §4)"}
 
     curve = None
-    if train and world > 1 and args.curve:
+    if train and world > 1 and args.curve and curve_groups is not None:
         # the same step on the first n ranks of THIS launch (the others wait at the barrier): absolute rays/s at n = 1, 2, 4, ... world from
         # one run.  Per-rank work is fixed (weak); the gradient all-reduce runs over the n ranks only.  (Afterwards the replicas have taken
         # different numbers of steps: everything below builds fresh steppers from the seeded initial weights.)
-        import datetime
         curve = {"n": [], "rays_per_s": [], "ms_per_step": [], "steps": 10, "rays_per_gpu": B,
                  "what": "weak: the step of this line on the first n ranks of the same launch, gradient all-reduce over those n ranks, max over them"}
         for n in [m for m in (1, 2, 4, 8, 16, 32) if m < world] + [world]:
-            grp = dist.new_group(ranks=list(range(n)), timeout=datetime.timedelta(seconds=args.dist_timeout)) if n < world else None
+            grp = curve_groups[n] if n < world else None
             dt_n = None
             if rank < n:
                 with D.use_group(grp):

@@ -295,3 +295,43 @@ def test_train_step_accepts_the_references_default_flags(fine_sp):
     got = float(taps_on["loss_sp"])
     assert want != 0.0 and abs(got - float(want)) < 1e-4 * max(1.0, abs(float(want))), (got, want)
     assert float(taps_off["loss_sp"]) == 0.0
+
+
+@pytest.mark.parametrize("Nf,bwd", [(12, "f16"), (0, "bf16")])
+def test_single_pass_f16_training_step(Nf, bwd):
+    """The single-pass training arithmetic (north_star's: ONE 16-bit MFMA per product; a labelled bench leg, never the default): NerfModel(
+    precision="f16") + backward_precision "f16" / "bf16".  Held to what 11-bit products give: losses within 2e-3, gradients with cosine
+    > 0.9999 and within 2e-2 of max|g| of the float64 loss_fn on the rows the device used; the whole-path step equals the staged one; the hi + lo backward is refused behind a forward that saved one plane."""
+    from samplenerfro_amd import _lib
+    from samplenerfro_amd.train import TrainState, train_step
+    model, state, batch, flags, ev = _setup(Nf)
+    model.precision = model.eval_precision = _lib.PREC_F16
+    model._packed = {}
+    flags.backward_precision = bwd
+    state = TrainState.create(model, state.variables, flags)
+    theta0 = state.theta.cpu().numpy().astype(np.float64)
+    rng = np.array([1, 2], np.uint32)
+    taps = {}
+    state, stats, _ = train_step(model, rng, state, batch, flags, taps=taps)
+    g = taps["grads"].cpu().numpy().astype(np.float64)
+    ref, parts = _reference_grads(model, state, batch, flags, taps, ev, theta0)
+    assert abs(float(stats.loss) - parts["loss"]) < 2e-3 * max(1.0, parts["loss"])
+    for name, (lo, hi) in state.segments.items():
+        a, b = g[lo:hi], ref[lo:hi]
+        cos = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b)))
+        err = np.abs(a - b).max() / np.abs(b).max()
+        print(f"[single pass, N_f={Nf}, bwd={bwd}] {name}: cosine {cos:.6f}, max err / max |g| {err:.2e}")
+        assert cos > 0.9999 and err < 2e-2, (name, cos, err)
+    # the product step (two C calls) on the same batch and keys: the staged sequence's gradient bits
+    model2, state2, batch2, flags2, _ = _setup(Nf)
+    model2.precision = model2.eval_precision = _lib.PREC_F16
+    model2._packed = {}
+    flags2.backward_precision = bwd
+    state2 = TrainState.create(model2, state2.variables, flags2)
+    train_step(model2, rng, state2, batch2, flags2)
+    # (this setup has weight decay: the two forms add 2 wd theta / n in different places, an ulp of the gradient apart; without it the bits are equal,
+    #  tests/test_gpu_whole_path.py)
+    assert (state2.grads[:state2.theta.numel()] - taps["grads"]).abs().max().item() <= 1e-10 * float(taps["grads"].abs().max()) + 1e-11
+    flags2.backward_precision = "f16x3"
+    with pytest.raises(ValueError, match="f16x3 forward"):
+        train_step(model2, rng, state2, batch2, flags2)
