@@ -121,3 +121,57 @@ def test_two_rank_data_parallel_adam(tmp_path):
         t = step + 1
         th = th - 1e-2 * (mu / (1 - 0.9 ** t)) / (np.sqrt(nu / (1 - 0.999 ** t)) + 1e-8)
     assert np.abs(t0.numpy() - th).max() < 1e-5
+
+
+def _world8_worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    assert D.init("gloo", timeout_s=60) == (rank, world)
+    H, W = 800, 3                                                    # BASELINE configs[4]'s row count: 100 image rows per rank on 8
+    lo, hi = D.shard_bounds(H, world, rank)
+    assert hi - lo == 100 and lo == 100 * rank
+    g = torch.Generator().manual_seed(1)
+    rays = Rays(torch.randn(H, W, 3, generator=g), None, torch.randn(H, W, 3, generator=g), None)
+    part = D.render_image_sharded(fake_render_fn, rays, prng.PRNGKey(3), False, chunk=128, gather=False)      # no collective at all
+    assert part[0].shape == (100, W, 3)
+    full = D.render_image_sharded(fake_render_fn, rays, prng.PRNGKey(3), True, chunk=128, gather=True)        # what pmap + all_gather returns
+    # a 4096-ray training batch = 512 rays per rank, one jax.random key per rank (train.py:338-339)
+    o = torch.arange(4096 * 3, dtype=torch.float32).reshape(4096, 3)
+    mine = D.shard_rays(Rays(o, None, o, None), world, rank)
+    assert mine.origins.shape == (512, 3) and float(mine.origins[0, 0]) == 512.0 * 3 * rank
+    keys = prng.split(prng.PRNGKey(20200823), world)
+    assert len({tuple(k) for k in keys.tolist()}) == world
+    # the step's exchange over all eight ranks, and over the first four only (bench.py's in-run scaling curve)
+    buf = torch.full((1 << 14,), float(rank))
+    D.allreduce_mean_([buf])
+    assert torch.allclose(buf, torch.full_like(buf, 3.5))
+    sub = dist.new_group(ranks=[0, 1, 2, 3])
+    if rank < 4:
+        with D.use_group(sub):
+            assert D.world() == (rank, 4) and D.active()
+            b2 = torch.full((100,), float(rank))
+            h = D.allreduce_begin(b2); D.allreduce_end_mean_(h, b2); D.barrier()
+            assert torch.allclose(b2, torch.full_like(b2, 1.5)) and D.max_over_ranks(float(rank)) == 3.0
+    assert D.world() == (rank, world)
+    D.barrier()
+    if rank == 0:
+        torch.save([t.clone() for t in full], tmp)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_eight_ranks_shards_keys_and_subgroups(tmp_path):
+    """World size 8 on CPU (gloo): the shard arithmetic of BASELINE configs[3] / [4] (512 rays, 100 image rows per rank), eight distinct
+    per-rank keys, the gradient all-reduce over all ranks and over a sub-group, and the assembled image equal to the single-process one."""
+    world = 8
+    port = _free_port()
+    out = str(tmp_path / "full8.pt")
+    mp.spawn(_world8_worker, args=(world, port, out), nprocs=world, join=True)
+    full = torch.load(out)
+    from samplenerfro_amd import utils
+    g = torch.Generator().manual_seed(1)
+    rays = Rays(torch.randn(800, 3, 3, generator=g), None, torch.randn(800, 3, 3, generator=g), None)
+    ref = utils.render_image(fake_render_fn, rays, prng.PRNGKey(3), True, chunk=97)
+    for k, (f, r) in enumerate(zip(full, ref)):
+        # (the stand-in's sigmoid runs through torch's CPU vector / remainder loops, which round differently for different chunk lengths: 1 ulp)
+        assert torch.allclose(f, r.reshape(f.shape), rtol=0, atol=1e-6 if k == 2 else 0.0), (k, (f - r.reshape(f.shape)).abs().max())
