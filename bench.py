@@ -28,6 +28,7 @@ MLP_FLOP_PER_ROW = 2 * 593408          # NerfMLP MACs*2 per sample row (BASELINE
 BKGD_FLOP_PER_RAY = 2 * 56448
 PEAK_MFMA_16BIT = 2.5e15               # dense bf16/f16 MFMA peak (MI355X_MICROARCH.md)
 PEAK_HBM = 8.0e12
+TABLE_LAYOUT = "reference"             # --table-layout bricks: the 2x2x2-brick order of the IoR table (same values and indices)
 PRIME_STEPS = 6                         # untimed steps every Stepper runs at construction, before the contract's W warm-up steps
 CPU_WARMUP, CPU_TIMED = 3, 5           # cpu_baseline: 3 warm-up + 5 timed passes, median
 PRECISION_NOTES = {
@@ -59,7 +60,7 @@ def build_scene(cfg, device, precision, fine, stage="radiance", eval_precision=N
         grid = torch.ones((G, G, G), dtype=torch.float32, device=device)
     model = models.NerfModel(ndim=ndim, nmin=nmin, nmax=nmax, grid=grid, near=cfg["near"], far=cfg["far"],
                              num_coarse_samples=cfg["S"], num_fine_samples=fine, num_path_samples=cfg["P"],
-                             precision=precision, eval_precision=eval_precision, device=device, stage=stage)
+                             precision=precision, eval_precision=eval_precision, device=device, stage=stage, table_layout=TABLE_LAYOUT)
     del grid
     pf = syn.init_params_flat(0, fine=fine > 0)
     flat = {k: torch.from_numpy(v).to(device) for k, v in pf.items()}
@@ -428,6 +429,8 @@ def main():
                          "(BASELINE config 4 as written: 4096 rays = 512 per GPU on 8 GPUs)")
     ap.add_argument("--mode", choices=["train", "forward"], default="train",
                     help="train: the whole optimisation step (BASELINE metric 'rays/sec (train step)'); forward: the render pass only")
+    ap.add_argument("--table-layout", choices=["reference", "bricks"], default="reference",
+                    help="memory order of the IoR table: the reference's flat index (default) or 2x2x2 bricks of one cache line (same bits; A/B switch)")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="nccl = RCCL over xGMI, one rank per GPU (default); gloo lets the tests drive the multi-rank branch with several ranks on one device")
     ap.add_argument("--dist-timeout", type=float, default=300.0,
@@ -441,6 +444,8 @@ def main():
     ap.add_argument("--fail-mode", choices=["exit", "hang"], default="exit", help=argparse.SUPPRESS)   # dies / stops responding after the warm-up
     args = ap.parse_args()
     args.backward = {"f32": "f16x3", "tf32": "f16"}.get(args.backward, args.backward)
+    global TABLE_LAYOUT
+    TABLE_LAYOUT = args.table_layout
     relaunch_for_gpus(args)
     if args.pipeline is None:
         args.pipeline = args.mode == "train"
