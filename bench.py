@@ -800,7 +800,9 @@ def main():
         torch.cuda.empty_cache()
         amodel, avars, _ = build_scene(rcfg, device, args.precision, 0, "all")
         run_variant("ship_refractive_128_stage_all", rcfg, amodel, avars, 0, vR, "stage all* (train.py:302-310): so3_mlp bends the gradient inside the march "
-                    "(evaluated by four waves per 32-ray block at every node of the boundary shell) and is trained through the march's adjoint", "all")
+                    "(evaluated by four waves per 16-ray workgroup at every node of the boundary shell) and is trained through the march's adjoint; the "
+                    "step includes the deterministic (node, ray) order of the shell pairs — one sort + two gathers, ~0.35 ms of device time — and "
+                    "the shell-coherent ray order of the batch (a coarse pre-march + a sort, ~0.3 ms)", "all")
         del amodel, avars
         torch.cuda.empty_cache()
         dcfg = dict(syn.CONFIGS["dolphin_train"])
@@ -978,6 +980,18 @@ def main():
             line["graph_replay"] = graph_replay
         if variants:
             line["variants"] = variants
+        if train and args.workload == "ship_straight" and fine == 0 and B == 4096:
+            # BASELINE.json north_star, as numbers: >= 1e7 rays/s whole-node on 8 GPUs at 128 samples per ray = 1.25e6 per GPU
+            share = 1.25e6
+            per_gpu = total_rays / dt / world
+            ns = {"target_rays_per_s_per_gpu": share, "this_line_rays_per_s_per_gpu": per_gpu, "frac_of_target": per_gpu / share,
+                  "arithmetic_of_this_line": dtype_label(args.precision, args.backward, True),
+                  "what": "north_star asks for >= 1e7 rays/s on 8 x MI355X (1.25e6 per GPU) in bf16-class MFMA arithmetic with <= 1e-4 RGB error; the "
+                          "headline is fp32-grade (3 MFMAs per product), the single-pass leg is the arithmetic north_star names"}
+            if legs and "train" in legs.get("f16", {}):
+                ns["single_pass_f16_leg_rays_per_s_per_gpu"] = legs["f16"]["train"]["rays_per_s"] / world
+                ns["single_pass_f16_leg_frac_of_target"] = legs["f16"]["train"]["rays_per_s"] / world / share
+            line["north_star"] = ns
         if legs:
             line["precision_legs"] = legs
             legs["what"] = ("the arithmetic north_star names (one 16-bit MFMA per product) on the headline workload, next to the fp32-grade default: "
