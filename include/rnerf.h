@@ -341,7 +341,8 @@ int rnerf_bkgd_backward_wgrad(const void* save, void* dy, int64_t n, float* grad
  *   rnerf_march_all_train  : rnerf_march_all + the record the backward needs: path_rdn float4[N][B] = (raw direction, n) per node, and
  *                            the compacted pairs (pair_count device int32, zeroed by the call; pair_id int32[cap][2] = (ray, node);
  *                            pair_x / pair_g float4[cap] = position / looked-up gradient; pair_of_node int32[N][B], -1 = none);
- *   rnerf_so3_forward_train: so3_mlp on pts4 float4[n] -> save (rnerf_so3_save_bytes(n); its tail float4[n] holds the raw outputs);
+ *   rnerf_so3_forward_train: so3_mlp on pts4 float4[n] -> save (rnerf_so3_save_bytes(n): fp32 [enc n x 60][X1..X4 n x 128][raw float4[n], at float offset
+ *                            572 n], then the layers' ReLU sign bits uint32[4][n][4], which is all the dgrad chain reads of the activations);
  *   rnerf_so3_backward     : cotangents d_raw4 float4[nb] -> dx4 float4[nb] (nullable, d / d point) and, if grads != NULL (nb == n_save),
  *                            grads float[RNERF_SO3MLP_PARAMS] += ...; row i uses the saved activations of row i % n_save, so the three
  *                            unit cotangents of every point run as one batch of 3 n_save rows (the rows of J = d raw / d x);

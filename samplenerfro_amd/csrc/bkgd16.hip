@@ -252,6 +252,7 @@ __global__ void __launch_bounds__(64) so3_16_fwd_train_kernel(const float* __res
     for (int p = 0; p < 30; ++p) save[(size_t)row * 60 + 2 * p + h] = enc[p];
   }
   auto save_x = [&](int k, const f32x16 (&xx)[4]) {     // X_k[row][f], f = 32t + 8g + 4h + i
+    so3_store_mask(save, n, row, k, xx, h, ok);         // + the 128 sign bits the dgrad reads (every lane takes part in the half-lane exchange)
     if (ok) {
       float* dst = save + (size_t)n * 60 + (size_t)(k - 1) * n * 128 + (size_t)row * 128;
 #pragma unroll

@@ -103,8 +103,11 @@ class NerfModel:
             raise NotImplementedError("the HIP NerfMLP kernel is specialised for the reference's 8x256 / skip 4 / 1x128 network")
         if (min_deg_point, max_deg_point, deg_view) != (0, 10, 4) or legacy_posenc_order or not use_viewdirs:
             raise NotImplementedError("the HIP kernels implement pos_enc degrees (0,10)/(0,4), non-legacy order, use_viewdirs=True")
-        if sh_deg >= 0 or sh_direnc_deg > 0 or noise_std or use_mask_bbox or lindisp:
-            raise NotImplementedError("sh / noise / mask_bbox / lindisp are disabled in every shipped config and not built")
+        if sh_deg >= 0 or sh_direnc_deg > 0 or noise_std or use_mask_bbox:
+            raise NotImplementedError("sh_deg / sh_direnc_deg / noise_std / use_mask_bbox are disabled in every shipped config and not built")
+        # lindisp: a field of the reference's NerfModel (rnerf/models.py:74) that its __call__ never reads — the samples come from the eikonal
+        # march, not from sample_along_rays — so it is accepted and, like there, has no effect
+        self.lindisp = bool(lindisp)
         if num_coarse_samples < 3:
             raise ValueError("num_coarse_samples must be >= 3")
         if precision not in PRECISIONS:

@@ -485,7 +485,7 @@ def so3_forward_train(so3_flat: torch.Tensor, window, pts4: torch.Tensor):
     save = torch.empty(lib.rnerf_so3_save_bytes(n) // 4, dtype=torch.float32, device=pts4.device)
     check(lib.rnerf_so3_forward_train(ptr(_chk(so3_flat, "so3_flat")), window.ctypes.data_as(C.c_void_p), ptr(_chk(pts4, "pts4")), n, ptr(save),
                                       current_stream()), "rnerf_so3_forward_train")
-    raw = save[n * (60 + 4 * 128):].view(n, 4)
+    raw = save[n * (60 + 4 * 128):n * (60 + 4 * 128 + 4)].view(n, 4)        # (behind it: the ReLU sign bits the dgrad reads)
     return raw, save
 
 
