@@ -351,6 +351,9 @@ _SHELL_CACHE: dict = {}
 # ray's own index, so nothing is permuted back.  ops.SHELL_ORDER = False marches the rays in the given order (a module attribute, set by tools /
 # tests; the product reads no environment variable for it).
 SHELL_ORDER = True
+# the pre-march takes num_nodes / SHELL_ORDER_COARSEN nodes of SHELL_ORDER_COARSEN x the step (8: ~0.1 ms at 4096 rays; finer = a better order
+# for more pre-march time — which train_step hides beside the NerfMLP wgrad when it knows the next batch)
+SHELL_ORDER_COARSEN = 8
 
 
 def _shell_order(table: torch.Tensor, spec: Grid, o: torch.Tensor, v: torch.Tensor, near: float, far: float, num_nodes: int):
@@ -366,7 +369,7 @@ def _shell_order(table: torch.Tensor, spec: Grid, o: torch.Tensor, v: torch.Tens
             ent[2].record_stream(torch.cuda.current_stream())
             _SHELL_CACHE[key] = (ent[0], ent[1], ent[2], None)
         return ent[2]
-    nc = max(int(num_nodes) // 8, 16)
+    nc = max(int(num_nodes) // int(SHELL_ORDER_COARSEN), 16)
     _, _, ior, _ = march(table, spec, o, v, near, far, nc, want_ior=True)
     g = ior[..., 1:4]
     m = (g * g).sum(-1) > 1e-6                                       # [nc, B]
