@@ -714,6 +714,15 @@ def main():
             return g
 
         g_ref = grads_of(model, "f16x3")
+        # the cheaper BACKWARD arithmetics behind the default forward (their step times: `other_backward_modes`): how far their gradient of
+        # this very batch is from the default's — the error of 11 / 8-bit products averages down with the number of rows (524 288 here;
+        # on a few hundred rows it is ~1e-3 / ~1e-2, tests/test_gpu_backward.py), which is why the default does not rely on it
+        bw_err = {}
+        for bw in ("f16", "bf16"):
+            gb = grads_of(model, bw)
+            bw_err[bw] = float((gb - g_ref).abs().max() / g_ref.abs().max())
+            del gb
+        legs["backward_modes_behind_the_f16x3_forward"] = {"grad_err_rel_max_vs_f16x3": bw_err, "rows": S * B}
         for pname in ("f16", "bf16"):
             mp = model_with_precision(model, pname)
             vp = models_fresh_variables(pf, device)
