@@ -663,7 +663,25 @@ def main():
         t_f = timed(lambda: lib.rnerf_nerfmlp_forward_train(packed.data_ptr(), model.precision, path_pd.data_ptr(), path_dr.data_ptr(), jp, S, B,
                                                             raw_t.data_ptr(), save_t.data_ptr(), BW, 0, _lib.current_stream()))
         t_d = timed(lambda: ops.nerfmlp_backward(pbwd, packed, model.precision, save_t, d_raw, rows, dy=dy_t, stages="d", backward=BW))
-        t_w = timed(lambda: ops.nerfmlp_backward(pbwd, packed, model.precision, save_t, d_raw, rows, grads=g_t, workspace=ws_t, dy=dy_t, stages="w", backward=BW))
+        t_w_alone = timed(lambda: ops.nerfmlp_backward(pbwd, packed, model.precision, save_t, d_raw, rows, grads=g_t, workspace=ws_t, dy=dy_t, stages="w", backward=BW))
+        t_w = t_w_alone
+        if args.pipeline and args.stage == "radiance":
+            # IN the step the wgrad hosts the next batch's march as co-resident waves (rnerf_prefetch.beside_wgrad): timed here the same way —
+            # the march forked onto the side stream right before the wgrad, the events around the wgrad on the launch stream — so that the
+            # figure is the kernel's duration as the step (and a rocprofv3 --stats of the step) sees it, not its stand-alone best case
+            side = torch.cuda.Stream()
+            cur = torch.cuda.current_stream()
+
+            def wgrad_with_march():
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    ops.march(model.table, model.spec, rays.origins, rays.viewdirs, cfg["near"], cfg["far"], N, out=(path_pd2, path_dr2))
+                ops.nerfmlp_backward(pbwd, packed, model.precision, save_t, d_raw, rows, grads=g_t, workspace=ws_t, dy=dy_t, stages="w", backward=BW)
+                # (no join here: the events bracket the wgrad alone; the next repetition's march waits for this wgrad, as the next step's does)
+
+            path_pd2, path_dr2 = torch.empty_like(path_pd), torch.empty_like(path_dr)
+            t_w = timed(wgrad_with_march)
+            del path_pd2, path_dr2
         R_pad = (rows + 255) // 256 * 256
         # sum over the wgrad jobs of (X slots + dY slots) x R x 32 B (x 2: hi + lo).  f16 modes: 11 jobs (the Dense_5 / Dense_10 concat rows and
         # the sigma head share their operand streams with the main block: 316 slot planes); bf16 body: 14 single-segment jobs (356)
@@ -681,6 +699,8 @@ def main():
             npass = MFMA_PASSES[args.precision] if "fwd" in name else ({"f16x3": 3, "f16": 2, "bf16": 2}[args.backward] if "dgrad" in name else {"f16x3": 3, "f16": 1, "bf16": 1}[args.backward])
             with_pass_ceiling(tk, npass, sustained["bf16"] if (sustained and args.backward == "bf16" and "fwd" not in name) else sus16)
             if byt is not None:
+                tk["avg_launch_ms_alone"] = t_w_alone
+                tk["launched"] = ("with the next batch's march co-resident, as in the step" if t_w is not t_w_alone else "alone")
                 tk["operand_stream"] = {"operand_stream_bytes": byt, "GB_per_s": byt / (ms * 1e-3) / 1e9, "frac_of_hbm_peak": byt / (ms * 1e-3) / PEAK_HBM,
                                         "note": "hi + lo f16 planes of the saved activations and of dY, read once: what paces this kernel (an "
                                                 "implementation choice, not algorithmic bytes)"}
