@@ -160,6 +160,8 @@ def test_training_on_the_example_view_raises_the_psnr(scene):
         batch = {"rays": U.Rays(o_d[idx], None, v_d[idx], None), "pixels": pix_d[idx], "annealed_alpha": (i + 1) / ANNEAL_MAX, "env_rays": env}
         state, stats, r = train_step(model, r, state, batch, flags)
         curve.append(stats.psnr.clone())            # (Stats fields are views into the step's device buffer: the next step overwrites them)
+        if i == 7:
+            early = state.theta.detach().clone()    # weights that have seen 8 batches of real pixels: the field is still partly opaque
     curve = torch.stack([c.reshape(()) for c in curve]).cpu().numpy()
     first, last = float(curve[:10].mean()), float(curve[-20:].mean())
     print("train PSNR, means of 100 steps:", [round(float(curve[k:k + 100].mean()), 2) for k in range(0, steps, 100)])
@@ -170,10 +172,36 @@ def test_training_on_the_example_view_raises_the_psnr(scene):
     mse = float(((rgb.reshape(-1, 3) - pix_d) ** 2).mean())
     psnr_view = U.compute_psnr(mse)
     print(f"example view: train PSNR {first:.2f} -> {last:.2f} dB over {steps} steps of {B} rays; rendered 400 x 400 view vs the photograph {psnr_view:.2f} dB")
+    # the same TRAINED weights rendered in the other arithmetics: fp32-grade f16x3 (the training arithmetic), the default render pass (f16f8)
+    # and the single-pass f16 leg — how far apart the pictures are on weights that have seen real data, not on an initialisation
+    # (on ONE view the field goes fully transparent within ~20 steps — the background MLP can explain a single photograph and the loss_bg term
+    #  rewards transparency; the independent host loop of the test above takes the same road, so this is the algorithm, not the kernels —
+    #  and from then on every arithmetic renders the same background: the comparison is made on the weights of step 8)
+    import copy
+    from samplenerfro_amd import _lib
+    from samplenerfro_amd.train import _bump
+    final = state.theta.detach().clone()
+    state.theta.copy_(early); _bump(state.theta)
+    pics = {"f16f8 (default render pass)": U.render_image(fn, rays_hw, prng.PRNGKey(1), False, chunk=8192)[0]}
+    for name in ("f16x3", "f16", "bf16"):
+        m2 = copy.copy(model)
+        m2.precision = m2.eval_precision = _lib.PRECISIONS[name]
+        m2._packed, m2._jit_cache, m2._ws, m2._key_cache, m2._u_lin, m2._side = {}, {}, {}, {}, None, None
+        f2 = lambda k0, k1, rays, path=None, m2=m2: m2.apply(state.variables, k0, k1, rays, False, path=path)
+        img = U.render_image(f2, rays_hw, prng.PRNGKey(1), False, chunk=8192)
+        pics[name] = img[0]
+        if name == "f16x3":
+            print("opacity of the step-8 field over the view: mean %.3e, max %.3e" % (float(img[2].mean()), float(img[2].max())))
+            assert float(img[2].mean()) > 0.02
+    d = {k: float((v - pics["f16x3"]).abs().max()) for k, v in pics.items() if k != "f16x3"}
+    print("max |dRGB| against the f16x3 render of the step-8 weights:", {k: f"{v:.2e}" for k, v in d.items()})
+    state.theta.copy_(final); _bump(state.theta)
+    assert d["f16f8 (default render pass)"] < 1e-4 and d["f16"] < 1e-3 and d["bf16"] < 1e-2
     assert np.isfinite(curve).all() and bool(torch.isfinite(rgb).all())
     # measured (MI355X, this seed): 100-step means 15.07, 16.10, 16.19, 16.34, 16.41, 16.48, 16.55, 16.54, 16.58, 16.61 dB; first 10 steps 12.55;
-    # the rendered view 16.6 dB.  (One view, 1000 steps: the background MLP's 4 view-direction octaves and a barely trained field — the
-    # marks are about the curve rising on real pixels through the whole product path, not about image quality.)
+    # the rendered view 16.6 dB.  (ONE view: within ~20 steps the optimiser makes the field transparent — opacity 0.64 -> exactly 0; the host
+    # oracle loop of the test above walks the same road — and what keeps improving afterwards is the background MLP with its 4 view-direction
+    # octaves.  The marks are about the curve rising on real pixels through the whole product path, not about image quality.)
     m = [float(curve[k:k + 100].mean()) for k in range(0, steps, 100)]
     assert m[0] < m[4] < m[9] and m[9] > m[0] + 1.2, m
     assert last > first + 3.5 and last > 16.2, (first, last)
@@ -184,7 +212,8 @@ def test_training_on_the_example_view_raises_the_psnr(scene):
 def test_single_pass_f16_arithmetic_trains_the_example_view_like_the_default(scene):
     """The single-pass leg (f16 forward + f16 backward: north_star's arithmetic, 1.58 x the default's rays/s) on the same real pixels, same
     batches and keys: its PSNR curve must follow the fp32-grade default's — the evidence that the leg is a usable training mode and not
-    only a fast one.  (Measured: 100-step means 15.07 / 16.10 / 16.19 / 16.34 / 16.41 / 16.48 dB for the default and 15.07 / 16.20 / 16.32 / 16.50 /
+    only a fast one.  (The volumetric field matters for the first ~20 steps only, see above; afterwards both runs train the background MLP,
+    whose arithmetic is the same in both.)  (Measured: 100-step means 15.07 / 16.10 / 16.19 / 16.34 / 16.41 / 16.48 dB for the default and 15.07 / 16.20 / 16.32 / 16.50 /
     16.46 / 16.51 for the leg — two trajectories of a chaotic optimisation 0.1-0.16 dB apart, neither consistently ahead; rendered views 16.50 / 16.53.)"""
     from samplenerfro_amd import _lib, prng, utils as U
     from samplenerfro_amd.train import TrainState, train_step
