@@ -55,11 +55,11 @@ enum rnerf_status {
  * a per-launch fallback decided on the device, F16X3's bits, no host round trip.  Own packed stream: pack with the precision you run.
  * Range of the f16-based modes.  The forward watches the largest f16 operand it forms per row; a weight of magnitude >= 256 (2^8-scaled
  * streams) or a hidden activation above f16's 65504 makes the first pass give the row up (NaN), never return a plausible wrong colour.
- * EVALUATION (rnerf_nerfmlp_forward with F16X3 / F16X2 / F16F8, hence rnerf_forward): every launch is followed on the device by a range-safe
+ * EVALUATION (rnerf_nerfmlp_forward with F16X3 / F16X2 / F16F8 / F16, hence rnerf_forward): every launch is followed on the device by a range-safe
  * second pass in BF16X3 (fp32's exponent range; its stream sits behind the others in the packed buffer) that recomputes exactly the rows
  * the first pass gave up on and touches no other row — the reference's fp32 nn.Dense (rnerf/model_utils.py:58-89) is finite there, and so is
- * this; without such a row the pass reads the outputs once (~5 us) and the first pass's bits stand.  F16 (single pass, a bench leg) and the
- * TRAINING forward (rnerf_nerfmlp_forward_train) have no second pass: such a row stays NaN and reaches the non-finite-gradient count of
+ * this; without such a row the pass reads the outputs once (~5 us) and the first pass's bits stand.  The
+ * TRAINING forward (rnerf_nerfmlp_forward_train) has no second pass: such a row stays NaN and reaches the non-finite-gradient count of
  * rnerf_adam_update (scratch[3]) — the saved f16 operands of the backward cannot represent it. */
 enum rnerf_precision {
   RNERF_PREC_F32 = 0,

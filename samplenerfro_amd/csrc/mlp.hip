@@ -2955,11 +2955,13 @@ constexpr size_t kF8Fallback = (Prec<RNERF_PREC_F16F8>::PACKED_BYTES + 255) & ~(
 // rnerf_nerfmlp_forward (nerfmlp_fwd_kernel's REDO mode) recomputes, in fp32's exponent range, the rows the f16 pass returned as NaN.
 constexpr size_t kX3Bytes = (Prec<RNERF_PREC_F16X3>::PACKED_BYTES + 255) & ~(size_t)255;
 constexpr size_t kSafeBytes = Prec<RNERF_PREC_BF16X3>::PACKED_BYTES;
+constexpr size_t kF16Bytes = (Prec<RNERF_PREC_F16>::PACKED_BYTES + 255) & ~(size_t)255;
 static size_t safe_stream_offset(int precision) {      // offset of that bf16x3 stream in a packed buffer of `precision` (0: it has none)
   switch (precision) {
     case RNERF_PREC_F16X3:
     case RNERF_PREC_F16X2: return kX3Bytes;
     case RNERF_PREC_F16F8: return kF8Fallback + kX3Bytes;
+    case RNERF_PREC_F16: return kF16Bytes;
     default: return 0;
   }
 }
@@ -2977,7 +2979,7 @@ extern "C" size_t rnerf_nerfmlp_packed_bytes(int precision) {
     case RNERF_PREC_F16X2: return kX3Bytes + kSafeBytes;                      // f16x2 reads the f16x3 stream; + the range-safe bf16x3 stream
     case RNERF_PREC_F16F8: return kF8Fallback + kX3Bytes + kSafeBytes;        // its own stream, the f16x3 stream it falls back to, the bf16x3 stream
     case RNERF_PREC_BF16X3: return Prec<RNERF_PREC_BF16X3>::PACKED_BYTES;
-    case RNERF_PREC_F16: return Prec<RNERF_PREC_F16>::PACKED_BYTES;
+    case RNERF_PREC_F16: return kF16Bytes + kSafeBytes;                       // the single-pass stream + the range-safe bf16x3 stream
     case RNERF_PREC_BF16: return Prec<RNERF_PREC_BF16>::PACKED_BYTES;
     default: set_error("rnerf_nerfmlp_packed_bytes: unsupported precision %d", precision); return 0;
   }
@@ -3173,7 +3175,9 @@ extern "C" int rnerf_nerfmlp_forward(const void* packed, int precision, const fl
       return launch_fwd_dbg<RNERF_PREC_BF16X3, 512>((const char*)packed + safe_stream_offset(precision), rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, nullptr, max_workgroups);
     }
     case RNERF_PREC_BF16X3: return launch_fwd<RNERF_PREC_BF16X3>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, max_workgroups);
-    case RNERF_PREC_F16: return launch_fwd<RNERF_PREC_F16>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, max_workgroups);
+    case RNERF_PREC_F16:
+      RNERF_TRY_(launch_fwd<RNERF_PREC_F16>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, max_workgroups));
+      return launch_fwd_dbg<RNERF_PREC_BF16X3, 512>((const char*)packed + safe_stream_offset(precision), rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, nullptr, max_workgroups);
     default: return launch_fwd<RNERF_PREC_BF16>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, max_workgroups);
   }
 }

@@ -34,6 +34,7 @@ def test_binding_covers_header(lib_path):
     assert lib.rnerf_nerfmlp_packed_bytes(_lib.PREC_F16X3) == al(stream3) + stream3
     assert lib.rnerf_nerfmlp_packed_bytes(_lib.PREC_F16X2) == al(stream3) + stream3
     assert lib.rnerf_nerfmlp_packed_bytes(_lib.PREC_F16F8) == al(stream3) + al(stream3) + stream3      # its own stream, the f16x3 stream it falls back to, bf16x3
+    assert lib.rnerf_nerfmlp_packed_bytes(_lib.PREC_F16) == al(1160 * 1024 + 3468 * 4) + stream3            # the single-pass stream + bf16x3
     assert lib.rnerf_nerfmlp_packed_bytes(_lib.PREC_F32) == 595844 * 4                            # the exact-fp32 arbiter reads the flat buffer itself
     # the Python names follow enum rnerf_precision of the header
     hdr = open(os.path.join(ROOT, "include", "rnerf.h")).read()

@@ -348,7 +348,7 @@ def test_nerf_mlp_f16_range_falls_back_to_bf16x3(scene):
     hot[off:off + 256] = 3.0e5
     want, exact = run(hot, _lib.PREC_BF16X3), run(hot, _lib.PREC_F32)
     assert np.isfinite(exact).all() and close(want, exact)
-    for prec in (_lib.PREC_F16X3, _lib.PREC_F16F8):
+    for prec in (_lib.PREC_F16X3, _lib.PREC_F16F8, _lib.PREC_F16):
         np.testing.assert_array_equal(run(hot, prec), want)
 
     # (c) only SOME rows leave the range (a large weight on the raw x coordinate: rows with |x| > ~2.2): those rows carry bf16x3's bits, every
