@@ -295,8 +295,10 @@ int rnerf_composite_backward(const float* raw, const float* rows_pd, const float
 
 /* ---- T1 (backward of P1+N1): gradient of the NerfMLP parameters, replacing jax.value_and_grad through
  * NerfMLP.__call__ (train.py:164; rnerf/model_utils.py:30-90).  `backward` is an enum rnerf_backward, the same in all calls of a step.
- *   rnerf_nerfmlp_forward_train : as rnerf_nerfmlp_forward (precision f16x3 only: bf16x3 / f16 / bf16 are inference precisions) and keeps
- *       the 16-bit operands of every layer in `save` (rnerf_nerfmlp_save_bytes(S*B, backward) bytes; F16X2: hi and lo parts);
+ *   rnerf_nerfmlp_forward_train : as rnerf_nerfmlp_forward — precision F16X3 (the fp32-grade default), or F16 with backward F16 / BF16 (the
+ *       single-pass training arithmetic: one MFMA per product, a labelled bench leg; the dgrad / wgrad calls of the step take the same
+ *       precision); bf16x3 / bf16 / f16x2 / f16f8 are inference precisions — and keeps
+ *       the 16-bit operands of every layer in `save` (rnerf_nerfmlp_save_bytes(S*B, backward) bytes; F16X3 backward: hi and lo parts);
  *   rnerf_nerfmlp_pack_bwd : transposed weight stream of the dgrad chain (rnerf_nerfmlp_bwd_packed_bytes() bytes);
  *   rnerf_nerfmlp_dgrad : d_raw float4[rows] (d loss / d raw rgb, sigma) -> dy (rnerf_nerfmlp_dy_bytes(rows, backward) bytes), the
  *       gradients w.r.t. every layer's pre-activation output (F16 modes: normalised per row, + the row scales);
