@@ -168,7 +168,8 @@ int rnerf_bkgd_forward(const float* params, const float* dirs, int32_t dir_strid
  * bkgd: float[B][3].  Outputs: rgb float[B][3], dist float[B], acc float[B], trans float[B],
  * trans_bkgd float[B][3]; weights (nullable) float[S][B]; alpha (nullable) float[S][B].
  * mask_mode / bbox (host double[6] = min xyz, max xyz): the bd_cut_dist masks of rnerf/models.py:479-524 — 0 none,
- * 1: density_delta *= mask_bbox (1 up to the last sample inside the box), 2: density_delta *= 1 - mask_bbox. */
+ * 1: density_delta *= mask_bbox (1 up to the last sample inside the box), 2: density_delta *= 1 - mask_bbox;
+ * 3: use_mask_bbox (rnerf/models.py:261-271,398-408): density_delta *= 1[this sample is inside the box]. */
 int rnerf_composite(const float* raw, const float* rows_pd, const float* rows_dr, const int32_t* node_of_sample,
                     int32_t S, int32_t B, const float* bkgd, int white_bkgd, double rgb_padding, double sigma_bias,
                     float* rgb, float* dist, float* acc, float* trans, float* trans_bkgd, float* weights,
@@ -285,13 +286,14 @@ int rnerf_theta_sumsq(const float* theta, int64_t n_theta, float* stats8, void* 
  * d_raw: float4[S][B]; d_bkgd: float[B][3] gradient w.r.t. the activated background colour (accumulated if
  * accumulate_bkgd != 0: both levels composite over the coarse pass's bkgd, rnerf/models.py:468-476).
  * white_bkgd: comp_rgb carried the + (1 - acc) term of rnerf/model_utils.py:307-308.
- * bd_cut_bbox (nullable, host double[6] = min xyz, max xyz): the level's trans / trans_bkgd are the bd_cut_dist pair of
- * rnerf/models.py:479-524 (trans = mask_mode-1 transmittance, trans_bkgd = trans * mask_mode-2 colour over bkgd). */
+ * mask_mode / bbox (host double[6] = min xyz, max xyz; NULL with mask_mode 0): 1 = the level's trans / trans_bkgd are the bd_cut_dist pair of
+ * rnerf/models.py:479-524 (trans = mask_mode-1 transmittance, trans_bkgd = trans * mask_mode-2 colour over bkgd); 3 = the level was rendered
+ * with use_mask_bbox (rnerf/models.py:261-271,398-408: density_delta *= 1[sample inside the box]), the gradient carries the same mask. */
 int rnerf_composite_backward(const float* raw, const float* rows_pd, const float* rows_dr, const int32_t* node_of_sample,
                              int32_t S, int32_t B, const float* bkgd, double rgb_padding, double sigma_bias, const float* rgb,
                              const float* pixels, const float* trans, const float* trans_bkgd, const float* sums,
                              double mse_scale, double bg_scale, float* d_raw, float* d_bkgd, int accumulate_bkgd, int white_bkgd,
-                             const double* bd_cut_bbox, void* stream);
+                             int mask_mode, const double* bbox, void* stream);
 
 /* ---- T1 (backward of P1+N1): gradient of the NerfMLP parameters, replacing jax.value_and_grad through
  * NerfMLP.__call__ (train.py:164; rnerf/model_utils.py:30-90).  `backward` is an enum rnerf_backward, the same in all calls of a step.
@@ -390,7 +392,9 @@ typedef struct rnerf_model {
   int32_t num_path;            /* P    (num_path_samples): N = N_c * P eikonal nodes */
   int32_t precision;           /* enum rnerf_precision of packed_coarse / packed_fine */
   int32_t white_bkgd;          /* rnerf/model_utils.py:307-308 */
-  int32_t bd_cut;              /* != 0: the fine level's trans / trans_rgb_bkgd are the bd_cut_dist pair (rnerf/models.py:479-524) */
+  int32_t bd_cut;              /* 1: the fine level's trans / trans_rgb_bkgd are the bd_cut_dist pair (rnerf/models.py:479-524);
+                                * 2: use_mask_bbox (rnerf/models.py:261-271,398-408): both levels keep density only at samples inside bd_cut_bbox
+                                *    (the reference's box is the grid's nmin / nmax) */
   double rgb_padding, sigma_bias;   /* rnerf/models.py:78-79 */
   double bd_cut_bbox[6];       /* min xyz, max xyz (rnerf/models.py:485-497) */
   const void* packed_coarse;   /* rnerf_nerfmlp_pack of coarse_mlp */

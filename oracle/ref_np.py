@@ -493,6 +493,7 @@ class ModelConfig:
         self.white_bkgd = white_bkgd; self.rgb_padding = rgb_padding; self.sigma_bias = sigma_bias
         self.use_online_sparsity = use_online_sparsity; self.use_fine_sparsity = use_fine_sparsity
         self.bd_cut_bbox = None   # [xmin,ymin,zmin,xmax,ymax,zmax] when NerfModel.bd_cut_dist is set (models.py:485-497)
+        self.use_mask_bbox = False  # models.py:85,261-271,398-408: density_delta *= 1[sample inside the grid's box], both levels
 
     @property
     def num_samples(self):
@@ -525,8 +526,16 @@ def nerf_forward(cfg: ModelConfig, params: Dict, table, origins, viewdirs, jitte
     rgb = rgb_activation(raw_rgb, cfg.rgb_padding)
     bkgd = rgb_activation(raw_bkgd, cfg.rgb_padding)
     sigma = sigma_activation(raw_sigma, cfg.sigma_bias)
+    def inside_grid_box(p):                                                                  # use_mask_bbox, "small mask bbox" (:261-271,398-408)
+        if not getattr(cfg, "use_mask_bbox", False):
+            return None
+        m = np.ones(p.shape[:2], bool)
+        for a in range(3):
+            m &= (p[..., a] >= dtype(cfg.nmin[a])) & (p[..., a] <= dtype(cfg.nmax[a]))
+        return m
+
     comp_rgb, disp, acc, weights, alpha, trans, trans_rgb_bkgd = volumetric_rendering(
-        rgb, sigma, ray_dist_c, ray_dir_c, cfg.white_bkgd, bkgd)                             # :341-349
+        rgb, sigma, ray_dist_c, ray_dir_c, cfg.white_bkgd, bkgd, mask_bbox=inside_grid_box(ray_pos_c))   # :341-349
     if cfg.use_online_sparsity:                                                               # :351-357
         mask = np.sqrt(_sum3_sq(idx_grad_c))[..., 0] > dtype(1e-6)
         loss_sp = (mask * safe_log(alpha)).sum() / (np.sum(mask) + 1)
@@ -548,7 +557,7 @@ def nerf_forward(cfg: ModelConfig, params: Dict, table, origins, viewdirs, jitte
         rgb = rgb_activation(raw_rgb, cfg.rgb_padding)
         sigma = sigma_activation(raw_sigma, cfg.sigma_bias)
         comp_rgb, disp, acc, w_f, alpha_f, trans, trans_rgb_bkgd = volumetric_rendering(
-            rgb, sigma, z_f, dir_f, cfg.white_bkgd, bkgd)                                    # :468-476 (coarse bkgd)
+            rgb, sigma, z_f, dir_f, cfg.white_bkgd, bkgd, mask_bbox=inside_grid_box(pos_f))  # :468-476 (coarse bkgd)
         if getattr(cfg, "bd_cut_bbox", None) is not None:                                    # :479-524
             bmin, bmax = cfg.bd_cut_bbox[:3], cfg.bd_cut_bbox[3:]
             inside = np.ones(pos_f.shape[:2], bool)

@@ -105,7 +105,7 @@ SIGNATURES = {
     "rnerf_env_smooth_backward": (C.c_int, [_vp, _i32, _dbl, _vp, _vp, _vp]),
     "rnerf_train_stats": (C.c_int, [_vp, _i32, _i32, _dbl, _vp, _i32, _dbl, _vp, _i64, _dbl, _i64, _vp, _vp]),
     "rnerf_composite_backward": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _dbl, _dbl, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl,
-                                           _vp, _vp, C.c_int, C.c_int, C.POINTER(C.c_double * 6), _vp]),
+                                           _vp, _vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double * 6), _vp]),
     "rnerf_nerfmlp_save_bytes": (C.c_size_t, [_i64, C.c_int]),
     "rnerf_nerfmlp_dy_bytes": (C.c_size_t, [_i64, C.c_int]),
     "rnerf_nerfmlp_bwd_packed_bytes": (C.c_size_t, []),

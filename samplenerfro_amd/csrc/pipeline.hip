@@ -324,6 +324,10 @@ static int check_model(const rnerf_model* m, int32_t B, const char* who) {
   return RNERF_OK;
 }
 
+// rnerf_model.bd_cut: 0 = none, 1 = the bd_cut_dist pair on the fine level (rnerf/models.py:479-524), 2 = use_mask_bbox (:261-271,398-408):
+// density only at samples inside rnerf_model.bd_cut_bbox (the host puts the grid's nmin / nmax there), in BOTH levels' renderings
+static inline int level_mask_mode(const rnerf_model* m) { return m->bd_cut == 2 ? 3 : 0; }
+static inline const double* level_mask_box(const rnerf_model* m) { return m->bd_cut == 2 ? m->bd_cut_bbox : nullptr; }
 struct Level { float *rgb, *dist, *acc, *trans, *tb; };
 static Level level_of(float* out, int32_t B) { return Level{out, out + 3 * (size_t)B, out + 4 * (size_t)B, out + 5 * (size_t)B, out + 6 * (size_t)B}; }
 
@@ -422,14 +426,14 @@ extern "C" int rnerf_forward(const rnerf_model* m, const float* origins, const f
   RNERF_TRY(rnerf_nerfmlp_forward(m->packed_coarse, m->precision, path_pd, path_dr, jitter, Nc, B, f.raw_c, max_workgroups, stream));
   Level c = level_of(out_coarse, B);
   RNERF_TRY(rnerf_composite(f.raw_c, path_pd, path_dr, jitter, Nc, B, f.bkgd, m->white_bkgd, m->rgb_padding, m->sigma_bias, c.rgb, c.dist, c.acc, c.trans, c.tb,
-                            Nf > 0 ? f.weights : nullptr, nullptr, 0, nullptr, stream));
+                            Nf > 0 ? f.weights : nullptr, nullptr, level_mask_mode(m), level_mask_box(m), stream));
   if (Nf > 0) {
     RNERF_TRY(rnerf_resample(path_pd, path_dr, N, B, jitter, Nc, f.weights, u_fine, u_per_ray, Nf, f.rows_pd, f.rows_dr, nullptr, f.scratch, stream));
     RNERF_TRY(rnerf_nerfmlp_forward(m->packed_fine, m->precision, f.rows_pd, f.rows_dr, nullptr, S, B, f.raw_f, max_workgroups, stream));
     Level o = level_of(out_fine, B);
     RNERF_TRY(rnerf_composite(f.raw_f, f.rows_pd, f.rows_dr, nullptr, S, B, f.bkgd, m->white_bkgd, m->rgb_padding, m->sigma_bias, o.rgb, o.dist, o.acc, o.trans,
-                              o.tb, nullptr, nullptr, 0, nullptr, stream));
-    if (m->bd_cut) RNERF_TRY(bd_cut_pair(m, f.raw_f, f.rows_pd, f.rows_dr, S, B, f.bkgd, o, f.tmp_level, f.tmp_level2, stream));
+                              o.tb, nullptr, nullptr, level_mask_mode(m), level_mask_box(m), stream));
+    if (m->bd_cut == 1) RNERF_TRY(bd_cut_pair(m, f.raw_f, f.rows_pd, f.rows_dr, S, B, f.bkgd, o, f.tmp_level, f.tmp_level2, stream));
   }
   return RNERF_OK;
 }
@@ -601,7 +605,7 @@ extern "C" int rnerf_train_forward_backward(const rnerf_model* m, const rnerf_tr
   RNERF_TRY(rnerf_nerfmlp_forward_train(t.packed_c, prec, path_pd, path_dr, jitter, Nc, B, f.raw_c, t.save_c, bwd, max_workgroups, stream));
   Level lc = level_of(t.level_c, B);
   RNERF_TRY(rnerf_composite(f.raw_c, path_pd, path_dr, jitter, Nc, B, bkgd, m->white_bkgd, m->rgb_padding, m->sigma_bias, lc.rgb, lc.dist, lc.acc, lc.trans, lc.tb,
-                            Nf > 0 ? f.weights : nullptr, nullptr, 0, nullptr, stream));
+                            Nf > 0 ? f.weights : nullptr, nullptr, level_mask_mode(m), level_mask_box(m), stream));
   Level lf = lc;
   if (Nf > 0) {
     const float* u = u_override;
@@ -613,8 +617,8 @@ extern "C" int rnerf_train_forward_backward(const rnerf_model* m, const rnerf_tr
     RNERF_TRY(rnerf_nerfmlp_forward_train(t.packed_f, prec, f.rows_pd, f.rows_dr, nullptr, S, B, f.raw_f, t.save_f, bwd, max_workgroups, stream));
     lf = level_of(t.level_f, B);
     RNERF_TRY(rnerf_composite(f.raw_f, f.rows_pd, f.rows_dr, nullptr, S, B, bkgd, m->white_bkgd, m->rgb_padding, m->sigma_bias, lf.rgb, lf.dist, lf.acc, lf.trans,
-                              lf.tb, nullptr, nullptr, 0, nullptr, stream));
-    if (m->bd_cut) RNERF_TRY(bd_cut_pair(m, f.raw_f, f.rows_pd, f.rows_dr, S, B, bkgd, lf, f.tmp_level, f.tmp_level2, stream));
+                              lf.tb, nullptr, nullptr, level_mask_mode(m), level_mask_box(m), stream));
+    if (m->bd_cut == 1) RNERF_TRY(bd_cut_pair(m, f.raw_f, f.rows_pd, f.rows_dr, S, B, bkgd, lf, f.tmp_level, f.tmp_level2, stream));
   }
   // ---- loss reductions (train.py:89-92,105) ----
   RNERF_TRY(rnerf_loss_reduce(Nf > 0 ? lc.rgb : nullptr, lf.rgb, lf.trans, lf.tb, pixels, B, t.sums, stream));
@@ -648,10 +652,10 @@ extern "C" int rnerf_train_forward_backward(const rnerf_model* m, const rnerf_tr
   void* dy_c = split_levels ? t.dy_c : t.dy;
   if (Nf > 0) {
     RNERF_TRY(rnerf_composite_backward(f.raw_f, f.rows_pd, f.rows_dr, nullptr, S, B, bkgd, m->rgb_padding, m->sigma_bias, lf.rgb, pixels, lf.trans, lf.tb, t.sums,
-                                       mse_scale, c->bg_weight * bg_on, t.d_raw, d_first, 0, m->white_bkgd, m->bd_cut ? m->bd_cut_bbox : nullptr, stream));
+                                       mse_scale, c->bg_weight * bg_on, t.d_raw, d_first, 0, m->white_bkgd, m->bd_cut == 1 ? 1 : level_mask_mode(m), m->bd_cut ? m->bd_cut_bbox : nullptr, stream));
     if (split_levels) {
       RNERF_TRY(rnerf_composite_backward(f.raw_c, path_pd, path_dr, jitter, Nc, B, bkgd, m->rgb_padding, m->sigma_bias, lc.rgb, pixels, nullptr, nullptr, nullptr,
-                                         mse_scale, 0.0, d_raw_c, d_first, 1, m->white_bkgd, nullptr, stream));
+                                         mse_scale, 0.0, d_raw_c, d_first, 1, m->white_bkgd, level_mask_mode(m), level_mask_box(m), stream));
       RNERF_TRY(rnerf_fork(stream, aux));
       if (bk_early) {      // d loss / d background is final (both compositing backwards have run): its whole backward goes beside the NerfMLP
         // chains — on the third stream when there is one (nothing waits behind it), else in front of the coarse level's on the aux stream.
@@ -678,10 +682,10 @@ extern "C" int rnerf_train_forward_backward(const rnerf_model* m, const rnerf_tr
     }
     else
       RNERF_TRY(rnerf_composite_backward(f.raw_c, path_pd, path_dr, jitter, Nc, B, bkgd, m->rgb_padding, m->sigma_bias, lc.rgb, pixels, nullptr, nullptr, nullptr,
-                                         mse_scale, 0.0, t.d_raw, d_first, 1, m->white_bkgd, nullptr, stream));
+                                         mse_scale, 0.0, t.d_raw, d_first, 1, m->white_bkgd, level_mask_mode(m), level_mask_box(m), stream));
   } else {
     RNERF_TRY(rnerf_composite_backward(f.raw_c, path_pd, path_dr, jitter, Nc, B, bkgd, m->rgb_padding, m->sigma_bias, lf.rgb, pixels, lf.trans, lf.tb, t.sums,
-                                       mse_scale, c->bg_weight * bg_on, t.d_raw, d_first, 0, m->white_bkgd, nullptr, stream));
+                                       mse_scale, c->bg_weight * bg_on, t.d_raw, d_first, 0, m->white_bkgd, level_mask_mode(m), level_mask_box(m), stream));
   }
   // (experiment, cfg->coresident_bkgd_wgrad: the background MLP's weight gradient as a co-resident kernel on the aux stream beside the
   //  NerfMLP wgrad — its dgrad chain then runs here, ahead of the NerfMLP dgrad; measured neutral at bench size)

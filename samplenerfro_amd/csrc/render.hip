@@ -54,9 +54,10 @@ __global__ void __launch_bounds__(64) composite_kernel(const float4* __restrict_
   auto rec = [&](int s) -> size_t { return (size_t)(node_of_sample ? node_of_sample[s] : s) * B + r; };
   const int G = (S + L - 1) / L;
   // mask_bbox = (cumsum(inside[::-1]) > 0)[::-1] (rnerf/models.py:498-503): 1 up to and including the LAST sample inside the
-  // box; mask_mode 1 uses it, mask_mode 2 uses 1 - mask (:505-523).
+  // box; mask_mode 1 uses it, mask_mode 2 uses 1 - mask (:505-523).  mask_mode 3 = use_mask_bbox (:261-271,398-408): the plain per-sample
+  // test "this sample is inside the box".
   int last_in = -1;
-  if (mask_mode != 0) {
+  if (mask_mode == 1 || mask_mode == 2) {
     for (int j = G - 1; j >= 0; --j) {
       const int s = L * j + q;
       if (s < S) {
@@ -72,13 +73,15 @@ __global__ void __launch_bounds__(64) composite_kernel(const float4* __restrict_
   float cum = 0.f, sr = 0.f, sg = 0.f, sb = 0.f, acc = 0.f, wt = 0.f;
   const float t0 = rows_pd[rec(0)].w;
   const float t_last = rows_pd[rec(S - 1)].w;
-  struct Rec { float4 d, rw; float t; };
+  struct Rec { float4 d, rw; float t; float in; };
   auto load = [&](int j) -> Rec {
     int s = L * j + q;
     if (s > S - 1) s = S - 1;
     const size_t o = rec(s);
     Rec x;
-    x.d = rows_dr[o]; x.rw = raw[(size_t)s * B + r]; x.t = rows_pd[o].w;
+    const float4 p = rows_pd[o];
+    x.d = rows_dr[o]; x.rw = raw[(size_t)s * B + r]; x.t = p.w;
+    x.in = (mask_mode != 3 || (p.x >= bx0 && p.x <= bx1 && p.y >= by0 && p.y <= by1 && p.z >= bz0 && p.z <= bz1)) ? 1.0f : 0.0f;
     return x;
   };
   // ordered accumulation of the L lanes' products: (((a + p0) + p1) + p2) + ...
@@ -104,7 +107,8 @@ __global__ void __launch_bounds__(64) composite_kernel(const float4* __restrict_
     const float cg = fsub(fmul(sigmoidf_ref(rw.y), pad_scale), pad);
     const float cb = fsub(fmul(sigmoidf_ref(rw.z), pad_scale), pad);
     float dd = fmul(sigma, delta);                           // :272
-    if (mask_mode != 0) dd = fmul(dd, ((s <= last_in) == (mask_mode == 1)) ? 1.0f : 0.0f);   // density_delta *= mask_bbox (:275-276)
+    if (mask_mode == 3) dd = fmul(dd, cur.in);
+    else if (mask_mode != 0) dd = fmul(dd, ((s <= last_in) == (mask_mode == 1)) ? 1.0f : 0.0f);   // density_delta *= mask_bbox (:275-276)
     if (!valid) dd = 0.f;                                    // padding lanes of the last group: alpha = 0, weight = 0
     const float a = fsub(1.0f, expf(-dd));                   // :285
     // optical depth before each of the group's samples, in order
@@ -188,8 +192,11 @@ __global__ void __launch_bounds__(64) composite_bwd_kernel(const float4* __restr
                                                            const float* __restrict__ trans, const float* __restrict__ tb,
                                                            const float* __restrict__ sums, float mse_scale, float bg_scale,
                                                            float4* __restrict__ d_raw, float* __restrict__ d_bkgd, int accumulate_bkgd,
-                                                           int bd_cut, float bx0, float by0, float bz0, float bx1, float by1, float bz1,
+                                                           int mask_mode, float bx0, float by0, float bz0, float bx1, float by1, float bz1,
                                                            int white_bkgd) {
+  // mask_mode: 0 = none; 1 = the bd_cut_dist pair (rnerf/models.py:479-524); 3 = use_mask_bbox (:261-271,398-408): density_delta *= 1[sample
+  // inside the box] in this level's rendering — the mask multiplies the segment length, so dd and every gradient through it carry it
+  const bool bd_cut = mask_mode == 1;
   // L lanes per ray, lane q owns samples L j + q (see composite_kernel): the ordered chains run through lane broadcasts
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   const int q = gid & (L - 1);
@@ -238,20 +245,22 @@ __global__ void __launch_bounds__(64) composite_bwd_kernel(const float4* __restr
       }
     }
   }
-  struct Rec { float4 d, rw; float t; };
+  struct Rec { float4 d, rw; float t; float in; };
   auto load = [&](int j) -> Rec {
     int s = L * j + q;
     if (s > S - 1) s = S - 1;
     const size_t o = rec(s);
     Rec x;
-    x.d = rows_dr[o]; x.rw = raw[(size_t)s * B + r]; x.t = rows_pd[o].w;
+    const float4 p = rows_pd[o];
+    x.d = rows_dr[o]; x.rw = raw[(size_t)s * B + r]; x.t = p.w;
+    x.in = (mask_mode != 3 || (p.x >= bx0 && p.x <= bx1 && p.y >= by0 && p.y <= by1 && p.z >= bz0 && p.z <= bz1)) ? 1.0f : 0.0f;
     return x;
   };
   // dd of this lane's sample (0 for the padding lanes of the last group), d softplus/dx and the segment length
   auto dd_of = [&](const Rec& c, int s, float t_next, float& sg_out, float& delta_out) -> float {
     const float tdist = (s + 1 < S) ? fsub(t_next, c.t) : 1e-3f;
     const float nrm = fsqrt(fadd(fadd(fmul(c.d.x, c.d.x), fmul(c.d.y, c.d.y)), fmul(c.d.z, c.d.z)));
-    delta_out = fmul(tdist, nrm);
+    delta_out = fmul(fmul(tdist, nrm), c.in);              // (use_mask_bbox: a sample outside the box has no density_delta and no gradient)
     const float x = fadd(c.rw.w, sigma_bias);
     sg_out = fdiv(1.0f, fadd(1.0f, expf(-x)));             // d softplus / dx
     return s < S ? fmul(softplusf_ref(x), delta_out) : 0.f;
@@ -529,7 +538,7 @@ extern "C" int rnerf_composite(const float* raw, const float* rows_pd, const flo
                                double rgb_padding, double sigma_bias, float* rgb, float* dist, float* acc, float* trans,
                                float* trans_bkgd, float* weights, float* alpha, int mask_mode, const double* bbox, void* stream) {
   RNERF_CHECK_ARG(raw && rows_pd && rows_dr && rgb && dist && acc && trans && trans_bkgd, "rnerf_composite: null pointer");
-  RNERF_CHECK_ARG(mask_mode >= 0 && mask_mode <= 2 && (mask_mode == 0 || bbox), "rnerf_composite: mask_mode 1/2 needs a bbox");
+  RNERF_CHECK_ARG(mask_mode >= 0 && mask_mode <= 3 && (mask_mode == 0 || bbox), "rnerf_composite: mask_mode 1 / 2 / 3 needs a bbox");
   float bb[6] = {0, 0, 0, 0, 0, 0};
   if (mask_mode != 0) for (int i = 0; i < 6; ++i) bb[i] = (float)bbox[i];
   RNERF_CHECK_ARG(S >= 1 && B >= 1, "rnerf_composite: need S >= 1 and B >= 1");
@@ -862,7 +871,10 @@ extern "C" int rnerf_composite_backward(const float* raw, const float* rows_pd, 
                                         int32_t S, int32_t B, const float* bkgd, double rgb_padding, double sigma_bias,
                                         const float* rgb, const float* pixels, const float* trans, const float* trans_bkgd,
                                         const float* sums, double mse_scale, double bg_scale, float* d_raw, float* d_bkgd,
-                                        int accumulate_bkgd, int white_bkgd, const double* bd_cut_bbox, void* stream) {
+                                        int accumulate_bkgd, int white_bkgd, int mask_mode, const double* bbox, void* stream) {
+  RNERF_CHECK_ARG((mask_mode == 0 || mask_mode == 1 || mask_mode == 3) && (mask_mode == 0 || bbox),
+                  "rnerf_composite_backward: mask_mode must be 0, 1 (bd_cut pair) or 3 (use_mask_bbox), the last two with a bbox");
+  const double* bd_cut_bbox = mask_mode != 0 ? bbox : nullptr;
   RNERF_CHECK_ARG(raw && rows_pd && rows_dr && bkgd && rgb && pixels && d_raw && d_bkgd, "rnerf_composite_backward: null pointer");
   RNERF_CHECK_ARG(bg_scale == 0.0 || (trans && trans_bkgd && sums), "rnerf_composite_backward: bg term needs trans, trans_bkgd and sums");
   RNERF_CHECK_ARG(S >= 1 && B >= 1, "rnerf_composite_backward: need S >= 1 and B >= 1");
@@ -872,7 +884,7 @@ extern "C" int rnerf_composite_backward(const float* raw, const float* rows_pd, 
   hipLaunchKernelGGL(composite_bwd_kernel<LL>, dim3((unsigned)(((long long)B * LL + 63) / 64)), dim3(64), 0, (hipStream_t)stream, (const float4*)raw, \
                      (const float4*)rows_pd, (const float4*)rows_dr, node_of_sample, S, B, bkgd, (float)(1 + 2 * rgb_padding),   \
                      (float)rgb_padding, (float)sigma_bias, rgb, pixels, trans, trans_bkgd, sums, (float)mse_scale, (float)bg_scale, \
-                     (float4*)d_raw, d_bkgd, accumulate_bkgd, bd_cut_bbox != nullptr, bd_cut_bbox ? (float)bd_cut_bbox[0] : 0.f,  \
+                     (float4*)d_raw, d_bkgd, accumulate_bkgd, mask_mode, bd_cut_bbox ? (float)bd_cut_bbox[0] : 0.f,  \
                      bd_cut_bbox ? (float)bd_cut_bbox[1] : 0.f, bd_cut_bbox ? (float)bd_cut_bbox[2] : 0.f, bd_cut_bbox ? (float)bd_cut_bbox[3] : 0.f, \
                      bd_cut_bbox ? (float)bd_cut_bbox[4] : 0.f, bd_cut_bbox ? (float)bd_cut_bbox[5] : 0.f, white_bkgd)
   const int lanes = composite_lanes(B);

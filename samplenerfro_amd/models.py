@@ -103,8 +103,12 @@ class NerfModel:
             raise NotImplementedError("the HIP NerfMLP kernel is specialised for the reference's 8x256 / skip 4 / 1x128 network")
         if (min_deg_point, max_deg_point, deg_view) != (0, 10, 4) or legacy_posenc_order or not use_viewdirs:
             raise NotImplementedError("the HIP kernels implement pos_enc degrees (0,10)/(0,4), non-legacy order, use_viewdirs=True")
-        if sh_deg >= 0 or sh_direnc_deg > 0 or noise_std or use_mask_bbox:
-            raise NotImplementedError("sh_deg / sh_direnc_deg / noise_std / use_mask_bbox are disabled in every shipped config and not built")
+        if sh_deg >= 0 or sh_direnc_deg > 0 or noise_std:
+            raise NotImplementedError("sh_deg / sh_direnc_deg / noise_std are disabled in every shipped config and not built")
+        if use_mask_bbox and bd_cut_dist is not None:
+            raise ValueError("'use_mask_bbox' is true (rnerf/models.py:480: bd_cut_dist and use_mask_bbox exclude each other)")
+        # use_mask_bbox (rnerf/models.py:261-271,398-408): density only at samples inside the grid's box [nmin, nmax], in both levels
+        self.use_mask_bbox = bool(use_mask_bbox)
         # lindisp: a field of the reference's NerfModel (rnerf/models.py:74) that its __call__ never reads — the samples come from the eikonal
         # march, not from sample_along_rays — so it is accepted and, like there, has no effect
         self.lindisp = bool(lindisp)
@@ -237,6 +241,10 @@ class NerfModel:
         u = (np.arange(F, dtype=np.float32) * np.float32(s))[None, :] + prng.uniform(key, (batch, F), maxval=s - eps)
         return np.ascontiguousarray(np.minimum(u, np.float32(1.0 - eps)).astype(np.float32).T)
 
+    def _mask_bbox(self):
+        """use_mask_bbox's box: the grid's own (rnerf/models.py:262-264, "small mask bbox")."""
+        return list(self.nmin) + list(self.nmax)
+
     def _bd_cut_bbox(self):
         """The scene-name-specific box of rnerf/models.py:485-497."""
         name = self.cfg_name or ""
@@ -334,6 +342,10 @@ class NerfModel:
         m.bd_cut = int(self.bd_cut_dist is not None and self.num_fine_samples > 0)
         if m.bd_cut:
             for i, v in enumerate(self._bd_cut_bbox()):
+                m.bd_cut_bbox[i] = float(v)
+        elif self.use_mask_bbox:          # rnerf_model.bd_cut = 2: the per-sample box mask of both levels, the box in bd_cut_bbox
+            m.bd_cut = 2
+            for i, v in enumerate(self._mask_bbox()):
                 m.bd_cut_bbox[i] = float(v)
         if variables is not None:
             m.packed_coarse = self._packed_weights(variables, "coarse_mlp", prec).data_ptr()
@@ -486,9 +498,12 @@ class NerfModel:
                                                             path_dr, jit, Nc, B, ctx.get("backward", _lib.BWD_F16X2),
                                                             max_workgroups=self._mlp_wg_limit)
             ctx.update(path_pd=path_pd, path_dr=path_dr, jit=jit, raw_c=raw_c, bkgd=bkgd, B=B)
+        mb = self._mask_bbox() if self.use_mask_bbox else None
+        if ctx is not None and mb is not None:
+            ctx["mask_bbox"] = mb
         rgb, dist, acc, trans, trans_bkgd, weights, alpha = ops.composite(
             raw_c, path_pd, path_dr, jit, Nc, B, bkgd, self.white_bkgd, self.rgb_padding, self.sigma_bias,
-            want_weights=True, want_alpha=sparsity)
+            want_weights=True, want_alpha=sparsity, mask_mode=3 if mb is not None else 0, bbox=mb)
         loss_sp = 0.0
         if sparsity:                                                      # rnerf/models.py:351-357
             g = path_ior[jit.long()][..., 1:4]
@@ -514,7 +529,7 @@ class NerfModel:
                 ctx.update(rows_pd=rows_pd, rows_dr=rows_dr, raw_f=raw_f)
             rgb, dist, acc, trans, trans_bkgd, w_f, alpha_f = ops.composite(
                 raw_f, rows_pd, rows_dr, None, S, B, bkgd, self.white_bkgd, self.rgb_padding, self.sigma_bias,
-                want_weights=taps is not None, want_alpha=fine_sp)
+                want_weights=taps is not None, want_alpha=fine_sp, mask_mode=3 if mb is not None else 0, bbox=mb)
             if fine_sp:                                                                   # rnerf/models.py:526-530
                 g = path_ior[idx.long(), torch.arange(B, device=self.device)[None, :]][..., 1:4]
                 mask = (torch.sqrt((g * g).sum(-1)) > 1e-6).float()
@@ -641,6 +656,7 @@ def construct_nerf(key, example_batch, args, ndim, nmin, nmax, grid, precision: 
         ndim=ndim, nmin=nmin, nmax=nmax, grid=grid, stage=args.stage, num_path_samples=args.num_path_samples,
         use_fine_sparsity=args.use_fine_sparsity, use_online_sparsity=args.use_online_sparsity,
         sh_direnc_deg=args.sh_direnc_deg, cfg_name=args.config, precision=precision, eval_precision=eval_precision, device=device,
-        bd_cut_dist=getattr(args, "bd_cut_dist", None))
+        bd_cut_dist=getattr(args, "bd_cut_dist", None),
+        use_mask_bbox=getattr(args, "use_mask_bbox", False))      # (both gin-bound attributes of NerfModel in the reference, configs/*.gin)
     key1, _key2, _key3 = prng.split(np.asarray(key, np.uint32), 3)
     return model, model.init(key1)

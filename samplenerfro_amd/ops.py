@@ -198,8 +198,12 @@ def loss_reduce(rgb_c: Optional[torch.Tensor], rgb_f: torch.Tensor, trans_f: tor
 def composite_backward(raw, rows_pd, rows_dr, node_of_sample, S: int, B: int, bkgd, rgb, pixels, trans=None, trans_bkgd=None,
                        sums=None, mse_scale: float = 0.0, bg_scale: float = 0.0, d_bkgd: Optional[torch.Tensor] = None,
                        rgb_padding: float = 0.001, sigma_bias: float = -1.0, bd_cut_bbox=None, white_bkgd: bool = False,
-                       accumulate_bkgd: Optional[bool] = None):
-    """T1: backward of activations + volumetric_rendering for one level. -> d_raw [S,B,4], d_bkgd [B,3] (accumulated if given)."""
+                       accumulate_bkgd: Optional[bool] = None, mask_bbox=None):
+    """T1: backward of activations + volumetric_rendering for one level. -> d_raw [S,B,4], d_bkgd [B,3] (accumulated if given).
+    bd_cut_bbox: the level's trans pair is the bd_cut_dist pair (mask mode 1); mask_bbox: the level was rendered with use_mask_bbox (mode 3)."""
+    if bd_cut_bbox is not None and mask_bbox is not None:
+        raise ValueError("bd_cut_dist and use_mask_bbox exclude each other (rnerf/models.py:480)")
+    mode, box = (1, bd_cut_bbox) if bd_cut_bbox is not None else ((3, mask_bbox) if mask_bbox is not None else (0, None))
     lib = _lib.load()
     dev = raw.device
     d_raw = torch.empty((S, B, 4), dtype=torch.float32, device=dev)
@@ -209,8 +213,8 @@ def composite_backward(raw, rows_pd, rows_dr, node_of_sample, S: int, B: int, bk
     check(lib.rnerf_composite_backward(ptr(_chk(raw, "raw")), ptr(rows_pd), ptr(rows_dr), ptr(node_of_sample), int(S), int(B),
                                        ptr(_chk(bkgd, "bkgd")), float(rgb_padding), float(sigma_bias), ptr(_chk(rgb, "rgb")),
                                        ptr(_chk(pixels, "pixels")), ptr(trans), ptr(trans_bkgd), ptr(sums), float(mse_scale),
-                                       float(bg_scale), ptr(d_raw), ptr(d_bkgd), int(acc), int(bool(white_bkgd)),
-                                       None if bd_cut_bbox is None else (C.c_double * 6)(*[float(v) for v in bd_cut_bbox]), current_stream()),
+                                       float(bg_scale), ptr(d_raw), ptr(d_bkgd), int(acc), int(bool(white_bkgd)), int(mode),
+                                       None if box is None else (C.c_double * 6)(*[float(v) for v in box]), current_stream()),
           "rnerf_composite_backward")
     return d_raw, d_bkgd
 

@@ -444,16 +444,17 @@ def train_step(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], 
         d_raw_f, d_bkgd = ops.composite_backward(ctx["raw_f"], ctx["rows_pd"], ctx["rows_dr"], None, Nc + Nf, B, ctx["bkgd"], rgb_f, pixels,
                                                  trans_f, tb_f, sums, mse_scale, flags.bg_weight * bg_on, rgb_padding=model.rgb_padding,
                                                  sigma_bias=model.sigma_bias, bd_cut_bbox=ctx.get("bd_cut_bbox"), white_bkgd=model.white_bkgd,
-                                                 d_bkgd=d_first, accumulate_bkgd=False)
+                                                 d_bkgd=d_first, accumulate_bkgd=False, mask_bbox=ctx.get("mask_bbox"))
         ops.nerfmlp_backward(_bwd_packed(model, state, "fine_mlp", bwd), model._packed_weights(variables, "fine_mlp"), prec, ctx["save_f"],
                              d_raw_f, (Nc + Nf) * B, grads=state.grad_view("fine_mlp"), backward=bwd)
         d_raw_c, d_bkgd = ops.composite_backward(ctx["raw_c"], ctx["path_pd"], ctx["path_dr"], ctx["jit"], Nc, B, ctx["bkgd"], rgb_c, pixels,
                                                  None, None, None, mse_scale, 0.0, d_bkgd=d_bkgd, rgb_padding=model.rgb_padding,
-                                                 sigma_bias=model.sigma_bias, white_bkgd=model.white_bkgd)
+                                                 sigma_bias=model.sigma_bias, white_bkgd=model.white_bkgd, mask_bbox=ctx.get("mask_bbox"))
     else:
         d_raw_c, d_bkgd = ops.composite_backward(ctx["raw_c"], ctx["path_pd"], ctx["path_dr"], ctx["jit"], Nc, B, ctx["bkgd"], rgb_f, pixels,
                                                  trans_f, tb_f, sums, mse_scale, flags.bg_weight * bg_on, rgb_padding=model.rgb_padding,
-                                                 sigma_bias=model.sigma_bias, white_bkgd=model.white_bkgd, d_bkgd=d_first, accumulate_bkgd=False)
+                                                 sigma_bias=model.sigma_bias, white_bkgd=model.white_bkgd, d_bkgd=d_first, accumulate_bkgd=False,
+                                                 mask_bbox=ctx.get("mask_bbox"))
     # The march of the NEXT step (it reads neither the trained parameters nor anything of this step) goes to the side stream after the
     # wgrad, beside the small kernels of the step's tail (background-MLP backward, loss glue, Adam).  Those are ~0.35 ms against 0.7-0.8 ms
     # of march, so ~0.4 ms of every step still waits for it (rocprof timeline) — but issuing it between the dgrad and the
