@@ -772,7 +772,26 @@ def main():
                                   "what": "NerfMLP gradient of one step on the bench batch against the default (f16x3 forward + f16x3 backward, itself held to "
                                           "1e-5 of max|g| vs float64 autograd by tests/test_gpu_backward.py), relative to max|g|"}
             del mp, vp, g
-        del g_ref
+        # the RANGE-SAFE training arithmetic (bf16x3 forward, its bf16 hi plane saved as it is, bf16 backward): what train_step(range_retry=True)
+        # re-runs a step in whose f16-based arithmetic met a row outside f16's range — never the headline, never the default
+        mp, vp = model_with_precision(model, "bf16x3"), models_fresh_variables(pf, device)
+        st = Stepper(args, cfg, mp, vp, rays, key, B, world, rank, fine, device, "bf16", "train", "radiance", args.pipeline, False)
+        dt_t = timed_steps(st, 2, 10, barrier, D, device)
+        st.close()
+        g = grads_of(mp, "bf16")
+        # ... and what the opt-in switch itself costs on the DEFAULT step: one host read of the non-finite count per step (no re-run happens here)
+        vs = models_fresh_variables(pf, device)
+        st = Stepper(args, cfg, model, vs, rays, key, B, world, rank, fine, device, args.backward, "train", "radiance", args.pipeline, False)
+        st.flags.range_retry = True
+        dt_s = timed_steps(st, 2, 10, barrier, D, device)
+        retries = st.tstate.range_retries
+        st.close()
+        legs["range_safe_train"] = {"ms_per_step": 1e3 * dt_t / 10, "rays_per_s": B * world * 10 / dt_t, "forward_precision": "bf16x3", "backward_precision": "bf16",
+                                    "grad_err_rel_max_vs_f16x3": float((g - g_ref).abs().max() / g_ref.abs().max()),
+                                    "default_step_with_range_retry_on": {"ms_per_step": 1e3 * dt_s / 10, "rays_per_s": B * world * 10 / dt_s, "re_runs": retries},
+                                    "what": "the step a range_retry re-run costs, on the bench batch (which is inside f16's range: the default never re-runs here), and "
+                                            "the default step with the switch on (one host read of the non-finite count per step: why it is opt-in)"}
+        del mp, vp, vs, g, g_ref
         torch.cuda.empty_cache()
 
     traffic, sq, pmc_meta = pmc_lookup(args.workload, fine, B, args.mode, args.backward, rnerf_cus, prec_fwd_name)

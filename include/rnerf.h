@@ -59,8 +59,9 @@ enum rnerf_status {
  * second pass in BF16X3 (fp32's exponent range; its stream sits behind the others in the packed buffer) that recomputes exactly the rows
  * the first pass gave up on and touches no other row — the reference's fp32 nn.Dense (rnerf/model_utils.py:58-89) is finite there, and so is
  * this; without such a row the pass reads the outputs once (~5 us) and the first pass's bits stand.  The
- * TRAINING forward (rnerf_nerfmlp_forward_train) has no second pass: such a row stays NaN and reaches the non-finite-gradient count of
- * rnerf_adam_update (scratch[3]) — the saved f16 operands of the backward cannot represent it. */
+ * TRAINING forward (rnerf_nerfmlp_forward_train) has no per-row second pass — the saved f16 operands of the backward cannot represent such a
+ * row: it stays NaN, reaches the non-finite-gradient count of rnerf_adam_update (scratch[3]), the update is skipped
+ * (rnerf_adam_cfg.skip_nonfinite) and the STEP is re-run in BF16X3 + backward BF16, the range-safe training arithmetic. */
 enum rnerf_precision {
   RNERF_PREC_F32 = 0,
   RNERF_PREC_F16X3 = 1,
@@ -297,9 +298,11 @@ int rnerf_composite_backward(const float* raw, const float* rows_pd, const float
 
 /* ---- T1 (backward of P1+N1): gradient of the NerfMLP parameters, replacing jax.value_and_grad through
  * NerfMLP.__call__ (train.py:164; rnerf/model_utils.py:30-90).  `backward` is an enum rnerf_backward, the same in all calls of a step.
- *   rnerf_nerfmlp_forward_train : as rnerf_nerfmlp_forward — precision F16X3 (the fp32-grade default), or F16 with backward F16 / BF16 (the
- *       single-pass training arithmetic: one MFMA per product, a labelled bench leg; the dgrad / wgrad calls of the step take the same
- *       precision); bf16x3 / bf16 / f16x2 / f16f8 are inference precisions — and keeps
+ *   rnerf_nerfmlp_forward_train : as rnerf_nerfmlp_forward — precision F16X3 (the fp32-grade default), F16 with backward F16 / BF16 (the
+ *       single-pass training arithmetic: one MFMA per product, a labelled bench leg), or BF16X3 with backward BF16 (the RANGE-SAFE training
+ *       arithmetic: fp32's exponent range in the forward, the saved operands and the gradients; 16-bit forward products, 8-bit gradients —
+ *       what a step whose f16-based run met a row outside f16's range is re-run in); the dgrad / wgrad calls of the step take the same
+ *       precision; bf16 / f16x2 / f16f8 are inference precisions — and keeps
  *       the 16-bit operands of every layer in `save` (rnerf_nerfmlp_save_bytes(S*B, backward) bytes; F16X3 backward: hi and lo parts);
  *   rnerf_nerfmlp_pack_bwd : transposed weight stream of the dgrad chain (rnerf_nerfmlp_bwd_packed_bytes() bytes);
  *   rnerf_nerfmlp_dgrad : d_raw float4[rows] (d loss / d raw rgb, sigma) -> dy (rnerf_nerfmlp_dy_bytes(rows, backward) bytes), the
@@ -480,10 +483,14 @@ int rnerf_train_forward_backward(const rnerf_model* m, const rnerf_train_cfg* c,
 /* ---- train.py:169-183 + optax.adam behind multi_transform (:312-317) on the flat buffers: weight-decay gradient 2 wd theta / n_all,
  * value clip, global-norm clip (over theta's gradient and the frozen variables' weight-decay gradient, frozen_params nullable),
  * Adam with bias correction and the reference's learning-rate schedule (rnerf/utils.py:490-528) evaluated on the device from the
- * device-resident step counter, which is incremented.  scratch: device float[RNERF_ADAM_SCRATCH_FLOATS]; after the call scratch[3]
- * holds the number of non-finite (inf / NaN) gradient entries the update met (0 in a healthy step: the f16 backward modes normalise every
- * row's gradient chain to 2^10 of headroom, a row that exceeds it overflows to inf — the count makes that visible). */
-#define RNERF_ADAM_SCRATCH_FLOATS 2052
+ * device-resident step counter, which is incremented.  scratch: device float[RNERF_ADAM_SCRATCH_FLOATS] (no initial contents needed); after
+ * the call scratch[3] holds the number of non-finite (inf / NaN) gradient entries the update met (0 in a healthy step: a forward row outside
+ * f16's range, or a gradient chain beyond the 2^10 of headroom the f16 backward modes normalise every row to, makes that visible), counted
+ * BEFORE the value clip (which would otherwise turn a NaN into +-grad_max_val).  skip_nonfinite != 0: an update that met such an entry
+ * leaves theta, mu and nu untouched (the step counter still advances) — the reference's fp32 step would have been finite on that batch, so
+ * the caller re-runs it in the range-safe arithmetic (precision BF16X3 + backward BF16; samplenerfro_amd.train does with
+ * range_retry) instead of writing NaN into every parameter. */
+#define RNERF_ADAM_SCRATCH_FLOATS 3076
 typedef struct rnerf_adam_cfg {
   double lr_init, lr_final, lr_delay_mult;
   int64_t max_steps, lr_delay_steps;
@@ -492,6 +499,7 @@ typedef struct rnerf_adam_cfg {
   int64_t n_all;               /* number of variables weight_l2 averages over (theta + frozen) */
   double lr_override;          /* the learning rate of this update when use_lr_override != 0 (a replaced schedule, tests); 0.0 is honoured */
   int32_t use_lr_override;     /* 0: the reference's schedule (rnerf/utils.py:490-528) from the device-resident step counter */
+  int32_t skip_nonfinite;      /* != 0: no update when a gradient entry is inf / NaN (see above) */
 } rnerf_adam_cfg;
 int rnerf_adam_update(const rnerf_adam_cfg* c, float* theta, float* mu, float* nu, float* grads, int64_t n_theta, const float* frozen_params,
                       int64_t n_frozen, int32_t* step_counter, float* scratch, void* stream);

@@ -82,3 +82,16 @@ def randint(key, n, minval, maxval):
         off = (((h % span) * mult) % M32 + (l % span)) % M32
         out.append(minval + off % span)
     return out
+
+
+def normal(key, n):
+    """`_normal_real` float32: sqrt(2) * erf_inv(u), u = uniform(key, n, nextafter(-1, 0), 1) — through the exact normal quantile
+    (sqrt(2) erf_inv(u) = Phi^-1((u + 1) / 2)) in double precision, rounded to float32.  XLA evaluates erf_inv by a float32 polynomial
+    (samplenerfro_amd/prng.erf_inv_f32): this reading bounds it (tests/test_prng.py), it does not reproduce its last bits."""
+    from statistics import NormalDist
+    lo = struct.unpack("<f", struct.pack("<I", struct.unpack("<I", struct.pack("<f", -1.0))[0] - 1))[0]      # nextafter(-1, 0) in float32
+    nd = NormalDist()
+    out = []
+    for u in uniform(key, n, lo, 1.0):
+        out.append(_f32(nd.inv_cdf((u + 1.0) / 2.0)) if -1.0 < u < 1.0 else float("-inf"))
+    return out

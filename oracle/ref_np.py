@@ -505,8 +505,11 @@ def safe_log(x, eps=1e-6):
 
 
 def nerf_forward(cfg: ModelConfig, params: Dict, table, origins, viewdirs, jitter, u_fine=None,
-                 dtype=F32, acc_dtype=None, taps: Optional[Dict] = None):
-    """NerfModel.__call__ (models.py:220-535), stage="radiance", use_viewdirs=True, sh off, noise off.
+                 dtype=F32, acc_dtype=None, taps: Optional[Dict] = None, noise_std=None, noise_c=None, noise_f=None):
+    """NerfModel.__call__ (models.py:220-535), stage="radiance", use_viewdirs=True, sh off.
+
+    noise_std with noise_c [B,N_c] / noise_f [B,N_c+N_f]: add_gaussian_noise (model_utils.py:438-453, models.py:310-317,445-452) with the
+    standard-normal draws supplied by the caller (the reference draws random.normal(key, raw_sigma.shape)).
 
     jitter: int [N_c] = arange(0,N,P) + randint (models.py:240-242), supplied by the caller.
     u_fine: [B,N_f] uniform draws or None (-> linspace, randomized=False).
@@ -523,6 +526,8 @@ def nerf_forward(cfg: ModelConfig, params: Dict, table, origins, viewdirs, jitte
     viewdirs_enc = pos_enc(ray_dir_c, 0, cfg.deg_view, dtype)                                # :289-294
     raw_bkgd = simple_mlp(params["bkgd_mlp"], viewdirs_enc[:, -1:], acc_dtype)[:, 0]        # :303
     raw_rgb, raw_sigma = nerf_mlp(params["coarse_mlp"], samples_enc, viewdirs_enc, acc_dtype)  # :305
+    if noise_std is not None and noise_c is not None:                                        # :310-317
+        raw_sigma = raw_sigma + np.asarray(noise_c, dtype).reshape(raw_sigma.shape) * dtype(noise_std)
     rgb = rgb_activation(raw_rgb, cfg.rgb_padding)
     bkgd = rgb_activation(raw_bkgd, cfg.rgb_padding)
     sigma = sigma_activation(raw_sigma, cfg.sigma_bias)
@@ -554,6 +559,8 @@ def nerf_forward(cfg: ModelConfig, params: Dict, table, origins, viewdirs, jitte
         samples_enc = pos_enc(pos_f, cfg.min_deg_point, cfg.max_deg_point, dtype)            # :394
         viewdirs_enc = pos_enc(dir_f, 0, cfg.deg_view, dtype)                                # :426
         raw_rgb, raw_sigma = nerf_mlp(params["fine_mlp"], samples_enc, viewdirs_enc, acc_dtype)  # :441
+        if noise_std is not None and noise_f is not None:                                    # :445-452
+            raw_sigma = raw_sigma + np.asarray(noise_f, dtype).reshape(raw_sigma.shape) * dtype(noise_std)
         rgb = rgb_activation(raw_rgb, cfg.rgb_padding)
         sigma = sigma_activation(raw_sigma, cfg.sigma_bias)
         comp_rgb, disp, acc, w_f, alpha_f, trans, trans_rgb_bkgd = volumetric_rendering(

@@ -69,7 +69,7 @@ class AdamCfg(C.Structure):
     _fields_ = [("lr_init", C.c_double), ("lr_final", C.c_double), ("lr_delay_mult", C.c_double), ("max_steps", C.c_int64),
                 ("lr_delay_steps", C.c_int64), ("b1", C.c_double), ("b2", C.c_double), ("eps", C.c_double), ("weight_decay_mult", C.c_double),
                 ("grad_max_val", C.c_double), ("grad_max_norm", C.c_double), ("n_all", C.c_int64), ("lr_override", C.c_double),
-                ("use_lr_override", C.c_int32)]
+                ("use_lr_override", C.c_int32), ("skip_nonfinite", C.c_int32)]
 
 
 class Prefetch(C.Structure):
@@ -79,7 +79,7 @@ class Prefetch(C.Structure):
 
 
 LEVEL_FLOATS = 9
-ADAM_SCRATCH_FLOATS = 2052
+ADAM_SCRATCH_FLOATS = 3076
 _vp, _i32, _i64, _dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
 _GP = C.POINTER(Grid)
 _MP, _TP, _AP = C.POINTER(Model), C.POINTER(TrainCfg), C.POINTER(AdamCfg)

@@ -3183,6 +3183,14 @@ extern "C" int rnerf_nerfmlp_forward(const void* packed, int precision, const fl
 }
 
 static bool bwd_ok(int b) { return b == RNERF_BWD_BF16 || b == RNERF_BWD_F16 || b == RNERF_BWD_F16X2; }
+// (forward precision, backward mode) pairs the training kernels are built for
+static bool train_combo_ok(int precision, int backward) {
+  return precision == RNERF_PREC_F16X3 || (precision == RNERF_PREC_F16 && backward != RNERF_BWD_F16X2) ||
+         (precision == RNERF_PREC_BF16X3 && backward == RNERF_BWD_BF16);
+}
+static size_t train_stream_bytes(int precision) {      // the aux floats (biases, heads) sit behind the forward's operand stream
+  return precision == RNERF_PREC_F16 ? Prec<RNERF_PREC_F16>::STREAM_BYTES : (precision == RNERF_PREC_BF16X3 ? Prec<RNERF_PREC_BF16X3>::STREAM_BYTES : Prec<RNERF_PREC_F16X3>::STREAM_BYTES);
+}
 
 extern "C" size_t rnerf_nerfmlp_save_bytes(int64_t rows, int backward) {
   const int64_t padded = (rows + 255) / 256 * 256;
@@ -3198,8 +3206,10 @@ extern "C" int rnerf_nerfmlp_forward_train(const void* packed, int precision, co
   // (the bf16x3 forward is an inference-only precision: its 8-bit saved operands would cap every backward mode at bf16 accuracy)
   // F16: the single-pass training forward (one MFMA per product, the hi plane IS the operand) — with the single-plane backward modes only:
   // the north-star arithmetic as a labelled bench leg, never the default (11-bit products against the reference's fp32)
-  RNERF_CHECK_ARG(precision == RNERF_PREC_F16X3 || (precision == RNERF_PREC_F16 && backward != RNERF_BWD_F16X2),
-                  "rnerf_nerfmlp_forward_train: the training forward is built for precision f16x3 (and f16 with the single-plane backward modes)");
+  // BF16X3 + backward BF16: the RANGE-SAFE training arithmetic (fp32's exponent range end to end: bf16 hi + lo products forward, the bf16 hi
+  // plane saved as it is, bf16 gradients) — what a step is re-run in when the f16-based one met a row outside f16's range (train.py)
+  RNERF_CHECK_ARG(train_combo_ok(precision, backward),
+                  "rnerf_nerfmlp_forward_train: the training forward is built for precision f16x3, f16 with the single-plane backward modes, and bf16x3 with backward bf16");
   RNERF_CHECK_ARG(S >= 1 && B >= 1, "rnerf_nerfmlp_forward_train: need S >= 1 and B >= 1");
   RNERF_CHECK_ARG((((uintptr_t)packed | (uintptr_t)rows_pd | (uintptr_t)rows_dr | (uintptr_t)out_raw | (uintptr_t)save) & 15) == 0,
                   "rnerf_nerfmlp_forward_train: buffers must be 16-byte aligned");
@@ -3210,6 +3220,7 @@ extern "C" int rnerf_nerfmlp_forward_train(const void* packed, int precision, co
     return launch_fwd_dbg<RNERF_PREC_F16X3, 256, 2>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, save, max_workgroups);
 #endif
   if (backward == RNERF_BWD_F16X2) return launch_fwd_dbg<RNERF_PREC_F16X3, 0, 2>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, save, max_workgroups);
+  if (precision == RNERF_PREC_BF16X3) return launch_fwd_dbg<RNERF_PREC_BF16X3, 0, 1>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, save, max_workgroups);
   if (precision == RNERF_PREC_F16) return launch_fwd_dbg<RNERF_PREC_F16, 0, 1>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, save, max_workgroups);
   return launch_fwd_dbg<RNERF_PREC_F16X3, 0, 1>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, save, max_workgroups);
 }
@@ -3288,12 +3299,11 @@ namespace rnerf {
 int nerfmlp_dgrad_impl(const void* packed_bwd, const void* packed_fwd, int fwd_precision, int backward, const void* save, const float* d_raw, int64_t rows,
                        void* dy, bool zero_ref, bool allow_half, hipStream_t st) {
   RNERF_CHECK_ARG(packed_bwd && packed_fwd && save && d_raw && dy, "rnerf_nerfmlp_dgrad: null pointer");
-  RNERF_CHECK_ARG(fwd_precision == RNERF_PREC_F16X3 || (fwd_precision == RNERF_PREC_F16 && backward != RNERF_BWD_F16X2),
-                  "rnerf_nerfmlp_dgrad: forward precision must be f16x3 (or f16 with a single-plane backward mode)");
+  RNERF_CHECK_ARG(train_combo_ok(fwd_precision, backward), "rnerf_nerfmlp_dgrad: forward precision must be f16x3 (f16 with a single-plane backward mode; bf16x3 with backward bf16)");
   RNERF_CHECK_ARG(bwd_ok(backward), "rnerf_nerfmlp_dgrad: unknown backward mode %d", backward);
   RNERF_CHECK_ARG(rows >= 1, "rnerf_nerfmlp_dgrad: rows must be >= 1");
   // the aux floats (biases, heads) sit behind the forward's operand stream, whose length depends on its precision
-  const float* fwd_aux = (const float*)((const char*)packed_fwd + (fwd_precision == RNERF_PREC_F16 ? Prec<RNERF_PREC_F16>::STREAM_BYTES : Prec<RNERF_PREC_F16X3>::STREAM_BYTES));
+  const float* fwd_aux = (const float*)((const char*)packed_fwd + train_stream_bytes(fwd_precision));
   if (backward == RNERF_BWD_F16X2) return launch_dgrad<RNERF_BWD_F16X2>(packed_bwd, fwd_aux, save, d_raw, rows, dy, st, zero_ref, allow_half);
   if (backward == RNERF_BWD_F16) return launch_dgrad<RNERF_BWD_F16>(packed_bwd, fwd_aux, save, d_raw, rows, dy, st, zero_ref, allow_half);
   return launch_dgrad<RNERF_BWD_BF16>(packed_bwd, fwd_aux, save, d_raw, rows, dy, st, zero_ref, allow_half);
@@ -3403,14 +3413,14 @@ extern "C" size_t rnerf_nerfmlp_wgrad_workspace_bytes(void) {
 extern "C" int rnerf_nerfmlp_wgrad(int fwd_precision, int backward, const void* save, const void* dy, int64_t rows, float* grads, void* workspace,
                                    void* stream) {
   RNERF_CHECK_ARG(save && dy && grads && workspace, "rnerf_nerfmlp_wgrad: null pointer");
-  RNERF_CHECK_ARG(fwd_precision == RNERF_PREC_F16X3 || (fwd_precision == RNERF_PREC_F16 && backward != RNERF_BWD_F16X2),
-                  "rnerf_nerfmlp_wgrad: forward precision must be f16x3 (or f16 with a single-plane backward mode)");
+  RNERF_CHECK_ARG(train_combo_ok(fwd_precision, backward), "rnerf_nerfmlp_wgrad: forward precision must be f16x3 (f16 with a single-plane backward mode; bf16x3 with backward bf16)");
   RNERF_CHECK_ARG(bwd_ok(backward), "rnerf_nerfmlp_wgrad: unknown backward mode %d", backward);
   RNERF_CHECK_ARG(rows >= 1, "rnerf_nerfmlp_wgrad: rows must be >= 1");
   const WgradTables& w = wgrad_tables();
   static DeviceOnce ready;
   if (ready.need()) {
     RNERF_CHECK_HIP(hipFuncSetAttribute((const void*)nerfmlp_wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+    RNERF_CHECK_HIP(hipFuncSetAttribute((const void*)nerfmlp_wgrad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
     RNERF_CHECK_HIP(hipFuncSetAttribute((const void*)nerfmlp_wgrad_tr_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, wgtr_lds_bytes<1>()));
     RNERF_CHECK_HIP(hipFuncSetAttribute((const void*)nerfmlp_wgrad_tr_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, wgtr_lds_bytes<2>()));
     ready.set();
@@ -3424,8 +3434,12 @@ extern "C" int rnerf_nerfmlp_wgrad(int fwd_precision, int backward, const void* 
   const WgradTable& tab = backward == RNERF_BWD_BF16 ? w.legacy : (rows <= kWgradSmallRows ? w.tr_small : w.tr);
   if (backward == RNERF_BWD_BF16) {
     const int n_chunks = (int)((rows + 127) / 128);
-    hipLaunchKernelGGL(nerfmlp_wgrad_kernel<true>, dim3(tab.wg0[tab.n]), dim3(512), 131072, st, (const uint4*)save, (const uint4*)dy, R,
-                       (long long)rows, n_chunks, (float*)workspace, tab);
+    if (fwd_precision == RNERF_PREC_BF16X3)      // the range-safe step: the saved plane is bf16 already
+      hipLaunchKernelGGL(nerfmlp_wgrad_kernel<false>, dim3(tab.wg0[tab.n]), dim3(512), 131072, st, (const uint4*)save, (const uint4*)dy, R,
+                         (long long)rows, n_chunks, (float*)workspace, tab);
+    else
+      hipLaunchKernelGGL(nerfmlp_wgrad_kernel<true>, dim3(tab.wg0[tab.n]), dim3(512), 131072, st, (const uint4*)save, (const uint4*)dy, R,
+                         (long long)rows, n_chunks, (float*)workspace, tab);
   } else if (backward == RNERF_BWD_F16) {
     hipLaunchKernelGGL(nerfmlp_wgrad_tr_kernel<1>, dim3(tab.wg0[tab.n]), dim3(512), wgtr_lds_bytes<1>(), st, (const uint4*)save, (const uint4*)dy, R,
                        (float*)workspace, tab, trace);

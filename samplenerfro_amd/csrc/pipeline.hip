@@ -187,23 +187,30 @@ __global__ void __launch_bounds__(256) bd_cut_mul_kernel(const float* __restrict
 
 // ---- optimiser ------------------------------------------------------------------------------------------------------------------
 constexpr int ADAM_BLOCKS = 1024;
-// g <- clip_value(g + wd2 * theta); partial sums of g^2 per block (deterministic two-level reduction, no float atomics)
+// g <- clip_value(g + wd2 * theta); partial sums of g^2 per block (deterministic two-level reduction, no float atomics) and, per block, the
+// number of non-finite entries BEFORE the value clip (fminf / fmaxf would turn a NaN into +-max_val: a silent, wrong, finite gradient)
 __global__ void __launch_bounds__(256) adam_prep_kernel(const float* __restrict__ theta, float* __restrict__ g, long long n, float wd2, float max_val,
-                                                        int want_norm, float* __restrict__ partial) {
+                                                        int want_norm, float* __restrict__ partial, float* __restrict__ bad_partial) {
   float s = 0.f;
+  int bad = 0;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     float v = g[i];
     if (wd2 != 0.f) v = v + theta[i] * wd2;
-    if (max_val > 0.f) v = fminf(fmaxf(v, -max_val), max_val);
+    const bool nf = !(fabsf(v) <= 3.402823466e38f);      // inf or NaN: e.g. a row whose f16 gradient chain overflowed
+    bad += nf;
+    if (max_val > 0.f && !nf) v = fminf(fmaxf(v, -max_val), max_val);
     g[i] = v;
     s += v * v;
   }
-  if (!want_norm) return;
   __shared__ float red[4];
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __shared__ int redb[4];
+  for (int o = 32; o > 0; o >>= 1) { s += __shfl_down(s, o); bad += __shfl_down(bad, o); }
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = s; redb[threadIdx.x >> 6] = bad; }
   __syncthreads();
-  if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  if (threadIdx.x == 0) {
+    if (want_norm) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    bad_partial[blockIdx.x] = (float)((redb[0] + redb[1]) + (redb[2] + redb[3]));
+  }
 }
 // the frozen variables' gradient is their weight-decay term (jax.grad returns it although their optimiser label is "zero")
 __global__ void __launch_bounds__(256) adam_frozen_sq_kernel(const float* __restrict__ frozen, long long n, float wd2, float max_val,
@@ -220,15 +227,23 @@ __global__ void __launch_bounds__(256) adam_frozen_sq_kernel(const float* __rest
   __syncthreads();
   if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
-struct AdamSched { double lr_init, lr_final, lr_delay_mult, max_steps, lr_delay_steps, b1, b2, max_norm, lr_override; int use_override; };
-// scal[0] = -lr / (1 - b1^t), scal[1] = 1 / (1 - b2^t), scal[2] = norm-clip multiplier; the step counter is incremented.
+struct AdamSched { double lr_init, lr_final, lr_delay_mult, max_steps, lr_delay_steps, b1, b2, max_norm, lr_override; int use_override, skip_nonfinite; };
+// scal[0] = -lr / (1 - b1^t), scal[1] = 1 / (1 - b2^t) (or -1: this update is skipped), scal[2] = norm-clip multiplier, scal[3] = the
+// non-finite entries adam_prep_kernel counted (bad_partial; nullptr: adam_apply_kernel counts); the step counter is incremented.
 // learning_rate_decay: rnerf/utils.py:490-528 in float64 like the host version.
 __global__ void __launch_bounds__(256) adam_scalars_kernel(AdamSched c, int* __restrict__ step, const float* __restrict__ partial, int n_partial,
-                                                           float* __restrict__ scal) {
+                                                           const float* __restrict__ bad_partial, float* __restrict__ scal) {
   __shared__ double red[256];
   double s = 0.0;
   for (int i = threadIdx.x; i < n_partial; i += 256) s += (double)partial[i];
   red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+  const double sumsq = red[0];
+  __syncthreads();
+  double nb = 0.0;
+  if (bad_partial) for (int i = threadIdx.x; i < ADAM_BLOCKS; i += 256) nb += (double)bad_partial[i];
+  red[threadIdx.x] = nb;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
   if (threadIdx.x != 0) return;
@@ -247,22 +262,24 @@ __global__ void __launch_bounds__(256) adam_scalars_kernel(AdamSched c, int* __r
     const double tt = fmin(fmax(fmax((double)count, 0.0) / c.max_steps, 0.0), 1.0);
     lr = start * delay * exp(log(c.lr_init) * (1.0 - tt) + log(c.lr_final) * tt);
   }
+  const double bad = red[0];
   scal[0] = (float)(-lr / (1.0 - pow(c.b1, t)));
-  scal[1] = (float)(1.0 / (1.0 - pow(c.b2, t)));
+  scal[1] = (c.skip_nonfinite && bad > 0.0) ? -1.0f : (float)(1.0 / (1.0 - pow(c.b2, t)));      // -1: adam_apply leaves theta, mu, nu alone
   float mult = 1.0f;
   if (c.max_norm > 0) {
-    const float norm = sqrtf((float)red[0]);
+    const float norm = sqrtf((float)sumsq);
     mult = fminf((float)c.max_norm / (1e-7f + norm), 1.0f);             // train.py:174-180
   }
   scal[2] = mult;
-  scal[3] = 0.f;          // adam_apply counts the non-finite gradient entries of this update here
-  *step = count + 1;
+  scal[3] = (float)bad;   // (no count from adam_prep: 0, and adam_apply counts the non-finite gradient entries of this update here)
+  *step = count + 1;      // a skipped update still counts: the schedule and the host's step number go on
 }
 // optax.scale_by_adam + scale_by_schedule: mu, nu, theta updated in place
 __global__ void __launch_bounds__(256) adam_apply_kernel(float* __restrict__ theta, float* __restrict__ mu, float* __restrict__ nu,
                                                          const float* __restrict__ g, long long n, float b1, float b2, float eps,
-                                                         float* __restrict__ scal) {
+                                                         float* __restrict__ scal, int count_bad) {
   const float a = scal[0], c2 = scal[1], mult = scal[2];
+  if (c2 < 0.f) return;                                // rnerf_adam_cfg.skip_nonfinite and a non-finite gradient entry: no update
   int bad = 0;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     const float gi = g[i] * mult;
@@ -272,7 +289,7 @@ __global__ void __launch_bounds__(256) adam_apply_kernel(float* __restrict__ the
     mu[i] = m; nu[i] = v;
     theta[i] = theta[i] + a * (m / (sqrtf(v * c2) + eps));
   }
-  if (__builtin_amdgcn_ballot_w64(bad != 0) != 0) {    // (never taken on finite gradients)
+  if (count_bad && __builtin_amdgcn_ballot_w64(bad != 0) != 0) {    // (never taken on finite gradients)
     for (int o = 32; o > 0; o >>= 1) bad += __shfl_down(bad, o);
     if ((threadIdx.x & 63) == 0 && bad) atomicAdd(&scal[3], (float)bad);
   }
@@ -530,8 +547,9 @@ extern "C" int rnerf_train_forward_backward(const rnerf_model* m, const rnerf_tr
                   "rnerf_train_forward_backward: give keys4, or the jitter (and the stratified draws) explicitly");
   RNERF_CHECK_ARG((path_pd == nullptr) == (path_dr == nullptr), "rnerf_train_forward_backward: give both path_pd and path_dr or neither");
   RNERF_CHECK_ARG(path_pd || (origins && viewdirs), "rnerf_train_forward_backward: origins / viewdirs are null and no marched path was given");
-  RNERF_CHECK_ARG(m->precision == RNERF_PREC_F16X3 || (m->precision == RNERF_PREC_F16 && c->backward != RNERF_BWD_F16X3),
-                  "rnerf_train_forward_backward: training is built on the f16x3 forward (f16: with backward f16 / bf16 only)");
+  RNERF_CHECK_ARG(m->precision == RNERF_PREC_F16X3 || (m->precision == RNERF_PREC_F16 && c->backward != RNERF_BWD_F16X3) ||
+                      (m->precision == RNERF_PREC_BF16X3 && c->backward == RNERF_BWD_BF16),
+                  "rnerf_train_forward_backward: training is built on the f16x3 forward (f16: with backward f16 / bf16 only; bf16x3 + backward bf16: the range-safe step)");
   RNERF_CHECK_ARG(((uintptr_t)workspace & 255) == 0, "rnerf_train_forward_backward: workspace must be 256-byte aligned");
   const bool smooth = c->bg_smooth_weight > 0;
   RNERF_CHECK_ARG(!smooth || (env_dirs && c->bg_patch_size >= 2), "rnerf_train_forward_backward: bg_smooth_weight > 0 needs env_dirs and bg_patch_size >= 2");
@@ -727,10 +745,12 @@ extern "C" int rnerf_adam_update(const rnerf_adam_cfg* c, float* theta, float* m
   const int want_norm = c->grad_max_norm > 0;
   float* scal = scratch;                      // [0..3]
   float* partial = scratch + 4;               // [ADAM_BLOCKS] + [ADAM_BLOCKS] (frozen part)
+  float* bad_partial = nullptr;               // [ADAM_BLOCKS] non-finite counts of adam_prep_kernel, when it runs
   int n_partial = 0;
-  if (wd2 != 0.0 || c->grad_max_val > 0 || want_norm) {
+  if (wd2 != 0.0 || c->grad_max_val > 0 || want_norm || c->skip_nonfinite) {
+    bad_partial = scratch + 4 + 2 * ADAM_BLOCKS;
     hipLaunchKernelGGL(adam_prep_kernel, dim3(ADAM_BLOCKS), dim3(256), 0, st, (const float*)theta, grads, (long long)n_theta, (float)wd2, (float)c->grad_max_val,
-                       want_norm, partial);
+                       want_norm, partial, bad_partial);
     if (want_norm) {
       n_partial = ADAM_BLOCKS;
       if (frozen_params && n_frozen > 0 && wd2 != 0.0) {
@@ -740,10 +760,11 @@ extern "C" int rnerf_adam_update(const rnerf_adam_cfg* c, float* theta, float* m
       }
     }
   }
-  AdamSched s{c->lr_init, c->lr_final, c->lr_delay_mult, (double)c->max_steps, (double)c->lr_delay_steps, c->b1, c->b2, c->grad_max_norm, c->lr_override, c->use_lr_override != 0};
-  hipLaunchKernelGGL(adam_scalars_kernel, dim3(1), dim3(256), 0, st, s, step_counter, (const float*)partial, n_partial, scal);
+  AdamSched s{c->lr_init, c->lr_final, c->lr_delay_mult, (double)c->max_steps, (double)c->lr_delay_steps, c->b1, c->b2, c->grad_max_norm, c->lr_override, c->use_lr_override != 0,
+              c->skip_nonfinite != 0};
+  hipLaunchKernelGGL(adam_scalars_kernel, dim3(1), dim3(256), 0, st, s, step_counter, (const float*)partial, n_partial, (const float*)bad_partial, scal);
   hipLaunchKernelGGL(adam_apply_kernel, dim3(ADAM_BLOCKS), dim3(256), 0, st, theta, mu, nu, (const float*)grads, (long long)n_theta, (float)c->b1, (float)c->b2,
-                     (float)c->eps, scal);
+                     (float)c->eps, scal, bad_partial == nullptr);
   RNERF_CHECK_LAUNCH();
   return RNERF_OK;
 }

@@ -103,8 +103,9 @@ class NerfModel:
             raise NotImplementedError("the HIP NerfMLP kernel is specialised for the reference's 8x256 / skip 4 / 1x128 network")
         if (min_deg_point, max_deg_point, deg_view) != (0, 10, 4) or legacy_posenc_order or not use_viewdirs:
             raise NotImplementedError("the HIP kernels implement pos_enc degrees (0,10)/(0,4), non-legacy order, use_viewdirs=True")
-        if sh_deg >= 0 or sh_direnc_deg > 0 or noise_std:
-            raise NotImplementedError("sh_deg / sh_direnc_deg / noise_std are disabled in every shipped config and not built")
+        if sh_deg >= 0 or sh_direnc_deg > 0:
+            raise NotImplementedError("sh_deg / sh_direnc_deg are disabled in every shipped config and not built")
+        self.noise_std = None if noise_std is None else float(noise_std)
         if use_mask_bbox and bd_cut_dist is not None:
             raise ValueError("'use_mask_bbox' is true (rnerf/models.py:480: bd_cut_dist and use_mask_bbox exclude each other)")
         # use_mask_bbox (rnerf/models.py:261-271,398-408): density only at samples inside the grid's box [nmin, nmax], in both levels
@@ -430,8 +431,12 @@ class NerfModel:
 
     def forward(self, variables, rng_0, rng_1, rays: Rays, randomized: bool, annealed_alpha: float = 1.0, *,
                 jitter=None, u_fine: Optional[torch.Tensor] = None, taps: Optional[dict] = None,
-                path: Optional["PathHandle"] = None, ctx: Optional[dict] = None):
+                path: Optional["PathHandle"] = None, ctx: Optional[dict] = None,
+                noise_c: Optional[torch.Tensor] = None, noise_f: Optional[torch.Tensor] = None):
         """NerfModel.__call__ (rnerf/models.py:220-535).
+
+        noise_c [B, Nc] / noise_f [B, Nc + Nf]: the standard-normal draws of the raw-sigma regulariser given explicitly (tests); drawn from
+        the key chain like the reference otherwise.  Used only when noise_std is set and `randomized`.
 
         ctx: a dict to fill with what the backward pass needs (samplenerfro_amd.train); the MLPs then run their training
         forward, which also stores the MFMA operands of every layer."""
@@ -439,7 +444,8 @@ class NerfModel:
         if origins.dim() != 2 or origins.shape[-1] != 3:
             raise ValueError("rays.origins must be [B, 3]")
         B = origins.shape[0]
-        if ctx is None and taps is None and self.whole_path and self.stage.startswith("radiance") and not self.use_online_sparsity:
+        noisy = self.noise_std is not None and randomized                                 # add_gaussian_noise (rnerf/model_utils.py:438-453)
+        if ctx is None and taps is None and self.whole_path and self.stage.startswith("radiance") and not self.use_online_sparsity and not noisy:
             # the product path: ONE call into librnerf.so (rnerf_forward) sequences every stage on the device; the stage-by-stage
             # code below is the same sequence with taps, kept for the parity tests and for the variants rnerf_forward does not cover
             return self._forward_whole(variables, rng_0, rng_1, rays, randomized, jitter, u_fine, path), 0.0
@@ -497,6 +503,10 @@ class NerfModel:
             raw_c, ctx["save_c"] = ops.nerfmlp_forward_train(self._packed_weights(variables, "coarse_mlp"), self.precision, path_pd,
                                                             path_dr, jit, Nc, B, ctx.get("backward", _lib.BWD_F16X2),
                                                             max_workgroups=self._mlp_wg_limit)
+        if noisy:                                                                         # rnerf/models.py:310-317: the key chain advances only here
+            key, rng_0 = prng.split(rng_0)
+            raw_c = self._add_sigma_noise(raw_c, key, noise_c)
+        if ctx is not None:
             ctx.update(path_pd=path_pd, path_dr=path_dr, jit=jit, raw_c=raw_c, bkgd=bkgd, B=B)
         mb = self._mask_bbox() if self.use_mask_bbox else None
         if ctx is not None and mb is not None:
@@ -526,6 +536,10 @@ class NerfModel:
                 raw_f, ctx["save_f"] = ops.nerfmlp_forward_train(self._packed_weights(variables, "fine_mlp"), self.precision, rows_pd,
                                                                 rows_dr, None, S, B, ctx.get("backward", _lib.BWD_F16X2),
                                                                 max_workgroups=self._mlp_wg_limit)
+            if noisy:                                                                     # rnerf/models.py:445-452
+                key, rng_1 = prng.split(rng_1)
+                raw_f = self._add_sigma_noise(raw_f, key, noise_f)
+            if ctx is not None:
                 ctx.update(rows_pd=rows_pd, rows_dr=rows_dr, raw_f=raw_f)
             rgb, dist, acc, trans, trans_bkgd, w_f, alpha_f = ops.composite(
                 raw_f, rows_pd, rows_dr, None, S, B, bkgd, self.white_bkgd, self.rgb_padding, self.sigma_bias,
@@ -549,6 +563,15 @@ class NerfModel:
             if taps is not None:
                 taps.update(rows_pd=rows_pd, rows_dr=rows_dr, idx_f=idx, raw_f=raw_f, weights_f=w_f, u=u)
         return ret, loss_sp
+
+    def _add_sigma_noise(self, raw: torch.Tensor, key, given: Optional[torch.Tensor]) -> torch.Tensor:
+        """raw [S, B, 4]: raw sigma += noise_std * N(0, 1), drawn in the reference's [B, S, 1] order (rnerf/model_utils.py:438-453).  In place:
+        the regulariser is additive, so the MLP backward is untouched and the composite's backward differentiates at the noisy raw."""
+        S, B = raw.shape[0], raw.shape[1]
+        z = prng.normal(key, (B, S)) if given is None else given
+        z = torch.as_tensor(z, dtype=torch.float32).to(raw.device, non_blocking=True).reshape(B, S)
+        raw[..., 3] += self.noise_std * z.t()
+        return raw
 
     __call__ = forward
 

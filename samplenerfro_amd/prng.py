@@ -74,6 +74,43 @@ def randint(key, shape, minval: int, maxval: int) -> np.ndarray:
     return (np.int64(minval) + off.astype(np.int64)).astype(np.int32)
 
 
+_ERFINV_CENTRAL = (2.81022636e-08, 3.43273939e-07, -3.5233877e-06, -4.39150654e-06, 0.00021858087, -0.00125372503, -0.00417768164,
+                   0.246640727, 1.50140941)
+_ERFINV_TAIL = (-0.000200214257, 0.000100950558, 0.00134934322, -0.00367342844, 0.00573950773, -0.0076224613, 0.00943887047,
+                1.00167406, 2.83297682)
+
+
+def erf_inv_f32(x: np.ndarray) -> np.ndarray:
+    """erf_inv as XLA evaluates it for float32: M. Giles' single-precision polynomial ("Approximating the erfinv function", 2010) in
+    w = -log1p(-x*x): degree 8 in (w - 2.5) for w < 5, degree 8 in (sqrt(w) - 3) otherwise, times x — every operation rounded to float32.
+    (jax.random.normal goes through lax.erf_inv; the exact inverse differs from this polynomial by up to ~3 ulp.)"""
+    f = np.float32
+    x = np.asarray(x, f)
+    edge = np.abs(x) == f(1.0)
+    w = (-np.log1p(-(np.where(edge, f(0), x) ** 2).astype(f))).astype(f)
+    central = w < f(5.0)
+    wc = (w - f(2.5)).astype(f)
+    wt = (np.sqrt(np.maximum(w, f(0))).astype(f) - f(3.0)).astype(f)
+
+    def horner(coef, t):
+        p = np.full_like(t, f(coef[0]))
+        for c in coef[1:]:
+            p = (f(c) + (p * t).astype(f)).astype(f)
+        return p
+
+    p = np.where(central, horner(_ERFINV_CENTRAL, wc), horner(_ERFINV_TAIL, wt))
+    return np.where(edge, np.copysign(f(np.inf), x), (p * x).astype(f)).astype(f)
+
+
+def normal(key, shape) -> np.ndarray:
+    """jax.random.normal for float32 (jax/_src/random.py `_normal_real`): sqrt(2) * erf_inv(uniform(key, shape, nextafter(-1, 0), 1)).
+    Pinned by the two values jax's own documentation prints (PRNGKey(0) -> -0.20584226; the second key of split(PRNGKey(0)) -> -1.2515389;
+    tests/test_prng.py).  Used by the raw-sigma regulariser (rnerf/model_utils.py:438-453)."""
+    lo = np.nextafter(np.float32(-1.0), np.float32(0.0))
+    u = uniform(key, shape, minval=lo, maxval=1.0)
+    return (np.float32(np.sqrt(2.0)) * erf_inv_f32(u)).astype(np.float32)
+
+
 def uniform(key, shape, minval: float = 0.0, maxval: float = 1.0) -> np.ndarray:
     """jax.random.uniform for float32."""
     bits = random_bits(key, shape)

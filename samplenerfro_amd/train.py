@@ -20,6 +20,7 @@ plain torch arithmetic on that flat buffer: weights and optimiser state stay on 
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import os
 import weakref
@@ -43,6 +44,7 @@ _MARCH_RESERVE = 0
 _AUX_STREAM = True                      # the second stream of rnerf_train_cfg (False: everything on one stream)
 _AUX2_STREAM = False                    # a third stream for the background backward of small hierarchical batches (see train_cfg)
 _CORESIDENT_BKGD_WGRAD = False          # the background-MLP weight gradient as a co-resident kernel beside the NerfMLP wgrad (see train_cfg)
+_SKIP_NONFINITE_UPDATES = True          # rnerf_adam_cfg.skip_nonfinite: an update with an inf / NaN gradient entry is skipped and counted (train_step)
 _ALL_CHAIN_BESIDE_WGRAD = True          # stage all*: the march's adjoint chain on the side stream beside the NerfMLP wgrad (see train_step)
 
 _N_STATS = 8        # loss, loss_c, loss_bg, loss_bg_smooth, weight_l2, (3 spare)
@@ -68,10 +70,14 @@ class TrainState:
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=theta.device) if theta.is_cuda else None
         self._step_dev_value = 0
         self.adam_scratch = torch.zeros(_lib.ADAM_SCRATCH_FLOATS, dtype=torch.float32, device=theta.device) if theta.is_cuda else None
+        self._staged_bad: Optional[int] = None
+        self.range_retries = 0         # steps train_step(range_retry=True) re-ran in the range-safe arithmetic
 
     def nonfinite_grads(self) -> int:
         """Non-finite gradient entries met by the last rnerf_adam_update (reads a device scalar: synchronises).  Non-zero means a row's
         f16 gradient chain left its 2^10 of headroom (backward modes "f16x3" / "f16") or the loss itself went non-finite."""
+        if self._staged_bad is not None:                 # the staged sequence of a range_retry step counted on the host side
+            return self._staged_bad
         return int(self.adam_scratch[3].item()) if self.adam_scratch is not None else 0
 
     def sync_step_counter(self) -> None:
@@ -174,6 +180,8 @@ def backward_mode(flags, model: NerfModel) -> int:
     if name not in _lib.BACKWARDS:
         raise ValueError(f"backward_precision must be one of {sorted(_lib.BACKWARDS)}")
     mode = _lib.BACKWARDS[name]
+    if model.precision == _lib.PREC_BF16X3 and mode == _lib.BWD_BF16:
+        return mode       # the range-safe training arithmetic (range_safe below; fp32's exponent range end to end, 8-bit gradients)
     if model.precision != _lib.PREC_F16X3 and not (model.precision == _lib.PREC_F16 and mode != _lib.BWD_F16X3):
         raise ValueError('training is built on the f16x3 forward (NerfModel(precision="f16x3")), or — one MFMA per product, the north-star '
                          'arithmetic as a labelled leg — on the f16 forward with backward_precision "f16" / "bf16"; the other precisions are inference modes')
@@ -285,6 +293,9 @@ def adam_cfg(state: TrainState, flags, lr_override: Optional[float] = None) -> "
     a.n_all = state.theta.numel() + frozen_sq_of(state, state.variables)[1]
     a.use_lr_override = int(lr_override is not None)      # an explicit switch: a replaced schedule may return exactly 0.0
     a.lr_override = float(lr_override) if lr_override is not None else 0.0
+    # a gradient with an inf / NaN entry (a row outside the f16-based arithmetic's range) never reaches the parameters: the update is
+    # skipped and counted (TrainState.nonfinite_grads()); train_step(range_retry=True) then re-runs the batch in the range-safe arithmetic
+    a.skip_nonfinite = int(_SKIP_NONFINITE_UPDATES)
     return a
 
 
@@ -355,6 +366,7 @@ def _train_step_whole(model: NerfModel, rng, state: TrainState, batch, flags, ji
                                      fs[1], state.step_dev.data_ptr(), state.adam_scratch.data_ptr(), st), "rnerf_adam_update")
     state.step += 1
     state._step_dev_value = state.step
+    state._staged_bad = None
     _bump(state.theta)
     s8 = G[n_theta:]
     two = model.num_fine_samples > 0
@@ -374,8 +386,55 @@ def _bump(t: torch.Tensor) -> None:
         t.add_(0)
 
 
-def train_step(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], flags=None, *, jitter=None, u_fine=None,
-               taps: Optional[dict] = None, path=None, next_rays: Optional[Rays] = None, forward_taps: Optional[dict] = None):
+@contextlib.contextmanager
+def range_safe(model: NerfModel, flags):
+    """Inside: the model trains in the range-safe arithmetic — NerfMLP forward in bf16x3 (fp32's exponent range, 16-bit products), its bf16 hi
+    plane saved as it is, backward "bf16" — with operand-stream caches of its own; everything else (march, compositing, background MLP, loss,
+    optimiser) is fp32 as always."""
+    saved = (model.precision, model._packed, getattr(flags, "backward_precision", "f16x3"))
+    model.precision, model._packed, flags.backward_precision = _lib.PREC_BF16X3, {}, "bf16"
+    try:
+        yield model
+    finally:
+        model.precision, model._packed, flags.backward_precision = saved
+
+
+_F16_BASED = (_lib.PREC_F16X3, _lib.PREC_F16)
+
+
+def train_step(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], flags=None, *, range_retry: Optional[bool] = None, **kw):
+    """One optimisation step (train.py:58-183): see _train_step_once for the arguments.
+
+    Range of the f16-based training arithmetic.  A sample whose hidden activations leave f16's range (|x| > 65504; weights >= 256) comes
+    out of the training forward as NaN, never as a plausible value, and so do the gradients; rnerf_adam_update counts the non-finite entries
+    and — always — SKIPS such an update (theta, mu, nu untouched; state.nonfinite_grads() tells).  The reference's fp32 step is finite on
+    such a batch.  range_retry=True (or flags.range_retry) makes this one too: the count is read after the step (one host synchronisation
+    per step: the price, and why it is opt-in) and a skipped step is run again on the same batch and keys in the range-safe arithmetic
+    (range_safe: bf16x3 forward, bf16 backward), whose update is applied; state.range_retries counts them.  Radiance stages only (stage
+    all*'s input gradients are built on the row-normalised f16 backward modes: skipped and counted there, not re-run)."""
+    flags = state.flags if flags is None else flags
+    retry = bool(getattr(flags, "range_retry", False)) if range_retry is None else bool(range_retry)
+    if not (retry and flags.stage.startswith("radiance") and model.precision in _F16_BASED):
+        return _train_step_once(model, rng, state, batch, flags, **kw)
+    step0 = state.step
+    out = _train_step_once(model, rng, state, batch, flags, _guard=True, **kw)
+    if state.nonfinite_grads() == 0:
+        return out
+    # the update was skipped: same batch, same keys, range-safe arithmetic.  The next batch's march the first attempt started stays.
+    next_path = state.next_path
+    state.step = step0
+    state.sync_step_counter()
+    kw = dict(kw, next_rays=None)
+    with range_safe(model, flags):
+        out = _train_step_once(model, rng, state, batch, flags, _guard=True, **kw)
+    state.next_path = next_path
+    state.range_retries += 1
+    return out
+
+
+def _train_step_once(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], flags=None, *, jitter=None, u_fine=None,
+                     taps: Optional[dict] = None, path=None, next_rays: Optional[Rays] = None, forward_taps: Optional[dict] = None,
+                     noise_c=None, noise_f=None, _guard: bool = False):
     """One optimisation step (train.py:58-183).  batch: {"rays": Rays of [B,3], "pixels": [B,>=3], "annealed_alpha": float,
     "env_rays": Rays with viewdirs [ps,ps,3] (when bg_smooth_weight > 0)}.  path: an optional NerfModel.prefetch_path handle for
     these rays (the march carries no gradient and does not read the trained parameters, so it may overlap the previous step);
@@ -392,7 +451,8 @@ def train_step(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], 
         raise ValueError("stage all*: build the model with the same stage (the march must evaluate so3_mlp)")
     if flags.beta_weight > 0 or flags.sparsity_weight > 0:
         pass        # both are multiplied by annealing_rate = 0.0 (train.py:156): no contribution to loss or gradient
-    if not all_stage and taps is None and forward_taps is None and getattr(model, "whole_path", False):
+    noisy = getattr(model, "noise_std", None) is not None and bool(flags.randomized)      # the raw-sigma regulariser: drawn on the host, staged path
+    if not all_stage and taps is None and forward_taps is None and getattr(model, "whole_path", False) and not noisy:
         # the product path: the whole forward + backward is ONE call into librnerf.so (rnerf_train_forward_backward), the update another
         # (rnerf_adam_update); what follows below is the same sequence stage by stage, with taps (parity tests, stage all*)
         return _train_step_whole(model, rng, state, batch, flags, jitter, u_fine, path, next_rays)
@@ -424,7 +484,7 @@ def train_step(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], 
         # gather chain: 64 waves, as fast on a few CUs as on many)
         hold["path"] = model.prefetch_path(next_rays, sync_inputs=True, reserve_cus=_MARCH_RESERVE)
     ret, _loss_sp = model.apply(variables, key_0, key_1, rays, flags.randomized, annealed, jitter=jitter, u_fine=u_fine, ctx=ctx, path=path,
-                             taps=forward_taps)
+                             taps=forward_taps, noise_c=noise_c, noise_f=noise_f)
     if "path" in hold:
         model.release_reserved_cus()
     B = ctx["B"]
@@ -534,7 +594,13 @@ def train_step(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], 
         grads.mul_(torch.clamp(flags.grad_max_norm / (1e-7 + norm), max=1.0))
     if taps is not None:
         taps.update(grads=grads.clone(), sums=sums, ctx=ctx, loss_sp=_loss_sp)
-    state.apply_gradients(grads)
+    state._staged_bad = None
+    if _guard:                             # range_retry on the staged sequence: count on the host (it synchronises anyway), skip like rnerf_adam_update
+        state._staged_bad = int((~torch.isfinite(grads)).sum().item())
+    if state._staged_bad:
+        state.step += 1
+    else:
+        state.apply_gradients(grads)
     # train.py:153-160: Stats.loss_sp = sparsity_weight * annealing_rate * loss_sp with annealing_rate = 0.0 — the reference's number is 0.0
     # whatever the term's value (models.py:351-357 keeps it finite: safe_log, a denominator >= 1); the value itself is in taps["loss_sp"]
     annealing_rate = 0.0

@@ -53,6 +53,25 @@ def test_published_jax_values():
     assert prng.split(k42).tolist() == [[2465931498, 3679230171], [255383827, 267815257]]
 
 
+def test_normal_published_values_and_the_exact_quantile():
+    """jax.random.normal: the two draws JAX 101's PRNG tutorial prints (`random.normal(PRNGKey(0), (1,))` -> -0.20584226; after
+    `key, subkey = random.split(key)`, `random.normal(subkey, (1,))` -> -1.2515389) pin the float32 erf_inv polynomial bit for bit (the
+    exact inverse gives -0.20584227 / -1.2515386).  A second reading through the exact normal quantile in double precision
+    (oracle/prng_ref.normal) bounds what the polynomial does everywhere else: same draw to 2e-7 relative at the median, 1e-5 in the tails."""
+    from oracle import prng_ref as PR
+    k0 = prng.PRNGKey(0)
+    assert float(prng.normal(k0, (1,))[0]) == float(np.float32(-0.20584226))
+    assert float(prng.normal(prng.split(k0)[1], (1,))[0]) == float(np.float32(-1.2515389))
+    k = prng.PRNGKey(5)
+    z = prng.normal(k, (20000,))
+    exact = np.array(PR.normal((int(k[0]), int(k[1])), 20000), np.float32)
+    rel = np.abs(z - exact) / np.maximum(np.abs(exact), 1e-30)
+    assert np.abs(z - exact).max() < 5e-5 and np.median(rel) < 2e-7 and rel.max() < 2e-5
+    assert z.dtype == np.float32 and abs(float(z.mean())) < 0.02 and abs(float(z.std()) - 1) < 0.02 and 3.5 < np.abs(z).max() < 5.5
+    e = prng.erf_inv_f32(np.array([-1.0, 0.0, 1.0, 0.5], np.float32))
+    assert e[0] == -np.inf and e[1] == 0 and e[2] == np.inf and abs(float(e[3]) - 0.4769362762) < 1e-7
+
+
 def test_two_independent_restatements_agree_on_a_million_draws():
     """oracle/prng_ref.py is a second reading of jax 0.2.22's random.py, written separately in plain Python integers (one draw at a time,
     explicit wraps); the vectorised numpy implementation the product uses must agree with it word for word: 2^18 key splits' worth of
