@@ -200,6 +200,26 @@ def test_adam_update_matches_the_optax_formulas():
         assert np.abs(upd - want).max() < 2e-7 + 1e-4 * np.abs(want).max(), (wd, gv, gn, count)
 
 
+def test_graph_step_skips_an_update_with_nonfinite_gradients():
+    """The skip of rnerf_adam_update (rnerf_adam_cfg.skip_nonfinite) is decided on the device, so it holds inside a captured graph too: a batch
+    whose rows leave f16's range leaves theta / mu / nu untouched replay after replay, the step counter advances, and the count is there to read."""
+    from samplenerfro_amd.graph import GraphTrainStep
+    from samplenerfro_amd import synthetic as syn, utils
+    B = 96
+    model, state, batch, flags = _train_setup(0, B)
+    lo, _ = state.segments["coarse_mlp"]
+    state.theta[lo + 63 * 256: lo + 63 * 256 + 256] = 3.0e5            # Dense_0 biases: every first-layer activation beyond 65504
+    theta0 = state.theta.clone()
+    g = GraphTrainStep(model, state, flags, B, np.array([4, 2], np.uint32), env_rays=batch["env_rays"], prefetch=False)
+    g.load(dict(rays=batch["rays"], pixels=batch["pixels"]))
+    for k in range(4):                                                  # eager warm-up, capture, replays
+        g.step()
+    g.synchronize()
+    assert state.nonfinite_grads() > 0 and torch.equal(state.theta, theta0) and float(state.mu.abs().max()) == 0.0 and float(state.nu.abs().max()) == 0.0
+    assert int(state.step_dev.item()) == 4 and state.step == 4
+    g.close()
+
+
 @pytest.mark.parametrize("Nf,prefetch", [(24, True), (0, False)])
 def test_graph_replay_equals_the_eager_steps(Nf, prefetch):
     """GraphTrainStep (one hipGraph launch per step, device-resident keys / step counter / schedule) against eager train_step calls fed
