@@ -696,7 +696,7 @@ def main():
             tk = {"kernel": name, "bound": "mfma", "achieved": flop / (ms * 1e-3) / 1e12, "peak": PEAK_MFMA_16BIT / 1e12,
                   "unit": "TFLOP/s", "frac": flop / (ms * 1e-3) / PEAK_MFMA_16BIT, "avg_launch_ms": ms, "algorithmic_flop_per_launch": flop}
             # MFMAs per algorithmic product: the forward in its precision; dgrad / wgrad: 3 with hi + lo planes, (W hi + W lo) x dY = 2 / 1 in f16, 2 / 1 in bf16
-            npass = MFMA_PASSES[args.precision] if "fwd" in name else ({"f16x3": 3, "f16": 2, "bf16": 2}[args.backward] if "dgrad" in name else {"f16x3": 3, "f16": 1, "bf16": 1}[args.backward])
+            npass = MFMA_PASSES[args.precision] if "fwd" in name else ({"f16x3": 3, "f16": (1 if args.precision == "f16" else 2), "bf16": 2}[args.backward] if "dgrad" in name else {"f16x3": 3, "f16": 1, "bf16": 1}[args.backward])
             with_pass_ceiling(tk, npass, sustained["bf16"] if (sustained and args.backward == "bf16" and "fwd" not in name) else sus16)
             if byt is not None:
                 tk["avg_launch_ms_alone"] = t_w_alone

@@ -1149,6 +1149,12 @@ constexpr int DY_L9 = 144, DY_HEADS = 152, DY_SLOTS = 153;
 #define RNERF_DGRAD_PASSES 22
 #endif
 constexpr int DGRAD_PASSES = RNERF_DGRAD_PASSES;
+// Internal dgrad variant of backward F16 (not an enum rnerf_backward value): ONE MFMA per product — the weights rounded to f16 like the
+// gradients — selected when the FORWARD is the single-pass f16 one too.  The step is then one MFMA per product end to end (the arithmetic
+// north_star names); behind the f16x3 forward the F16 backward keeps its exact (hi + lo) weights (passes 22): there the rounded weights
+// would be the largest error left (gradient 4.9e-6 -> 4.1e-5 of max|g| from the default's on the bench batch), behind the f16 forward they
+// change nothing measurable (9.2e-5 both ways) and take 0.19 ms off the dgrad (1.21 -> 1.03 ms; tools/r05/t_dg1.sh).
+constexpr int kBwdF16OnePass = 3;
 constexpr int kBwdBlocks = 8 * 8 + 8 * 16 * 8;   // (k-steps over n) x (8 input-feature tiles): L9 then L8..L1
 
 // dgrad layer order: index 0 = MFMA layer 9 (Dense_10), 1 = layer 8 (Dense_9), 2..8 = layers 7..1 (Dense_7..Dense_1)
@@ -1239,7 +1245,7 @@ template <int BWD> struct Bwd {
   static constexpr bool F16 = BWD != RNERF_BWD_BF16;
   static constexpr int NP = BWD == RNERF_BWD_F16X2 ? 2 : 1;                               // 16-bit parts stored per gradient / consumed per activation
   static constexpr int PREC = F16 ? RNERF_PREC_F16X3 : RNERF_PREC_BF16X3;                 // operand type + weight split of the dgrad MFMAs
-  static constexpr int PASSES = BWD == RNERF_BWD_F16X2 ? 3 : (BWD == RNERF_BWD_F16 ? 22 : DGRAD_PASSES);
+  static constexpr int PASSES = BWD == RNERF_BWD_F16X2 ? 3 : (BWD == RNERF_BWD_F16 ? 22 : (BWD == kBwdF16OnePass ? 1 : DGRAD_PASSES));
   static constexpr bool NEED_LO = PASSES != 22 && PASSES != 1;
 };
 // dy buffer: uint4[DY_SLOTS * NP][R][2] operand planes (hi, then lo), then float row_scale[R] and uint32 m_ref bits (F16 modes)
@@ -3269,11 +3275,11 @@ static int launch_dgrad(const void* packed_bwd, const float* fwd_aux, const void
     attr_set.set();
   }
   const long long R = (long long)n_tiles * 256;
-  if (Bwd<BWD>::F16 && zero_ref) RNERF_CHECK_HIP(hipMemsetAsync(nerfmlp_dgrad_scale_ref(BWD, dy, rows), 0, 4 * sizeof(float), st));
+  if (Bwd<BWD>::F16 && zero_ref) RNERF_CHECK_HIP(hipMemsetAsync(nerfmlp_dgrad_scale_ref(BWD == kBwdF16OnePass ? RNERF_BWD_F16 : BWD, dy, rows), 0, 4 * sizeof(float), st));
   // Few rows: 128-row tiles when they all fit one round (see launch_fwd_dbg) — unless the caller runs another level's dgrad beside this one
   // (allow_half = false): two kernels that each own whole CUs then share the chip, and with twice the workgroups of half the work the
   // step measures the same or slower (512 rays, levels side by side: 2.05 -> 2.09 ms; alone, a 256-ray single-level step: 1.17 -> 1.12 ms).
-  if constexpr (BWD == RNERF_BWD_F16X2 || BWD == RNERF_BWD_F16) {
+  if constexpr (BWD == RNERF_BWD_F16X2 || BWD == RNERF_BWD_F16 || BWD == kBwdF16OnePass) {
     static const int half_lim = [] { const char* e = RNERF_ENV("RNERF_DGRAD_HALF_TILES"); return e ? atoi(e) : -1; }();      // 0: off, n: at most n tiles
     if (allow_half && half_lim != 0 && 2 * n_tiles <= (half_lim > 1 ? half_lim : cus)) {
       const size_t lds1 = 2 * (size_t)PB::SLAB;
@@ -3305,6 +3311,7 @@ int nerfmlp_dgrad_impl(const void* packed_bwd, const void* packed_fwd, int fwd_p
   // the aux floats (biases, heads) sit behind the forward's operand stream, whose length depends on its precision
   const float* fwd_aux = (const float*)((const char*)packed_fwd + train_stream_bytes(fwd_precision));
   if (backward == RNERF_BWD_F16X2) return launch_dgrad<RNERF_BWD_F16X2>(packed_bwd, fwd_aux, save, d_raw, rows, dy, st, zero_ref, allow_half);
+  if (backward == RNERF_BWD_F16 && fwd_precision == RNERF_PREC_F16) return launch_dgrad<kBwdF16OnePass>(packed_bwd, fwd_aux, save, d_raw, rows, dy, st, zero_ref, allow_half);
   if (backward == RNERF_BWD_F16) return launch_dgrad<RNERF_BWD_F16>(packed_bwd, fwd_aux, save, d_raw, rows, dy, st, zero_ref, allow_half);
   return launch_dgrad<RNERF_BWD_BF16>(packed_bwd, fwd_aux, save, d_raw, rows, dy, st, zero_ref, allow_half);
 }
