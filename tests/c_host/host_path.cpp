@@ -94,6 +94,7 @@ int main(int argc, char** argv) {
   rnerf_adam_cfg a = {};
   a.lr_init = 5e-4; a.lr_final = 5e-6; a.lr_delay_mult = 0.01; a.max_steps = 1000000; a.lr_delay_steps = 2500;
   a.b1 = 0.9; a.b2 = 0.999; a.eps = 1e-8; a.n_all = (int64_t)n_theta;
+  a.skip_nonfinite = 1;      // (what samplenerfro_amd.train sets: an update with an inf / NaN gradient entry writes nothing)
   float *mu = dev_alloc<float>(n_theta), *nu = dev_alloc<float>(n_theta), *scratch = dev_alloc<float>(RNERF_ADAM_SCRATCH_FLOATS);
   int32_t* step = dev_alloc<int32_t>(1);
   RN_OK(rnerf_adam_update(&a, theta, mu, nu, grads, (int64_t)n_theta, nullptr, 0, step, scratch, s));
