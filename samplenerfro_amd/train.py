@@ -299,6 +299,24 @@ def adam_cfg(state: TrainState, flags, lr_override: Optional[float] = None) -> "
     return a
 
 
+def _adam_update_on_device(state: TrainState, flags) -> None:
+    """train.py:169-183 + optax.adam on the flat buffers as ONE C call (rnerf_adam_update): weight-decay gradient, value / norm clip, Adam
+    with the reference's schedule from the device-resident step counter, and the non-finite guard (adam_cfg: an update that met an inf / NaN
+    gradient entry writes nothing and is counted).  state.grads holds the (all-reduced) gradient of the data terms."""
+    lib = _lib.load()
+    default_lr = state._lr_fn_default is state.lr_fn
+    a = adam_cfg(state, flags, None if default_lr else float(state.lr_fn(state.step)))
+    state.sync_step_counter()
+    fs = frozen_sq_of(state, state.variables)
+    frozen = state.variables["flat"].get("so3_mlp") if fs[1] > 0 else None
+    _lib.check(lib.rnerf_adam_update(C.byref(a), state.theta.data_ptr(), state.mu.data_ptr(), state.nu.data_ptr(), state.grads.data_ptr(), state.theta.numel(),
+                                     _lib.ptr(frozen), fs[1], state.step_dev.data_ptr(), state.adam_scratch.data_ptr(), _lib.current_stream()), "rnerf_adam_update")
+    state.step += 1
+    state._step_dev_value = state.step
+    state._staged_bad = None
+    _bump(state.theta)
+
+
 def _train_step_whole(model: NerfModel, rng, state: TrainState, batch, flags, jitter, u_fine, path, next_rays):
     """train_step for the radiance stages through the whole-path entry points (include/rnerf.h, csrc/pipeline.hip)."""
     lib = _lib.load()
@@ -357,17 +375,7 @@ def _train_step_whole(model: NerfModel, rng, state: TrainState, batch, flags, ji
         distributed.allreduce_end_mean_(pending, G[:n_big])
     else:
         distributed.allreduce_mean_([G])
-    default_lr = state._lr_fn_default is state.lr_fn
-    a = adam_cfg(state, flags, None if default_lr else float(state.lr_fn(state.step)))
-    state.sync_step_counter()
-    fs = frozen_sq_of(state, state.variables)
-    frozen = state.variables["flat"].get("so3_mlp") if fs[1] > 0 else None
-    _lib.check(lib.rnerf_adam_update(C.byref(a), state.theta.data_ptr(), state.mu.data_ptr(), state.nu.data_ptr(), G.data_ptr(), n_theta, _lib.ptr(frozen),
-                                     fs[1], state.step_dev.data_ptr(), state.adam_scratch.data_ptr(), st), "rnerf_adam_update")
-    state.step += 1
-    state._step_dev_value = state.step
-    state._staged_bad = None
-    _bump(state.theta)
+    _adam_update_on_device(state, flags)
     s8 = G[n_theta:]
     two = model.num_fine_samples > 0
     stats = Stats(loss=s8[0], psnr=s8[6], loss_c=s8[1], psnr_c=(s8[7] if two else 0.0), weight_l2=s8[4], loss_sp=0.0, loss_nrm=0.0,
@@ -577,6 +585,16 @@ def _train_step_once(model: NerfModel, rng, state: TrainState, batch: Dict[str, 
     distributed.allreduce_mean_([G[n_big:]])
     distributed.allreduce_end_mean_(pending, G[:n_big])
     grads = G[:n_theta]
+    if taps is None and state.adam_scratch is not None:
+        # nobody looks at the gradient: the product form of the update — one C call with the non-finite guard — instead of the tensor
+        # arithmetic below (stage all*, the noise_std steps: the sequences the whole-path entry does not cover)
+        _adam_update_on_device(state, flags)
+        annealing_rate = 0.0
+        stats = Stats(loss=st[0], psnr=st[6], loss_c=st[1], psnr_c=(st[7] if rgb_c is not None else 0.0),
+                      weight_l2=st[4], loss_sp=flags.sparsity_weight * annealing_rate * _loss_sp, loss_nrm=0.0, annealing_rate=annealed, coarse_alpha_target=0.0,
+                      fine_alpha_target=0.0, loss_bg=st[2], loss_bg_c=0.0, loss_bg_smooth=st[3])
+        state.next_path = next_path
+        return state, stats, rng
     if flags.weight_decay_mult > 0:      # d (weight_decay_mult * weight_l2) / d theta: identical on every rank, so it is added after the mean
         grads.add_(state.theta, alpha=2.0 * flags.weight_decay_mult / n_all)
     if flags.grad_max_val > 0:                                                            # train.py:169-172

@@ -152,3 +152,18 @@ def test_all_stage_training_reduces_the_loss():
         losses.append(float(stats.loss))
     assert losses[-1] < 0.7 * losses[0], losses[::6]
     assert float((state.variables["flat"]["so3_mlp"] - so3_0).abs().max()) > 1e-4        # path_sampler is being trained (train.py:302-310)
+
+
+def test_all_stage_skips_an_update_with_nonfinite_gradients():
+    """Stage all* runs the staged sequence, whose update is rnerf_adam_update like the product step's: a batch whose coarse rows leave f16's
+    range (non-finite gradient) writes nothing — theta (so3_mlp included), mu, nu keep their bits — and is counted; the step counter advances.
+    (It is not re-run in the range-safe arithmetic: the input gradients of this stage are built on the row-normalised f16 backward modes.)"""
+    from samplenerfro_amd.train import train_step
+    model, state, batch, flags, *_ = _setup(0)
+    lo, _ = state.segments["coarse_mlp"]
+    state.theta[lo + 63 * 256: lo + 63 * 256 + 256] = 3.0e5            # Dense_0 biases: every first-layer activation beyond 65504
+    state.step = 5
+    theta0 = state.theta.clone()
+    state, stats, _ = train_step(model, np.array([1, 2], np.uint32), state, batch, flags, range_retry=True)
+    assert state.nonfinite_grads() > 0 and state.range_retries == 0 and not np.isfinite(float(stats.loss))
+    assert torch.equal(state.theta, theta0) and float(state.mu.abs().max()) == 0.0 and state.step == 6 and int(state.step_dev.item()) == 6
