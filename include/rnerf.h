@@ -488,8 +488,8 @@ int rnerf_train_forward_backward(const rnerf_model* m, const rnerf_train_cfg* c,
  * f16's range, or a gradient chain beyond the 2^10 of headroom the f16 backward modes normalise every row to, makes that visible), counted
  * BEFORE the value clip (which would otherwise turn a NaN into +-grad_max_val).  skip_nonfinite != 0: an update that met such an entry
  * leaves theta, mu and nu untouched (the step counter still advances) — the reference's fp32 step would have been finite on that batch, so
- * the caller re-runs it in the range-safe arithmetic (precision BF16X3 + backward BF16; samplenerfro_amd.train does with
- * range_retry) instead of writing NaN into every parameter. */
+ * the caller re-runs it in the range-safe arithmetic (precision BF16X3 + backward BF16; samplenerfro_amd.train does — by default two steps
+ * later, from a pinned copy of scratch[3], without a per-step synchronisation) instead of writing NaN into every parameter. */
 #define RNERF_ADAM_SCRATCH_FLOATS 3076
 typedef struct rnerf_adam_cfg {
   double lr_init, lr_final, lr_delay_mult;

@@ -44,6 +44,8 @@ _MARCH_RESERVE = 0
 _AUX_STREAM = True                      # the second stream of rnerf_train_cfg (False: everything on one stream)
 _AUX2_STREAM = False                    # a third stream for the background backward of small hierarchical batches (see train_cfg)
 _CORESIDENT_BKGD_WGRAD = False          # the background-MLP weight gradient as a co-resident kernel beside the NerfMLP wgrad (see train_cfg)
+_RANGE_RETRY_LAG = 2                    # range_retry="lag": the count of step k - 2 is read after step k has been queued (train_step)
+_LAG_SLOTS = 8
 _SKIP_NONFINITE_UPDATES = True          # rnerf_adam_cfg.skip_nonfinite: an update with an inf / NaN gradient entry is skipped and counted (train_step)
 _ALL_CHAIN_BESIDE_WGRAD = True          # stage all*: the march's adjoint chain on the side stream beside the NerfMLP wgrad (see train_step)
 
@@ -72,6 +74,10 @@ class TrainState:
         self.adam_scratch = torch.zeros(_lib.ADAM_SCRATCH_FLOATS, dtype=torch.float32, device=theta.device) if theta.is_cuda else None
         self._staged_bad: Optional[int] = None
         self.range_retries = 0         # steps train_step(range_retry=True) re-ran in the range-safe arithmetic
+        self._lag_pending = []         # range_retry="lag": the steps whose non-finite count has not been looked at yet (at most _RANGE_RETRY_LAG)
+        self._lag_host = torch.zeros(_LAG_SLOTS, dtype=torch.float32).pin_memory() if theta.is_cuda else None
+        self._lag_count = 0
+        self.last_retry_stats = None
 
     def nonfinite_grads(self) -> int:
         """Non-finite gradient entries met by the last rnerf_adam_update (reads a device scalar: synchronises).  Non-zero means a row's
@@ -410,7 +416,7 @@ def range_safe(model: NerfModel, flags):
 _F16_BASED = (_lib.PREC_F16X3, _lib.PREC_F16)
 
 
-def train_step(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], flags=None, *, range_retry: Optional[bool] = None, **kw):
+def train_step(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], flags=None, *, range_retry=None, **kw):
     """One optimisation step (train.py:58-183): see _train_step_once for the arguments.
 
     Range of the f16-based training arithmetic.  A sample whose hidden activations leave f16's range (|x| > 65504; weights >= 256) comes
@@ -419,11 +425,32 @@ def train_step(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], 
     such a batch.  range_retry=True (or flags.range_retry) makes this one too: the count is read after the step (one host synchronisation
     per step: the price, and why it is opt-in) and a skipped step is run again on the same batch and keys in the range-safe arithmetic
     (range_safe: bf16x3 forward, bf16 backward), whose update is applied; state.range_retries counts them.  Radiance stages only (stage
-    all*'s input gradients are built on the row-normalised f16 backward modes: skipped and counted there, not re-run)."""
+    all*'s input gradients are built on the row-normalised f16 backward modes: skipped and counted there, not re-run).
+
+    range_retry="lag" (the default of utils.default_flags): the same without the per-step read.  The count of step k - 2 is read AFTER step k
+    has been queued (a pinned host word written behind that step's update; the device never idles, the host still runs two steps ahead,
+    every rank looks at the same lag), and a skipped batch is re-run then, behind step k — on the parameters step k left, which is what
+    costs nothing: in the rare re-run the batch moves two places down the order.
+    The Stats returned for the skipped step were non-finite; the re-run's are in state.last_retry_stats.  Call
+    flush_range_retry(model, state) before reading the parameters for good (checkpoint, end of training): it settles the last step."""
     flags = state.flags if flags is None else flags
-    retry = bool(getattr(flags, "range_retry", False)) if range_retry is None else bool(range_retry)
+    mode = getattr(flags, "range_retry", False) if range_retry is None else range_retry
+    retry = bool(mode)
     if not (retry and flags.stage.startswith("radiance") and model.precision in _F16_BASED):
         return _train_step_once(model, rng, state, batch, flags, **kw)
+    if mode == "lag":
+        if kw.get("taps") is not None or kw.get("forward_taps") is not None:
+            return _train_step_once(model, rng, state, batch, flags, **kw)      # a tapped step is looked at now, not re-run later (range_retry=True does both)
+        out = _train_step_once(model, rng, state, batch, flags, **kw)
+        slot = state._lag_count % _LAG_SLOTS
+        state._lag_count += 1
+        state._lag_host[slot:slot + 1].copy_(state.adam_scratch[3:4], non_blocking=True)      # behind this step's update, on its stream
+        ev = torch.cuda.Event(); ev.record()
+        replay = dict(kw, next_rays=None, path=None)                 # (the marched path of that step may be overwritten by then: marched again)
+        state._lag_pending.append((ev, slot, rng, batch, flags, replay))
+        while len(state._lag_pending) > _RANGE_RETRY_LAG:
+            _settle_lagged(model, state, state._lag_pending.pop(0))
+        return out
     step0 = state.step
     out = _train_step_once(model, rng, state, batch, flags, _guard=True, **kw)
     if state.nonfinite_grads() == 0:
@@ -438,6 +465,27 @@ def train_step(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], 
     state.next_path = next_path
     state.range_retries += 1
     return out
+
+
+def _settle_lagged(model: NerfModel, state: TrainState, pending) -> None:
+    ev, slot, rng, batch, flags, replay = pending
+    ev.synchronize()                                                 # that step has long finished: the device is busy with the one queued after it
+    if float(state._lag_host[slot]) == 0.0:
+        return
+    next_path = state.next_path
+    state.step -= 1                                                  # the skipped update had counted as a step: the re-run takes its place
+    state.sync_step_counter()
+    with range_safe(model, flags):
+        _, stats, _ = _train_step_once(model, rng, state, batch, flags, **replay)
+    state.next_path = next_path
+    state.last_retry_stats = stats
+    state.range_retries += 1
+
+
+def flush_range_retry(model: NerfModel, state: TrainState) -> None:
+    """range_retry="lag": settle the last queued step (read its count; re-run it if its update was skipped)."""
+    while state._lag_pending:
+        _settle_lagged(model, state, state._lag_pending.pop(0))
 
 
 def _train_step_once(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], flags=None, *, jitter=None, u_fine=None,

@@ -56,7 +56,8 @@ def default_flags(**overrides) -> types.SimpleNamespace:
         use_online_sparsity=True, normal_loss_weight=0.0, normal_smooth_weight=0.0, beta_weight=0.0, bg_weight=0.0,
         bg_smooth_weight=0.0, bg_patch_size=0, chunk=8192,
         backward_precision="f16x3",      # not a reference flag: arithmetic of the HIP backward (train.backward_mode)
-        range_retry=False,               # not a reference flag: re-run a step whose f16-based arithmetic left its range (train.train_step)
+        range_retry="lag",               # not a reference flag: re-run a step whose f16-based arithmetic left its range (train.train_step):
+                                         # "lag" = decided two steps later (no per-step host read), True = in place (one read per step), False = never
     )
     f.update(overrides)
     return types.SimpleNamespace(**f)

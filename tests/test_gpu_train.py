@@ -593,3 +593,46 @@ def test_a_step_outside_f16_range_is_skipped_then_rerun_range_safe(Nf):
     # the next step (inside or outside the range again) goes on from the applied update
     s2, st4, _ = train_step(model, rng2, s2, batch, flags, jitter=jitter, range_retry=True)
     assert np.isfinite(float(st4.loss)) and s2.step == 7
+
+
+def test_lagged_range_retry_settles_one_step_later():
+    """range_retry="lag": the count of step k - 2 is read after step k has been queued, a skipped batch is re-run then.  Four steps — inside,
+    OUTSIDE, inside, inside f16's range (the doctored coarse network leaves it for x > ~1.6: the batch halves are the rays that do / do not
+    get there) — end with one re-run, four counted steps, finite parameters near the synchronous form's (which re-runs the batch in place: the
+    two differ by the order of two updates), and nothing left pending after the flush."""
+    from samplenerfro_amd import utils
+    from samplenerfro_amd.train import TrainState, train_step, flush_range_retry
+    model, state, batch, flags, ev = _setup(0)
+    _out_of_range_coarse(state)
+    o = batch["rays"].origins.cpu().numpy(); d = batch["rays"].viewdirs.cpu().numpy()
+    order = np.argsort(-np.maximum(o[:, 0] + 2 * d[:, 0], o[:, 0] + 6 * d[:, 0]), kind="stable")
+    half = len(order) // 2
+
+    def sub(idx):
+        t = torch.from_numpy(np.ascontiguousarray(idx)).to("cuda:0")
+        return dict(batch, rays=utils.Rays(batch["rays"].origins[t].contiguous(), None, batch["rays"].viewdirs[t].contiguous(), None), pixels=batch["pixels"][t].contiguous())
+
+    hot, cool = sub(order[:half]), sub(order[half:])
+    jitter = np.arange(0, 32, 4) + 1
+    results = {}
+    for mode in ("lag", True):
+        s = TrainState.create(model, state.variables, flags); s.step = 5
+        s.lr_fn = lambda c: 1e-3
+        rng = np.array([1, 2], np.uint32)
+        seen = []
+        for k, b in enumerate((cool, hot, cool, cool)):
+            s, stats, rng = train_step(model, rng, s, b, flags, jitter=jitter, range_retry=mode)
+            seen.append((s.range_retries, bool(np.isfinite(float(stats.loss)))))
+        if mode == "lag":
+            assert seen == [(0, True), (0, False), (0, True), (1, True)], seen      # the re-run happened behind step 3; step 1's own stats were non-finite
+            assert len(s._lag_pending) == 2 and np.isfinite(float(s.last_retry_stats.loss))
+            flush_range_retry(model, s)
+            assert s._lag_pending == []
+        else:
+            assert seen == [(0, True), (1, True), (1, True), (1, True)], seen
+        assert s.range_retries == 1 and s.step == 9 and int(s.step_dev.item()) == 9 and bool(torch.isfinite(s.theta).all())
+        results[mode] = s.theta.clone()
+    # the same four batches, two of them in the other order: Adam's first updates are ~lr per entry whatever the gradient, so the two
+    # parameter sets stay within (updates) x 2 lr of each other — and they are not the same
+    assert 0 < (results["lag"] - results[True]).abs().max().item() < 4 * 2 * 1e-3
+    assert not torch.equal(results["lag"], state.theta)
