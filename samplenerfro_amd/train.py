@@ -439,8 +439,9 @@ def train_step(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], 
     if not (retry and flags.stage.startswith("radiance") and model.precision in _F16_BASED):
         return _train_step_once(model, rng, state, batch, flags, **kw)
     if mode == "lag":
-        if kw.get("taps") is not None or kw.get("forward_taps") is not None:
-            return _train_step_once(model, rng, state, batch, flags, **kw)      # a tapped step is looked at now, not re-run later (range_retry=True does both)
+        if kw.get("taps") is not None or kw.get("forward_taps") is not None or torch.cuda.is_current_stream_capturing():
+            # a tapped step is looked at now, not re-run later (range_retry=True does both); inside a stream capture there is no host to decide
+            return _train_step_once(model, rng, state, batch, flags, **kw)
         out = _train_step_once(model, rng, state, batch, flags, **kw)
         slot = state._lag_count % _LAG_SLOTS
         state._lag_count += 1
