@@ -475,13 +475,16 @@ def finalize_pairs(rec: dict) -> dict:
         # The kernel hands out pair slots with one atomicAdd per pair, i.e. in arrival order: run-to-run different, and with it the summation
         # order of so3_mlp's weight gradient.  Re-order the compacted list by its (node, ray) key — unique, so the order is a function of the
         # batch alone — and re-point pair_of_node: every kernel downstream sees the same pairs in the same slots on every run.
-        key = pid[:, 1].to(torch.int64) * B + pid[:, 0].to(torch.int64)
-        perm = torch.argsort(key)
+        # (int32 keys when they fit, sort + index_select instead of argsort + advanced indexing: the same permutation in fewer, shorter
+        #  launches — 319 -> 270 us for 208 k pairs, tools/r05/dbg_sort.py)
+        small = int(N) * int(B) < 2 ** 31
+        key = pid[:, 1] * B + pid[:, 0] if small else pid[:, 1].to(torch.int64) * B + pid[:, 0].to(torch.int64)
+        perm = torch.sort(key)[1]
         inv = torch.empty(n, dtype=torch.int32, device=dev)
-        inv[perm] = torch.arange(n, dtype=torch.int32, device=dev)
-        pid, px, pg = pid[perm], px[perm], pg[perm]
+        inv.index_copy_(0, perm, torch.arange(n, dtype=torch.int32, device=dev))
+        pid, px, pg = pid.index_select(0, perm), px.index_select(0, perm), pg.index_select(0, perm)
         flat = pair_of_node.view(-1)
-        pair_of_node = torch.where(flat >= 0, inv[flat.clamp(min=0).to(torch.int64)], flat).view(N, B)
+        pair_of_node = torch.where(flat >= 0, inv.index_select(0, flat.clamp(min=0)), flat).view(N, B)
     rec.update(n_pairs=n, pair_id=pid, pair_x=px.contiguous(), pair_g=pg.contiguous(), pair_of_node=pair_of_node)
     return rec
 
