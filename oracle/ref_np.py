@@ -1,5 +1,9 @@
 """numpy restatement of the SampleNeRFRO hot path (TEST INFRASTRUCTURE, parity unpinned).
 
+Pinned by the reference itself: build_table's gradient columns, linear3 and generate_rays — against vectors its own numpy-only methods
+compute (rnerf/datasets.py Grid._compute_grad / _linear3, Dataset / OpenCV._generate_rays; tests/test_reference_numpy_pin.py).  Everything
+else is held only by analytic known-answer tests, published jax.random values and a second, independently written reading.
+
 Every function cites the reference lines it restates (paths relative to
 /root/reference).  The arithmetic is done in `dtype` (float32 by default, the
 reference's precision; float64 gives the "truth" twin used to set tolerances).
