@@ -5,7 +5,8 @@
 
 Reads /root/reference/example_data/imgs/r_0_depth_0001.exr (800 x 800, three identical float32 channels, ZIP compression: decoded here
 with zlib — no OpenEXR in the image) and stores every 8th pixel of it, rows and columns 4, 12, ..., 796 (`z` [100, 100] float32; 1e10 =
-no surface), with the pixel indices.  The values are Blender's Z pass: distance ALONG THE VIEW AXIS to the first surface of the object
+no surface), with the pixel indices, and the same pixels of r_0_normal_0001.exr (`normal` [100, 100, 3]: world-space unit normals of that surface).
+The depth values are Blender's Z pass: distance ALONG THE VIEW AXIS to the first surface of the object
 whose voxelisation is example_data/voxelize/mesh_4_128_1.5_1.165.obj.  tests/test_example_depth.py checks the camera model, the grid's
 placement and axis order and the voxeliser against it.  The file holds pixels only — no text of any reference source."""
 import os
@@ -16,6 +17,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = "/root/reference/example_data/imgs/r_0_depth_0001.exr"
+SRC_NORMAL = "/root/reference/example_data/imgs/r_0_normal_0001.exr"
 
 
 def read_exr_zip(path):
@@ -56,8 +58,10 @@ def main():
     z = ch["R"]
     assert z.shape == (800, 800) and np.array_equal(z, ch["G"]) and np.array_equal(z, ch["B"])
     sel = np.arange(4, 800, 8)
+    nm = read_exr_zip(SRC_NORMAL)                                       # Blender's normal pass: world-space unit normals, channels R, G, B = x, y, z
+    normal = np.stack([nm["R"], nm["G"], nm["B"]], -1)
     out = os.path.join(HERE, "example_depth.npz")
-    np.savez_compressed(out, z=z[sel][:, sel].copy(), rows=sel, cols=sel)
+    np.savez_compressed(out, z=z[sel][:, sel].copy(), normal=normal[sel][:, sel].copy(), rows=sel, cols=sel)
     hit = z < 1e9
     print(out, os.path.getsize(out), "bytes; surface on", float(hit.mean()), "of the pixels, depth", float(z[hit].min()), "..", float(z[hit].max()))
 

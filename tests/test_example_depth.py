@@ -25,6 +25,25 @@ def _depth():
     return z["z"], z["rows"], z["cols"]
 
 
+def _surface_points_and_normals(origins, viewdirs):
+    """World positions of Blender's first surface along the sampled rays (from its depth pass) and its world-space normals there."""
+    f = np.load(os.path.join(HERE, "golden", "example_depth.npz"))
+    z, n = f["z"].reshape(-1).astype(np.float64), f["normal"].reshape(-1, 3).astype(np.float64)
+    axis = -cases.EXAMPLE_C2W[:3, 2].astype(np.float64)
+    hit = z < 1e9
+    t = z[hit] / (viewdirs[hit].astype(np.float64) @ axis)
+    return origins[hit].astype(np.float64) + t[:, None] * viewdirs[hit].astype(np.float64), n[hit]
+
+
+def _check_normals(grad, normals):
+    """grad [n, 3]: the table's (d n / d x, y, z) at the surface points.  The index of refraction rises INTO the object: grad || -normal."""
+    g = grad.astype(np.float64)
+    cos = -(g / np.linalg.norm(g, axis=-1, keepdims=True) * normals / np.linalg.norm(normals, axis=-1, keepdims=True)).sum(-1)
+    print(f"{len(cos)} surface points: cos(grad n, -normal) median {np.median(cos):.4f}, mean {cos.mean():.4f}, 10th percentile {np.percentile(cos, 10):.4f}")
+    assert np.median(cos) > 0.999 and cos.mean() > 0.99 and np.percentile(cos, 10) > 0.97
+    assert np.linalg.norm(g, axis=-1).min() > 1.0                         # every one of them sits in the boundary shell (|grad n| ~ 6.5 there)
+
+
 def _check(first_hit_t, viewdirs, z):
     """first_hit_t [n]: ray parameter of the first sample whose inside fraction reaches 1/2 (inf: none); viewdirs [n, 3] unit; z [n] Blender's."""
     axis = -cases.EXAMPLE_C2W[:3, 2].astype(np.float64)                        # the camera looks along -z of its own frame
@@ -85,3 +104,37 @@ def test_device_rays_voxeliser_and_lookup_against_blenders_depth_pass():
         occ = (f >= 0.5) & inside
         first[i:i + 1000] = torch.where(occ.any(1), t[occ.float().argmax(1)], torch.full_like(first[i:i + 1000], float("inf")))
     _check(first.cpu().numpy().astype(np.float64), V.cpu().numpy(), z.reshape(-1))
+
+
+def test_oracle_gradient_table_points_along_blenders_normals():
+    """Rows G1 + G2 + G3 on the example scene: prefilter (3, 1.0), gradient table, trilinear lookup — evaluated at the surface points
+    Blender's depth pass gives, against Blender's normal pass (example_data/imgs/r_0_normal_0001.exr): axis order and sign of the gradient."""
+    _, rows, cols = _depth()
+    H = W = 800
+    focal = 0.5 * W / math.tan(0.5 * cases.EXAMPLE_CAMERA_ANGLE_X)
+    o, _, v = R.generate_rays(cases.EXAMPLE_C2W, H, W, focal=focal)
+    P, N = _surface_points_and_normals(o[rows][:, cols].reshape(-1, 3), v[rows][:, cols].reshape(-1, 3))
+    _, _, counts = cases.load_example_obj()
+    table = R.build_table(cases.example_grid(counts).astype(np.float32), [128] * 3, [-1.5] * 3, [1.5] * 3)
+    _check_normals(R.linear3(table, P.astype(np.float32), [128] * 3, [-1.5] * 3, [1.5] * 3)[:, 1:4], N)
+
+
+@pytest.mark.gpu
+def test_device_gradient_table_points_along_blenders_normals():
+    """The same through rnerf_voxelize -> (ri scaling) -> rnerf_grid_prefilter -> rnerf_grid_build_table -> rnerf_grid_query."""
+    torch = pytest.importorskip("torch")
+    from samplenerfro_amd import _lib, ops, voxelize as VX
+    dev = torch.device("cuda:0")
+    _, rows, cols = _depth()
+    H = W = 800
+    focal = 0.5 * W / math.tan(0.5 * cases.EXAMPLE_CAMERA_ANGLE_X)
+    o, _, v = ops.generate_rays(cases.EXAMPLE_C2W, H, W, dev, focal=focal)
+    o, v = o.cpu().numpy(), v.cpu().numpy()
+    P, N = _surface_points_and_normals(o[rows][:, cols].reshape(-1, 3), v[rows][:, cols].reshape(-1, 3))
+    verts, faces, _ = cases.load_example_obj()
+    data, ndim, nmin, nmax = VX.voxelize(cases.example_obj_world(verts), faces, 128, extent=1.5, num_samples=4, device=dev)
+    scaled = ((data.double() - 1.0) * 0.5 / 0.33 + 1.0).float()          # train.py:222, ri = 0.5 (configs/example.yaml)
+    spec = _lib.Grid.make(ndim, nmin, nmax)
+    table = ops.grid_build_table(ops.grid_prefilter(scaled, 3, 1.0), spec)
+    got = ops.grid_query(table, spec, torch.from_numpy(P.astype(np.float32)).to(dev)).cpu().numpy()
+    _check_normals(got[:, 1:4], N)
