@@ -665,6 +665,17 @@ def generate_rays(camtoworld, h, w, focal=None, cam_mat=None, pixel_center=True)
     return origins, directions.astype(F32), viewdirs.astype(F32)
 
 
+def ray_radii(directions):
+    """The `radii` of Dataset._generate_rays (rnerf/datasets.py:230-239; the cone footprint mip.cast_rays takes): distance of each pixel's
+    direction to its neighbour in the NEXT IMAGE ROW (the reference's comment says x, its axis is the rows'), the last row repeating the
+    one before, times 2 / sqrt(12).  directions [h, w, 3] -> [h, w, 1] float32."""
+    d = np.asarray(directions, F32)
+    diff = d[:-1] - d[1:]
+    dx = np.sqrt(_seqsum(diff * diff, axis=-1))
+    dx = np.concatenate([dx, dx[-2:-1]], 0)
+    return (dx[..., None] * F32(2) / np.sqrt(F32(12))).astype(F32)
+
+
 # ----------------------------------------------------------------------------
 # SURVEY 8f N2: voxeliser                       (voxelize_mesh.py:54-106)
 # ----------------------------------------------------------------------------

@@ -323,6 +323,16 @@ def generate_rays(camtoworld, H: int, W: int, device, focal: Optional[float] = N
     return o, d, v
 
 
+def ray_radii(directions: torch.Tensor) -> torch.Tensor:
+    """Rays.radii of Dataset._generate_rays (rnerf/datasets.py:230-239) from the directions of a WHOLE image [H, W, 3] on the device
+    (generate_rays(..., want_directions=True)): |d[r] - d[r + 1]| per pixel, the last row repeating the one before, times 2 / sqrt(12).
+    Feeds integrated_pos_enc (the reference's commented mip path); plain tensor arithmetic — one pass over H x W x 3 floats."""
+    diff = directions[:-1] - directions[1:]
+    dx = torch.sqrt((diff * diff).sum(-1))
+    dx = torch.cat([dx, dx[-2:-1]], 0)
+    return dx[..., None] * (2.0 / 12.0 ** 0.5)
+
+
 def so3_window(annealed_alpha: float, max_deg_point: int = 10):
     """cosine_easing_window(0, max_deg-1, max_deg, annealed_alpha * max_deg) in fp32 (rnerf/model_utils.py:218-233, ior_utils.py:283)."""
     import numpy as np

@@ -54,6 +54,17 @@ def test_oracle_ray_generation_equals_the_references_bit_for_bit():
                 assert np.array_equal(o, y[pre + "origins"][cam]) and np.array_equal(d, y[pre + "directions"][cam]) and np.array_equal(v, y[pre + "viewdirs"][cam]), (tag, pc, cam)
 
 
+def test_oracle_radii_agree_with_the_references():
+    """The reference's radii come out float64 under this NumPy (np.sqrt(12) is a float64 SCALAR, which NumPy >= 2 no longer demotes) and
+    float32 under the NumPy it pins: the oracle's float32 values agree to float32 rounding."""
+    x, y, _ = _load()
+    for cam in range(x["c2w"].shape[0]):
+        for pre in ("blender_pc1_", "opencv_pc0_"):
+            r = R.ray_radii(y[pre + "directions"][cam])
+            want = y[pre + "radii"][cam]
+            assert r.shape == want.shape and r.dtype == F32 and np.abs(r / want - 1).max() < 3e-7
+
+
 def test_oracle_gradient_table_equals_the_references_bit_for_bit():
     """Grid._compute_grad: edge padding + central differences / (2 ndelta), per axis — the gradient columns of the path's table (row G2)."""
     x, y, _ = _load()
@@ -93,6 +104,7 @@ def test_hip_entry_points_against_the_references_vectors():
                 pre = f"{tag}_pc{int(pc)}_"
                 assert np.array_equal(o.cpu().numpy(), y[pre + "origins"][cam]) and np.array_equal(d.cpu().numpy(), y[pre + "directions"][cam])
                 assert np.array_equal(v.cpu().numpy(), y[pre + "viewdirs"][cam]), (tag, pc, cam)
+                assert np.abs(ops.ray_radii(d).cpu().numpy() / y[pre + "radii"][cam] - 1).max() < 1e-6
     ndim, nmin, nmax = _grid(x)
     for layout in ("reference", "bricks"):
         spec = _lib.Grid.make(ndim, nmin, nmax, layout)
