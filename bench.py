@@ -353,7 +353,7 @@ def pmc_lookup(workload, fine, B, mode, backward, rnerf_cus, precision="f16x3"):
     import hashlib
     old = {"f16x3": "f32", "f16": "tf32"}.get(backward, backward)       # (the mode names of rounds 2-4, in the file names of profiles/r04)
     rel = None
-    for rnd, bw in (("r05", backward), ("r04", old)):                   # the newest committed pass whose stamp still matches wins
+    for rnd, bw in (("r06", backward), ("r05", backward), ("r04", old)):                   # the newest committed pass whose stamp still matches wins
         psuf = "" if precision in ("f16x3", "f16f8") else "_p" + precision        # (the default arithmetics carry no suffix: forward f16f8, train f16x3)
         cand = os.path.join("profiles", rnd, "pmc_%s_f%d_%s%s.json" % (workload, fine, mode if mode == "forward" else "train_" + bw, psuf))
         if os.path.exists(os.path.join(ROOT, cand)):
@@ -398,8 +398,8 @@ def main():
     ap.add_argument("--fine", type=int, default=None, help="num_fine_samples (default: the workload's flat variant, 0)")
     ap.add_argument("--precision", default="f16x3", help="arithmetic of training and of every tapped path")
     ap.add_argument("--eval-precision", default=None,
-                    help="arithmetic of the pure render pass (forward mode, the frame): default = construct_nerf's default, f16f8 (f16 main term + fp8 "
-                         "cross terms, device-side fallback to f16x3 when a weight is out of its range), when --precision is f16x3; else --precision")
+                    help="arithmetic of the pure render pass (forward mode, the frame): default = construct_nerf's default = --precision (round 6; f16f8 "
+                         "— f16 main term + fp8 cross terms — is opt-in: --eval-precision f16f8)")
     ap.add_argument("--rays", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pipeline", dest="pipeline", action="store_true", default=None,
@@ -417,7 +417,7 @@ def main():
                     help="skip the 800x800 full-frame render (ms/frame, the second part of BASELINE's metric; ~1 s)")
     ap.add_argument("--reserve-cus", type=int, default=32, help="CUs kept free of MLP workgroups for the overlapped march (forward mode)")
     ap.add_argument("--cpu-rays", type=int, default=None, help="rays in the CPU baseline sample (default 4096 forward / 512 train)")
-    ap.add_argument("--backward", choices=["f16x3", "f16", "bf16", "f32", "tf32"], default="f16x3",
+    ap.add_argument("--backward", choices=["f16x3", "f16x3lo8", "f16", "bf16", "f32", "tf32"], default="f16x3",
                     help="arithmetic of the NerfMLP backward: f16x3 = hi + lo f16 parts, 3 MFMAs per product (fp32-grade, the reference differentiates "
                          "in fp32; default), f16 = f16 parts (11-bit significand), bf16 = 8-bit significand (round 1's arithmetic); f32 / tf32 = the "
                          "older names of the first two")
@@ -452,7 +452,9 @@ def main():
     if args.cpu_rays is None:
         args.cpu_rays = 4096 if args.mode == "forward" else 512
     if args.eval_precision is None:
-        args.eval_precision = "f16f8" if args.precision == "f16x3" else args.precision
+        # the render pass runs the training arithmetic (fp32-grade f16x3) since round 6, like construct_nerf's default: f16f8 — the default of
+        # rounds 4-5 — measures 2e-4 RGB on trained-like weights (tests/test_gpu_parity.py), outside north_star's 1e-4; it stays a labelled leg
+        args.eval_precision = args.precision
 
     import torch
     import torch.distributed as dist
@@ -593,8 +595,8 @@ def main():
         # the same step with the other backward arithmetics (5 steps each, after 2 warm-up steps), for the record in the same line
         other_modes = {}
         stepper.close()
-        for name in ("f16x3", "f16", "bf16"):
-            if name == args.backward or (args.stage == "all" and name == "bf16") or (name == "f16x3" and args.precision != "f16x3"):
+        for name in ("f16x3", "f16x3lo8", "f16", "bf16"):
+            if name == args.backward or (args.stage == "all" and name == "bf16") or (name in ("f16x3", "f16x3lo8") and args.precision != "f16x3"):
                 continue
             s2 = Stepper(args, cfg, model, variables, rays, key, B, world, rank, fine, device, name, args.mode, args.stage, args.pipeline, args.graph)
             dt_m = timed_steps(s2, 2, 5, barrier, D, device)
@@ -686,7 +688,7 @@ def main():
         # sum over the wgrad jobs of (X slots + dY slots) x R x 32 B (x 2: hi + lo).  f16 modes: 11 jobs (the Dense_5 / Dense_10 concat rows and
         # the sigma head share their operand streams with the main block: 316 slot planes); bf16 body: 14 single-segment jobs (356)
         wgrad_slots = (8 * 32 + 2 * 20 + 17 + 24 + 10 + 9) if args.backward == "bf16" else (20 + 4 * 32 + 36 + 2 * 32 + 33 + 26 + 9)
-        wgrad_bytes = wgrad_slots * R_pad * 32 * (2 if args.backward == "f16x3" else 1)
+        wgrad_bytes = wgrad_slots * R_pad * 32 * {"f16x3": 2.0, "f16x3lo8": 1.5}.get(args.backward, 1.0)
         # the MLP phase is MFMA-bound and its algorithmic work is 2 x 593 408 FLOP per row (forward and wgrad) / 2 x 557 696
         # (dgrad: the encodings take no gradient).  The saved-operand / dY planes the kernels stream through HBM are an implementation
         # choice (like the path record): reported next to it as `operand_stream`, never as the algorithmic fraction.
@@ -696,14 +698,21 @@ def main():
             tk = {"kernel": name, "bound": "mfma", "achieved": flop / (ms * 1e-3) / 1e12, "peak": PEAK_MFMA_16BIT / 1e12,
                   "unit": "TFLOP/s", "frac": flop / (ms * 1e-3) / PEAK_MFMA_16BIT, "avg_launch_ms": ms, "algorithmic_flop_per_launch": flop}
             # MFMAs per algorithmic product: the forward in its precision; dgrad / wgrad: 3 with hi + lo planes, (W hi + W lo) x dY = 2 / 1 in f16, 2 / 1 in bf16
-            npass = MFMA_PASSES[args.precision] if "fwd" in name else ({"f16x3": 3, "f16": (1 if args.precision == "f16" else 2), "bf16": 2}[args.backward] if "dgrad" in name else {"f16x3": 3, "f16": 1, "bf16": 1}[args.backward])
+            npass = MFMA_PASSES[args.precision] if "fwd" in name else ({"f16x3": 3, "f16x3lo8": 3, "f16": (1 if args.precision == "f16" else 2), "bf16": 2}[args.backward] if "dgrad" in name else {"f16x3": 3, "f16x3lo8": 3, "f16": 1, "bf16": 1}[args.backward])
             with_pass_ceiling(tk, npass, sustained["bf16"] if (sustained and args.backward == "bf16" and "fwd" not in name) else sus16)
             if byt is not None:
                 tk["avg_launch_ms_alone"] = t_w_alone
                 tk["launched"] = ("with the next batch's march co-resident, as in the step" if t_w is not t_w_alone else "alone")
-                tk["operand_stream"] = {"operand_stream_bytes": byt, "GB_per_s": byt / (ms * 1e-3) / 1e9, "frac_of_hbm_peak": byt / (ms * 1e-3) / PEAK_HBM,
-                                        "note": "hi + lo f16 planes of the saved activations and of dY, read once: what paces this kernel (an "
-                                                "implementation choice, not algorithmic bytes)"}
+                # What bounds the wgrad is the HBM stream of its operands — X and dY of every layer, read exactly once, 4 B per value in the
+                # fp32-grade mode (f16 hi + lo: the size of the fp32 tensors the reference's backward reads) — not the matrix pipe (0.50 busy):
+                # reported as an HBM roofline, with the MFMA view of the same launch beside it
+                mf = {k: tk[k] for k in ("achieved", "peak", "unit", "frac", "algorithmic_flop_per_launch", "passes", "sustained_mfma_tflops", "frac_of_pass_ceiling") if k in tk}
+                for k in ("passes", "sustained_mfma_tflops", "frac_of_pass_ceiling"):
+                    tk.pop(k, None)
+                tk.update({"bound": "hbm", "achieved": byt / (ms * 1e-3) / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": byt / (ms * 1e-3) / PEAK_HBM,
+                           "algorithmic_bytes_per_launch": byt, "mfma": mf,
+                           "bytes_note": "%d slot planes x 32 B x %d plane(s) per row: the saved activations and the gradients of every layer, read "
+                                         "once (DESIGN.md §3.3); `traffic` = the PMC counters' bytes of the same launch" % (wgrad_slots, 2 if args.backward in ("f16x3", "f16x3lo8") else 1)})
             train_kernels.append(tk)
         del raw_t, save_t, dy_t, ws_t
         torch.cuda.empty_cache()
@@ -738,7 +747,7 @@ def main():
         # this very batch is from the default's — the error of 11 / 8-bit products averages down with the number of rows (524 288 here;
         # on a few hundred rows it is ~1e-3 / ~1e-2, tests/test_gpu_backward.py), which is why the default does not rely on it
         bw_err = {}
-        for bw in ("f16", "bf16"):
+        for bw in ("f16x3lo8", "f16", "bf16"):       # (f16x3lo8: the hi + lo mode with its lo planes stored as e4m3 bytes — 3/4 of the operand bytes)
             gb = grads_of(model, bw)
             bw_err[bw] = float((gb - g_ref).abs().max() / g_ref.abs().max())
             del gb
@@ -799,7 +808,61 @@ def main():
                                     "what": "the step a range_retry re-run costs, on the bench batch (which is inside f16's range: nothing is re-run here); the headline "
                                             "runs with flags.range_retry = 'lag' (the count of step k - 2 is read after step k is queued: no per-step host read) — beside it "
                                             "the same step with the decision in place (True: one host read per step) and with no re-run at all (False)"}
-        del mp, vp, vs, vl, g, g_ref
+        del mp, vp, vs, vl, g
+        torch.cuda.empty_cache()
+
+        # ---- the range retry WHERE IT FIRES: a coarse network doctored so that ~1 % of the rows of an ordinary batch leave
+        # f16's range (Dense_0 unit 7 = relu(200 x), Dense_1[7 -> 3] = 200: 4e4 x, beyond 65504 for x > 1.64 — the first samples of the ~9 % of
+        # the rays that start on that side), 50 steps, every tenth batch such an ordinary one, the others drawn from rays that stay inside:
+        # what a re-run costs at bench size, in the lagged default and decided in place, and how far the two parameter sets end up apart
+        def retry_run(mode, hot_every):
+            vv = models_fresh_variables(pf, device)
+            fl = U.default_flags(num_coarse_samples=cfg["S"], num_fine_samples=fine, num_path_samples=cfg["P"], white_bkgd=False, bg_weight=0.025,
+                                 bg_smooth_weight=0.0, use_online_sparsity=False, randomized=True, near=cfg["near"], far=cfg["far"],
+                                 batch_size=B * world, backward_precision="f16x3", stage="radiance", range_retry=mode, lr_delay_steps=0)
+            ts = TrainState.create(model, vv, fl)
+            lo_c = ts.segments["coarse_mlp"][0]
+            ts.theta[lo_c:lo_c + 256] = 0.0
+            ts.theta[lo_c + 7] = 200.0
+            ts.theta[lo_c + 63 * 256 + 256 + 7 * 256 + 3] = 200.0
+            po, pdv = syn.sphere_rays(16 * B, seed=syn.SEED + 77 + rank)
+            hot = np.maximum(po[:, 0] + cfg["near"] * pdv[:, 0], po[:, 0] + cfg["far"] * pdv[:, 0]) > 1.55
+            cool_idx = np.nonzero(~hot)[0]
+            gen = np.random.default_rng(syn.SEED + 78 + rank)
+            mk = lambda idx: {"rays": Rays(torch.from_numpy(po[idx]).to(device), None, torch.from_numpy(pdv[idx]).to(device), None),
+                              "pixels": torch.from_numpy(gen.uniform(0, 1, (B, 3)).astype(np.float32)).to(device), "annealed_alpha": 0.5}
+            cool = [mk(cool_idx[i * B:(i + 1) * B]) for i in range(4)]
+            ordinary = mk(np.arange(B))                    # as drawn: ~9 % of its rays start on the hot side
+            from samplenerfro_amd.train import flush_range_retry
+            rk = key
+            n_steps, losses = 50, []
+            for k in range(-5, n_steps):
+                if k == 0:
+                    barrier(); t0 = time.perf_counter()
+                bt = ordinary if (hot_every and k >= 0 and k % hot_every == hot_every // 2) else cool[k % 4]
+                ts, stt, rk = train_step(model, rk, ts, bt, fl)
+                losses.append(stt.loss)
+            flush_range_retry(model, ts)
+            barrier()
+            dt_r = time.perf_counter() - t0
+            fin = [bool(torch.isfinite(x)) for x in losses[5:]]
+            out = {"ms_per_step": 1e3 * dt_r / n_steps, "re_runs": ts.range_retries, "re_runs_failed": ts.range_retry_failures,
+                   "steps_whose_first_attempt_was_skipped": fin.count(False), "parameters_finite": bool(torch.isfinite(ts.theta).all())}
+            th = ts.theta.clone()
+            del ts, vv
+            return out, th
+
+        live_lag, th_lag = retry_run("lag", 10)
+        live_in, th_in = retry_run(True, 10)
+        live_none, _ = retry_run("lag", 0)
+        legs["range_retry_live"] = {"lagged_default": live_lag, "decided_in_place": live_in, "same_loop_without_a_batch_out_of_range": live_none,
+                                    "ms_per_re_run": (live_lag["ms_per_step"] - live_none["ms_per_step"]) * 50 / max(live_lag["re_runs"], 1),
+                                    "max_abs_theta_lagged_vs_in_place": float((th_lag - th_in).abs().max()),
+                                    "what": "50 steps of 4096 x 128; every tenth batch has ~1 % of its rows outside f16's range: its update is skipped on the "
+                                            "device and the batch re-run in bf16x3 + bf16 (two steps later by default, or in place); the two orders differ by "
+                                            "the position of 5 updates (|dtheta| of a few learning rates); trajectory against the float64 loop: "
+                                            "tests/test_gpu_train.py::test_range_retry_trajectory_follows_the_float64_loop_over_50_steps"}
+        del th_lag, th_in, g_ref
         torch.cuda.empty_cache()
 
     traffic, sq, pmc_meta = pmc_lookup(args.workload, fine, B, args.mode, args.backward, rnerf_cus, prec_fwd_name)
@@ -939,21 +1002,34 @@ def main():
             del gm, gv
             torch.cuda.empty_cache()
             frame["glass_frame"]["precision"] = args.eval_precision
-            rgb_img = U.render_image(fn, fr, key, False, chunk=chunk)[0] if (args.eval_precision != args.precision) else None
-        if args.extra and args.eval_precision != args.precision and args.stage == "radiance":
-            # the same frame in the TRAINING arithmetic (f16x3, fp32-grade): its time and the largest colour difference between the two frames
-            # (same weights: build_scene is seeded)
-            m8, v8, _ = build_scene(cfg, device, args.precision, fine, args.stage)
-            fn8 = lambda k0, k1, r, path=None: m8.apply(v8, k0, k1, r, False, path=path)
-            U.render_image(fn8, fr, key, False, chunk=chunk)
+            rgb_img = None
+        if args.extra and args.stage == "radiance":
+            # the same frame in the other render arithmetic — f16f8 (opt-in since round 6) beside the default f16x3, or the training arithmetic
+            # beside an --eval-precision of the caller's: its time and the largest colour difference between the two frames (same weights:
+            # build_scene is seeded) — and the default frame at the reference's own chunk size (rnerf/utils.py:241-244: 8192 rays)
+            other = "f16f8" if args.eval_precision == args.precision == "f16x3" else (args.precision if args.eval_precision != args.precision else None)
+            if other is not None:
+                if rgb_img is None:
+                    rgb_img = U.render_image(fn, fr, key, False, chunk=chunk)[0]
+                m8, v8, _ = build_scene(cfg, device, args.precision, fine, args.stage, other)
+                fn8 = lambda k0, k1, r, path=None: m8.apply(v8, k0, k1, r, False, path=path)
+                U.render_image(fn8, fr, key, False, chunk=chunk)
+                barrier()
+                t1 = time.perf_counter()
+                rgb8, _, _ = U.render_image(fn8, fr, key, False, chunk=chunk)
+                barrier()
+                frame[other] = {"ms_per_frame": 1e3 * D.max_over_ranks(time.perf_counter() - t1, device),
+                                "max_abs_rgb_vs_the_frame_above": float((rgb8 - rgb_img).abs().max()), "finite": bool(torch.isfinite(rgb8).all()),
+                                "what": ("opt-in render arithmetic (f16 main term + fp8 cross terms): within 1e-4 RGB of the oracle on these glorot-initialised "
+                                         "weights, 2e-4 on trained-like ones — not the default" if other == "f16f8" else "the training arithmetic")}
+                del m8, v8, rgb8
+                torch.cuda.empty_cache()
+            U.render_image(fn, fr, key, False, chunk=8192)
             barrier()
             t1 = time.perf_counter()
-            rgb8, _, _ = U.render_image(fn8, fr, key, False, chunk=chunk)
+            U.render_image(fn, fr, key, False, chunk=8192)
             barrier()
-            frame[args.precision] = {"ms_per_frame": 1e3 * D.max_over_ranks(time.perf_counter() - t1, device),
-                                     "max_abs_rgb_vs_the_frame_above": float((rgb8 - rgb_img).abs().max()), "finite": bool(torch.isfinite(rgb8).all())}
-            del m8, v8, rgb8
-            torch.cuda.empty_cache()
+            frame["ms_per_frame_chunk8192"] = 1e3 * D.max_over_ranks(time.perf_counter() - t1, device)
     if rank == 0:
         total_rays = B * args.steps * world
         rows_per_ray = S + (S + fine if fine > 0 else 0)
@@ -995,7 +1071,7 @@ def main():
         }
         if train:
             # the dominant kernel of a train step: the longest of training forward / dgrad / wgrad (algorithmic FLOP against the MFMA peak)
-            fk = "nerfmlp_fwd_kernel<%d, 0, %d," % (_lib.PRECISIONS[args.precision], 2 if args.backward == "f16x3" else 1)      # (+ the tile-size argument)
+            fk = "nerfmlp_fwd_kernel<%d, 0, %d," % (_lib.PRECISIONS[args.precision], {"f16x3": 2, "f16x3lo8": 3}.get(args.backward, 1))      # (+ the tile-size argument)
             for tk, pref in zip(train_kernels, (fk, "nerfmlp_dgrad_kernel", "nerfmlp_wgrad")):
                 tk["traffic"] = traffic_of(pref)
                 tk["counters"] = counters_of(pref)

@@ -31,8 +31,11 @@ extern "C" {
 /* Version of this header: entry points AND struct layouts.  2 (round 5): rnerf_grid carries `layout` (so every later field of rnerf_model
  * moved), rnerf_train_cfg carries grads_stream / aux2_stream, rnerf_adam_cfg carries use_lr_override (lr_override alone is ignored).  A
  * consumer compares rnerf_version() with the RNERF_VERSION it was compiled against before the first call (the Python binding does:
- * samplenerfro_amd/_lib.py load()). */
-#define RNERF_VERSION 2
+ * samplenerfro_amd/_lib.py load()).
+ * 3 (round 6): everything that moved after the first version-2 header — rnerf_composite_backward takes `int mask_mode`, rnerf_adam_cfg carries
+ * skip_nonfinite, RNERF_ADAM_SCRATCH_FLOATS is 3076 (was 2052), every f16-based packed NerfMLP buffer ends with a bf16x3 range-safe
+ * stream (rnerf_nerfmlp_packed_bytes grew) — and this round's additions: enum rnerf_backward gains F16X3_LO8, rnerf_sample_batch. */
+#define RNERF_VERSION 3
 
 enum rnerf_status {
   RNERF_OK = 0,
@@ -53,6 +56,9 @@ enum rnerf_status {
  * oracle 2e-6.  Its operand stream scales the weights by 2^14: a NerfMLP weight of magnitude >= 3.99 raises a flag in rnerf_nerfmlp_pack, and
  * every rnerf_nerfmlp_forward launch then steps aside for the F16X3 launch queued behind it (the F16F8 packed buffer carries both streams):
  * a per-launch fallback decided on the device, F16X3's bits, no host round trip.  Own packed stream: pack with the precision you run.
+ * Round 6: a row with an operand of magnitude >= 448 (e4m3's largest value: fp8(x) of the W_lo cross term would be clamped) is given up like
+ * a row out of f16's range and recomputed by the range-safe second pass.  Accuracy depends on the weights: 2e-6 |dRGB| on glorot-initialised
+ * networks, 2e-4 with hidden kernels x 1.5 and N(0, 0.3) biases (outside the 1e-4 contract): an opt-in precision, not a default.
  * Range of the f16-based modes.  The forward watches the largest f16 operand it forms per row; a weight of magnitude >= 256 (2^8-scaled
  * streams) or a hidden activation above f16's 65504 makes the first pass give the row up (NaN), never return a plausible wrong colour.
  * EVALUATION (rnerf_nerfmlp_forward with F16X3 / F16X2 / F16F8 / F16, hence rnerf_forward): every launch is followed on the device by a range-safe
@@ -78,12 +84,19 @@ enum rnerf_precision {
  *           the normalised values fit f16's range whatever the loss scale); f16 operands (11-bit significand, the class of the TF32
  *           tensor-core arithmetic XLA uses for fp32 matmuls on the authors' Ampere GPU): 1 MFMA per product, same HBM traffic as BF16.
  *   F16X3 : as F16 with hi + lo parts of the saved activations and of every gradient (22 bits), 3 MFMAs per product: fp32-grade
- *           (<= 1e-5 of the largest gradient entry against float64); twice the saved bytes. */
+ *           (<= 1e-5 of the largest gradient entry against float64); twice the saved bytes.
+ *   F16X3_LO8 (round 6): F16X3 with the lo plane of every saved activation and of every gradient STORED as one e4m3 byte per value
+ *           (scaled by a fixed power of two, clamped instead of overflowing) and decoded back to f16 inside the wgrad: the same three f16
+ *           MFMAs per product with the exact f16 hi parts in both cross terms, three quarters of the bytes of every operand stream of
+ *           the step (hi 2 B + lo 1 B per value).  The dgrad chain itself runs on the full hi + lo f16 parts (registers); only what the
+ *           wgrad reads is 8-bit.  An 11 + 4 bit significand per operand: measured gradient error vs float64 in DESIGN.md §3.3.
+ *           Buffer sizes are those of F16X3 (the lo planes use half of their region). */
 enum rnerf_backward {
   RNERF_BWD_BF16 = 0,
   RNERF_BWD_F16 = 1,
   RNERF_BWD_F16X3 = 2,   /* hi + lo f16 planes, 3 MFMAs per product */
-  RNERF_BWD_F16X2 = 2    /* the name of versions <= 1 (two planes); same value */
+  RNERF_BWD_F16X2 = 2,   /* the name of versions <= 1 (two planes); same value */
+  RNERF_BWD_F16X3_LO8 = 4   /* hi f16 plane + lo e4m3 plane (3 is an internal dgrad variant) */
 };
 
 /* Voxel grid geometry: reference VoxMLP.ndim/nmin/nmax (rnerf/ior_utils.py:124-144).  Doubles, because the
@@ -247,6 +260,20 @@ int rnerf_march_all(const float* table, const rnerf_grid* g, const float* so3_pa
  * origins / directions (nullable) / viewdirs: device float[rows][W][3]. */
 int rnerf_generate_rays(const float* camtoworld, int32_t opencv, double fx, double fy, double cx, double cy, double pixel_center,
                         int32_t W, int32_t row0, int32_t rows, float* origins, float* directions, float* viewdirs, void* stream);
+
+/* ---- the gather half of Dataset._next_train (rnerf/datasets.py:151-176: `batch_pixels = self.images[...][ray_indices]`,
+ * `batch_rays = namedtuple_map(lambda r: r[...][ray_indices], self.rays)`; :178-197 for the env-map patch) on the device.  The training
+ * views stay resident: camtoworlds DEVICE float[n_img][3][4], images DEVICE float[n_img][H][W][channels] (nullable together with
+ * `pixels`: rays only, the env-map patch).  ray_indices: DEVICE int64[B], flat `image * H * W + row * W + column` — "all_images" batching
+ * indexes the concatenation of all views exactly like that (datasets.py:131-136), "single_image" adds image_index * H * W on the host.  The
+ * rays of the drawn pixels are generated on the fly by the arithmetic of rnerf_generate_rays (same camera arguments: bit-identical to
+ * indexing the reference's ray arrays); no ray array is ever stored.  bad_count: DEVICE int32, incremented for every index outside
+ * [0, n_img * H * W) (such a ray reads pixel 0; the caller zeroes and checks the counter).  origins / directions (nullable) / viewdirs:
+ * float[B][3]; pixels: float[B][channels].  The index DRAW stays the caller's (the reference draws with numpy's global generator,
+ * datasets.py:154-169: a host sequence this library does not restate). */
+int rnerf_sample_batch(const float* camtoworlds, int32_t n_img, int32_t opencv, double fx, double fy, double cx, double cy, double pixel_center,
+                       int32_t W, int32_t H, const float* images, int32_t channels, const int64_t* ray_indices, int32_t B, float* origins,
+                       float* directions, float* viewdirs, float* pixels, int32_t* bad_count, void* stream);
 
 /* ---- mip-style integrated positional encoding along the curved ray.  Replaces mip.cast_rays(t_vals, ray_pos_c, ray_dir_c,
  * rays.radii, "cone", near) + mip.integrated_pos_enc(samples, min_deg, max_deg) (rnerf/mip.py:26-57,60-91,116-175) as the commented call sites

@@ -17,11 +17,13 @@ PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3, "bf16x3": PREC_BF16X3, "f16"
 # differentiates in fp32, train.py:164); "f16" = single f16 parts (11-bit significand); "bf16" = 8-bit significand.
 BWD_BF16, BWD_F16, BWD_F16X2 = 0, 1, 2
 BWD_F16X3 = BWD_F16X2
+BWD_F16X3_LO8 = 4        # f16x3 with the lo planes of the saved operands / gradients stored as e4m3 bytes (decoded to f16 in the wgrad): 3/4 of the bytes
 # named for what they compute in (gfx950 has neither an fp32 nor a TF32 matrix path worth the name): "f16x3" = hi + lo f16 planes, 3 MFMAs per
 # product; "f16" = one f16 plane; "bf16".  "f32" / "tf32" are the names of rounds 2-4, kept as aliases.
-BACKWARDS = {"f16x3": BWD_F16X3, "f16": BWD_F16, "bf16": BWD_BF16, "f32": BWD_F16X3, "tf32": BWD_F16}
-BACKWARD_NAMES = {BWD_F16X3: "f16x3", BWD_F16: "f16", BWD_BF16: "bf16"}
-ABI_VERSION = 2          # == RNERF_VERSION of include/rnerf.h; load() refuses a library that answers anything else
+BACKWARDS = {"f16x3": BWD_F16X3, "f16x3lo8": BWD_F16X3_LO8, "f16": BWD_F16, "bf16": BWD_BF16, "f32": BWD_F16X3, "tf32": BWD_F16}
+BACKWARD_NAMES = {BWD_F16X3: "f16x3", BWD_F16X3_LO8: "f16x3lo8", BWD_F16: "f16", BWD_BF16: "bf16"}
+TWO_PLANE_BACKWARDS = (BWD_F16X3, BWD_F16X3_LO8)
+ABI_VERSION = 3          # == RNERF_VERSION of include/rnerf.h; load() refuses a library that answers anything else
 NERFMLP_PARAMS = 595844
 BKGDMLP_PARAMS = 56963
 SO3MLP_PARAMS = 65411
@@ -120,6 +122,7 @@ SIGNATURES = {
     "rnerf_so3_query": (C.c_int, [_vp, _GP, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "rnerf_march_all": (C.c_int, [_vp, _GP, _vp, _vp, _vp, _vp, _vp, _i32, _dbl, _dbl, _i32, _vp, _vp, _vp, _vp, _vp]),
     "rnerf_generate_rays": (C.c_int, [_vp, _i32, _dbl, _dbl, _dbl, _dbl, _dbl, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "rnerf_sample_batch": (C.c_int, [_vp, _i32, _i32, _dbl, _dbl, _dbl, _dbl, _dbl, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rnerf_stratified_u": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
     "rnerf_bkgd_save_bytes": (C.c_size_t, [_i64]),
     "rnerf_bkgd_dy_bytes": (C.c_size_t, [_i64]),

@@ -182,6 +182,8 @@ def params_to_state_dict(variables: Dict[str, Any], step: int = 0, train_state=N
     opt_state follows optax.multi_transform over the four transforms of train.py:312-316 with the stage's labels (:286-310): the
     trained groups carry (ScaleByAdamState(count, mu, nu), ScaleByScheduleState(count)), the rest MaskedNode / EmptyState.  Without a
     train_state the moments are zeros and count = step (a weights-only export that still restores)."""
+    if train_state is not None and getattr(train_state, "_lag_pending", None):
+        train_state.state_dict()      # settles the steps range_retry="lag" still holds (re-runs a skipped batch), or raises: never a silent loss
     params = _np_tree(variables["params"])
     trained = {"radiance": {"coarse_mlp", "fine_mlp", "bkgd_mlp"}, "ior": {"path_sampler"},
                "all": {"coarse_mlp", "fine_mlp", "bkgd_mlp", "path_sampler"}}["radiance" if stage.startswith("radiance") else

@@ -129,6 +129,45 @@ __device__ __forceinline__ uint4 f8x_lo_part(const float (&x)[8], const uint32_t
   return make_uint4(o[0], o[1], o[2], o[3]);
 }
 
+// ---- 8-bit lo planes of the training tensors (backward mode RNERF_BWD_F16X3_LO8) ------------------------------------------------------
+// The lo part of an operand (x - f16(x): at most half an ulp of the hi part) is STORED as e4m3 of lo / scale and decoded back to f16 by the
+// wgrad (v_cvt_scalef32_pk_f16_fp8 multiplies by the same scale operand; probed: tools/ubench/tr8_cvt_probe.hip): hi 2 B + lo 1 B per
+// value.  Fixed power-of-two scales: saved activations 2^-13 (full 3-bit lo significand for 0.004 <= |x| < 128, absolute resolution
+// 2^-22 below, the lo part clamped — f16-hi precision — above), gradients 2^-14 (rows are normalised to 32 <= max |d raw| < 64: full
+// precision for 2^-7 <= |dY| < 64).  Overflow: v_cvt_scalef32_pk_fp8_f16 returns NaN above 448 unless MODE.FP16_OVFL is set — the training
+// forward sets it (its range watch then takes f16's clamp value as "left the range", like f16f8), the dgrad clamps the f16 lo parts first
+// (its f16 overflow must stay inf: that is how a gradient chain that left its headroom shows).
+constexpr float LO8_SCALE_X = 1.0f / 8192.f, LO8_SCALE_D = 1.0f / 16384.f;
+template <bool HI>
+__device__ __forceinline__ uint32_t lo8_pair(uint32_t old, uint32_t f16x2, float scale) {      // ORDER CONTRACT of f8_pair: low half first
+  uint32_t r = old;
+  if constexpr (HI) asm("v_cvt_scalef32_pk_fp8_f16 %0, %1, %2 op_sel:[0,0,1]" : "+v"(r) : "v"(f16x2), "v"(scale));
+  else asm("v_cvt_scalef32_pk_fp8_f16 %0, %1, %2" : "=v"(r) : "v"(f16x2), "v"(scale));
+  return r;
+}
+template <bool CLAMP>
+__device__ __forceinline__ uint2 lo8_pack(const uint4& lo, float scale) {
+  uint32_t w[4] = {lo.x, lo.y, lo.z, lo.w};
+  if constexpr (CLAMP) {      // |lo| <= 448 scale as packed f16 (448 * 2^-14 = 0.02734375 = 0x2700)
+    static_assert(LO8_SCALE_D == 1.0f / 16384.f, "clamp constant");
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      asm("v_pk_min_f16 %0, %0, %1" : "+v"(w[p]) : "v"(0x27002700u));
+      asm("v_pk_max_f16 %0, %0, %1" : "+v"(w[p]) : "v"(0xA700A700u));
+    }
+  }
+  uint2 o;
+  o.x = lo8_pair<true>(lo8_pair<false>(0u, w[0], scale), w[1], scale);
+  o.y = lo8_pair<true>(lo8_pair<false>(0u, w[2], scale), w[3], scale);
+  return o;
+}
+typedef int int2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ half8 lo8_decode(const int2v v, float scale) {      // 8 e4m3 bytes -> 8 f16 (x scale)
+  const half2v a = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8((unsigned)v.x, scale, false), b = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8((unsigned)v.x, scale, true);
+  const half2v c = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8((unsigned)v.y, scale, false), d = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8((unsigned)v.y, scale, true);
+  return half8{a[0], a[1], b[0], b[1], c[0], c[1], d[0], d[1]};
+}
+
 
 // input feature (row of the Dense kernel) for MFMA layer l, k-step s, half h, slot j; -1 = zero padding
 __host__ __device__ constexpr int in_feature(int l, int s, int h, int j) {
@@ -290,6 +329,15 @@ __device__ __forceinline__ uint4 stream_load(const uint4* p) {
   return make_uint4(t.x, t.y, t.z, t.w);
 }
 #endif
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void stream_store8(uint2* p, const uint2 v) {
+#ifdef RNERF_NO_NT
+  *p = v;
+#else
+  u32x2_t t = {v.x, v.y};
+  __builtin_nontemporal_store(t, (u32x2_t*)p);
+#endif
+}
 
 template <int PREC>
 __device__ __forceinline__ void split8(const float (&x)[8], uint4& hi, uint4& lo) {
@@ -636,7 +684,8 @@ __device__ __forceinline__ uint32_t nz_nibbles(const uint4& o) {
 }
 __device__ __forceinline__ uint32_t nz_byte(uint32_t nib) { return (nib & 0xFu) | (nib >> 12); }   // even flags | odd flags << 4
 
-// TRAIN: 0 = evaluation, 1 = training forward keeping the hi 16-bit operand parts, 2 = hi and lo parts (fp32-grade backward)
+// TRAIN: 0 = evaluation, 1 = training forward keeping the hi 16-bit operand parts, 2 = hi and lo parts (fp32-grade backward),
+// 3 = hi parts + the lo parts as e4m3 bytes (RNERF_BWD_F16X3_LO8: lo8 plane = uint2[...] at the lo plane's place, same (tile, slot, row, half) order)
 template <int PREC, int dbg, int TRAIN, bool ONE = false>
 __global__ void __launch_bounds__(256, 1)
 nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ rows_pd, const float4* __restrict__ rows_dr,
@@ -660,7 +709,8 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
   constexpr int SLAB = PP::SLAB;
   constexpr int WROWS = ONE ? 32 : 64, TROWS = 4 * WROWS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  if constexpr (PP::F8X) f8x_mode();
+  constexpr bool OVFL_MODE = PP::F8X || TRAIN == 3;      // fp8 conversions clamp; f16 overflow clamps to 65504 too (see `watch`)
+  if constexpr (OVFL_MODE) f8x_mode();
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = lane & 31, h = lane >> 5;
@@ -757,6 +807,11 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
           uint4* dl = dst + sv_lo0(save_rows);
           stream_store(dl, o.l0);
           if constexpr (!ONE) stream_store(dl + (size_t)SAVE_SLOTS * 64, o.l1);
+        }
+        if constexpr (TRAIN == 3) {            // lo plane as e4m3 bytes: 8 B per (row, half)
+          uint2* dl = (uint2*)(save + sv_lo0(save_rows)) + sv_addr(q, t32_0, m, h);
+          stream_store8(dl, lo8_pack<false>(o.l0, LO8_SCALE_X));
+          if constexpr (!ONE) stream_store8(dl + (size_t)SAVE_SLOTS * 64, lo8_pack<false>(o.l1, LO8_SCALE_X));
         }
 #endif
       }
@@ -1069,7 +1124,7 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
             float a0[8], a1[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) { a0[j] = rv0[8 * half + j]; a1[j] = rv1[8 * half + j]; }
-            if constexpr (TRAIN == 2) { split8<PREC>(a0, o.h0, o.l0); split8<PREC>(a1, o.h1, o.l1); }
+            if constexpr (TRAIN >= 2) { split8<PREC>(a0, o.h0, o.l0); split8<PREC>(a1, o.h1, o.l1); }
             else {
               o.h0 = make_uint4(pack2<PP::F16>(a0[0], a0[1]), pack2<PP::F16>(a0[2], a0[3]), pack2<PP::F16>(a0[4], a0[5]), pack2<PP::F16>(a0[6], a0[7]));
               o.h1 = make_uint4(pack2<PP::F16>(a1[0], a1[1]), pack2<PP::F16>(a1[2], a1[3]), pack2<PP::F16>(a1[4], a1[5]), pack2<PP::F16>(a1[6], a1[7]));
@@ -1095,7 +1150,10 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
         // f16f8 runs with MODE.FP16_OVFL (f8x_mode: the fp8 conversions must clamp) — and that bit also makes every f16 conversion clamp an
         // overflow to 65504 (0x7BFF) instead of producing inf: the watch has to take the clamp value itself as "left the range" there (found
         // in round 5 by the second-pass test: hidden activations of 3e5 rendered finite, wrong colours in the default eval precision)
-        constexpr uint32_t OVF = PP::F8X ? 0x7BFFu : (PP::F16 ? 0x7C00u : 0x7F80u);
+        // f16f8 also feeds fp8(x) into its W_lo cross term: an activation beyond e4m3's 448 is clamped there (a silent 2^-12 relative error per
+        // product that compounds over the layers — measured 1e-2 RGB on hidden kernels x 4, round 6): the watch hands every row with an
+        // operand >= 448 (0x5F00) to the range-safe second pass as well
+        constexpr uint32_t OVF = PP::F8X ? 0x5F00u : (OVFL_MODE ? 0x7BFFu : (PP::F16 ? 0x7C00u : 0x7F80u));
         if ((ovf0 & 0xFFFFu) >= OVF || (ovf0 >> 16) >= OVF) { p0[0] = p0[1] = p0[2] = qn; sig0 = qn; }
         if ((ovf1 & 0xFFFFu) >= OVF || (ovf1 >> 16) >= OVF) { p1[0] = p1[1] = p1[2] = qn; sig1 = qn; }
       }
@@ -1243,9 +1301,10 @@ struct GradConv {
 // the wgrad multiplies the saved activations by m_row / m_ref again (m_ref = max m_row, collected with an atomic).
 template <int BWD> struct Bwd {
   static constexpr bool F16 = BWD != RNERF_BWD_BF16;
-  static constexpr int NP = BWD == RNERF_BWD_F16X2 ? 2 : 1;                               // 16-bit parts stored per gradient / consumed per activation
+  static constexpr bool LO8 = BWD == RNERF_BWD_F16X3_LO8;                                 // the lo plane is stored as e4m3 bytes (lo8_pack)
+  static constexpr int NP = (BWD == RNERF_BWD_F16X2 || LO8) ? 2 : 1;                      // parts stored per gradient / consumed per activation
   static constexpr int PREC = F16 ? RNERF_PREC_F16X3 : RNERF_PREC_BF16X3;                 // operand type + weight split of the dgrad MFMAs
-  static constexpr int PASSES = BWD == RNERF_BWD_F16X2 ? 3 : (BWD == RNERF_BWD_F16 ? 22 : (BWD == kBwdF16OnePass ? 1 : DGRAD_PASSES));
+  static constexpr int PASSES = (BWD == RNERF_BWD_F16X2 || LO8) ? 3 : (BWD == RNERF_BWD_F16 ? 22 : (BWD == kBwdF16OnePass ? 1 : DGRAD_PASSES));
   static constexpr bool NEED_LO = PASSES != 22 && PASSES != 1;
 };
 // dy buffer: uint4[DY_SLOTS * NP][R][2] operand planes (hi, then lo), then float row_scale[R] and uint32 m_ref bits (F16 modes)
@@ -1323,7 +1382,11 @@ nerfmlp_dgrad_kernel(const char* __restrict__ packed_bwd, const float* __restric
       uint4* dst = dy + dy_addr(q, t32_0, m, h);
       stream_store(dst, o.h0);
       if constexpr (!ONE) stream_store(dst + (size_t)DY_SLOTS * 64, o.h1);
-      if constexpr (BW::NP == 2) {
+      if constexpr (BW::LO8) {
+        uint2* dl = (uint2*)(dy + dy_plane_uint4(save_rows, 1)) + dy_addr(q, t32_0, m, h);
+        stream_store8(dl, lo8_pack<true>(o.l0, LO8_SCALE_D));
+        if constexpr (!ONE) stream_store8(dl + (size_t)DY_SLOTS * 64, lo8_pack<true>(o.l1, LO8_SCALE_D));
+      } else if constexpr (BW::NP == 2) {
         uint4* dl = dst + dy_plane_uint4(save_rows, 1);
         stream_store(dl, o.l0);
         if constexpr (!ONE) stream_store(dl + (size_t)DY_SLOTS * 64, o.l1);
@@ -1916,6 +1979,228 @@ __device__ __forceinline__ void wgrad_body_tr(const uint4* __restrict__ saved, c
   }
 }
 
+// ---- the same body for RNERF_BWD_F16X3_LO8: f16 hi planes as above, the lo planes as e4m3 bytes -------------------------------------------
+// A lo tile of a 16-row step is 512 B in LDS, [row r][slot parity a][16 B = half 0 | half 1]; ONE DMA instruction builds TWO of them (lane
+// L: tile L >> 5, row (L & 31) >> 1, parity L & 1 — 16 B = both halves of (slot, row), contiguous in the lo8 plane).  The 8-bit transpose
+// read ds_read_b64_tr_b8 (within a 16-lane group destination lane i, byte j receives byte i & 7 of the 8 bytes addressed by source lane
+// 2 j + (i >> 3): tools/ubench/tr8_cvt_probe.hip) hands lane (m = 16 a + i, kh) the 8 rows 8 kh .. 8 kh + 7 of feature position m in ONE
+// read; four v_cvt_scalef32_pk_f16_fp8 turn them into the f16 lo fragment, and the three f16 MFMAs per product are those of the f16 lo
+// planes — with the exact f16 hi parts in both cross terms.  Per step: (KT + NT) KiB of hi + (KT + NT) / 2 KiB of lo blocks.
+template <int KT, int NT> struct WgTr8 {
+  static constexpr int NHI = KT + NT, NLX = (KT + 1) / 2, NLD = (NT + 1) / 2;
+  static constexpr int NBLK = NHI + NLX + NLD, NDMA = (NBLK + 7) / 8, STEP_BYTES = (NBLK + 1) * 1024;
+  static constexpr int LOX = NHI * 1024, LOD = (NHI + NLX) * 1024, SCALES = NBLK * 1024;
+};
+#ifndef RNERF_WGTR8_NBUF
+#define RNERF_WGTR8_NBUF 4
+#endif
+constexpr int wgtr8_lds_bytes() { return RNERF_WGTR8_NBUF * WgTr8<10, 8>::STEP_BYTES; }      // largest job: 10 k-tiles + 8 n-tiles
+#if defined(RNERF_WGTR_ABL) && (RNERF_WGTR_ABL & 2)
+__device__ __forceinline__ int2v tr_read8b(const char* p) { const int v = (int)((size_t)p & 7); return int2v{v, v}; }
+#else
+__device__ __forceinline__ int2v tr_read8b(const char* p) {
+  typedef __attribute__((address_space(3))) int2v lds_int2;
+  return __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_int2*)p);
+}
+#endif
+
+template <int KT, int NT>
+__device__ __forceinline__ void wgrad_body_tr8(const uint4* __restrict__ saved, const uint4* __restrict__ dy, long long R, float* __restrict__ pg,
+                                                float* __restrict__ pbias, const WgTrSegs sg, int g, int G, char* smem) {
+  using SH = WgTrShape<KT, NT>;
+  using L8 = WgTr8<KT, NT>;
+  constexpr int TK = SH::TK, TN = SH::TN;
+  constexpr int NHI = L8::NHI, NBLK = L8::NBLK, NDMA = L8::NDMA, STEP_BYTES = L8::STEP_BYTES;
+  constexpr int WGTR_NBUF = RNERF_WGTR8_NBUF, AHEAD = WGTR_NBUF - 1;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wk = wave / SH::WN, wn = wave % SH::WN;
+  const bool active = wave < SH::WK * SH::WN;
+  const float* __restrict__ rs = (const float*)(dy + dy_plane_uint4(R, 2));
+  const float mref = rs[R];
+  const float inv_mref = mref > 0.f ? 1.0f / mref : 0.f;
+  // slot pair of X tile t / dY tile nt (see wgrad_body_tr)
+  auto x_slots = [&](int t, int& s0, int& s1) { s0 = t < sg.KTa ? sg.qx + 2 * t : sg.qx2 + 2 * (t - sg.KTa); s1 = s0 + 1; };
+  auto d_slots = [&](int nt, int& s0, int& s1) {
+    const int rel = nt < sg.NTa ? 2 * nt : 2 * (nt - sg.NTa);
+    const int qb = nt < sg.NTa ? sg.qd : sg.qd2, ks = nt < sg.NTa ? sg.KSd : sg.KSd2;
+    s0 = qb + (rel < ks ? rel : ks - 1);
+    s1 = qb + (rel + 1 < ks ? rel + 1 : ks - 1);
+  };
+  const char* sbase[NDMA];
+  unsigned tstride[NDMA], hstride[NDMA], voff[NDMA], lds_blk[NDMA];
+#pragma unroll
+  for (int i = 0; i < NDMA; ++i) {
+    int b = wave + 8 * i;
+    b = b < NBLK ? b : NBLK - 1;
+    lds_blk[i] = (unsigned)b * 1024u;
+    if (b < NHI) {                      // f16 hi block of tile b: lane = 4 r + 2 a + h, 16 B = (slot a, row r, half h)
+      const int r = lane >> 2, a = (lane >> 1) & 1, h = lane & 1;
+      int s0, s1;
+      const bool is_x = b < KT;
+      if (is_x) x_slots(b, s0, s1); else d_slots(b - KT, s0, s1);
+      sbase[i] = (const char*)((is_x ? saved : dy) + sv_addr(__builtin_amdgcn_readfirstlane(s0), 0, 0, 0));
+      voff[i] = (unsigned)((sv_addr(a ? __builtin_amdgcn_readfirstlane(s1 - s0) : 0, 0, r, h)) * sizeof(uint4));
+      tstride[i] = (unsigned)((is_x ? SAVE_SLOTS : DY_SLOTS) * 64 * sizeof(uint4));
+      hstride[i] = (unsigned)(32 * sizeof(uint4));
+    } else {                            // e4m3 lo block: two tiles, lane = 32 (tile parity) + 2 r + a, 16 B = (slot a, row r, both halves)
+      const int lb = b - NHI;
+      const bool is_x = lb < L8::NLX;
+      const int t0 = 2 * (is_x ? lb : lb - L8::NLX) + (lane >> 5);
+      const int r = (lane & 31) >> 1, a = lane & 1;
+      int s0, s1;
+      if (is_x) x_slots(t0 < KT ? t0 : KT - 1, s0, s1); else d_slots(t0 < NT ? t0 : NT - 1, s0, s1);
+      sbase[i] = is_x ? (const char*)(saved + sv_lo0(R)) : (const char*)(dy + dy_plane_uint4(R, 1));
+      voff[i] = (unsigned)(((a ? s1 : s0) * 32 + r) * 16);
+      tstride[i] = (unsigned)((is_x ? SAVE_SLOTS : DY_SLOTS) * 32 * 16);
+      hstride[i] = 16u * 16u;
+    }
+  }
+  const float* rs_src = rs + 4 * (lane & 3);
+  const long long n_t32 = R / 32;
+  const int my_tiles = g < n_t32 ? (int)((n_t32 - 1 - g) / G) + 1 : 0;
+  const int n_steps = 2 * my_tiles;
+  auto issue = [&](int s) {
+    const int sc = s < n_steps ? s : n_steps - 1;
+    const size_t t32 = (size_t)g + (size_t)(sc >> 1) * G;
+    const unsigned ring = (unsigned)(s % WGTR_NBUF) * STEP_BYTES;
+#pragma unroll
+    for (int i = 0; i < NDMA; ++i)
+      glds16_nt_s(sbase[i] + t32 * tstride[i] + (sc & 1) * hstride[i], voff[i], __builtin_amdgcn_readfirstlane(ring + lds_blk[i]));
+    if (wave == 0) glds16_nt((const char*)(rs_src + t32 * 32 + (sc & 1) * 16), __builtin_amdgcn_readfirstlane(ring + L8::SCALES));
+  };
+  const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  f32x16 acc[TK][TN], acce = zero;
+  float accb = 0.f;
+#pragma unroll
+  for (int i = 0; i < TK; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = zero;
+  if (n_steps > 0) {
+#pragma unroll
+    for (int s = 0; s < AHEAD; ++s) issue(s);
+    const unsigned lane_off = (unsigned)((8 * (lane >> 5) + ((lane & 15) >> 2)) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8);
+    // lo tile: row (8 kh + (i >> 1)) * 32 + slot parity a * 16 + (i & 1) * 8, i = lane & 15
+    const unsigned lane_off8 = (unsigned)((8 * (lane >> 5) + ((lane & 15) >> 1)) * 32 + ((lane >> 4) & 1) * 16 + (lane & 1) * 8);
+    const int kh = lane >> 5;
+    for (int s = 0; s < n_steps; ++s) {
+      if (wave == 0) wait_vmcnt<(AHEAD - 1) * (NDMA + 1)>(); else
+      wait_vmcnt<(AHEAD - 1) * NDMA>();
+      __syncthreads();
+      issue(s + AHEAD);
+      if (active) {
+        const char* ring0 = smem + (s % WGTR_NBUF) * STEP_BYTES;
+        const char* ring = ring0 + lane_off;
+        const char* ring8 = ring0 + lane_off8;
+        const float4 s0 = *(const float4*)(ring0 + L8::SCALES + kh * 32), s1 = *(const float4*)(ring0 + L8::SCALES + kh * 32 + 16);
+        const half8 sc8 = {(_Float16)(s0.x * inv_mref), (_Float16)(s0.y * inv_mref), (_Float16)(s0.z * inv_mref), (_Float16)(s0.w * inv_mref),
+                           (_Float16)(s1.x * inv_mref), (_Float16)(s1.y * inv_mref), (_Float16)(s1.z * inv_mref), (_Float16)(s1.w * inv_mref)};
+        half8 beh, bel;
+        if constexpr (SH::EXTRA) {
+          beh = tr_read8(ring + (KT + NT - 1) * 1024);
+          bel = lo8_decode(tr_read8b(ring8 + L8::LOD + (NT - 1) * 512), LO8_SCALE_D);
+        }
+        static_assert(SH::WK >= TN, "bias owners");
+        auto read_a = [&](int i, half8& h, half8& l) {
+          const int t = wk * TK + i;
+          h = tr_read8(ring + t * 1024) * sc8;
+          l = lo8_decode(tr_read8b(ring8 + L8::LOX + t * 512), LO8_SCALE_X) * sc8;
+        };
+        auto read_b = [&](int j, half8& h, half8& l) {
+          const int nt = wn * TN + j;
+          h = tr_read8(ring + (KT + nt) * 1024);
+          l = lo8_decode(tr_read8b(ring8 + L8::LOD + nt * 512), LO8_SCALE_D);
+        };
+        auto dot8 = [&](const half8& x, float c) -> float {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) c = __builtin_amdgcn_fdot2(half2v{sc8[2 * k], sc8[2 * k + 1]}, half2v{x[2 * k], x[2 * k + 1]}, c, false);
+          return c;
+        };
+        auto bias_row = [&](int j, const half8& h, const half8& l) {
+          if (wk == j) { accb = dot8(h, accb); accb = dot8(l, accb); }
+        };
+        half8 ae_h, ae_l;
+        if constexpr (TK > TN) {            // B resident, A streams
+          half8 bh[TN], bl[TN];
+#pragma unroll
+          for (int j = 0; j < TN; ++j) read_b(j, bh[j], bl[j]);
+          half8 an_h, an_l;
+          read_a(0, an_h, an_l);
+#pragma unroll
+          for (int i = 0; i < TK; ++i) {
+            const half8 ah = an_h, al = an_l;
+            if (i + 1 < TK) read_a(i + 1, an_h, an_l);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = mfma_h8(ah, bh[j], acc[i][j]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = mfma_h8(ah, bl[j], acc[i][j]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = mfma_h8(al, bh[j], acc[i][j]);
+          }
+#pragma unroll
+          for (int j = 0; j < TN; ++j) bias_row(j, bh[j], bl[j]);
+        } else {                            // A resident, B streams in chunks of NCH n-tiles
+          constexpr int NCH = RNERF_WGTR_NCH < TN ? RNERF_WGTR_NCH : TN;
+          static_assert(TN % NCH == 0, "n-tile chunks");
+          half8 ah[TK], al[TK];
+#pragma unroll
+          for (int i = 0; i < TK; ++i) read_a(i, ah[i], al[i]);
+#pragma unroll
+          for (int c = 0; c < TN / NCH; ++c) {
+            half8 bh[NCH], bl[NCH];
+#pragma unroll
+            for (int jj = 0; jj < NCH; ++jj) read_b(c * NCH + jj, bh[jj], bl[jj]);
+#pragma unroll
+            for (int i = 0; i < TK; ++i)
+#pragma unroll
+              for (int jj = 0; jj < NCH; ++jj) acc[i][c * NCH + jj] = mfma_h8(ah[i], bh[jj], acc[i][c * NCH + jj]);
+#pragma unroll
+            for (int i = 0; i < TK; ++i)
+#pragma unroll
+              for (int jj = 0; jj < NCH; ++jj) acc[i][c * NCH + jj] = mfma_h8(ah[i], bl[jj], acc[i][c * NCH + jj]);
+#pragma unroll
+            for (int i = 0; i < TK; ++i)
+#pragma unroll
+              for (int jj = 0; jj < NCH; ++jj) acc[i][c * NCH + jj] = mfma_h8(al[i], bh[jj], acc[i][c * NCH + jj]);
+#pragma unroll
+            for (int jj = 0; jj < NCH; ++jj) bias_row(c * NCH + jj, bh[jj], bl[jj]);
+          }
+          if constexpr (SH::EXTRA) { ae_h = wn ? ah[1] : ah[0]; ae_l = wn ? al[1] : al[0]; }
+        }
+        if constexpr (SH::EXTRA) {
+          static_assert(!SH::EXTRA || TK <= TN, "the extra tile reads the resident A fragments");
+          acce = mfma_h8(ae_h, beh, acce);
+          acce = mfma_h8(ae_h, bel, acce);
+          acce = mfma_h8(ae_l, beh, acce);
+        }
+      }
+    }
+    wait_vmcnt<0>();
+  }
+  constexpr size_t ldn = (size_t)NT * 32;
+  const int m = lane & 31, h = lane >> 5;
+  if (active) {
+#pragma unroll
+    for (int i = 0; i < TK; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+          pg[(size_t)((wk * TK + i) * 32 + row) * ldn + (wn * TN + j) * 32 + m] = acc[i][j][r];
+        }
+    if constexpr (SH::EXTRA) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        pg[(size_t)((wk * TK + wn) * 32 + row) * ldn + (NT - 1) * 32 + m] = acce[r];
+      }
+    }
+    const float bsum = accb + __shfl_xor(accb, 32);
+    if (wk < TN && h == 0) pbias[(wn * TN + wk) * 32 + m] = bsum;
+  }
+}
+
 // At most 224 VGPRs per wave: two of these waves per SIMD then leave 64 registers — one wave of the march kernel — on every SIMD, so
 // the next batch's march (a latency-bound chain that needs a wave slot on every CU, no LDS) can be co-resident with this HBM-paced kernel
 // instead of waiting for whole CUs to drain.
@@ -1942,6 +2227,30 @@ nerfmlp_wgrad_tr_kernel(const uint4* __restrict__ saved, const uint4* __restrict
 #define RNERF_WGRAD_CASE(KT_, NT_)                                                                                                  \
   if (KT == (KT_) && NT == (NT_)) {                                                                                                 \
     wgrad_body_tr<NP, KT_, NT_>(saved, dy, R, pg, pb, sg, g, G, smem);                                                              \
+    if (trace && threadIdx.x == 0) trace[2 * blockIdx.x + 1] = (long long)__builtin_amdgcn_s_memrealtime();                         \
+    return;                                                                                                                         \
+  }
+  RNERF_WGRAD_CASE(8, 8) RNERF_WGRAD_CASE(2, 8) RNERF_WGRAD_CASE(10, 8) RNERF_WGRAD_CASE(8, 9) RNERF_WGRAD_CASE(9, 4) RNERF_WGRAD_CASE(4, 1)
+#undef RNERF_WGRAD_CASE
+  __builtin_trap();
+}
+
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(RNERF_WGRAD_VGPRS)))
+nerfmlp_wgrad_tr8_kernel(const uint4* __restrict__ saved, const uint4* __restrict__ dy, long long R, float* __restrict__ workspace, const WgradTable tab,
+                         long long* __restrict__ trace) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (trace && threadIdx.x == 0) trace[2 * blockIdx.x] = (long long)__builtin_amdgcn_s_memrealtime();
+  int j = 0;
+  while ((int)blockIdx.x >= tab.wg0[j + 1]) ++j;
+  const WgradJob job = tab.job[j];
+  const int g = blockIdx.x - tab.wg0[j], G = tab.wg0[j + 1] - tab.wg0[j];
+  const int KT = job.KT, NT = job.NT;
+  float* pg = workspace + tab.poff[j] + (size_t)g * (size_t)KT * 32 * NT * 32;
+  float* pb = workspace + tab.pboff[j] + (size_t)g * NT * 32;
+  const WgTrSegs sg = {tab.qx[j], job.KTa, tab.qx2[j], tab.qd[j], job.NTa, tab.KSd[j], tab.qd2[j], tab.KSd2[j]};
+#define RNERF_WGRAD_CASE(KT_, NT_)                                                                                                  \
+  if (KT == (KT_) && NT == (NT_)) {                                                                                                 \
+    wgrad_body_tr8<KT_, NT_>(saved, dy, R, pg, pb, sg, g, G, smem);                                                                 \
     if (trace && threadIdx.x == 0) trace[2 * blockIdx.x + 1] = (long long)__builtin_amdgcn_s_memrealtime();                         \
     return;                                                                                                                         \
   }
@@ -3141,7 +3450,7 @@ static int launch_fwd_dbg(const void* packed, const float* rows_pd, const float*
   }
   int* tileq = nullptr;
   if (TRAIN != 0 && grid < cus && grid < n_tiles) {      // capped training forward: dynamic tile queue in the tail of the save buffer
-    tileq = (int*)((char*)save + save_payload_bytes((long long)n_tiles * 256, TRAIN == 2));
+    tileq = (int*)((char*)save + save_payload_bytes((long long)n_tiles * 256, TRAIN >= 2));
     RNERF_CHECK_HIP(hipMemsetAsync(tileq, 0, sizeof(int), st));
   }
   hipLaunchKernelGGL((nerfmlp_fwd_kernel<PREC, DBG, TRAIN>), dim3(grid), dim3(256), lds, st, (const char*)packed, (const float4*)rows_pd,
@@ -3188,10 +3497,11 @@ extern "C" int rnerf_nerfmlp_forward(const void* packed, int precision, const fl
   }
 }
 
-static bool bwd_ok(int b) { return b == RNERF_BWD_BF16 || b == RNERF_BWD_F16 || b == RNERF_BWD_F16X2; }
+static bool bwd_ok(int b) { return b == RNERF_BWD_BF16 || b == RNERF_BWD_F16 || b == RNERF_BWD_F16X2 || b == RNERF_BWD_F16X3_LO8; }
+static bool bwd_two_planes(int b) { return b == RNERF_BWD_F16X2 || b == RNERF_BWD_F16X3_LO8; }      // (LO8: the lo planes use half of their region)
 // (forward precision, backward mode) pairs the training kernels are built for
 static bool train_combo_ok(int precision, int backward) {
-  return precision == RNERF_PREC_F16X3 || (precision == RNERF_PREC_F16 && backward != RNERF_BWD_F16X2) ||
+  return precision == RNERF_PREC_F16X3 || (precision == RNERF_PREC_F16 && !bwd_two_planes(backward)) ||
          (precision == RNERF_PREC_BF16X3 && backward == RNERF_BWD_BF16);
 }
 static size_t train_stream_bytes(int precision) {      // the aux floats (biases, heads) sit behind the forward's operand stream
@@ -3200,7 +3510,7 @@ static size_t train_stream_bytes(int precision) {      // the aux floats (biases
 
 extern "C" size_t rnerf_nerfmlp_save_bytes(int64_t rows, int backward) {
   const int64_t padded = (rows + 255) / 256 * 256;
-  return save_payload_bytes(padded, backward == RNERF_BWD_F16X2) + SAVE_QUEUE_BYTES;
+  return save_payload_bytes(padded, bwd_two_planes(backward)) + SAVE_QUEUE_BYTES;
 }
 
 extern "C" int rnerf_nerfmlp_forward_train(const void* packed, int precision, const float* rows_pd, const float* rows_dr,
@@ -3226,6 +3536,7 @@ extern "C" int rnerf_nerfmlp_forward_train(const void* packed, int precision, co
     return launch_fwd_dbg<RNERF_PREC_F16X3, 256, 2>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, save, max_workgroups);
 #endif
   if (backward == RNERF_BWD_F16X2) return launch_fwd_dbg<RNERF_PREC_F16X3, 0, 2>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, save, max_workgroups);
+  if (backward == RNERF_BWD_F16X3_LO8) return launch_fwd_dbg<RNERF_PREC_F16X3, 0, 3>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, save, max_workgroups);
   if (precision == RNERF_PREC_BF16X3) return launch_fwd_dbg<RNERF_PREC_BF16X3, 0, 1>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, save, max_workgroups);
   if (precision == RNERF_PREC_F16) return launch_fwd_dbg<RNERF_PREC_F16, 0, 1>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, save, max_workgroups);
   return launch_fwd_dbg<RNERF_PREC_F16X3, 0, 1>(packed, rows_pd, rows_dr, node_of_sample, B, total, out_raw, st, save, max_workgroups);
@@ -3234,7 +3545,7 @@ extern "C" int rnerf_nerfmlp_forward_train(const void* packed, int precision, co
 extern "C" size_t rnerf_nerfmlp_bwd_packed_bytes(void) { return (size_t)kBwdBlocks * 2 * 1024; }
 extern "C" size_t rnerf_nerfmlp_dy_bytes(int64_t rows, int backward) {
   const int64_t padded = (rows + 255) / 256 * 256;
-  const int np = backward == RNERF_BWD_F16X2 ? 2 : 1;
+  const int np = bwd_two_planes(backward) ? 2 : 1;
   return dy_plane_uint4(padded, np) * sizeof(uint4) + (backward == RNERF_BWD_BF16 ? 0 : ((size_t)padded + 4) * sizeof(float));
 }
 
@@ -3254,7 +3565,7 @@ extern "C" int rnerf_nerfmlp_pack_bwd(const float* params, int backward, void* p
 // must be zero when the kernel starts: launch_dgrad zeroes it unless the caller already has (nerfmlp_step_zero)
 void* rnerf::nerfmlp_dgrad_scale_ref(int backward, void* dy, int64_t rows) {
   const long long R = (rows + 255) / 256 * 256;
-  if (backward == RNERF_BWD_F16X2) return (char*)dy + dy_plane_uint4(R, Bwd<RNERF_BWD_F16X2>::NP) * sizeof(uint4) + (size_t)R * sizeof(float);
+  if (bwd_two_planes(backward)) return (char*)dy + dy_plane_uint4(R, Bwd<RNERF_BWD_F16X2>::NP) * sizeof(uint4) + (size_t)R * sizeof(float);
   if (backward == RNERF_BWD_F16) return (char*)dy + dy_plane_uint4(R, Bwd<RNERF_BWD_F16>::NP) * sizeof(uint4) + (size_t)R * sizeof(float);
   return nullptr;
 }
@@ -3279,7 +3590,7 @@ static int launch_dgrad(const void* packed_bwd, const float* fwd_aux, const void
   // Few rows: 128-row tiles when they all fit one round (see launch_fwd_dbg) — unless the caller runs another level's dgrad beside this one
   // (allow_half = false): two kernels that each own whole CUs then share the chip, and with twice the workgroups of half the work the
   // step measures the same or slower (512 rays, levels side by side: 2.05 -> 2.09 ms; alone, a 256-ray single-level step: 1.17 -> 1.12 ms).
-  if constexpr (BWD == RNERF_BWD_F16X2 || BWD == RNERF_BWD_F16 || BWD == kBwdF16OnePass) {
+  if constexpr (BWD == RNERF_BWD_F16X2 || BWD == RNERF_BWD_F16 || BWD == kBwdF16OnePass || BWD == RNERF_BWD_F16X3_LO8) {
     static const int half_lim = [] { const char* e = RNERF_ENV("RNERF_DGRAD_HALF_TILES"); return e ? atoi(e) : -1; }();      // 0: off, n: at most n tiles
     if (allow_half && half_lim != 0 && 2 * n_tiles <= (half_lim > 1 ? half_lim : cus)) {
       const size_t lds1 = 2 * (size_t)PB::SLAB;
@@ -3311,6 +3622,7 @@ int nerfmlp_dgrad_impl(const void* packed_bwd, const void* packed_fwd, int fwd_p
   // the aux floats (biases, heads) sit behind the forward's operand stream, whose length depends on its precision
   const float* fwd_aux = (const float*)((const char*)packed_fwd + train_stream_bytes(fwd_precision));
   if (backward == RNERF_BWD_F16X2) return launch_dgrad<RNERF_BWD_F16X2>(packed_bwd, fwd_aux, save, d_raw, rows, dy, st, zero_ref, allow_half);
+  if (backward == RNERF_BWD_F16X3_LO8) return launch_dgrad<RNERF_BWD_F16X3_LO8>(packed_bwd, fwd_aux, save, d_raw, rows, dy, st, zero_ref, allow_half);
   if (backward == RNERF_BWD_F16 && fwd_precision == RNERF_PREC_F16) return launch_dgrad<kBwdF16OnePass>(packed_bwd, fwd_aux, save, d_raw, rows, dy, st, zero_ref, allow_half);
   if (backward == RNERF_BWD_F16) return launch_dgrad<RNERF_BWD_F16>(packed_bwd, fwd_aux, save, d_raw, rows, dy, st, zero_ref, allow_half);
   return launch_dgrad<RNERF_BWD_BF16>(packed_bwd, fwd_aux, save, d_raw, rows, dy, st, zero_ref, allow_half);
@@ -3430,6 +3742,7 @@ extern "C" int rnerf_nerfmlp_wgrad(int fwd_precision, int backward, const void* 
     RNERF_CHECK_HIP(hipFuncSetAttribute((const void*)nerfmlp_wgrad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
     RNERF_CHECK_HIP(hipFuncSetAttribute((const void*)nerfmlp_wgrad_tr_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, wgtr_lds_bytes<1>()));
     RNERF_CHECK_HIP(hipFuncSetAttribute((const void*)nerfmlp_wgrad_tr_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, wgtr_lds_bytes<2>()));
+    RNERF_CHECK_HIP(hipFuncSetAttribute((const void*)nerfmlp_wgrad_tr8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, wgtr8_lds_bytes()));
     ready.set();
   }
   const long long R = (rows + 255) / 256 * 256;
@@ -3451,6 +3764,10 @@ extern "C" int rnerf_nerfmlp_wgrad(int fwd_precision, int backward, const void* 
     hipLaunchKernelGGL(nerfmlp_wgrad_tr_kernel<1>, dim3(tab.wg0[tab.n]), dim3(512), wgtr_lds_bytes<1>(), st, (const uint4*)save, (const uint4*)dy, R,
                        (float*)workspace, tab, trace);
     out_scale = (const float*)((const uint4*)dy + dy_plane_uint4(R, 1)) + R;
+  } else if (backward == RNERF_BWD_F16X3_LO8) {
+    hipLaunchKernelGGL(nerfmlp_wgrad_tr8_kernel, dim3(tab.wg0[tab.n]), dim3(512), wgtr8_lds_bytes(), st, (const uint4*)save, (const uint4*)dy, R,
+                       (float*)workspace, tab, trace);
+    out_scale = (const float*)((const uint4*)dy + dy_plane_uint4(R, 2)) + R;
   } else {
     hipLaunchKernelGGL(nerfmlp_wgrad_tr_kernel<2>, dim3(tab.wg0[tab.n]), dim3(512), wgtr_lds_bytes<2>(), st, (const uint4*)save, (const uint4*)dy, R,
                        (float*)workspace, tab, trace);

@@ -547,7 +547,7 @@ extern "C" int rnerf_train_forward_backward(const rnerf_model* m, const rnerf_tr
                   "rnerf_train_forward_backward: give keys4, or the jitter (and the stratified draws) explicitly");
   RNERF_CHECK_ARG((path_pd == nullptr) == (path_dr == nullptr), "rnerf_train_forward_backward: give both path_pd and path_dr or neither");
   RNERF_CHECK_ARG(path_pd || (origins && viewdirs), "rnerf_train_forward_backward: origins / viewdirs are null and no marched path was given");
-  RNERF_CHECK_ARG(m->precision == RNERF_PREC_F16X3 || (m->precision == RNERF_PREC_F16 && c->backward != RNERF_BWD_F16X3) ||
+  RNERF_CHECK_ARG(m->precision == RNERF_PREC_F16X3 || (m->precision == RNERF_PREC_F16 && c->backward != RNERF_BWD_F16X3 && c->backward != RNERF_BWD_F16X3_LO8) ||
                       (m->precision == RNERF_PREC_BF16X3 && c->backward == RNERF_BWD_BF16),
                   "rnerf_train_forward_backward: training is built on the f16x3 forward (f16: with backward f16 / bf16 only; bf16x3 + backward bf16: the range-safe step)");
   RNERF_CHECK_ARG(((uintptr_t)workspace & 255) == 0, "rnerf_train_forward_backward: workspace must be 256-byte aligned");

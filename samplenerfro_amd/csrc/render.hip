@@ -666,6 +666,57 @@ __global__ void __launch_bounds__(256) generate_rays_kernel(RayCam c, int W, int
   }
 }
 
+// ---- the gather half of Dataset._next_train (rnerf/datasets.py:151-176,178-197) on the device.  The reference keeps the rays
+// of every training view as host arrays ([n_img, H*W, 3] x 3) and indexes them and the images with the drawn ray indices; here the images
+// and the cameras are resident on the device, a batch is "B flat indices (image * H * W + row * W + column)", and the rays of exactly those
+// pixels are generated on the fly with the arithmetic of generate_rays_kernel — the same bits as indexing the reference's arrays — next
+// to the pixel gather: one thread per ray, no ray arrays in memory, no per-step host tensor work.
+__device__ __forceinline__ void pinhole_ray(const float* __restrict__ r, float fx, float fy, float cx, float cy, float pc, int opencv, int col, int row,
+                                            float (&d)[3], float (&v)[3]) {
+  float cam[3];
+  if (!opencv) {
+    cam[0] = fdiv(fsub(fadd((float)col, pc), cx), fx);
+    cam[1] = -fdiv(fsub(fadd((float)row, pc), cy), fy);
+    cam[2] = -1.0f;
+  } else {
+    cam[0] = fdiv(fadd(fsub((float)col, cx), pc), fx);
+    cam[1] = fdiv(fadd(fsub((float)row, cy), pc), fy);
+    cam[2] = 1.0f;
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) d[k] = fadd(fadd(fmul(cam[0], r[3 * k]), fmul(cam[1], r[3 * k + 1])), fmul(cam[2], r[3 * k + 2]));
+  const float nrm = fsqrt(fadd(fadd(fmul(d[0], d[0]), fmul(d[1], d[1])), fmul(d[2], d[2])));
+#pragma unroll
+  for (int k = 0; k < 3; ++k) v[k] = fdiv(d[k], nrm);
+}
+struct BatchCam { float fx, fy, cx, cy, pc; int opencv; };
+__global__ void __launch_bounds__(256) sample_batch_kernel(const float* __restrict__ camtoworlds, BatchCam c, int W, int H, int n_img,
+                                                           const float* __restrict__ images, int channels, const long long* __restrict__ idx,
+                                                           int B, float* __restrict__ origins, float* __restrict__ directions,
+                                                           float* __restrict__ viewdirs, float* __restrict__ pixels, int* __restrict__ bad) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  long long i = idx[b];
+  const long long hw = (long long)H * W;
+  if (i < 0 || i >= hw * n_img) { atomicAdd(bad, 1); i = 0; }      // reported by the host wrapper: never read out of bounds
+  const int img = (int)(i / hw), pix = (int)(i - (long long)img * hw);
+  const int row = pix / W, col = pix - row * W;
+  const float* __restrict__ m = camtoworlds + 12 * img;             // [3][4] row-major: rotation | translation
+  const float r[9] = {m[0], m[1], m[2], m[4], m[5], m[6], m[8], m[9], m[10]};
+  float d[3], v[3];
+  pinhole_ray(r, c.fx, c.fy, c.cx, c.cy, c.pc, c.opencv, col, row, d, v);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    origins[3 * b + k] = m[4 * k + 3];
+    if (directions) directions[3 * b + k] = d[k];
+    viewdirs[3 * b + k] = v[k];
+  }
+  if (pixels) {
+    const float* __restrict__ src = images + (size_t)i * channels;
+    for (int k = 0; k < channels; ++k) pixels[(size_t)b * channels + k] = src[k];
+  }
+}
+
 // ---- mip-style integrated positional encoding along the CURVED ray (rnerf/mip.py:26-57,60-91,116-175), as the commented
 // call sites would use it (rnerf/models.py:249-254): the coarse samples of a marched path are the axes of conical frusta between
 // consecutive depths; each frustum becomes a diagonal Gaussian whose mean is accumulated ALONG the bent path (cumsum of d * dt), and the
@@ -751,6 +802,21 @@ extern "C" int rnerf_generate_rays(const float* camtoworld, int32_t opencv, doub
   const long long n = (long long)rows * W;
   hipLaunchKernelGGL(generate_rays_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, c, W, row0, n, origins, directions,
                      viewdirs);
+  RNERF_CHECK_LAUNCH();
+  return RNERF_OK;
+}
+
+extern "C" int rnerf_sample_batch(const float* camtoworlds, int32_t n_img, int32_t opencv, double fx, double fy, double cx, double cy, double pixel_center,
+                                  int32_t W, int32_t H, const float* images, int32_t channels, const int64_t* ray_indices, int32_t B, float* origins,
+                                  float* directions, float* viewdirs, float* pixels, int32_t* bad_count, void* stream) {
+  RNERF_CHECK_ARG(camtoworlds && ray_indices && origins && viewdirs && bad_count, "rnerf_sample_batch: null pointer");
+  RNERF_CHECK_ARG((images == nullptr) == (pixels == nullptr), "rnerf_sample_batch: give both images and pixels (a training batch) or neither (rays only: the env-map patch)");
+  RNERF_CHECK_ARG(n_img >= 1 && W >= 1 && H >= 1 && B >= 1, "rnerf_sample_batch: need n_img, W, H, B >= 1");
+  RNERF_CHECK_ARG(images == nullptr || (channels >= 1 && channels <= 4), "rnerf_sample_batch: 1..4 channels");
+  BatchCam c;
+  c.fx = (float)fx; c.fy = (float)fy; c.cx = (float)cx; c.cy = (float)cy; c.pc = (float)pixel_center; c.opencv = opencv;
+  hipLaunchKernelGGL(sample_batch_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, camtoworlds, c, W, H, n_img, images,
+                     channels, (const long long*)ray_indices, B, origins, directions, viewdirs, pixels, bad_count);
   RNERF_CHECK_LAUNCH();
   return RNERF_OK;
 }

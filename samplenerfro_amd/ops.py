@@ -323,6 +323,41 @@ def generate_rays(camtoworld, H: int, W: int, device, focal: Optional[float] = N
     return o, d, v
 
 
+def sample_batch(camtoworlds: torch.Tensor, images: Optional[torch.Tensor], ray_indices: torch.Tensor, H: int, W: int, *, focal: Optional[float] = None,
+                 cam_mat=None, pixel_center: bool = True, bad_count: Optional[torch.Tensor] = None, want_directions: bool = False):
+    """`images[...][ray_indices]` and `rays[...][ray_indices]` of Dataset._next_train (rnerf/datasets.py:151-176) on the device.
+    camtoworlds [n, 3, 4] and images [n, H, W, C] (None: rays only) are device tensors; ray_indices int64 [B] are flat over (image, row,
+    column).  -> (origins, directions | None, viewdirs, pixels | None); rays are generated for the drawn pixels only (rnerf_sample_batch)."""
+    lib = _lib.load()
+    c2w = _chk(camtoworlds, "camtoworlds")
+    idx = ray_indices.contiguous()
+    if idx.dtype != torch.int64 or not idx.is_cuda:
+        raise ValueError("sample_batch: ray_indices must be an int64 device tensor")
+    n, B, dev = int(c2w.shape[0]), int(idx.numel()), idx.device
+    if tuple(c2w.shape[1:]) != (3, 4):
+        raise ValueError("sample_batch: camtoworlds must be [n, 3, 4]")
+    ch = 0
+    if images is not None:
+        images = _chk(images, "images")
+        if tuple(images.shape[:3]) != (n, H, W):
+            raise ValueError("sample_batch: images must be [n, H, W, C] for the n cameras")
+        ch = int(images.shape[3])
+    o = torch.empty((B, 3), dtype=torch.float32, device=dev)
+    v = torch.empty_like(o)
+    d = torch.empty_like(o) if want_directions else None
+    pix = torch.empty((B, ch), dtype=torch.float32, device=dev) if images is not None else None
+    if bad_count is None:
+        bad_count = torch.zeros(1, dtype=torch.int32, device=dev)
+    pc = 0.5 if pixel_center else 0.0
+    if cam_mat is None:
+        cam = (0, float(focal), float(focal), W * 0.5, H * 0.5)
+    else:
+        cam = (1, float(cam_mat[0][0]), float(cam_mat[1][1]), float(cam_mat[0][2]), float(cam_mat[1][2]))
+    check(lib.rnerf_sample_batch(ptr(c2w), n, cam[0], cam[1], cam[2], cam[3], cam[4], pc, int(W), int(H), ptr(images), ch, ptr(idx), B, ptr(o), ptr(d),
+                                 ptr(v), ptr(pix), ptr(bad_count), current_stream()), "rnerf_sample_batch")
+    return o, d, v, pix
+
+
 def ray_radii(directions: torch.Tensor) -> torch.Tensor:
     """Rays.radii of Dataset._generate_rays (rnerf/datasets.py:230-239) from the directions of a WHOLE image [H, W, 3] on the device
     (generate_rays(..., want_directions=True)): |d[r] - d[r + 1]| per pixel, the last row repeating the one before, times 2 / sqrt(12).

@@ -74,6 +74,8 @@ class TrainState:
         self.adam_scratch = torch.zeros(_lib.ADAM_SCRATCH_FLOATS, dtype=torch.float32, device=theta.device) if theta.is_cuda else None
         self._staged_bad: Optional[int] = None
         self.range_retries = 0         # steps train_step(range_retry=True) re-ran in the range-safe arithmetic
+        self.range_retry_failures = 0  # re-runs whose range-safe gradient was non-finite too: that update stayed skipped (a warning tells)
+        self._model_ref = None         # weakref to the model of the last lagged step: state_dict() settles the pending steps with it
         self._lag_pending = []         # range_retry="lag": the steps whose non-finite count has not been looked at yet (at most _RANGE_RETRY_LAG)
         self._lag_host = torch.zeros(_LAG_SLOTS, dtype=torch.float32).pin_memory() if theta.is_cuda else None
         self._lag_count = 0
@@ -133,6 +135,15 @@ class TrainState:
         return self
 
     def state_dict(self) -> Dict[str, Any]:
+        """The parameters for good (checkpoint, end of training).  range_retry="lag" may still hold up to two steps whose non-finite count has
+        not been looked at: they are settled first (a skipped batch is re-run) — a checkpoint never loses a batch silently.  Raises when the
+        model those steps ran on is gone (flush_range_retry(model, state) was the caller's job then)."""
+        if self._lag_pending:
+            model = self._model_ref() if self._model_ref is not None else None
+            if model is None:
+                raise RuntimeError("TrainState.state_dict(): steps of range_retry='lag' are still pending and their model is gone; "
+                                   "call flush_range_retry(model, state) before reading the parameters")
+            flush_range_retry(model, self)
         return {"step": self.step, "theta": self.theta, "mu": self.mu, "nu": self.nu}
 
     def restore_flax(self, state: Dict[str, Any]) -> "TrainState":
@@ -161,6 +172,7 @@ class TrainState:
         return self
 
     def load_state_dict(self, d: Dict[str, Any]) -> None:
+        self._lag_pending.clear()          # pending steps belong to the parameters that are being replaced
         self.step = int(d["step"])
         for k in ("theta", "mu", "nu"):
             getattr(self, k).copy_(d[k])
@@ -188,7 +200,7 @@ def backward_mode(flags, model: NerfModel) -> int:
     mode = _lib.BACKWARDS[name]
     if model.precision == _lib.PREC_BF16X3 and mode == _lib.BWD_BF16:
         return mode       # the range-safe training arithmetic (range_safe below; fp32's exponent range end to end, 8-bit gradients)
-    if model.precision != _lib.PREC_F16X3 and not (model.precision == _lib.PREC_F16 and mode != _lib.BWD_F16X3):
+    if model.precision != _lib.PREC_F16X3 and not (model.precision == _lib.PREC_F16 and mode not in _lib.TWO_PLANE_BACKWARDS):
         raise ValueError('training is built on the f16x3 forward (NerfModel(precision="f16x3")), or — one MFMA per product, the north-star '
                          'arithmetic as a labelled leg — on the f16 forward with backward_precision "f16" / "bf16"; the other precisions are inference modes')
     return mode
@@ -442,15 +454,23 @@ def train_step(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], 
         if kw.get("taps") is not None or kw.get("forward_taps") is not None or torch.cuda.is_current_stream_capturing():
             # a tapped step is looked at now, not re-run later (range_retry=True does both); inside a stream capture there is no host to decide
             return _train_step_once(model, rng, state, batch, flags, **kw)
+        ctx = _dist_context()
         out = _train_step_once(model, rng, state, batch, flags, **kw)
         slot = state._lag_count % _LAG_SLOTS
         state._lag_count += 1
         state._lag_host[slot:slot + 1].copy_(state.adam_scratch[3:4], non_blocking=True)      # behind this step's update, on its stream
         ev = torch.cuda.Event(); ev.record()
         replay = dict(kw, next_rays=None, path=None)                 # (the marched path of that step may be overwritten by then: marched again)
-        state._lag_pending.append((ev, slot, rng, batch, flags, replay))
+        # the re-run happens two steps later: it must see THIS step's batch even when the caller's loader refills its staging tensors in
+        # place (147 KB for 4096 rays: three small device copies per step)
+        state._lag_pending.append((ev, slot, rng, _clone_batch(batch), flags, replay, ctx))
+        state._model_ref = weakref.ref(model)
         while len(state._lag_pending) > _RANGE_RETRY_LAG:
-            _settle_lagged(model, state, state._lag_pending.pop(0))
+            pend = state._lag_pending.pop(0)
+            if _lag_flag(state, pend):
+                # the Stats of THIS step are views into state.grads' tail, which the re-run is about to overwrite: hand out copies
+                out = (out[0], _clone_stats(out[1]), out[2])
+            _settle_lagged(model, state, pend)
         return out
     step0 = state.step
     out = _train_step_once(model, rng, state, batch, flags, _guard=True, **kw)
@@ -464,23 +484,75 @@ def train_step(model: NerfModel, rng, state: TrainState, batch: Dict[str, Any], 
     with range_safe(model, flags):
         out = _train_step_once(model, rng, state, batch, flags, _guard=True, **kw)
     state.next_path = next_path
-    state.range_retries += 1
+    _count_rerun(state)
     return out
 
 
+def _dist_context():
+    """What decides which ranks a step's collectives run over (distributed.use_group) and whether they run at all (skip_allreduce): kept
+    with a lagged step, so that its re-run — two steps later, possibly after the caller left that context — issues exactly the collectives
+    the first attempt did, on the same group (a re-run on another group would leave one rank alone in an all-reduce: a hang)."""
+    return (distributed._GROUP, bool(distributed._skip()))
+
+
+@contextlib.contextmanager
+def _in_dist_context(ctx):
+    saved = (distributed._GROUP, distributed._SKIP)
+    distributed._GROUP, distributed._SKIP = ctx
+    try:
+        yield
+    finally:
+        distributed._GROUP, distributed._SKIP = saved
+
+
+def _clone_batch(batch: Dict[str, Any]) -> Dict[str, Any]:
+    def cp(v):
+        if isinstance(v, torch.Tensor):
+            return v.clone()
+        if isinstance(v, tuple) and hasattr(v, "_fields"):            # Rays
+            return type(v)(*[cp(x) for x in v])
+        return v
+    return {k: cp(v) for k, v in batch.items()}
+
+
+def _clone_stats(stats: Stats) -> Stats:
+    import dataclasses
+    return dataclasses.replace(stats, **{f.name: getattr(stats, f.name).clone() for f in dataclasses.fields(stats)
+                                         if isinstance(getattr(stats, f.name), torch.Tensor)})
+
+
+def _count_rerun(state: TrainState) -> None:
+    """A re-run in the range-safe arithmetic has been applied — or skipped as well when its gradient is non-finite too (a NaN pixel, a loss
+    that overflowed fp32): counted apart and said aloud, never booked as a success.  (One host read, on the rare path only.)
+    Note for both cases: a skipped update still advances the update count — Adam's bias-correction t and the learning-rate schedule move
+    on, the moments do not: deliberately unlike optax.apply_if_finite, which the reference does not use either (its step would have
+    written NaN parameters)."""
+    state.range_retries += 1
+    if state.nonfinite_grads() != 0:
+        state.range_retry_failures += 1
+        import warnings
+        warnings.warn("train_step: the range-safe re-run of a skipped batch has a non-finite gradient too; its update stays skipped "
+                      f"({state.range_retry_failures} so far)", RuntimeWarning, stacklevel=3)
+
+
+def _lag_flag(state: TrainState, pending) -> bool:
+    """True when the lagged step's update was skipped (its non-finite count, written to pinned host memory behind the update)."""
+    pending[0].synchronize()                                         # that step has long finished: the device is busy with the one queued after it
+    return float(state._lag_host[pending[1]]) != 0.0
+
+
 def _settle_lagged(model: NerfModel, state: TrainState, pending) -> None:
-    ev, slot, rng, batch, flags, replay = pending
-    ev.synchronize()                                                 # that step has long finished: the device is busy with the one queued after it
-    if float(state._lag_host[slot]) == 0.0:
+    ev, slot, rng, batch, flags, replay, ctx = pending
+    if not _lag_flag(state, pending):
         return
     next_path = state.next_path
     state.step -= 1                                                  # the skipped update had counted as a step: the re-run takes its place
     state.sync_step_counter()
-    with range_safe(model, flags):
+    with range_safe(model, flags), _in_dist_context(ctx):
         _, stats, _ = _train_step_once(model, rng, state, batch, flags, **replay)
     state.next_path = next_path
-    state.last_retry_stats = stats
-    state.range_retries += 1
+    state.last_retry_stats = _clone_stats(stats)
+    _count_rerun(state)
 
 
 def flush_range_retry(model: NerfModel, state: TrainState) -> None:

@@ -28,24 +28,58 @@ WANTED = {("Dataset", "_generate_rays"), ("OpenCV", "_generate_rays"), ("Grid", 
 Rays = collections.namedtuple("Rays", ("origins", "directions", "viewdirs", "radii"))        # field names of rnerf/utils.py's Rays
 
 
-def reference_methods():
-    """{(class, method): function} compiled from the reference's own text; {} when the reference is not on this machine."""
+# what the four methods may name besides `np` and `utils`: nothing that opens files, imports, or evaluates text
+SAFE_BUILTINS = {k: __builtins__[k] if isinstance(__builtins__, dict) else getattr(__builtins__, k)
+                 for k in ("range", "len", "int", "float", "min", "max", "abs", "list", "tuple", "zip", "enumerate", "isinstance", "print", "sum")}
+
+
+def _numpy_only_import(name, *args, **kwargs):
+    """numpy's C code imports its own submodules lazily through the calling frame's builtins: allow exactly that."""
+    if name.split(".")[0] != "numpy":
+        raise ImportError(f"the reference's methods may import numpy only, not {name!r}")
+    import builtins
+    return builtins.__import__(name, *args, **kwargs)
+
+
+SAFE_BUILTINS["__import__"] = _numpy_only_import
+
+
+def source_sha256():
+    """sha256 of the reference file the methods are read from (None when it is not on this machine) — nothing is parsed or executed."""
+    if not os.path.exists(SRC):
+        return None
+    return hashlib.sha256(open(SRC, "rb").read()).hexdigest()
+
+
+def reference_methods(expect_sha256=None):
+    """{(class, method): function} compiled from the reference's own text; {} when the reference is not on this machine.
+
+    The reference tree is untrusted content: the file's hash is taken BEFORE anything of it is compiled, and with `expect_sha256` (the test
+    passes the hash committed in reference_numpy.npz) a file that is not the one the fixture was made from is refused unexecuted —
+    decorators and default-argument expressions of a FunctionDef run at exec time.  The methods run with a whitelist of builtins."""
     if not os.path.exists(SRC):
         return {}, None
-    text = open(SRC).read()
+    raw = open(SRC, "rb").read()
+    sha = hashlib.sha256(raw).hexdigest()
+    if expect_sha256 is not None and sha != expect_sha256:
+        raise RuntimeError(f"{SRC}: sha256 {sha[:16]} is not the source the committed vectors were made from ({expect_sha256[:16]}): "
+                           "nothing of it was executed; re-run tests/golden/make_from_reference_numpy.py after reading the diff")
+    text = raw.decode()
     tree = ast.parse(text, SRC)
     out = {}
     for cls in (n for n in tree.body if isinstance(n, ast.ClassDef)):
         for fn in (n for n in cls.body if isinstance(n, ast.FunctionDef)):
             if (cls.name, fn.name) in WANTED:
+                if fn.decorator_list:
+                    raise RuntimeError(f"{SRC}: {cls.name}.{fn.name} carries a decorator: refusing to execute it")
                 mod = ast.Module(body=[fn], type_ignores=[])
-                ns = {"np": np, "utils": types.SimpleNamespace(Rays=Rays)}
+                ns = {"__builtins__": dict(SAFE_BUILTINS), "np": np, "utils": types.SimpleNamespace(Rays=Rays)}
                 exec(compile(mod, SRC, "exec"), ns)
                 out[(cls.name, fn.name)] = ns[fn.name]
     missing = WANTED - set(out)
     if missing:
         raise RuntimeError(f"{SRC}: methods not found: {sorted(missing)}")
-    return out, hashlib.sha256(text.encode()).hexdigest()
+    return out, sha
 
 
 def inputs():

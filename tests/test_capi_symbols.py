@@ -25,7 +25,7 @@ def test_header_symbols_exported(lib_path):
 def test_binding_covers_header(lib_path):
     assert sorted(_lib.SIGNATURES) == declared_symbols()
     lib = _lib.load()
-    assert lib.rnerf_version() == 2
+    assert lib.rnerf_version() == 3
     stream3 = 1160 * 2 * 1024 + 3468 * 4      # a three-pass operand stream + aux floats (biases, heads, the zero block, the range flag)
     al = lambda n: (n + 255) // 256 * 256
     assert lib.rnerf_nerfmlp_packed_bytes(_lib.PREC_BF16X3) == stream3

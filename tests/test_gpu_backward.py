@@ -89,7 +89,9 @@ def test_loss_and_composite_backward(bg_weight, bd_cut, white):
 
 # worst error of a gradient tensor relative to its largest entry, at 581 rows (mixed-sign sums: the relative error of an entry is
 # about the operand rounding itself, whatever the row count).  f32 = hi + lo f16 parts (2^-22), tf32 = f16 (2^-11), bf16 (2^-8).
-@pytest.mark.parametrize("prec,bwd,tol", [("f16x3", "f32", 1e-5), ("f16x3", "tf32", 2e-3), ("f16x3", "bf16", 1.5e-2)])
+# f16x3lo8 = f16x3 with the lo planes stored as e4m3 bytes (11 + 4 significand bits per operand): measured 1.6e-5 — OUTSIDE the 1e-5 the default is
+# held to, which is why it is an opt-in mode.
+@pytest.mark.parametrize("prec,bwd,tol", [("f16x3", "f32", 1e-5), ("f16x3", "f16x3lo8", 3e-5), ("f16x3", "tf32", 2e-3), ("f16x3", "bf16", 1.5e-2)])
 def test_nerfmlp_backward(prec, bwd, tol):
     """Flat parameter gradient of the NerfMLP (dgrad chain + wgrad on the matrix cores) vs torch.autograd in float64."""
     from samplenerfro_amd import ops, synthetic as syn
@@ -162,7 +164,7 @@ def test_bkgd_mlp_backward():
             assert err < 2e-5, f"bkgd Dense_{k} {name}: rel err {err:.3e}"      # exact-fp32 MFMA chain + fp32 atomics
 
 
-@pytest.mark.parametrize("bwd", ["f32", "tf32"])
+@pytest.mark.parametrize("bwd", ["f32", "tf32", "f16x3lo8"])
 def test_nerfmlp_backward_is_reproducible(bwd):
     """The same inputs give the same bits, run after run (fixed workgroup -> rows assignment, no atomics in the sums): a race in the
     DMA ring / vmcnt accounting of the transpose-read wgrad, or in the forward's tile hand-over, would show as differences.  Rows with
@@ -190,7 +192,7 @@ def test_nerfmlp_backward_is_reproducible(bwd):
                 assert torch.equal(ref[0], raw) and torch.equal(ref[1], grads)
 
 
-@pytest.mark.parametrize("mode", ["f32", "tf32", "bf16"])
+@pytest.mark.parametrize("mode", ["f32", "tf32", "bf16", "f16x3lo8"])
 def test_backward_kernels_are_bit_stable_from_run_to_run(mode):
     """dgrad + wgrad of the same inputs, 6 times: every gradient bit identical (no data hazard, no atomics in the reduction order).
     Round 2 saw run-to-run differences in one compiler schedule of the f16 dgrad (SLP vectoriser on; tests/test_hazards.py scans the ISA
@@ -208,7 +210,9 @@ def test_backward_kernels_are_bit_stable_from_run_to_run(mode):
     raw, save = ops.nerfmlp_forward_train(packed, P, pd, dr, None, S, B, BW)
     ref_g = ref_dy = None
     for i in range(6):
-        grads, dy = ops.nerfmlp_backward(pbwd, packed, P, save, d_raw, S * B, backward=BW, return_dy=True)
+        # (a zeroed buffer: f16x3lo8 writes only half of its lo-plane region — 8 of the 16 bytes per (row, slot, half))
+        dy0 = torch.zeros(_lib.load().rnerf_nerfmlp_dy_bytes(S * B, BW), dtype=torch.uint8, device=dev)
+        grads, dy = ops.nerfmlp_backward(pbwd, packed, P, save, d_raw, S * B, backward=BW, return_dy=True, dy=dy0)
         torch.cuda.synchronize()
         if ref_g is None:
             ref_g, ref_dy = grads.clone(), dy.clone()
@@ -216,3 +220,33 @@ def test_backward_kernels_are_bit_stable_from_run_to_run(mode):
         else:
             assert torch.equal(grads, ref_g), f"run {i}: the parameter gradient differs from the first run"
             assert torch.equal(dy, ref_dy), f"run {i}: the dY planes differ from the first run"
+
+
+def test_lo8_planes_saturate_instead_of_overflowing():
+    """backward f16x3lo8: a lo part beyond the e4m3 range (activations >= 128: lo > 448 * 2^-13; gradients >= 64 x the row's head gradient) is
+    CLAMPED — that operand falls back to f16-hi precision — never turned into the NaN v_cvt_scalef32_pk_fp8_f16 produces without saturation.
+    Hidden kernels x 3 put the activations in the hundreds: the gradient stays finite and within f16-grade error of the two-f16-plane mode."""
+    from samplenerfro_amd import ops, synthetic as syn
+    rng = np.random.default_rng(10)
+    B, S = 83, 7
+    pf = syn.init_params_flat(12, fine=False, bias_scale=0.1)["coarse_mlp"].copy()
+    off = 0
+    for k, (i, o) in enumerate(TR.NERF_MLP_SHAPES):
+        if 1 <= k <= 7:
+            pf[off:off + i * o] *= 3.0
+        off += i * o + o
+    pd = np.concatenate([rng.uniform(-3, 3, (S, B, 3)), np.zeros((S, B, 1))], -1).astype(F32)
+    dr = np.concatenate([R.safe_l2_normalize(rng.standard_normal((S, B, 3)).astype(F32)), np.zeros((S, B, 1), F32)], -1)
+    cot = (rng.standard_normal((S, B, 4)) * 1e-3).astype(F32)
+    P = _lib.PREC_F16X3
+    flat_d = T(pf)
+    packed = ops.nerfmlp_pack(flat_d, P)
+    g = {}
+    for name in ("f16x3", "f16x3lo8"):
+        BW = _lib.BACKWARDS[name]
+        raw, save = ops.nerfmlp_forward_train(packed, P, T(pd), T(dr), None, S, B, BW)
+        g[name] = ops.nerfmlp_backward(ops.nerfmlp_pack_bwd(flat_d, None, BW), packed, P, save, T(cot), S * B, backward=BW).double()
+        assert bool(torch.isfinite(g[name]).all()) and bool(torch.isfinite(raw).all())
+    err = float((g["f16x3lo8"] - g["f16x3"]).abs().max() / g["f16x3"].abs().max())
+    print(f"hidden kernels x 3: f16x3lo8 against f16x3, whole gradient: {err:.2e} of max|g|")
+    assert err < 1e-3

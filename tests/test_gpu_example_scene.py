@@ -172,7 +172,7 @@ def test_training_on_the_example_view_raises_the_psnr(scene):
     mse = float(((rgb.reshape(-1, 3) - pix_d) ** 2).mean())
     psnr_view = U.compute_psnr(mse)
     print(f"example view: train PSNR {first:.2f} -> {last:.2f} dB over {steps} steps of {B} rays; rendered 400 x 400 view vs the photograph {psnr_view:.2f} dB")
-    # the same TRAINED weights rendered in the other arithmetics: fp32-grade f16x3 (the training arithmetic), the default render pass (f16f8)
+    # the same TRAINED weights rendered in the other arithmetics: fp32-grade f16x3 (the training arithmetic and the default render pass), f16f8
     # and the single-pass f16 leg — how far apart the pictures are on weights that have seen real data, not on an initialisation
     # (on ONE view the field goes fully transparent within ~20 steps — the background MLP can explain a single photograph and the loss_bg term
     #  rewards transparency; the independent host loop of the test above takes the same road, so this is the algorithm, not the kernels —
@@ -182,8 +182,8 @@ def test_training_on_the_example_view_raises_the_psnr(scene):
     from samplenerfro_amd.train import _bump
     final = state.theta.detach().clone()
     state.theta.copy_(early); _bump(state.theta)
-    pics = {"f16f8 (default render pass)": U.render_image(fn, rays_hw, prng.PRNGKey(1), False, chunk=8192)[0]}
-    for name in ("f16x3", "f16", "bf16"):
+    pics = {}
+    for name in ("f16x3", "f16f8", "f16", "bf16"):
         m2 = copy.copy(model)
         m2.precision = m2.eval_precision = _lib.PRECISIONS[name]
         m2._packed, m2._jit_cache, m2._ws, m2._key_cache, m2._u_lin, m2._side = {}, {}, {}, {}, None, None
@@ -196,7 +196,8 @@ def test_training_on_the_example_view_raises_the_psnr(scene):
     d = {k: float((v - pics["f16x3"]).abs().max()) for k, v in pics.items() if k != "f16x3"}
     print("max |dRGB| against the f16x3 render of the step-8 weights:", {k: f"{v:.2e}" for k, v in d.items()})
     state.theta.copy_(final); _bump(state.theta)
-    assert d["f16f8 (default render pass)"] < 1e-4 and d["f16"] < 1e-3 and d["bf16"] < 1e-2
+    assert model.eval_precision == model.precision == _lib.PREC_F16X3      # the default render pass IS the training arithmetic (round 6)
+    assert d["f16f8"] < 1e-4 and d["f16"] < 1e-3 and d["bf16"] < 1e-2
     assert np.isfinite(curve).all() and bool(torch.isfinite(rgb).all())
     # measured (MI355X, this seed): 100-step means 15.07, 16.10, 16.19, 16.34, 16.41, 16.48, 16.55, 16.54, 16.58, 16.61 dB; first 10 steps 12.55;
     # the rendered view 16.6 dB.  (ONE view: within ~20 steps the optimiser makes the field transparent — opacity 0.64 -> exactly 0; the host

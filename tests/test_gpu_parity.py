@@ -440,7 +440,7 @@ def test_nerf_mlp_workgroup_cap_and_training_forward_agree(scene):
     for cap in (1, 4):
         out = ops.nerfmlp_forward(packed, _lib.PREC_F16X3, T(pd), T(dr), None, S, B, max_workgroups=cap).cpu().numpy()
         np.testing.assert_array_equal(out, ref)
-    for bwd in (_lib.BWD_F16X2, _lib.BWD_F16):
+    for bwd in (_lib.BWD_F16X2, _lib.BWD_F16, _lib.BWD_F16X3_LO8):
         for cap in (0, 2):
             raw, _save = ops.nerfmlp_forward_train(packed, _lib.PREC_F16X3, T(pd), T(dr), None, S, B, bwd, max_workgroups=cap)
             np.testing.assert_array_equal(raw.cpu().numpy(), ref)
@@ -473,12 +473,62 @@ def test_model_end_to_end(prec, fine):
         errs = [np.abs(a.cpu().numpy() - b).max() for a, b in zip(g, o)]
         print(f"[{prec}] level {lvl}: max abs err rgb={errs[0]:.2e} dist={errs[1]:.2e} acc={errs[2]:.2e} trans={errs[3]:.2e} tb={errs[4]:.2e}")
         assert errs[0] < tol and errs[2] < tol and errs[3] < tol and errs[4] < tol
-        assert errs[1] < 1e-3       # expected depth (a ratio of sums over [2,6])
+        # expected depth (a ratio of sums over [2, 6]): north_star's 1e-4 too — measured 1e-6 .. 9e-6 for f16x3 / bf16x3 / f16f8.  The opt-in
+        # f16x2 (exact weights x f16-rounded activations, 2 MFMAs) sits at 1.3e-4: it is documented as outside the margin (include/rnerf.h)
+        assert errs[1] < (1e-4 if prec != "f16x2" else 1e-3)
     if fine:
-        # the resample indices agree wherever the coarse weights agree to the last bit; report the match rate
+        # the resample indices agree wherever the coarse weights agree to the last bit; report the match rate (measured 1.0000 here for every
+        # precision; the full-size config tests hold f16x3 to >= 0.998 on their ray samples, tests/test_gpu_fullsize.py)
         same = (taps["idx_f"].cpu().numpy().T == otaps["idx_f"]).mean()
         print(f"[{prec}] fine node-index agreement with the oracle (MLP outputs differ in the last bits): {same:.4f}")
-        assert same > (0.98 if prec not in ("f16x2", "f16f8") else 0.9)      # f16x2: coarse weights differ by ~1e-5, more picks flip
+        assert same > (0.995 if prec not in ("f16x2", "f16f8") else 0.98)
+
+
+@pytest.mark.parametrize("scale,bias", [(1.5, 0.3), (4.0, 0.3)])
+def test_render_arithmetics_on_trained_like_weights(scale, bias):
+    """construct_nerf's default render arithmetic (f16f8) and the training arithmetic (f16x3) on weights shaped like a
+    trained network's — hidden kernels Dense_1..7 x 1.5 / x 4 and N(0, 0.3) biases on BOTH levels (larger pre-activations than glorot init;
+    x 4 also puts weights beyond f16f8's |W| < 3.99: its launch steps aside for f16x3 on the device) — against the oracle, end to end through
+    march, hierarchical resampling and compositing: RGB and expected depth within north_star's 1e-4, fine node indices reported and held."""
+    from samplenerfro_amd import models, prng
+    from samplenerfro_amd.utils import Rays
+    sc = Scene(B=160, seed=11)
+    P, S, F = 4, 16, 24
+    pf = syn.init_params_flat(2, fine=True, bias_scale=0.05)
+    for k in ("coarse_mlp", "fine_mlp"):
+        pf[k] = _scaled_weights({"coarse_mlp": pf[k]}, scale, bias)
+    cfg = R.ModelConfig(sc.ndim, sc.nmin, sc.nmax, num_coarse_samples=S, num_fine_samples=F, num_path_samples=P)
+    rays = Rays(T(sc.o), None, T(sc.d), None)
+    key = prng.PRNGKey(5)
+    for prec in ("f16x3", "f16f8"):
+        model = models.NerfModel(ndim=sc.ndim, nmin=sc.nmin, nmax=sc.nmax, grid=T(sc.grid), near=2.0, far=6.0,
+                                 num_coarse_samples=S, num_fine_samples=F, num_path_samples=P, precision=prec)
+        variables = models.make_variables({k: T(v) for k, v in pf.items()})
+        taps = {}
+        ret, _ = model.apply(variables, key, key, rays, False, taps=taps)
+        otaps = {}
+        oret, _ = R.nerf_forward(cfg, syn.params_tree(pf), sc.table, sc.o, sc.d, taps["jitter"], taps=otaps)
+        for lvl, (g, o) in enumerate(zip(ret, oret)):
+            errs = [float(np.abs(a.cpu().numpy() - b).max()) for a, b in zip(g, o)]
+            print(f"[x{scale}, bias {bias}; {prec}] level {lvl}: max abs err rgb={errs[0]:.2e} dist={errs[1]:.2e} acc={errs[2]:.2e}")
+            # f16x3 (the default of training AND, since round 6, of the render pass): inside north_star's 1e-4 with margin.
+            # f16f8 (rounds 4-5's render default): measured 2.0e-4 RGB / 4.1e-4 depth at x 1.5 — outside the contract, which is why it is
+            # opt-in now; held to 1e-3 here so that a regression of the opt-in mode still shows
+            tol = 1e-4 if prec == "f16x3" else 1e-3
+            assert errs[0] < tol and errs[1] < tol and errs[2] < tol
+        same = float((taps["idx_f"].cpu().numpy().T == otaps["idx_f"]).mean())
+        print(f"[x{scale}, bias {bias}; {prec}] fine node-index agreement with the oracle: {same:.4f}")
+        assert same > (0.995 if prec == "f16x3" else 0.95)
+    # the product render pass (no taps: ONE rnerf_forward call) in construct_nerf's default arithmetic: RGB within 1e-4 of the oracle
+    from samplenerfro_amd import utils as U
+    flags = U.default_flags(num_coarse_samples=S, num_fine_samples=F, num_path_samples=P, near=2.0, far=6.0, white_bkgd=False, use_online_sparsity=False)
+    m2, v2 = models.construct_nerf(np.array([0, 1], np.uint32), None, flags, sc.ndim, sc.nmin, sc.nmax, T(sc.grid))
+    assert m2.eval_precision == m2.precision == _lib.PREC_F16X3
+    for k in ("coarse_mlp", "fine_mlp", "bkgd_mlp"):
+        v2["flat"][k].copy_(T(pf[k]))
+    r2, _ = m2.apply(v2, key, key, rays, False)
+    for lvl in range(2):
+        assert float(np.abs(r2[lvl][0].cpu().numpy() - oret[lvl][0]).max()) < 1e-4
 
 
 def test_packed_weight_cache_follows_the_variables():
@@ -633,14 +683,17 @@ def test_construct_nerf_surface():
 
 
 def test_eval_precision_of_the_reference_surface():
-    """construct_nerf (rnerf/models.py:538) renders in the default eval arithmetic f16f8 and trains in f16x3: model.apply as eval.py calls it
-    equals a NerfModel built with precision="f16f8" bit for bit, is within 1e-5 of the f16x3 render, the tapped / staged path (what the
-    parity tests and the training forward run) stays f16x3, and eval_precision=None restores one arithmetic for everything."""
+    """construct_nerf (rnerf/models.py:538) renders AND trains in f16x3 (round 6: eval_precision defaults to None — f16f8 is outside the 1e-4
+    contract on trained-like weights, test_render_arithmetics_on_trained_like_weights); eval_precision="f16f8" opts in: model.apply as
+    eval.py calls it then equals a NerfModel built with precision="f16f8" bit for bit, is within 1e-5 of the f16x3 render on these glorot
+    weights, and the tapped / staged path (what the parity tests and the training forward run) stays f16x3."""
     from samplenerfro_amd import _lib, models, prng, utils
     sc = Scene(B=96, seed=3)
     flags = utils.default_flags(num_coarse_samples=16, num_fine_samples=24, num_path_samples=4, white_bkgd=False, use_online_sparsity=False)
     kw = dict(ndim=sc.ndim, nmin=sc.nmin, nmax=sc.nmax, grid=T(sc.grid))
-    model, variables = models.construct_nerf(prng.PRNGKey(7), None, flags, **kw)
+    same, _ = models.construct_nerf(prng.PRNGKey(7), None, flags, **kw)
+    assert same.eval_precision == same.precision == _lib.PREC_F16X3
+    model, variables = models.construct_nerf(prng.PRNGKey(7), None, flags, eval_precision="f16f8", **kw)
     assert model.precision == _lib.PREC_F16X3 and model.eval_precision == _lib.PREC_F16F8
     pf = syn.init_params_flat(2, fine=True, bias_scale=0.05)
     variables = models.make_variables({k: T(v) for k, v in pf.items()})
@@ -658,8 +711,6 @@ def test_eval_precision_of_the_reference_surface():
     taps = {}
     rt, _ = model.apply(variables, k0, k1, rays, False, taps=taps)              # tapped = staged = the training arithmetic
     assert torch.equal(rt[1][0], r3[1][0])
-    same, _ = models.construct_nerf(prng.PRNGKey(7), None, flags, eval_precision=None, **kw)
-    assert same.eval_precision == same.precision == _lib.PREC_F16X3
     r, _ = same.apply(variables, k0, k1, rays, False)
     assert torch.equal(r[1][0], r3[1][0])
 

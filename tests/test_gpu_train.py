@@ -636,3 +636,149 @@ def test_lagged_range_retry_settles_one_step_later():
     # parameter sets stay within (updates) x 2 lr of each other — and they are not the same
     assert 0 < (results["lag"] - results[True]).abs().max().item() < 4 * 2 * 1e-3
     assert not torch.equal(results["lag"], state.theta)
+
+
+def test_lagged_retry_is_settled_by_state_dict_and_sees_the_batch_of_its_step():
+    """(1) TrainState.state_dict() — every checkpoint goes through it — settles the steps range_retry="lag" still holds instead of
+    silently losing a skipped batch; (2) the re-run two steps later trains on the batch of ITS step even when the caller refills one
+    staging batch in place; (3) load_state_dict drops pending steps (they belong to the replaced parameters)."""
+    from samplenerfro_amd import utils
+    from samplenerfro_amd.train import TrainState, train_step, flush_range_retry
+    model, state, batch, flags, ev = _setup(0)
+    _out_of_range_coarse(state)
+    o = batch["rays"].origins.cpu().numpy(); d = batch["rays"].viewdirs.cpu().numpy()
+    order = np.argsort(-np.maximum(o[:, 0] + 2 * d[:, 0], o[:, 0] + 6 * d[:, 0]), kind="stable")
+    half = len(order) // 2
+
+    def sub(idx):
+        t = torch.from_numpy(np.ascontiguousarray(idx)).to("cuda:0")
+        return dict(batch, rays=utils.Rays(batch["rays"].origins[t].contiguous(), None, batch["rays"].viewdirs[t].contiguous(), None), pixels=batch["pixels"][t].contiguous())
+
+    hot, cool = sub(order[:half]), sub(order[half:])
+    jitter = np.arange(0, 32, 4) + 1
+    thetas = {}
+    for staging in (False, True):
+        s = TrainState.create(model, state.variables, flags); s.step = 5
+        s.lr_fn = lambda c: 1e-3
+        rng = np.array([1, 2], np.uint32)
+        stage = dict(cool, rays=utils.Rays(cool["rays"].origins.clone(), None, cool["rays"].viewdirs.clone(), None), pixels=cool["pixels"].clone())
+        for k, b in enumerate((cool, hot, cool, cool)):
+            if staging:                    # a loader that refills ONE set of device tensors in place
+                stage["rays"].origins.copy_(b["rays"].origins); stage["rays"].viewdirs.copy_(b["rays"].viewdirs); stage["pixels"].copy_(b["pixels"])
+                b = stage
+            s, stats, rng = train_step(model, rng, s, b, flags, jitter=jitter, range_retry="lag")
+            if k == 1 and not staging:
+                assert len(s._lag_pending) == 2 and s.range_retries == 0
+                sd = s.state_dict()        # a checkpoint right behind the skipped step: it is re-run first
+                assert s._lag_pending == [] and s.range_retries == 1 and bool(torch.isfinite(sd["theta"]).all())
+        flush_range_retry(model, s)
+        assert s.range_retries == 1 and s.range_retry_failures == 0 and s.step == 9
+        thetas[staging] = s.theta.clone()
+    # with the staging tensors the re-run of "hot" happens after they were refilled with "cool" twice: it must still have trained on "hot".
+    # Reference for that order: the plain lag run of test_lagged_range_retry_settles_one_step_later (separate tensors per batch)
+    s = TrainState.create(model, state.variables, flags); s.step = 5
+    s.lr_fn = lambda c: 1e-3
+    rng = np.array([1, 2], np.uint32)
+    for b in (cool, hot, cool, cool):
+        s, stats, rng = train_step(model, rng, s, b, flags, jitter=jitter, range_retry="lag")
+    flush_range_retry(model, s)
+    assert torch.equal(thetas[True], s.theta), "the re-run saw a refilled staging batch"
+    # pending steps do not survive a restore
+    s2 = TrainState.create(model, state.variables, flags)
+    s2, _, rng = train_step(model, rng, s2, hot, flags, jitter=jitter, range_retry="lag")
+    assert len(s2._lag_pending) == 1
+    s2.load_state_dict({"step": 3, "theta": s.theta, "mu": s.mu, "nu": s.nu})
+    assert s2._lag_pending == [] and s2.step == 3
+
+
+@pytest.mark.timeout(900)
+def test_range_retry_trajectory_follows_the_float64_loop_over_50_steps():
+    """the lagged range retry where it fires — 50 steps, every fifth batch leaves f16's range (its update is skipped, the
+    batch re-run two steps later in the range-safe arithmetic on the parameters of that moment) — against the SAME sequence of updates in
+    torch float64 (autograd + the optax Adam formulas, the update counts the device used): every applied update's loss within 1e-4, the
+    re-runs included, ten re-runs, none failed, nothing pending at the end, and the parameters close to the float64 loop's."""
+    from samplenerfro_amd import utils
+    from samplenerfro_amd.train import TrainState, train_step, flush_range_retry
+    model, state, batch, flags, ev = _setup(0)
+    flags.weight_decay_mult = 0.0
+    flags.bg_smooth_weight = 0.0
+    _out_of_range_coarse(state)
+    o = batch["rays"].origins.cpu().numpy(); d = batch["rays"].viewdirs.cpu().numpy()
+    order = np.argsort(-np.maximum(o[:, 0] + 2 * d[:, 0], o[:, 0] + 6 * d[:, 0]), kind="stable")
+    half = len(order) // 2
+
+    def sub(idx):
+        t = torch.from_numpy(np.ascontiguousarray(idx)).to("cuda:0")
+        return dict(batch, rays=utils.Rays(batch["rays"].origins[t].contiguous(), None, batch["rays"].viewdirs[t].contiguous(), None),
+                    pixels=batch["pixels"][t].contiguous(), env_rays=None)
+
+    batches = {"hot": sub(order[:half]), "cool": sub(order[half:])}
+    jitter = np.arange(0, 32, 4) + 1
+    lr = 1e-3
+    # the rows of the two batches (flat N_f = 0 and a fixed jitter: they do not depend on the parameters): one tapped step each on a scratch state
+    rows = {}
+    for name, b in batches.items():
+        scratch = TrainState.create(model, state.variables, flags)
+        scratch.lr_fn = lambda c: 0.0
+        taps = {}
+        train_step(model, np.array([1, 2], np.uint32), scratch, b, flags, jitter=jitter, taps=taps, range_retry=False)
+        ctx = taps["ctx"]
+        jit = ctx["jit"].cpu().long()
+        pd, dr = ctx["path_pd"].cpu()[jit], ctx["path_dr"].cpu()[jit]
+        S, Bh = pd.shape[0], pd.shape[1]
+        pos = pd[..., :3].permute(1, 0, 2).reshape(-1, 3).numpy(); dirs = dr[..., :3].permute(1, 0, 2).reshape(-1, 3).numpy()
+        rows[name] = dict(enc=torch.tensor(R.pos_enc(pos, 0, 10), dtype=torch.float64), venc=torch.tensor(R.pos_enc(dirs, 0, 4), dtype=torch.float64),
+                          t=pd[..., 3].permute(1, 0).double(), dirs=torch.tensor(dirs, dtype=torch.float64).reshape(Bh, S, 3), B=Bh, S=S,
+                          last=torch.tensor(R.pos_enc(ctx["path_dr"].cpu()[int(jit[-1])][:, :3].numpy(), 0, 4), dtype=torch.float64),
+                          pix=b["pixels"].cpu().double())
+    # ---- the device loop: product steps (two C calls each), lagged retry
+    s = TrainState.create(model, state.variables, flags)
+    s.lr_fn = lambda c: lr
+    theta0 = s.theta.cpu().numpy().astype(np.float64)
+    rng = np.array([1, 2], np.uint32)
+    seq = ["hot" if k % 5 == 2 else "cool" for k in range(50)]
+    applied = []                                    # (batch name, update count the device used, device loss) in the order the updates were applied
+    for k, name in enumerate(seq):
+        count, before = s.step, s.range_retries
+        s, stats, rng = train_step(model, rng, s, batches[name], flags, jitter=jitter, range_retry="lag")
+        loss = float(stats.loss)
+        if np.isfinite(loss):
+            applied.append((name, count, loss))
+        else:
+            assert name == "hot"
+        if s.range_retries > before:                # the batch of step k - 2 was re-run behind this step, with this step's count
+            assert seq[k - 2] == "hot"
+            applied.append((seq[k - 2], count, float(s.last_retry_stats.loss)))
+    before = s.range_retries
+    flush_range_retry(model, s)
+    if s.range_retries > before:
+        applied.append(("hot", s.step - 1, float(s.last_retry_stats.loss)))
+    assert s.range_retries == 10 and s.range_retry_failures == 0 and s._lag_pending == [] and s.step == 50 and len(applied) == 50
+    assert [a[0] for a in applied].count("hot") == 10
+    # ---- the same updates in float64
+    th = torch.tensor(theta0, dtype=torch.float64, requires_grad=True)
+    seg = s.segments
+    mu = torch.zeros_like(th); nu = torch.zeros_like(th)
+    worst = {"cool": 0.0, "hot": 0.0}
+    for name, count, dev_loss in applied:
+        r = rows[name]
+        bflat = th[seg["bkgd_mlp"][0]:seg["bkgd_mlp"][1]]
+        bk = TR.bkgd_mlp(bflat, r["last"], model.rgb_padding)
+        raw = TR.nerf_mlp(th[seg["coarse_mlp"][0]:seg["coarse_mlp"][1]], r["enc"], r["venc"]).reshape(r["B"], r["S"], 4)
+        rgb, sigma = TR.activations(raw, model.rgb_padding, model.sigma_bias)
+        comp, acc, w, trans, tb = TR.volumetric_rendering(rgb, sigma, r["t"], r["dirs"], bk)
+        total, parts = TR.radiance_loss([(comp, trans, tb)], r["pix"], flags.bg_weight, batch["annealed_alpha"])
+        total.backward()
+        want = float(parts["loss"].detach())
+        worst[name] = max(worst[name], abs(dev_loss - want))
+        assert abs(dev_loss - want) < 1e-4 * max(1.0, want / 1e-2), (name, count, dev_loss, want)
+        with torch.no_grad():
+            g = th.grad
+            mu = 0.9 * mu + 0.1 * g; nu = 0.999 * nu + 0.001 * g * g
+            t_ = count + 1
+            th -= lr * (mu / (1 - 0.9 ** t_)) / (torch.sqrt(nu / (1 - 0.999 ** t_)) + 1e-8)
+            th.grad = None
+    dtheta = float((s.theta.cpu().double() - th.detach()).abs().max())
+    print(f"50 steps, 10 lagged re-runs: worst |device loss - float64 loop| {worst['cool']:.2e} (f16x3 steps) / {worst['hot']:.2e} (range-safe re-runs); "
+          f"max |theta - float64 theta| {dtheta:.2e} after 50 updates of lr {lr}")
+    assert dtheta < 10 * lr                         # Adam's steps are ~lr per entry: the two parameter sets stay a few steps apart at most

@@ -30,11 +30,12 @@ def test_the_committed_vectors_are_what_the_reference_computes():
     """Wherever the reference is on the machine (the build container; not the GPU box) the generator is run again: same source hash, same bits."""
     spec = importlib.util.spec_from_file_location("make_from_reference_numpy", os.path.join(HERE, "golden", "make_from_reference_numpy.py"))
     gen = importlib.util.module_from_spec(spec); spec.loader.exec_module(gen)
-    meth, sha = gen.reference_methods()
-    if not meth:
+    if gen.source_sha256() is None:
         pytest.skip("the reference is not on this machine")
     x, y, committed_sha = _load()
-    assert sha == committed_sha, "rnerf/datasets.py changed: re-run tests/golden/make_from_reference_numpy.py"
+    # the hash is compared BEFORE anything of the (untrusted) reference file is compiled or executed
+    assert gen.source_sha256() == committed_sha, "rnerf/datasets.py changed: read the diff, then re-run tests/golden/make_from_reference_numpy.py"
+    meth, sha = gen.reference_methods(expect_sha256=committed_sha)
     again = gen.compute(meth, gen.inputs())
     assert set(again) == set(y)
     for k in y:
