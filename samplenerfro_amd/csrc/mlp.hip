@@ -1737,6 +1737,9 @@ template <int KT, int NT> struct WgTrShape {
   static constexpr int TK = KT / WK, TN = NTR / WN;
   static_assert(WK * TK == KT && WN * TN == NTR && WK * WN <= 8 && (!EXTRA || (TK == 2 && WN == 2)), "tile split");
 };
+#ifndef RNERF_WGTR_LATE_DMA
+#define RNERF_WGTR_LATE_DMA 1      /* round 6, tools/r06/ab_wgrad.py: f16x3 wgrad 2.008 / 2.010 -> 1.987 / 1.973 ms, f16x3lo8 1.907 / 1.900 -> 1.872 / 1.899 */
+#endif
 #ifndef RNERF_WGTR_NCH
 #define RNERF_WGTR_NCH 2      /* n-tiles of B fragments fetched at a time when the A side is resident */
 #endif
@@ -1848,7 +1851,12 @@ __device__ __forceinline__ void wgrad_body_tr(const uint4* __restrict__ saved, c
       if (wave == 0) wait_vmcnt<(AHEAD - 1) * (NDMA + 1)>(); else
       wait_vmcnt<(AHEAD - 1) * NDMA>();                         // this wave's part of step s has landed (the later steps may be in flight)
       __syncthreads();                                          // ... everybody's has, and everybody is done with the ring slot of step s - 1
-      issue(s + AHEAD);
+      // An LDS-DMA instruction costs ~100 issue cycles and a wave issues NDMA of them per step.  Right behind the barrier all eight waves
+      // would do that at once, with the matrix pipe idle: the second wave of every SIMD (waves 4..7) issues its share after its first chunk
+      // of MFMAs instead, so that one wave's DMA issue overlaps its partner's MFMAs (RNERF_WGTR_LATE_DMA; the slot written is the one of
+      // step s - 1, free since the barrier)
+      const bool dma_late = RNERF_WGTR_LATE_DMA && wave >= 4 && active;
+      if (!dma_late) issue(s + AHEAD);
       if (active) {
         const char* ring0 = smem + (s & (WGTR_NBUF - 1)) * STEP_BYTES;
         const char* ring = ring0 + lane_off;
@@ -1910,6 +1918,7 @@ __device__ __forceinline__ void wgrad_body_tr(const uint4* __restrict__ saved, c
 #pragma unroll
               for (int j = 0; j < TN; ++j) acc[i][j] = mfma_h8(al, bh[j], acc[i][j]);
             }
+            if (i == 0 && dma_late) issue(s + AHEAD);
           }
 #pragma unroll
           for (int j = 0; j < TN; ++j) bias_row(j, bh[j], bl[j]);
@@ -1940,6 +1949,7 @@ __device__ __forceinline__ void wgrad_body_tr(const uint4* __restrict__ saved, c
             }
 #pragma unroll
             for (int jj = 0; jj < NCH; ++jj) bias_row(c * NCH + jj, bh[jj], bl[jj]);
+            if (c == 0 && dma_late) issue(s + AHEAD);
           }
           if constexpr (SH::EXTRA) { ae_h = wn ? ah[1] : ah[0]; if constexpr (NP == 2) ae_l = wn ? al[1] : al[0]; }
         }
@@ -2087,7 +2097,8 @@ __device__ __forceinline__ void wgrad_body_tr8(const uint4* __restrict__ saved, 
       if (wave == 0) wait_vmcnt<(AHEAD - 1) * (NDMA + 1)>(); else
       wait_vmcnt<(AHEAD - 1) * NDMA>();
       __syncthreads();
-      issue(s + AHEAD);
+      const bool dma_late = RNERF_WGTR_LATE_DMA && wave >= 4 && active;      // see wgrad_body_tr
+      if (!dma_late) issue(s + AHEAD);
       if (active) {
         const char* ring0 = smem + (s % WGTR_NBUF) * STEP_BYTES;
         const char* ring = ring0 + lane_off;
@@ -2136,6 +2147,7 @@ __device__ __forceinline__ void wgrad_body_tr8(const uint4* __restrict__ saved, 
             for (int j = 0; j < TN; ++j) acc[i][j] = mfma_h8(ah, bl[j], acc[i][j]);
 #pragma unroll
             for (int j = 0; j < TN; ++j) acc[i][j] = mfma_h8(al, bh[j], acc[i][j]);
+            if (i == 0 && dma_late) issue(s + AHEAD);
           }
 #pragma unroll
           for (int j = 0; j < TN; ++j) bias_row(j, bh[j], bl[j]);
@@ -2164,6 +2176,7 @@ __device__ __forceinline__ void wgrad_body_tr8(const uint4* __restrict__ saved, 
               for (int jj = 0; jj < NCH; ++jj) acc[i][c * NCH + jj] = mfma_h8(al[i], bh[jj], acc[i][c * NCH + jj]);
 #pragma unroll
             for (int jj = 0; jj < NCH; ++jj) bias_row(c * NCH + jj, bh[jj], bl[jj]);
+            if (c == 0 && dma_late) issue(s + AHEAD);
           }
           if constexpr (SH::EXTRA) { ae_h = wn ? ah[1] : ah[0]; ae_l = wn ? al[1] : al[0]; }
         }
@@ -3071,6 +3084,7 @@ __constant__ BkgdUnit kSo3Units[20] = {
     {4, 128, 128, 2, 4, 4, 3, so3_koff(4), 3, -1},                   {4, 128, 128, 3, 4, 4, 3, so3_koff(4), 3, -1}};
 template <int KIND> struct SmallNet {
   static constexpr int ENC_LD = KIND == 0 ? 28 : 60, NPARAMS = KIND == 0 ? RNERF_BKGDMLP_PARAMS : RNERF_SO3MLP_PARAMS, UNITS = KIND == 0 ? 18 : 20;
+  static constexpr int CHUNKS_PER_WG = KIND == 0 ? 1 : 4;      // 256-row chunks summed by one workgroup of the weight-gradient kernel (one partial each)
 };
 
 template <int KIND>
@@ -3081,10 +3095,13 @@ __global__ void __launch_bounds__(256) bkgd_wgrad_kernel(const float* __restrict
   // unit slot % UNITS of chunk 8 (slot / UNITS) + xcd: the UNITS workgroups that read the same 256 rows of dY (each layer's dY by its
   // 4-5 k-tiles) run back to back on ONE XCD and share them in its L2 (with (chunk, unit) as grid (x, y) they were `chunks` workgroups
   // apart: every re-read went to memory).
-  constexpr int UNITS = SmallNet<KIND>::UNITS;
+  // CPW 256-row chunks per workgroup (so3: 4 — its 208 k pair rows made 813 partials of 65 411 floats, 213 MB written and read again by the
+  // reduction: 0.56 + 0.10 ms of the stage-all step's tail; the background MLP keeps 1: a few dozen chunks, and the
+  // default step's bits stay what they were)
+  constexpr int UNITS = SmallNet<KIND>::UNITS, CPW = SmallNet<KIND>::CHUNKS_PER_WG;
   const int slot = blockIdx.x >> 3, xcd = blockIdx.x & 7;
-  const int chunk = 8 * (slot / UNITS) + xcd, unit = slot % UNITS;
-  if ((long long)chunk * 256 >= n) return;
+  const int chunk = 8 * (slot / UNITS) + xcd, unit = slot % UNITS;      // (the index of the partial: CPW consecutive 256-row chunks)
+  if ((long long)chunk * 256 * CPW >= n) return;
   const BkgdUnit u = KIND == 0 ? kBkgdUnits[unit] : kSo3Units[unit];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 31, h = lane >> 5;
   const float* __restrict__ X = u.xk == 0 ? save : save + (size_t)n * SmallNet<KIND>::ENC_LD + (size_t)(u.xk - 1) * n * 128;
@@ -3095,7 +3112,7 @@ __global__ void __launch_bounds__(256) bkgd_wgrad_kernel(const float* __restrict
   const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   f32x16 acc[4] = {zero, zero, zero, zero};
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};               // bias row: this lane's share of sum_rows dY[row][its column] (plain VALU adds)
-  const long long r0 = (long long)chunk * 256 + wave * 64;
+  long long r0 = (long long)chunk * 256 * CPW + wave * 64;
   // Operand loads: unconditional, from clamped addresses, a BATCH of 8 row pairs ahead of the MFMAs that consume them, and made opaque
   // (empty asm on the loaded registers) before the row / column predicates are applied.  Without the last step hipcc turns
   // `ok ? load : 0` back into a branch around the load followed by s_waitcnt vmcnt(0): two exposed round trips per 4 MFMAs
@@ -3150,8 +3167,12 @@ __global__ void __launch_bounds__(256) bkgd_wgrad_kernel(const float* __restrict
     }
   };
   using I1 = std::integral_constant<int, 1>; using I4 = std::integral_constant<int, 4>;
-  if (NT == 4) { if (bias) rows(I4{}, std::true_type{}); else rows(I4{}, std::false_type{}); }
-  else { if (bias) rows(I1{}, std::true_type{}); else rows(I1{}, std::false_type{}); }
+#pragma unroll 1
+  for (int cc = 0; cc < CPW; ++cc, r0 += 256) {
+    if (cc > 0 && (long long)(chunk * CPW + cc) * 256 >= n) break;      // (workgroup-uniform)
+    if (NT == 4) { if (bias) rows(I4{}, std::true_type{}); else rows(I4{}, std::false_type{}); }
+    else { if (bias) rows(I1{}, std::true_type{}); else rows(I1{}, std::false_type{}); }
+  }
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt)
     if (nt < NT) {

