@@ -1047,6 +1047,8 @@ def main():
                        "backward_precision": (None if not train else args.backward),
                        "backward_precision_note": (None if not train else {
                            "f16x3": "row-normalised f16 hi + lo parts of every saved activation and gradient (22 bits), 3 MFMAs per product: within 1e-5 of max|g| vs float64",
+                           "f16x3lo8": "f16x3 with the lo planes of the saved activations / gradients stored as e4m3 bytes and decoded in the wgrad (11 + 4 significand "
+                                       "bits per operand, 3/4 of the operand bytes): 1.6e-5 of max|g| vs float64 at 581 rows — outside the default's 1e-5: a labelled mode",
                            "f16": "row-normalised f16 parts (11-bit significand), 1-2 MFMAs per product: ~1e-3 of max|g| on small batches, ~1e-5 at this size",
                            "bf16": "bf16 parts (8-bit significand), round 1's arithmetic: ~6e-3 of max|g| on small batches"}[args.backward]),
                        "launch": ("one hipGraph launch per step (key split, march branch, forward, backward, Adam: csrc/pipeline.hip)" if graph_used
