@@ -338,10 +338,26 @@ def timed_steps(stepper, warmup, steps, barrier, D, device):
     barrier()
     t0 = time.perf_counter()
     out = None
+    trace = [] if getattr(stepper.args, "trace_steps", False) else None
+    if trace is not None:
+        import gc
+        def _gc_cb(phase, info, _st={}):
+            if phase == "start":
+                _st["t"] = time.perf_counter()
+            else:
+                print("[trace-steps] gc generation %d: %.2f ms, collected %s (step index %d)" % (info["generation"], 1e3 * (time.perf_counter() - _st["t"]), info.get("collected"), len(trace)), file=sys.stderr)
+        gc.callbacks.append(_gc_cb)
     for i in range(steps):
+        if trace is not None:
+            t1 = time.perf_counter()
         out = stepper.step()
+        if trace is not None:
+            trace.append(1e3 * (time.perf_counter() - t1))
     barrier()
     dt = D.max_over_ranks(time.perf_counter() - t0, device)
+    if trace is not None:
+        gc.callbacks.remove(_gc_cb)
+        print("[trace-steps] host ms per step() call: " + " ".join("%.2f" % x for x in trace) + "  | window %.3f ms per step" % (1e3 * dt / steps), file=sys.stderr)
     assert bool(torch.isfinite(out).all())
     return dt
 
@@ -394,6 +410,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--trace-steps", action="store_true", help="print the host time of every step() call of every timed window to stderr (diagnostics)")
     ap.add_argument("--workload", default="ship_straight")
     ap.add_argument("--fine", type=int, default=None, help="num_fine_samples (default: the workload's flat variant, 0)")
     ap.add_argument("--precision", default="f16x3", help="arithmetic of training and of every tapped path")
@@ -528,6 +545,15 @@ def main():
         if args.fail_mode == "exit":
             os._exit(17)
         time.sleep(20.0 * args.dist_timeout)
+    # The host's garbage collector: a full (generation-2) collection walks every container object of the process — torch's and numpy's import
+    # graphs included — and takes 45 ms here (measured: --trace-steps; round 6).  It comes once per ~70 000 container allocations, i.e. every
+    # few hundred steps of a training loop (~1 % of its time), but when it lands in a 20-step window it adds 2 ms to every step of it: the
+    # slow window every committed `stability` record of rounds 3-5 shows (7.5 among 6.2 ms) was that, and in round 6 it moved into the
+    # headline window.  Set-up is over here: what exists now is moved to the permanent generation, later collections walk only what the
+    # steps allocate (the usual practice for serving / training loops; nothing of the timed work is skipped).
+    import gc
+    gc.collect()
+    gc.freeze()
     dt = timed_steps(stepper, args.warmup, args.steps, barrier, D, device)
     graph_used = stepper.g is not None
     replicas = None
@@ -1045,6 +1071,8 @@ def main():
                        "precision": prec_fwd_name + ": forward — " + PRECISION_NOTES.get(prec_fwd_name, "single 16-bit MFMA per product, fp32 accumulate"),
                        "eval_precision": args.eval_precision,
                        "backward_precision": (None if not train else args.backward),
+                       "host_gc": "gc.collect() + gc.freeze() after set-up, before the warm-up steps: a generation-2 collection of the whole import graph takes 45 ms "
+                                  "of host time and used to land in one 20-step window per run (bench.py; --trace-steps shows it)",
                        "backward_precision_note": (None if not train else {
                            "f16x3": "row-normalised f16 hi + lo parts of every saved activation and gradient (22 bits), 3 MFMAs per product: within 1e-5 of max|g| vs float64",
                            "f16x3lo8": "f16x3 with the lo planes of the saved activations / gradients stored as e4m3 bytes and decoded in the wgrad (11 + 4 significand "
