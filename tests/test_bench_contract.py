@@ -1,4 +1,4 @@
-"""The bench line's contract, checked on the committed driver-shaped lines of the current round (profiles/r05/bench_*.json: runs of
+"""The bench line's contract, checked on the committed driver-shaped lines of the current round (profiles/r06/bench_*.json: runs of
 `python bench.py ...` on an MI355X) — a CPU test: the keys and units the driver and the judge read must be there, and the numbers must be
 consistent with each other (value = rays / time, frac = achieved / peak, the roofline's algorithmic work = SURVEY 8(d)'s per-unit figure x
 the units one launch processes)."""
@@ -8,14 +8,15 @@ import os
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-P = os.path.join(ROOT, "profiles", "r05")
+P = os.path.join(ROOT, "profiles", "r06")
+P5 = os.path.join(ROOT, "profiles", "r05")
 
 
 def _line(name):
     return json.loads([l for l in open(os.path.join(P, name)) if l.startswith("{")][0])
 
 
-@pytest.mark.parametrize("name", ["bench_default.json", "bench_forward.json", "bench_train_f16.json", "bench_forward_f16.json", "bench_forward_bf16.json"])
+@pytest.mark.parametrize("name", ["bench_default.json", "bench_forward.json", "bench_train_lo8.json", "bench_train_f16.json", "bench_forward_f16f8.json"])
 def test_committed_line_has_the_contract_fields(name):
     d = _line(name)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
@@ -26,23 +27,36 @@ def test_committed_line_has_the_contract_fields(name):
     rays = d["config"]["rays_per_gpu"] * d["steps"] * d["n_gpus"]
     assert abs(d["value"] - rays / (d["ms_per_step"] * d["steps"] * 1e-3)) < 1e-6 * d["value"]
     r = d["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "passes", "sustained_mfma_tflops", "frac_of_pass_ceiling"):
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
-    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["avg_launch_ms"] <= d["ms_per_step"]
     # algorithmic FLOP per launch = 1 186 816 (forward, wgrad) or 1 115 392 (dgrad) per row x 4096 x 128 rows
     assert r["algorithmic_flop_per_launch"] in (1186816 * 4096 * 128, 1115392 * 4096 * 128)
-    assert abs(r["achieved"] - r["algorithmic_flop_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e12) < 1e-6 * r["achieved"]
-    assert abs(r["frac_of_pass_ceiling"] - r["achieved"] * r["passes"] / r["sustained_mfma_tflops"]) < 1e-9
-    assert 1000.0 < r["sustained_mfma_tflops"] < 2500.0            # measured in the run, below the data-sheet peak
-    assert r["traffic"] is not None and r["traffic"] > 0           # HBM bytes per launch from the committed PMC pass of the same command
-    assert d["pmc_profile"]["kernels_unchanged_since"] is True and "COMMITTED" in d["pmc_profile"]["source"]
-    assert r["avg_launch_ms"] <= d["ms_per_step"]
+    if r["bound"] == "hbm":
+        # the weight-gradient kernel (round 6: reported as what bounds it): operand bytes read once / launch time against 8 TB/s, the
+        # MFMA view of the same launch beside it
+        assert r["kernel"].startswith("nerfmlp_wgrad") and r["unit"] == "GB/s" and r["peak"] == 8000.0
+        planes = {"f16x3": 2.0, "f16x3lo8": 1.5, "f16": 1.0}[d["config"]["backward_precision"]]
+        assert r["algorithmic_bytes_per_launch"] == 316 * 32 * planes * 4096 * 128
+        assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+        m = r["mfma"]
+    else:
+        assert r["unit"] == "TFLOP/s" and r["peak"] == 2500.0
+        m = r
+    assert abs(m["achieved"] - r["algorithmic_flop_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e12) < 1e-6 * m["achieved"]
+    assert abs(m["frac_of_pass_ceiling"] - m["achieved"] * m["passes"] / m["sustained_mfma_tflops"]) < 1e-9
+    assert 1000.0 < m["sustained_mfma_tflops"] < 2500.0            # measured in the run, below the data-sheet peak
+    if name != "bench_train_f16.json" and name != "bench_forward_f16f8.json":      # (the PMC passes of round 6 cover the default commands and the lo8 leg)
+        assert r["traffic"] is not None and r["traffic"] > 0       # HBM bytes per launch from the committed PMC pass of the same command
+        assert d["pmc_profile"]["kernels_unchanged_since"] is True and "COMMITTED" in d["pmc_profile"]["source"]
+        if r["bound"] == "hbm":
+            assert 0.95 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.1      # nothing is read twice
 
 
 def test_default_line_carries_the_baseline_legs_and_north_star_arithmetic():
     d = _line("bench_default.json")
     assert d["metric"] == "rays/sec (train step)" and d["dtype"] == "f16x3/fp32-acc" and d["config"]["backward_precision"] == "f16x3"
+    assert d["config"]["eval_precision"] == "f16x3" and "gc.freeze" in d["config"]["host_gc"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "rays/s" and c["value"] > 0 and c["cores"] >= 1 and "sample" in c
     assert d["parity"]["max_abs_rgb"] < 1e-4                        # the GPU path against the oracle on 4096 rays of the same workload
@@ -50,18 +64,30 @@ def test_default_line_carries_the_baseline_legs_and_north_star_arithmetic():
     assert d["roofline_march"]["algorithmic_bytes_per_launch"] == 4096 * (1536 * 128 + 24)
     k = {t["kernel"].split("<")[0]: t for t in d["roofline_train_kernels"]}
     assert set(k) == {"nerfmlp_fwd_kernel", "nerfmlp_dgrad_kernel", "nerfmlp_wgrad_tr_kernel"}
-    assert all(t["passes"] == 3 and 0.4 < t["frac_of_pass_ceiling"] < 1.0 for t in k.values())
+    assert k["nerfmlp_wgrad_tr_kernel"]["bound"] == "hbm" and k["nerfmlp_fwd_kernel"]["bound"] == "mfma"
+    assert all((t.get("mfma") or t)["passes"] == 3 and 0.4 < (t.get("mfma") or t)["frac_of_pass_ceiling"] < 1.0 for t in k.values())
+    # the headline window is not the odd one out any more (the host collector's 45 ms pause used to land in one window per run)
+    st = d["stability"]
+    assert abs(d["ms_per_step"] - st["median_ms"]) < 0.05 * st["median_ms"] and st["spread_frac"] < 0.06
     legs = d["precision_legs"]
     assert legs["f16"]["forward"]["parity_vs_oracle"]["max_abs_rgb"] < 1e-4 < legs["bf16"]["forward"]["parity_vs_oracle"]["max_abs_rgb"]
     assert legs["f16"]["train"]["rays_per_s"] > 1.3 * d["value"] and legs["f16"]["train"]["grad_err_rel_max_vs_f16x3"] < 1e-3
     assert legs["f16"]["forward"]["roofline"]["passes"] == 1
-    assert d["frame"]["height"] == 800 and d["frame"]["samples"] == 128 and d["frame"]["ms_per_frame"] > 0 and d["frame"]["glass_frame"]["eikonal_steps"] == 6144
+    live = legs["range_retry_live"]                               # the retry where it fires
+    assert live["lagged_default"]["re_runs"] == 5 and live["decided_in_place"]["re_runs"] == 5 and live["lagged_default"]["re_runs_failed"] == 0
+    assert live["same_loop_without_a_batch_out_of_range"]["re_runs"] == 0 and live["lagged_default"]["parameters_finite"] is True
+    assert 0 < live["ms_per_re_run"] < 2 * d["ms_per_step"]
+    assert legs["backward_modes_behind_the_f16x3_forward"]["grad_err_rel_max_vs_f16x3"]["f16x3lo8"] < 1e-5
+    assert d["other_backward_modes"]["f16x3lo8"]["ms_per_step"] < d["ms_per_step"]
+    f = d["frame"]
+    assert f["height"] == 800 and f["samples"] == 128 and f["ms_per_frame"] > 0 and f["precision"] == "f16x3" and f["glass_frame"]["eikonal_steps"] == 6144
+    assert f["f16f8"]["ms_per_frame"] < f["ms_per_frame"] and f["f16f8"]["max_abs_rgb_vs_the_frame_above"] < 1e-4 and f["ms_per_frame_chunk8192"] > 0
     v = d["variants"]
     assert {"ship_refractive_128", "ship_refractive_128_stage_all", "dolphin_train_4096", "dolphin_train_512"} <= set(v)
 
 
 def test_rehearsal_line_has_every_multi_rank_field():
-    d = _line("rehearsal_8_ranks_one_device.json")
+    d = json.loads([l for l in open(os.path.join(P5, "rehearsal_8_ranks_one_device.json")) if l.startswith("{")][0])      # round 5's record (the rehearsal itself runs in tests/test_gpu_bench_world8.py)
     assert d["n_gpus"] == 8 and d["collectives"]["ranks"] == 8 and d["collectives"]["replicas"]["parameters_bit_identical"] is True
     assert d["collectives"]["replicas"]["distinct_rank_keys"] == 8 and d["scaling_curve"]["n"] == [1, 2, 4, 8]
     assert d["variants"]["dolphin_train_global4096_strong"]["rays_per_gpu"] == 512
