@@ -5,6 +5,9 @@ rnerf/datasets.py cannot be imported here (its module-level `import jax` fails o
   OpenCV._generate_rays  (:486-518)   OpenCV pinhole rays           -> SURVEY 8f N4 (cam_mat form)
   Grid._linear3          (:278-313)   trilinear lookup, clamp to edge -> row G3 (the same index arithmetic as ior_utils' jax _linear3)
   Grid._compute_grad     (:315-322)   central-difference gradients  -> row G2
+  Dataset._next_train    (:151-205)   the training batch sampler (numpy's global generator + fancy indexing of images / rays)
+                                      -> SURVEY 8f N4, second half (rnerf_sample_batch, datasets.DeviceBatcher); it calls
+                                      utils.namedtuple_map (rnerf/utils.py:70-72, pure Python), read out of the reference the same way
 This script reads those FunctionDefs out of the reference's source with `ast` (nothing is imported from the reference, nothing of it is
 copied into this repository), compiles each one as it stands, and calls it on seeded inputs with a plain attribute holder as `self` and a
 namedtuple with the reference's field names as `utils.Rays`.  Inputs and outputs go to tests/golden/reference_numpy.npz — data, not source.
@@ -24,7 +27,8 @@ import numpy as np
 REF = os.environ.get("RNERF_REFERENCE_ROOT", "/root/reference")
 SRC = os.path.join(REF, "rnerf", "datasets.py")
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_numpy.npz")
-WANTED = {("Dataset", "_generate_rays"), ("OpenCV", "_generate_rays"), ("Grid", "_linear3"), ("Grid", "_compute_grad")}
+SRC_UTILS = os.path.join(REF, "rnerf", "utils.py")
+WANTED = {("Dataset", "_generate_rays"), ("OpenCV", "_generate_rays"), ("Grid", "_linear3"), ("Grid", "_compute_grad"), ("Dataset", "_next_train")}
 Rays = collections.namedtuple("Rays", ("origins", "directions", "viewdirs", "radii"))        # field names of rnerf/utils.py's Rays
 
 
@@ -45,10 +49,24 @@ SAFE_BUILTINS["__import__"] = _numpy_only_import
 
 
 def source_sha256():
-    """sha256 of the reference file the methods are read from (None when it is not on this machine) — nothing is parsed or executed."""
-    if not os.path.exists(SRC):
+    """sha256 of the reference files the methods are read from (None when they are not on this machine) — nothing is parsed or executed.
+    One digest over rnerf/datasets.py and rnerf/utils.py (the second only contributes namedtuple_map)."""
+    if not (os.path.exists(SRC) and os.path.exists(SRC_UTILS)):
         return None
-    return hashlib.sha256(open(SRC, "rb").read()).hexdigest()
+    return hashlib.sha256(open(SRC, "rb").read() + b"\0" + open(SRC_UTILS, "rb").read()).hexdigest()
+
+
+def _reference_namedtuple_map():
+    """rnerf/utils.py:70-72 compiled from the reference's text (the module itself imports jax: not importable here)."""
+    tree = ast.parse(open(SRC_UTILS).read(), SRC_UTILS)
+    for fn in (n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "namedtuple_map"):
+        if fn.decorator_list:
+            raise RuntimeError(f"{SRC_UTILS}: namedtuple_map carries a decorator: refusing to execute it")
+        b = dict(SAFE_BUILTINS); b.update(type=type, map=map)
+        ns = {"__builtins__": b}
+        exec(compile(ast.Module(body=[fn], type_ignores=[]), SRC_UTILS, "exec"), ns)
+        return ns["namedtuple_map"]
+    raise RuntimeError(f"{SRC_UTILS}: namedtuple_map not found")
 
 
 def reference_methods(expect_sha256=None):
@@ -57,15 +75,16 @@ def reference_methods(expect_sha256=None):
     The reference tree is untrusted content: the file's hash is taken BEFORE anything of it is compiled, and with `expect_sha256` (the test
     passes the hash committed in reference_numpy.npz) a file that is not the one the fixture was made from is refused unexecuted —
     decorators and default-argument expressions of a FunctionDef run at exec time.  The methods run with a whitelist of builtins."""
-    if not os.path.exists(SRC):
+    if not (os.path.exists(SRC) and os.path.exists(SRC_UTILS)):
         return {}, None
     raw = open(SRC, "rb").read()
-    sha = hashlib.sha256(raw).hexdigest()
+    sha = source_sha256()
     if expect_sha256 is not None and sha != expect_sha256:
         raise RuntimeError(f"{SRC}: sha256 {sha[:16]} is not the source the committed vectors were made from ({expect_sha256[:16]}): "
                            "nothing of it was executed; re-run tests/golden/make_from_reference_numpy.py after reading the diff")
     text = raw.decode()
     tree = ast.parse(text, SRC)
+    ntmap = _reference_namedtuple_map()
     out = {}
     for cls in (n for n in tree.body if isinstance(n, ast.ClassDef)):
         for fn in (n for n in cls.body if isinstance(n, ast.FunctionDef)):
@@ -73,7 +92,7 @@ def reference_methods(expect_sha256=None):
                 if fn.decorator_list:
                     raise RuntimeError(f"{SRC}: {cls.name}.{fn.name} carries a decorator: refusing to execute it")
                 mod = ast.Module(body=[fn], type_ignores=[])
-                ns = {"__builtins__": dict(SAFE_BUILTINS), "np": np, "utils": types.SimpleNamespace(Rays=Rays)}
+                ns = {"__builtins__": dict(SAFE_BUILTINS), "np": np, "utils": types.SimpleNamespace(Rays=Rays, namedtuple_map=ntmap)}
                 exec(compile(mod, SRC, "exec"), ns)
                 out[(cls.name, fn.name)] = ns[fn.name]
     missing = WANTED - set(out)
@@ -98,8 +117,10 @@ def inputs():
     k = rng.integers(0, [ndim[0], ndim[1], ndim[2]], (64, 3))
     on_nodes = np.array(nmin) + k * np.array(ndelta)                             # ... and exactly on nodes / cell faces
     pts = np.concatenate([pts, on_nodes]).astype(np.float32)
+    bat_images = rng.uniform(0, 1, (2, H, W, 3)).astype(np.float32)              # two decoded views for the batch sampler (after every other draw: the older vectors keep their bits)
     return dict(c2w=c2w, H=H, W=W, focal=focal, cam_mat=cam_mat, ndim=np.array(ndim), nmin=np.array(nmin), nmax=np.array(nmax), ior=ior, pts=pts,
-                ndelta=np.array(ndelta))
+                ndelta=np.array(ndelta), bat_images=bat_images, bat_seed=np.array(7), bat_batch_size=np.array(16), bat_patch_size=np.array(2),
+                bat_precrop_iters=np.array(2), bat_precrop_frac=np.array(0.5), bat_steps=np.array(4))
 
 
 def compute(meth, x):
@@ -122,6 +143,34 @@ def compute(meth, x):
     out["grad"] = np.asarray(grad)
     data = np.concatenate([x["ior"].reshape(-1, 1), grad.reshape(-1, 3)], -1)    # (n, dn/dx, dn/dy, dn/dz) per node: what the path's table holds
     out["lookup"] = np.asarray(meth[("Grid", "_linear3")](g, data, x["pts"]))
+    # Dataset._next_train as the training loop calls it (datasets.py:113-116), on the state _train_init leaves (:123-143): the rays of
+    # _generate_rays and the images, [n, H*W, .] ("single_image") or flattened over the views ("all_images"); numpy's GLOBAL generator,
+    # seeded, is what the reference draws from — its state is put back afterwards
+    me = types.SimpleNamespace(w=W, h=H, use_pixel_centers=True, camtoworlds=x["c2w"], **blender)
+    meth[("Dataset", "_generate_rays")](me)
+    n = x["c2w"].shape[0]
+    keep = np.random.get_state()
+    try:
+        for batching in ("single_image", "all_images"):
+            if batching == "single_image":
+                images = x["bat_images"].reshape([-1, H * W, 3])
+                rays = Rays(*[None if r is None else r.reshape([-1, H * W, r.shape[-1]]) for r in me.rays])
+            else:
+                images = x["bat_images"].reshape([-1, 3])
+                rays = Rays(*[None if r is None else r.reshape([-1, r.shape[-1]]) for r in me.rays])
+            ds = types.SimpleNamespace(batching=batching, rays=rays, images=images, batch_size=int(x["bat_batch_size"]), n_examples=n, train_it=0,
+                                       precrop_iters=int(x["bat_precrop_iters"]), precrop_frac=float(x["bat_precrop_frac"]), h=H, w=W,
+                                       patch_size=int(x["bat_patch_size"]) if batching == "single_image" else 0)      # (the reference's patch branch indexes rays[0][0].shape[0]: per-view layout only)
+            np.random.seed(int(x["bat_seed"]))
+            for it in range(int(x["bat_steps"])):
+                b = meth[("Dataset", "_next_train")](ds)
+                out[f"bat_{batching}_{it}_pixels"] = np.asarray(b["pixels"])
+                for f in ("origins", "directions", "viewdirs"):
+                    out[f"bat_{batching}_{it}_{f}"] = np.asarray(getattr(b["rays"], f))
+                    if batching == "single_image":
+                        out[f"bat_{batching}_{it}_env_{f}"] = np.asarray(getattr(b["env_rays"], f))
+    finally:
+        np.random.set_state(keep)
     return out
 
 

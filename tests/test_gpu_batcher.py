@@ -5,7 +5,12 @@ made for every pixel — with indices drawn from numpy's global generator.  samp
 (same numpy calls, same order) and gathers on the device (rnerf_sample_batch: pixels from the resident image, rays generated for the drawn
 pixels only).  Checked here against exactly that numpy indexing, on the reference's photograph and camera (tests/golden/example_image.npz,
 cases.EXAMPLE_C2W) plus a second synthetic view: pixels and rays bit for bit, both batching modes, the pre-crop phase, the env-map patch,
-both camera models."""
+both camera models.
+
+And PINNED BY THE REFERENCE ITSELF: tests/golden/reference_numpy.npz holds batches computed by the reference's own `Dataset._next_train`
+(executed from its source, with its own `utils.namedtuple_map`, on the rays of its own `_generate_rays`:
+tests/golden/make_from_reference_numpy.py) — the draws of DeviceBatcher indexed into the oracle's arrays (CPU) and the device gather (GPU)
+must reproduce them bit for bit."""
 import math
 import os
 import sys
@@ -141,3 +146,64 @@ def test_draws_follow_the_references_call_order_without_a_device():
             assert d["ray_indices"].dtype == np.int64 and d["ray_indices"].shape == (64,) and d["env_indices"].shape == (4, 4)
             assert 0 <= d["ray_indices"].min() and d["ray_indices"].max() < 3 * hw
             assert ref.randint(1 << 30) == b.rng.randint(1 << 30), (batching, it)           # both generators are in the same state
+
+
+def _golden():
+    d = np.load(os.path.join(HERE, "golden", "reference_numpy.npz"))
+    x = {k[3:]: d[k] for k in d.files if k.startswith("in_")}
+    y = {k[4:]: d[k] for k in d.files if k.startswith("out_")}
+    return x, y
+
+
+def _golden_batcher(x, batching, device, cls=None):
+    from samplenerfro_amd import datasets
+    kw = dict(batch_size=int(x["bat_batch_size"]), batching=batching, patch_size=int(x["bat_patch_size"]) if batching == "single_image" else 0,
+              precrop_iters=int(x["bat_precrop_iters"]), precrop_frac=float(x["bat_precrop_frac"]), rng=np.random.RandomState(int(x["bat_seed"])), prefetch=0,
+              focal=float(x["focal"]), pixel_center=True)
+    return (cls or datasets.DeviceBatcher)(x["bat_images"], x["c2w"], device=device, **kw)
+
+
+def test_draws_reproduce_the_references_own_next_train_without_a_device():
+    """The index half against batches the REFERENCE computed (its _next_train, from its source): DeviceBatcher's draws, used to index the
+    oracle's ray arrays (bit-equal to the reference's _generate_rays, tests/test_reference_numpy_pin.py) and the images, give its pixels and
+    rays bit for bit — both batching modes, two pre-crop batches, two full-image ones, the env-map patch."""
+    from samplenerfro_amd import datasets
+    x, y = _golden()
+    H, W, n = int(x["H"]), int(x["W"]), x["c2w"].shape[0]
+    per_view = [R.generate_rays(x["c2w"][i], H, W, pixel_center=True, focal=float(x["focal"])) for i in range(n)]
+    flat = [np.concatenate([pv[k].reshape(-1, 3) for pv in per_view]) for k in range(3)]      # origins, directions, viewdirs over (view, row, column)
+    img = x["bat_images"].reshape(-1, 3)
+
+    class NoDevice(datasets.DeviceBatcher):
+        def __init__(self, images, c2w, device=None, **kw):
+            self.n_examples, self.h, self.w = n, H, W
+            self.batch_size, self.batching, self.patch_size = kw["batch_size"], kw["batching"], kw["patch_size"]
+            self.precrop_iters, self.precrop_frac, self.train_it, self.rng = kw["precrop_iters"], kw["precrop_frac"], 0, kw["rng"]
+
+    for batching in ("single_image", "all_images"):
+        bat = _golden_batcher(x, batching, None, NoDevice)
+        for it in range(int(x["bat_steps"])):
+            d = bat.draw()
+            pre = f"bat_{batching}_{it}_"
+            assert np.array_equal(img[d["ray_indices"]], y[pre + "pixels"]), (batching, it)
+            for k, f in enumerate(("origins", "directions", "viewdirs")):
+                assert np.array_equal(flat[k][d["ray_indices"]], y[pre + f]), (batching, it, f)
+                if batching == "single_image":
+                    assert np.array_equal(flat[k][d["env_indices"]], y[pre + "env_" + f]), (batching, it, f)
+
+
+@pytest.mark.gpu
+def test_device_batches_equal_the_references_own_next_train():
+    """The whole batcher on the device against the batches the reference's own _next_train computed (tests/golden/reference_numpy.npz)."""
+    x, y = _golden()
+    for batching in ("single_image", "all_images"):
+        bat = _golden_batcher(x, batching, "cuda:0")
+        for it in range(int(x["bat_steps"])):
+            b = next(bat)
+            pre = f"bat_{batching}_{it}_"
+            assert np.array_equal(b["pixels"].cpu().numpy(), y[pre + "pixels"]), (batching, it)
+            for f in ("origins", "directions", "viewdirs"):
+                assert np.array_equal(getattr(b["rays"], f).cpu().numpy(), y[pre + f]), (batching, it, f)
+                if batching == "single_image":
+                    assert np.array_equal(getattr(b["env_rays"], f).cpu().numpy(), y[pre + "env_" + f]), (batching, it, f)
+        assert bat.out_of_range_indices() == 0
