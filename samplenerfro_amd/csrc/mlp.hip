@@ -611,6 +611,16 @@ __device__ __forceinline__ void tile_mfma(f32x16& a0, f32x16& a1, const uint4 ah
 // one k-step (block KOFF of the slab) of MFMAs for NT n-tiles x 2 m-tiles; FIRST: accumulators start from 0.
 // The A fragments of tile t+1 are read from LDS before the MFMAs of tile t are issued.
 struct NoDma { __device__ __forceinline__ void operator()() const {} };
+// Training kernels: the four operand / gradient stores of a k-step (hi and lo parts of both m-tiles) used to be issued at the head of the
+// k-step, right behind the slab barrier and in front of the first MFMA — four 1 KiB vector stores with the matrix pipe idle (the ISA of every
+// steady k-step begins `S S S S ds_read x 10 s_waitcnt M ...`).  RNERF_SPREAD_STORES: one store behind each of tiles 2..5 instead (the store
+// hook `st` of kstep_mfma), in the MFMAs' shadow like the conversion chunks.  Measured (round 6, tools/r06/ab_wgrad.py, one box, alternating):
+// training forward 2.016 / 1.974 -> 1.963 / 1.972 ms (inside the noise), dgrad 1.771 / 1.783 -> 1.838 / 1.842 ms (its spills grow from 259 to
+// 301 registers) — the seventh re-placement of work in these engines that does not pay: OFF.
+#ifndef RNERF_SPREAD_STORES
+#define RNERF_SPREAD_STORES 0
+#endif
+struct NoStore { template <int K> __device__ __forceinline__ void part() const {} };
 
 // `dma` is invoked after tile 1: the weight DMA of the next slab is issued while MFMAs are already in the matrix pipe and
 // the A fragments of tiles 0..3 are already on their way (an LDS-DMA instruction costs ~100 issue cycles).
@@ -618,8 +628,8 @@ struct NoDma { __device__ __forceinline__ void operator()() const {} };
 // number of reads in flight (latency x concurrency), not by the 256 B/clk peak.
 constexpr int FRAG_DEPTH = 4;
 
-template <int PREC, int NT, int KOFF, bool FIRST, typename W, bool NOREAD = false, typename D = NoDma, int PASSES = Prec<PREC>::PASSES, typename BOPS = KOps>
-__device__ __forceinline__ void kstep_mfma(f32x16 (&acc0)[8], f32x16 (&acc1)[8], const BOPS& b, const char* slab, int lane, W& work, D dma = D()) {
+template <int PREC, int NT, int KOFF, bool FIRST, typename W, bool NOREAD = false, typename D = NoDma, int PASSES = Prec<PREC>::PASSES, typename BOPS = KOps, typename ST = NoStore>
+__device__ __forceinline__ void kstep_mfma(f32x16 (&acc0)[8], f32x16 (&acc1)[8], const BOPS& b, const char* slab, int lane, W& work, D dma = D(), const ST& st = ST()) {
   using PP = Prec<PREC>;
   const uint4* a = (const uint4*)slab + lane + (size_t)KOFF * NT * PP::NP * 64;
   uint4 fh[FRAG_DEPTH], fl[FRAG_DEPTH];
@@ -651,7 +661,15 @@ __device__ __forceinline__ void kstep_mfma(f32x16 (&acc0)[8], f32x16 (&acc1)[8],
   }
   RNERF_TILE(0) RNERF_TILE(1)
   dma();
-  RNERF_TILE(2) RNERF_TILE(3) RNERF_TILE(4) RNERF_TILE(5) RNERF_TILE(6) RNERF_TILE(7)
+  RNERF_TILE(2)
+  if constexpr (NT == 8) { st.template part<0>(); RNERF_PIN(); }
+  RNERF_TILE(3)
+  if constexpr (NT == 8) { st.template part<1>(); RNERF_PIN(); }
+  RNERF_TILE(4)
+  if constexpr (NT == 8) { st.template part<2>(); RNERF_PIN(); }
+  RNERF_TILE(5)
+  if constexpr (NT == 8) { st.template part<3>(); RNERF_PIN(); }
+  RNERF_TILE(6) RNERF_TILE(7)
 #undef RNERF_TILE
 }
 
@@ -683,6 +701,32 @@ __device__ __forceinline__ uint32_t nz_nibbles(const uint4& o) {
   return pk_min1(o.x) | (pk_min1(o.y) << 1) | (pk_min1(o.z) << 2) | (pk_min1(o.w) << 3);
 }
 __device__ __forceinline__ uint32_t nz_byte(uint32_t nib) { return (nib & 0xFu) | (nib >> 12); }   // even flags | odd flags << 4
+
+// The saves of one k-step one at a time (kstep_mfma's store hook, RNERF_SPREAD_STORES): part 0 / 1 = the hi parts of m-tile 0 / 1, 2 / 3 = the
+// lo parts (TRAIN = 2: f16, 3: e4m3 bytes).  (Namespace scope: a local class cannot have a member template.)
+template <int TRAIN, bool ONE>
+struct SaveParts {
+  uint4* save; long long save_rows, t32_0; int q, m, h; const KOpsT<ONE>& o;
+  template <int K> __device__ __forceinline__ void part() const {
+    if constexpr (TRAIN != 0) {
+#ifndef RNERF_FWD_NOSAVE
+      uint4* dst = save + sv_addr(q, t32_0, m, h);
+      if constexpr (K == 0) stream_store(dst, o.h0);
+      if constexpr (K == 1 && !ONE) stream_store(dst + (size_t)SAVE_SLOTS * 64, o.h1);
+      if constexpr (TRAIN == 2) {
+        uint4* dl = dst + sv_lo0(save_rows);
+        if constexpr (K == 2) stream_store(dl, o.l0);
+        if constexpr (K == 3 && !ONE) stream_store(dl + (size_t)SAVE_SLOTS * 64, o.l1);
+      }
+      if constexpr (TRAIN == 3) {
+        uint2* dl = (uint2*)(save + sv_lo0(save_rows)) + sv_addr(q, t32_0, m, h);
+        if constexpr (K == 2) stream_store8(dl, lo8_pack<false>(o.l0, LO8_SCALE_X));
+        if constexpr (K == 3 && !ONE) stream_store8(dl + (size_t)SAVE_SLOTS * 64, lo8_pack<false>(o.l1, LO8_SCALE_X));
+      }
+#endif
+    }
+  }
+};
 
 // TRAIN: 0 = evaluation, 1 = training forward keeping the hi 16-bit operand parts, 2 = hi and lo parts (fp32-grade backward),
 // 3 = hi parts + the lo parts as e4m3 bytes (RNERF_BWD_F16X3_LO8: lo8 plane = uint2[...] at the lo plane's place, same (tile, slot, row, half) order)
@@ -974,7 +1018,8 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
       const float* __restrict__ wsel = auxt + (l == 8 ? AUX_WSIG : AUX_ZERO);
 #define RNERF_KSTEP(S)                                                                                              \
       {                                                                                                              \
-        save_ops(SAVE_L1 + 16 * (l - 1) + S, cur);                                                                   \
+        const SaveParts<TRAIN, ONE> sp{save, save_rows, t32_0, SAVE_L1 + 16 * (l - 1) + S, m, h, cur};                            \
+        if constexpr (!(RNERF_SPREAD_STORES && TRAIN != 0)) save_ops(SAVE_L1 + 16 * (l - 1) + S, cur);               \
         watch(cur, false);                                                                                           \
         if constexpr (TRAIN != 0 && S == 0) save_mask(l - 1, 0, nz_nibbles(cur.h0), nz_nibbles(cur.h1));                  \
         if constexpr (S == 13) { load_bias8(0, bias + 256, seam.cv.b); load_bias8(0, wseam, seam.cv.ws); }           \
@@ -988,14 +1033,16 @@ nerfmlp_fwd_kernel(const char* __restrict__ packed, const float4* __restrict__ r
           _Pragma("unroll") for (int j = 0; j < 8; ++j) { cv.b[j] = bnext[j]; cv.ws[j] = wnext[j]; }                 \
           load_state8(S + 1, cv.v1);                                                                                 \
           if (dbg & 8) { kstep_mfma<PREC, 8, 0, S == 0, NoWork, (dbg & 16) != 0>(acc0, acc1, cur, smem + buf * SLAB, lane, nowork, dma); } \
-          else { if (!(dbg & 2)) kstep_mfma<PREC, 8, 0, S == 0, PrevConv<PREC, S + 1, TRAIN != 0, true, ONE>, (dbg & 16) != 0, decltype(dma)>(acc0, acc1, cur, smem + buf * SLAB, lane, cv, dma);              \
+          else { if (!(dbg & 2)) { if constexpr (RNERF_SPREAD_STORES && TRAIN != 0) kstep_mfma<PREC, 8, 0, S == 0, PrevConv<PREC, S + 1, TRAIN != 0, true, ONE>, (dbg & 16) != 0, decltype(dma), Prec<PREC>::PASSES, KOps, SaveParts<TRAIN, ONE>>(acc0, acc1, cur, smem + buf * SLAB, lane, cv, dma, sp); else \
+            kstep_mfma<PREC, 8, 0, S == 0, PrevConv<PREC, S + 1, TRAIN != 0, true, ONE>, (dbg & 16) != 0, decltype(dma)>(acc0, acc1, cur, smem + buf * SLAB, lane, cv, dma); }              \
           cur = cv.result();                                                                                         \
           sig0 += cv.sg0; sig1 += cv.sg1;                                                                            \
           save_mask(l - 1, S + 1, cv.nz[0], cv.nz[1]); }                                                             \
         } else {                                                                                                     \
           /* also for l == 5, whose last k-step is the 4th skip slab: that one runs the seam again on the final sums (no branch here: */ \
           /* a run-time choice of the work functor splits the accumulators' live ranges and hipcc spills them around it) */ \
-          if (!(dbg & 2)) kstep_mfma<PREC, 8, 0, false, SeamWork<PREC, TRAIN != 0, ONE>, false, decltype(dma)>(acc0, acc1, cur, smem + buf * SLAB, lane, seam, dma); \
+          if (!(dbg & 2)) { if constexpr (RNERF_SPREAD_STORES && TRAIN != 0) kstep_mfma<PREC, 8, 0, false, SeamWork<PREC, TRAIN != 0, ONE>, false, decltype(dma), Prec<PREC>::PASSES, KOps, SaveParts<TRAIN, ONE>>(acc0, acc1, cur, smem + buf * SLAB, lane, seam, dma, sp); else \
+            kstep_mfma<PREC, 8, 0, false, SeamWork<PREC, TRAIN != 0, ONE>, false, decltype(dma)>(acc0, acc1, cur, smem + buf * SLAB, lane, seam, dma); } \
         }                                                                                                            \
         if constexpr (S + 2 <= 16) { _Pragma("unroll") for (int j = 0; j < 8; ++j) { bnext[j] = bnn[j]; wnext[j] = wnn[j]; } } \
         SLAB_DONE();                                                                                                 \
@@ -1311,6 +1358,28 @@ template <int BWD> struct Bwd {
 __host__ __device__ constexpr size_t dy_plane_uint4(long long R, int np) { return (size_t)DY_SLOTS * np * (size_t)R * 2; }
 __host__ __device__ constexpr size_t dy_addr(int q, long long t32, int m, int h) { return (((size_t)t32 * DY_SLOTS + q) * 32 + m) * 2 + h; }     // tile-major, see sv_addr
 
+// the dY stores of one dgrad k-step one at a time (see SaveParts)
+template <bool LO8, int NP, bool ONE>
+struct DyParts {
+  uint4* dy; long long save_rows, t32_0; int q, m, h; const KOpsT<ONE>& o;
+  template <int K> __device__ __forceinline__ void part() const {
+#ifndef RNERF_DGRAD_NOSTORE
+    uint4* dst = dy + dy_addr(q, t32_0, m, h);
+    if constexpr (K == 0) stream_store(dst, o.h0);
+    if constexpr (K == 1 && !ONE) stream_store(dst + (size_t)DY_SLOTS * 64, o.h1);
+    if constexpr (LO8) {
+      uint2* dl = (uint2*)(dy + dy_plane_uint4(save_rows, 1)) + dy_addr(q, t32_0, m, h);
+      if constexpr (K == 2) stream_store8(dl, lo8_pack<true>(o.l0, LO8_SCALE_D));
+      if constexpr (K == 3 && !ONE) stream_store8(dl + (size_t)DY_SLOTS * 64, lo8_pack<true>(o.l1, LO8_SCALE_D));
+    } else if constexpr (NP == 2) {
+      uint4* dl = dst + dy_plane_uint4(save_rows, 1);
+      if constexpr (K == 2) stream_store(dl, o.l0);
+      if constexpr (K == 3 && !ONE) stream_store(dl + (size_t)DY_SLOTS * 64, o.l1);
+    }
+#endif
+  }
+};
+
 template <int BWD, bool ONE = false>
 __global__ void __launch_bounds__(256, 1)
 nerfmlp_dgrad_kernel(const char* __restrict__ packed_bwd, const float* __restrict__ fwd_aux, const uint4* __restrict__ saved,
@@ -1484,7 +1553,8 @@ nerfmlp_dgrad_kernel(const char* __restrict__ packed_bwd, const float* __restric
       DPH(1);
 #define RNERF_DG_KSTEP(S, NSTEPS, SLOT0, PREFETCH_STMT)                                                                       \
       {                                                                                                                         \
-        dy_store((SLOT0) + S, cur);                                                                                             \
+        const DyParts<BW::LO8, BW::NP, ONE> dp{dy, save_rows, t32_0, (SLOT0) + S, m, h, cur};                                    \
+        if constexpr (!RNERF_SPREAD_STORES) dy_store((SLOT0) + S, cur);                                                         \
         auto dma = [&]() { PREFETCH_STMT; };   /* issued after the first two tiles' MFMAs (an LDS-DMA instruction costs ~100 issue cycles) */ \
         if constexpr (S + 1 < NSTEPS) {                                                                                         \
           GradConv<PREC, S + 1, NEED_LO, ONE> cv(prev0[(S + 1) >> 1]);                                                                   \
@@ -1501,9 +1571,11 @@ nerfmlp_dgrad_kernel(const char* __restrict__ packed_bwd, const float* __restric
           }                                                                                                                     \
           cv.w0 = ((S + 1) >> 2) == 0 ? ma.x : (((S + 1) >> 2) == 1 ? ma.y : (((S + 1) >> 2) == 2 ? ma.z : ma.w));             \
           cv.w1 = ((S + 1) >> 2) == 0 ? mb.x : (((S + 1) >> 2) == 1 ? mb.y : (((S + 1) >> 2) == 2 ? mb.z : mb.w));             \
+          if constexpr (RNERF_SPREAD_STORES) kstep_mfma<PREC, 8, 0, S == 0, GradConv<PREC, S + 1, NEED_LO, ONE>, false, decltype(dma), DGP, KOps, DyParts<BW::LO8, BW::NP, ONE>>(acc0, acc1, cur, smem + buf * SLAB, lane, cv, dma, dp); else \
           kstep_mfma<PREC, 8, 0, S == 0, GradConv<PREC, S + 1, NEED_LO, ONE>, false, decltype(dma), DGP>(acc0, acc1, cur, smem + buf * SLAB, lane, cv, dma); \
           cur = cv.result();                                                                                                    \
         } else {                                                                                                                \
+          if constexpr (RNERF_SPREAD_STORES) kstep_mfma<PREC, 8, 0, false, NoWork, false, decltype(dma), DGP, KOps, DyParts<BW::LO8, BW::NP, ONE>>(acc0, acc1, cur, smem + buf * SLAB, lane, nowork, dma, dp); else \
           kstep_mfma<PREC, 8, 0, false, NoWork, false, decltype(dma), DGP>(acc0, acc1, cur, smem + buf * SLAB, lane, nowork, dma);  \
         }                                                                                                                       \
         SLAB_DONE();                                                                                                            \
