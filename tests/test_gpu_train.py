@@ -352,7 +352,8 @@ def test_single_pass_f16_training_converges_like_the_default_on_a_teacher():
     """A teacher network renders target pixels for random rays through a refracting sphere; a differently initialised student is trained on
     them (flat, fixed quadrature nodes, 400 steps of 2048 rays: the field stays opaque and matters throughout, unlike on the single real
     view of tests/test_gpu_example_scene.py).  The single-pass leg (f16 forward + f16 backward) must converge like the fp32-grade default:
-    same PSNR curve within a fraction of a dB, no non-finite gradient."""
+    same PSNR curve within a fraction of a dB, no non-finite gradient.  Round 6: so must the opt-in backward f16x3lo8 (e4m3 lo planes behind
+    the f16x3 forward) — held ten times tighter: its gradients differ from the default's by 5e-7 of max|g| at such batch sizes."""
     from samplenerfro_amd import _lib, models, prng, synthetic as syn, utils as U
     from samplenerfro_amd.train import TrainState, train_step
     dev = torch.device("cuda:0")
@@ -362,7 +363,7 @@ def test_single_pass_f16_training_converges_like_the_default_on_a_teacher():
     fixed = np.arange(0, S * P, P) + P // 2
     key = np.array([9, 9], np.uint32)
     curves = {}
-    for name in ("f16x3", "f16"):
+    for name in ("f16x3", "f16", "f16x3lo8"):
         flags = U.default_flags(num_coarse_samples=S, num_fine_samples=0, num_path_samples=P, white_bkgd=False, bg_weight=0.0, bg_smooth_weight=0.0,
                                 use_online_sparsity=False, randomized=True, lr_init=1e-3, lr_final=1e-4, lr_delay_steps=0, max_steps=steps,
                                 backward_precision=name)
@@ -387,6 +388,7 @@ def test_single_pass_f16_training_converges_like_the_default_on_a_teacher():
     print("teacher / student PSNR, 50-step means:", {k: [round(x, 2) for x in v] for k, v in m.items()})
     assert m["f16x3"][-1] > m["f16x3"][0] + 6.0                        # it learns (by a lot)
     assert max(abs(a - b) for a, b in zip(m["f16"], m["f16x3"])) < 0.5
+    assert max(abs(a - b) for a, b in zip(m["f16x3lo8"], m["f16x3"])) < 0.05
 
 
 @pytest.mark.parametrize("Nf", [12, 0])
