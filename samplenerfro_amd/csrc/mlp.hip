@@ -1810,7 +1810,8 @@ template <int KT, int NT> struct WgTrShape {
   static_assert(WK * TK == KT && WN * TN == NTR && WK * WN <= 8 && (!EXTRA || (TK == 2 && WN == 2)), "tile split");
 };
 #ifndef RNERF_WGTR_LATE_DMA
-#define RNERF_WGTR_LATE_DMA 1      /* round 6, tools/r06/ab_wgrad.py: f16x3 wgrad 2.008 / 2.010 -> 1.987 / 1.973 ms, f16x3lo8 1.907 / 1.900 -> 1.872 / 1.899 */
+#define RNERF_WGTR_LATE_DMA 0      /* round 6: launched ALONE it pays (tools/r06/ab_wgrad.py: f16x3 wgrad 2.008 / 2.010 -> 1.987 / 1.973 ms), in the STEP — the next batch's \
+                                      march co-resident on the same SIMDs — it does not (tools/r06/ab_step.py, three alternating pairs: 6.352 / 6.352 / 6.355 ms with it, 6.348 / 6.319 / 6.319 without): off */
 #endif
 #ifndef RNERF_WGTR_NCH
 #define RNERF_WGTR_NCH 2      /* n-tiles of B fragments fetched at a time when the A side is resident */
