@@ -550,7 +550,8 @@ def main():
     # few hundred steps of a training loop (~1 % of its time), but when it lands in a 20-step window it adds 2 ms to every step of it: the
     # slow window every committed `stability` record of rounds 3-5 shows (7.5 among 6.2 ms) was that, and in round 6 it moved into the
     # headline window.  Set-up is over here: what exists now is moved to the permanent generation, later collections walk only what the
-    # steps allocate (the usual practice for serving / training loops; nothing of the timed work is skipped).
+    # steps allocate (nothing of the timed work is skipped).  The reference's own training loop runs with the collector switched OFF
+    # altogether (/root/reference/train.py:340-341: `gc.disable()  # Disable automatic garbage collection for efficiency.`, `gc.collect()`).
     import gc
     gc.collect()
     gc.freeze()
