@@ -506,13 +506,39 @@ def _in_dist_context(ctx):
 
 
 def _clone_batch(batch: Dict[str, Any]) -> Dict[str, Any]:
-    def cp(v):
+    """A private copy of the batch's tensors (rays, pixels, env-map directions: ~350 KB at 4096 rays) in ONE device launch: every float32
+    tensor gets a 256-byte aligned slice of one staging buffer, filled by a single multi-tensor copy (four separate clones were four
+    serial 6 us copies behind every step — 4 % of a 128-ray step, rocprof timeline of round 6)."""
+    srcs = []
+
+    def walk(v):
         if isinstance(v, torch.Tensor):
-            return v.clone()
+            if v.is_cuda and v.dtype == torch.float32:
+                srcs.append(v)
+                return ("t", len(srcs) - 1)
+            return ("c", v.clone())
         if isinstance(v, tuple) and hasattr(v, "_fields"):            # Rays
-            return type(v)(*[cp(x) for x in v])
-        return v
-    return {k: cp(v) for k, v in batch.items()}
+            return ("n", type(v), [walk(x) for x in v])
+        return ("c", v)
+
+    plan = {k: walk(v) for k, v in batch.items()}
+    views = []
+    if srcs:
+        offs, total = [], 0
+        for t in srcs:
+            offs.append(total)
+            total += (t.numel() + 63) // 64 * 64
+        flat = torch.empty(total, dtype=torch.float32, device=srcs[0].device)
+        views = [flat[o:o + t.numel()].view(t.shape) for o, t in zip(offs, srcs)]
+        torch._foreach_copy_(views, [t if t.is_contiguous() else t.contiguous() for t in srcs])
+
+    def build(node):
+        if node[0] == "t":
+            return views[node[1]]
+        if node[0] == "n":
+            return node[1](*[build(x) for x in node[2]])
+        return node[1]
+    return {k: build(v) for k, v in plan.items()}
 
 
 def _clone_stats(stats: Stats) -> Stats:
