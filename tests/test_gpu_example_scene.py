@@ -249,3 +249,45 @@ def test_single_pass_f16_arithmetic_trains_the_example_view_like_the_default(sce
     assert np.isfinite(curves["f16"]).all()
     assert max(abs(a - b) for a, b in zip(m["f16"], m["f16x3"])) < 0.35
     assert abs(views["f16"] - views["f16x3"]) < 0.3 and m["f16"][-1] > m["f16"][0] + 1.0
+
+
+def test_the_training_loop_through_the_device_batcher_equals_host_indexed_batches(scene):
+    """SURVEY 8f N4 in the loop: `for batch in DeviceBatcher(...)` -> train_step on the reference's photograph and camera (views resident on
+    the device, the reference's numpy draws, ONE gather launch per ray set) gives the very losses and parameters of the same steps fed with
+    batches indexed on the host out of the ray arrays `_generate_rays` makes (what the reference's Dataset does) — bit for bit."""
+    import cases
+    from samplenerfro_amd import prng, utils as U
+    from samplenerfro_amd.datasets import DeviceBatcher
+    from samplenerfro_amd.train import train_step, flush_range_retry
+    B, steps, ps = 96, 4, 8
+    H, W = scene["H"], scene["W"]
+    focal = 0.5 * W / math.tan(0.5 * cases.EXAMPLE_CAMERA_ANGLE_X)
+    flags = _flags(B, 200000)
+    flags.bg_patch_size = ps
+    images = scene["pixels"].reshape(1, H, W, 3)
+    c2w = np.asarray(cases.EXAMPLE_C2W, F32)[None, :3, :4]
+    o_np, d_np, v_np = R.generate_rays(cases.EXAMPLE_C2W, H, W, focal=focal)
+    o_np, d_np, v_np = (a.reshape(-1, 3) for a in (o_np, d_np, v_np))
+    kw = dict(batch_size=B, batching="single_image", patch_size=ps, focal=focal, device="cuda:0", prefetch=0)
+    out = {}
+    for how in ("device", "host"):
+        model, state, pf = _device_setup(scene, flags, 3)
+        bat = DeviceBatcher(images, c2w, rng=np.random.RandomState(11), **kw)
+        r = prng.PRNGKey(20200823)
+        losses = []
+        for i in range(steps):
+            if how == "device":
+                batch = next(bat)
+            else:
+                dr = bat.draw()
+                idx, env = dr["ray_indices"], dr["env_indices"]
+                batch = {"rays": U.Rays(T(o_np[idx]), T(d_np[idx]), T(v_np[idx]), None), "pixels": T(scene["pixels"][idx]),
+                         "env_rays": U.Rays(T(o_np[env]), T(d_np[env]), T(v_np[env]), None)}
+            batch["annealed_alpha"] = max(i + 1, 0) / ANNEAL_MAX
+            state, stats, r = train_step(model, r, state, batch, flags)
+            losses.append((float(stats.loss), float(stats.loss_c), float(stats.loss_bg), float(stats.loss_bg_smooth)))
+        flush_range_retry(model, state)
+        out[how] = (losses, state.theta.clone())
+    assert out["device"][0] == out["host"][0], (out["device"][0], out["host"][0])
+    assert torch.equal(out["device"][1], out["host"][1])
+    assert all(np.isfinite(v) for l in out["device"][0] for v in l)
